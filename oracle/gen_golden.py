@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz by running the REFERENCE's own code
+(imported from /root/reference via oracle/ref_shim.py) on the seeded inputs of oracle/synth.py, and
+pins oracle/frcnn_oracle.py against it (every restated function must reproduce the reference output
+bit-for-bit on these tie-free inputs).  Runs only in the build container.
+
+    python oracle/gen_golden.py            # regenerate fixtures + pin report
+    python oracle/gen_golden.py --check    # pin only (no files written); exit 1 on mismatch
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim  # noqa: E402
+import synth  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
+f32 = np.float32
+FAIL = []
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def pin(name, ref_out, ora_out):
+    ref_out = ref_out if isinstance(ref_out, (tuple, list)) else (ref_out,)
+    ora_out = ora_out if isinstance(ora_out, (tuple, list)) else (ora_out,)
+    ok = len(ref_out) == len(ora_out)
+    for r, o in zip(ref_out, ora_out):
+        r, o = np.asarray(r), np.asarray(o)
+        ok = ok and r.shape == o.shape and r.dtype == o.dtype and np.array_equal(r, o)
+    print("  pin %-38s %s" % (name, "bit-exact" if ok else "MISMATCH"))
+    if not ok:
+        FAIL.append(name)
+
+
+def main(write=True):
+    ref = ref_shim.load_reference()
+    import frcnn_oracle as ora  # after the reference: module names do not collide
+    cfg = ref.cfg
+    out = {}
+
+    # ---- anchors (generate_anchors.py:41-52, snippets.py:14-30)
+    g = {}
+    for tag, (H, W, scales) in {"a9_38x63": (38, 63, (8, 16, 32)), "a12_38x63": (38, 63, (4, 8, 16, 32)),
+                                "a15_50x84": (50, 84, (2, 4, 8, 16, 32))}.items():
+        ratios = (0.5, 1, 2)
+        base = ref.generate_anchors(ratios=np.array(ratios), scales=np.array(scales))
+        anc, n = ref.generate_anchors_pre(H, W, 16, scales, ratios)
+        oanc, on = ora.generate_anchors_pre(H, W, 16, scales, ratios)
+        pin("generate_anchors_pre " + tag, (anc, n), (oanc, on))
+        pin("generate_anchors " + tag, base, ora.generate_anchors(ratios=ratios, scales=scales))
+        g[tag + "_base"] = base
+        g[tag + "_first"] = anc[:64]
+        g[tag + "_last"] = anc[-64:]
+        g[tag + "_sha"] = np.frombuffer(bytes.fromhex(sha(anc)), dtype=np.uint8)
+        g[tag + "_n"] = np.int64(n)
+    out["anchors"] = g
+
+    # ---- codec (bbox_transform.py:35-81)
+    anchors, _ = ref.generate_anchors_pre(38, 63, 16, (8, 16, 32), (0.5, 1, 2))
+    rng = np.random.RandomState(3)
+    sel = rng.permutation(anchors.shape[0])[:4096]
+    deltas = (rng.randn(4096, 4) * 0.4).astype(f32)
+    dec = ref.bbox_transform_inv(anchors[sel], deltas)
+    clip = ref.clip_boxes(dec.copy(), np.array([600, 1000], dtype=f32))
+    pin("bbox_transform_inv", dec, ora.bbox_transform_inv(anchors[sel], deltas))
+    pin("clip_boxes", clip, ora.clip_boxes(dec.copy(), np.array([600, 1000], dtype=f32)))
+    gtb = synth.gt_boxes(4096, 21, seed=5)
+    enc = ref.bbox_transform(clip, gtb[:, :4])
+    pin("bbox_transform", enc, ora.bbox_transform(clip, gtb[:, :4]))
+    out["codec"] = dict(sel=sel.astype(np.int32), deltas=deltas, decoded=dec, clipped=clip, encoded=enc)
+
+    # ---- proposal_layer (proposal_layer.py:16-53) / proposal_top_layer
+    g = {}
+    im_info = np.array([600, 1000, 1.6], dtype=f32)
+    for tag, (H, W, scales, key, post, info) in {
+            "test_38x63_a9": (38, 63, (8, 16, 32), "TEST", 300, im_info),
+            "train_38x63_a9": (38, 63, (8, 16, 32), "TRAIN", 2000, im_info),
+            "test_10x14_a9": (10, 14, (8, 16, 32), "TEST", 300, np.array([160, 224, 1.0], dtype=f32)),
+            "test_50x84_a15": (50, 84, (2, 4, 8, 16, 32), "TEST", 1000, np.array([800, 1333, 1.6], dtype=f32))}.items():
+        A = 3 * len(scales)
+        prob, dl = synth.rpn_outputs(H, W, A, seed=3)
+        anc, _ = ref.generate_anchors_pre(H, W, 16, scales, (0.5, 1, 2))
+        cfg[key].RPN_POST_NMS_TOP_N = post
+        blob, sc = ref.proposal_layer(prob, dl, info, key, [16], anc, A)
+        oblob, osc = ora.proposal_layer(prob, dl, info, key, [16], anc, A, post_nms_topN=post)
+        pin("proposal_layer " + tag, (blob, sc), (oblob, osc))
+        g[tag + "_rois"], g[tag + "_scores"] = blob, sc
+        g[tag + "_in_sha"] = np.frombuffer(bytes.fromhex(sha(prob) + sha(dl)), dtype=np.uint8)
+    cfg.TEST.RPN_POST_NMS_TOP_N, cfg.TRAIN.RPN_POST_NMS_TOP_N = 300, 2000
+    prob, dl = synth.rpn_outputs(38, 63, 9, seed=3)
+    anc, _ = ref.generate_anchors_pre(38, 63, 16, (8, 16, 32), (0.5, 1, 2))
+    blob, sc = ref.proposal_top_layer(prob, dl, im_info, [16], anc, 9)
+    pin("proposal_top_layer", (blob, sc), ora.proposal_top_layer(prob, dl, im_info, [16], anc, 9))
+    g["top_38x63_a9_rois"], g["top_38x63_a9_scores"] = blob, sc
+    out["proposal"] = g
+
+    # ---- cpu_nms (cpu_nms.pyx:17-68) + py_cpu_nms cross statement
+    g = {}
+    for tag, (k, thr, cl) in {"u3000_t07": (3000, 0.7, 0), "c3000_t03": (3000, 0.3, 12), "c6000_t07": (6000, 0.7, 40),
+                              "c700_t05": (700, 0.5, 5), "one": (1, 0.3, 0)}.items():
+        d = synth.random_dets(k, seed=11, cluster=cl)
+        keep = np.array(ref.cpu_nms(d, thr), dtype=np.int64)
+        pin("cpu_nms " + tag, keep, np.array(ora.cpu_nms(d, thr), dtype=np.int64))
+        g[tag + "_keep"] = keep.astype(np.int32)
+        g[tag + "_in_sha"] = np.frombuffer(bytes.fromhex(sha(d)), dtype=np.uint8)
+    out["nms"] = g
+
+    # ---- per-class post-processing (test.py:95-102,162-180), built from the reference's pieces
+    g = {}
+    for tag, (R, C, W, H) in {"voc_300x21": (300, 21, 1000.0, 600.0), "coco_1000x81": (1000, 81, 1333.0, 800.0)}.items():
+        prob, bp, rois = synth.rcnn_outputs(R, C, seed=7, im_w=W, im_h=H)
+        scale = 1.6
+        im_shape = (int(H / scale), int(W / scale), 3)
+        boxes = rois[:, 1:5] / np.float64(scale)                       # test.py:95 (float64 under NEP-50)
+        pred = ref.bbox_transform_inv(boxes, bp)                        # test.py:101
+        pred[:, 0::4] = np.maximum(pred[:, 0::4], 0)                    # test.py:67-77
+        pred[:, 1::4] = np.maximum(pred[:, 1::4], 0)
+        pred[:, 2::4] = np.minimum(pred[:, 2::4], im_shape[1] - 1)
+        pred[:, 3::4] = np.minimum(pred[:, 3::4], im_shape[0] - 1)
+        per = [np.zeros((0, 5), dtype=f32)]
+        for j in range(1, C):                                           # test.py:162-170
+            inds = np.where(prob[:, j] > 0.)[0]
+            cd = np.hstack((pred[inds, j * 4:(j + 1) * 4], prob[inds, j][:, np.newaxis])).astype(f32, copy=False)
+            per.append(cd[ref.nms(cd, 0.3), :])
+        allsc = np.hstack([per[j][:, -1] for j in range(1, C)])         # test.py:173-180
+        if len(allsc) > 100:
+            cut = np.sort(allsc)[-100]
+            for j in range(1, C):
+                per[j] = per[j][np.where(per[j][:, -1] >= cut)[0], :]
+        rec = ora.detections_to_records(per)
+        osc, obox = ora.im_detect_post(prob, bp, rois, scale, im_shape)
+        pin("im_detect_post " + tag, pred, obox)
+        pin("test_net_post " + tag, rec, ora.detections_to_records(ora.test_net_post(osc, obox, C)))
+        g[tag + "_boxes_sha"] = np.frombuffer(bytes.fromhex(sha(pred)), dtype=np.uint8)
+        g[tag + "_records"] = rec
+    out["perclass"] = g
+
+    # ---- bbox_overlaps (bbox.pyx:15-55) + target layers (seeded numpy global RNG)
+    g = {}
+    d = synth.random_dets(600, seed=13)[:, :4].astype(np.float64)
+    q = synth.gt_boxes(12, 21, seed=14).astype(np.float64)
+    ov = ref.bbox_overlaps(d, q)
+    pin("bbox_overlaps", ov, ora.bbox_overlaps(d, q[:, :4]))
+    g["overlaps"] = ov
+    H, W, A = 38, 63, 9
+    anc, _ = ref.generate_anchors_pre(H, W, 16, (8, 16, 32), (0.5, 1, 2))
+    gt = synth.gt_boxes(7, 21, seed=15)
+    score = np.zeros((1, H, W, 2 * A), dtype=f32)
+    np.random.seed(3)
+    at = ref.anchor_target_layer(score, gt, im_info, [16], anc, A)
+    pin("anchor_target_layer", at, ora.anchor_target_layer(score, gt, im_info, [16], anc, A, rng=np.random.RandomState(3)))
+    g["at_labels"], g["at_targets"], g["at_inside"], g["at_outside"] = at
+    prob, dl = synth.rpn_outputs(H, W, A, seed=3)
+    cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO = 256, 0.0            # experiments/cfgs/res101.yml:9,11
+    rois, rsc = ref.proposal_layer(prob, dl, im_info, "TRAIN", [16], anc, A)
+    np.random.seed(3)
+    pt = ref.proposal_target_layer(rois, rsc, gt, 21)
+    pin("proposal_target_layer", pt, ora.proposal_target_layer(rois, rsc, gt, 21, rng=np.random.RandomState(3)))
+    for n_, v in zip(("rois", "scores", "labels", "targets", "inside", "outside"), pt):
+        g["pt_" + n_] = v
+    g["gt"] = gt
+    out["targets"] = g
+
+    if write:
+        os.makedirs(GOLD, exist_ok=True)
+        for name, arrs in out.items():
+            path = os.path.join(GOLD, name + ".npz")
+            np.savez_compressed(path, **arrs)
+            print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+    if FAIL:
+        print("ORACLE NOT PINNED:", FAIL)
+        return 1
+    print("oracle pinned against the reference on all cases")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(write="--check" not in sys.argv))
