@@ -1,0 +1,155 @@
+/* frcnn_hip.h -- C ABI of libfrcnn_hip.so: the MI355X (gfx950) hot path of Faster R-CNN behind the
+ * interfaces of endernewton/tf-faster-rcnn.  Plain pointers and sizes only; no torch / TF types.
+ *
+ * Conventions:
+ *   - every pointer named *_d / documented "dev" is a DEVICE pointer (HBM); everything else is host.
+ *   - `stream` is a hipStream_t passed as void*; the library never synchronises, never allocates,
+ *     never calls hipSetDevice and never prints.  Scratch memory comes from the caller
+ *     (`ws`, sized by the matching *_workspace_bytes query).  Distinct streams are thread-safe.
+ *   - return value: 0 = ok, FRCNN_E_ARG (-1) bad argument, FRCNN_E_WS (-2) workspace too small,
+ *     FRCNN_E_UNSUPPORTED (-3) shape outside the kernels' limits, -(1000 + hipError_t) HIP failure.
+ *   - tensors are NHWC float32, exactly the layouts the reference's TF graph uses.
+ * Reference citations are relative to /root/reference.
+ */
+#ifndef FRCNN_HIP_H_
+#define FRCNN_HIP_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRCNN_OK 0
+#define FRCNN_E_ARG (-1)
+#define FRCNN_E_WS (-2)
+#define FRCNN_E_UNSUPPORTED (-3)
+#define FRCNN_E_HIP(e) (-(1000 + (int)(e)))
+
+#define FRCNN_ACT_NONE 0
+#define FRCNN_ACT_RELU 1
+#define FRCNN_ACT_RELU6 2
+
+/* ---- library ------------------------------------------------------------------------------- */
+int frcnn_abi_version(void);                 /* bumps when a signature changes */
+const char* frcnn_build_info(void);          /* "gfx950 ..." */
+
+/* ---- NMS: replaces lib/nms/gpu_nms.hpp:1-2 (`_nms`), lib/nms/cpu_nms.pyx:17-68 -------------- */
+/* Source-compatible with the reference's extern "C++" `_nms` (lib/nms/gpu_nms.hpp:1-2, driver
+ * lib/nms/nms_kernel.cu:91-144): HOST pointers, blocking, boxes [n, boxes_dim>=4] already sorted
+ * by descending score, keep_out capacity n.  Difference on purpose: suppression uses the CPU/Cython
+ * rule `ovr >= thresh` (cpu_nms.pyx:65) -- the path BASELINE.json names -- not the CUDA kernel's
+ * `>` (nms_kernel.cu:71).  Allocates/frees its own device scratch like the original did. */
+void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
+          float nms_overlap_thresh, int device_id);
+
+size_t frcnn_nms_workspace_bytes(int max_boxes);
+/* cpu_nms(dets, thresh) on device: dets_d [k,5] f32 (x1,y1,x2,y2,score) in ANY order.
+ * keep_d [max_keep] int32 receives kept ORIGINAL indices in descending-score order
+ * (ties: lower index first), num_keep_d the count (<= max_keep; the greedy scan stops there, which
+ * equals truncating the full keep list, lib/layer_utils/proposal_layer.py:44-45).
+ * Suppress iff (double)ovr >= thresh, exactly as lib/nms/cpu_nms.c:2239-2241.  k <= 16384. */
+int frcnn_nms(const float* dets_d, int k, double thresh, int max_keep, int* keep_d, int* num_keep_d,
+              void* ws, size_t ws_bytes, void* stream);
+/* Same, for input already sorted by descending score (boxes_d rows of `stride` floats, the first
+ * four are x1,y1,x2,y2): the device-pointer form of `_nms`. */
+int frcnn_nms_sorted(const float* boxes_d, int k, int stride, double thresh, int max_keep, int* keep_d,
+                     int* num_keep_d, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- anchors: replaces lib/layer_utils/generate_anchors.py:41-105, snippets.py:14-30 --------- */
+/* HOST: base anchors, float64 [n_ratios*n_scales, 4], ratio-major; np.round half-to-even. */
+int frcnn_generate_anchors(int base_size, const double* ratios, int n_ratios, const double* scales,
+                           int n_scales, double* out_base);
+/* DEVICE: all shifted anchors f32 [H*W*A,4], index (y*W+x)*A+a.  base_d = device copy of the
+ * float64 base anchors [A,4]. */
+int frcnn_generate_anchors_pre(int height, int width, int feat_stride, const double* base_d, int A,
+                               float* anchors_d, void* stream);
+
+/* ---- proposal layers: replaces lib/layer_utils/proposal_layer.py:16-53, proposal_top_layer.py:17-55
+ * (the tf.py_func seams at lib/nets/network.py:100-103,123-126) ------------------------------ */
+size_t frcnn_proposal_workspace_bytes(int H, int W, int A, int pre_nms_topn);
+/* rpn_cls_prob_d [1,H,W,2A] (fg = channels [A,2A)), rpn_bbox_pred_d [1,H,W,4A], im_h/im_w =
+ * im_info[0], im_info[1] (scaled image), base_d = float64 base anchors [A,4] (anchors are
+ * re-generated in-kernel from the anchor index; they are never read from HBM).
+ * rois_d [post_nms_topn,5] = (0,x1,y1,x2,y2), scores_d [post_nms_topn]; rows >= *num_d are zero.
+ * pre_nms_topn <= 0 means "all" (proposal_layer.py:35); min(pre,N) <= 16384. */
+int frcnn_proposal_layer(const float* rpn_cls_prob_d, const float* rpn_bbox_pred_d, float im_h,
+                         float im_w, int H, int W, int A, int feat_stride, const double* base_d,
+                         int pre_nms_topn, int post_nms_topn, double nms_thresh, float* rois_d,
+                         float* scores_d, int* num_d, void* ws, size_t ws_bytes, void* stream);
+/* TEST.MODE 'top': top rpn_top_n by score, decode+clip, no NMS; requires H*W*A >= rpn_top_n. */
+int frcnn_proposal_top_layer(const float* rpn_cls_prob_d, const float* rpn_bbox_pred_d, float im_h,
+                             float im_w, int H, int W, int A, int feat_stride, const double* base_d,
+                             int rpn_top_n, float* rois_d, float* scores_d, void* ws, size_t ws_bytes,
+                             void* stream);
+
+/* ---- RoI pooling: replaces tf.image.crop_and_resize as called from lib/nets/resnet_v1.py:55-76
+ * and lib/nets/network.py:141-157 ----------------------------------------------------------- */
+/* feat_d [H,W,C] (batch 1), rois_d [R,5] image coords, out_d [R,pool,pool,C].  fuse_max2x2 != 0:
+ * sample a (2*pool)^2 grid and take the 2x2/2 max (network.py:152-157).  C % 4 == 0. */
+int frcnn_crop_and_resize(const float* feat_d, int H, int W, int C, const float* rois_d, int R,
+                          float feat_stride, int pool, int fuse_max2x2, float* out_d, void* stream);
+
+/* ---- test-time post-processing: replaces lib/model/test.py:95-102 (im_detect) and :162-180
+ * (test_net per-class NMS + max_per_image cut) ----------------------------------------------- */
+size_t frcnn_detect_post_workspace_bytes(int R, int C);
+/* cls_prob_d [R,C], bbox_pred_d [R,4C] (already *stds+means), rois_d [R,5] (scaled image coords),
+ * num_rois_d: device int (rows >= it are ignored) or NULL.  im_scale: float64 like im_scales[0];
+ * im_h, im_w: ORIGINAL image size.  out_dets_d [max_out,6] = x1,y1,x2,y2,score,class (class-major,
+ * score-descending inside a class == all_boxes[j][i] order), *out_count_d = number of detections
+ * (may exceed max_out only when ties straddle the max_per_image cut; excess rows are dropped).
+ * R <= 1024. */
+int frcnn_detect_post(const float* cls_prob_d, const float* bbox_pred_d, const float* rois_d,
+                      const int* num_rois_d, int R, int C, double im_scale, int im_h, int im_w,
+                      double nms_thresh, float score_thresh, int max_per_image, float* out_dets_d,
+                      int* out_count_d, int max_out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- IoU matrix: replaces lib/utils/bbox.pyx:15-55 ------------------------------------------ */
+/* boxes_d [n,4] f64, query_d [k,4] f64 -> out_d [n,k] f64. */
+int frcnn_bbox_overlaps(const double* boxes_d, int n, const double* query_d, int k, double* out_d, void* stream);
+
+/* ---- dense ops (the TF/slim call sites of lib/nets/network.py:323-378, resnet_v1.py:80-125,
+ * vgg16.py:26-60, mobilenet_v1.py:114-172) ---------------------------------------------------- */
+/* Implicit-GEMM convolution on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32).
+ *   x_d  [N,H,W,Cin] NHWC;   w_d packed [Cout][KH][KW][Cin] (see frcnn_pack_filter_hwio);
+ *   y_d  [N,OH,OW,Cout] = act( conv(x,w) + bias [+ residual] )
+ *   ih = oh*stride - pad_top + kh, iw = ow*stride - pad_left + kw, zero outside the image
+ *   (covers slim `SAME` for stride 1, resnet_utils.conv2d_same and explicit-pad + VALID).
+ *   bias_d [Cout] or NULL.  residual_d NULL or an NHWC tensor [N,RH,RW,Cout] read at
+ *   (oh*res_stride, ow*res_stride): res_stride 1 = plain skip, 2 = slim `subsample` shortcut.
+ *   Requires Cin % 32 == 0, or Cin == 4 with fold_w (7x7 stem: the kw taps are folded into the
+ *   channel run, w_d packed [Cout][KH][8][4]). */
+int frcnn_conv2d_nhwc(const float* x_d, int N, int H, int W, int Cin, const float* w_d, const float* bias_d,
+                      const float* residual_d, int RH, int RW, int res_stride, float* y_d, int OH, int OW,
+                      int Cout, int KH, int KW, int stride, int pad_top, int pad_left, int act, int fold_w,
+                      void* stream);
+/* HOST helper: HWIO (TF layout, [KH][KW][Cin][Cout]) -> packed [Cout][KH][KW][Cin], optionally
+ * multiplying output channel o by scale[o] (folded frozen batch-norm gamma/sqrt(var+eps)). */
+int frcnn_pack_filter_hwio(const float* w_hwio, int KH, int KW, int Cin, int Cout, const float* scale, float* out);
+/* max-pool NHWC, window k, stride s, zero/neg-inf-free: out-of-image taps are ignored; (pad_top,
+ * pad_left) shift the window (ResNet pool1: k3 s2 pad 1; VGG: k2 s2 SAME pad 0). */
+int frcnn_maxpool_nhwc(const float* x_d, int N, int H, int W, int C, int k, int stride, int pad_top,
+                       int pad_left, float* y_d, int OH, int OW, void* stream);
+/* depthwise 3x3 (MobileNet, lib/nets/mobilenet_v1.py:21-49): w_d [3][3][C], bias, act. */
+int frcnn_dwconv3x3_nhwc(const float* x_d, int N, int H, int W, int C, const float* w_d, const float* bias_d,
+                         float* y_d, int OH, int OW, int stride, int pad_top, int pad_left, int act, void* stream);
+/* mean over the HW positions of [N,HW,C] -> [N,C]  (resnet_v1.py:124, mobilenet_v1.py:249). */
+int frcnn_spatial_mean(const float* x_d, int N, int HW, int C, float* y_d, void* stream);
+/* row softmax [R,C] (network.py:80-86, cls_prob). */
+int frcnn_softmax_rows(const float* x_d, int R, int C, int ld, float* y_d, void* stream);
+/* RPN pairwise softmax (network.py:68-86,331-334): score_d [HW, ld] channels (a, A+a) ->
+ * prob_d [HW,2A]. */
+int frcnn_rpn_softmax(const float* score_d, int HW, int A, int ld, float* prob_d, void* stream);
+/* strided 2-D copy  dst[r, 0:cols] = src[r, col0:col0+cols]  (splits fused head outputs). */
+int frcnn_copy_cols(const float* src_d, int R, int ld_src, int col0, int cols, float* dst_d, int ld_dst, void* stream);
+
+/* ---- stream capture (one hipGraph per image-shape; replaces the per-image sess.run) ---------- */
+int frcnn_graph_begin(void* stream);
+int frcnn_graph_end(void* stream, void** graph_exec_out);
+int frcnn_graph_launch(void* graph_exec, void* stream);
+int frcnn_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRCNN_HIP_H_ */

@@ -1,0 +1,147 @@
+"""GPU numerics: dense HIP kernels vs a plain torch float64 CPU reference of the same op.
+Tolerance: f32 MFMA == fmaf chain, so |err| <= ~1e-6 * sum|a*b|; asserted as 2e-5 relative to the
+output scale (the end-to-end budget is 1e-4, BASELINE.json)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_conv(x, w_hwio, bias, stride, pad, act, residual=None, res_stride=1):
+    xd = torch.from_numpy(x).double().permute(0, 3, 1, 2)
+    wd = torch.from_numpy(w_hwio).double().permute(3, 2, 0, 1)
+    xd = F.pad(xd, (pad[2], pad[3], pad[0], pad[1]))
+    y = F.conv2d(xd, wd, None if bias is None else torch.from_numpy(bias).double(), stride=stride)
+    if residual is not None:
+        y = y + torch.from_numpy(residual).double().permute(0, 3, 1, 2)[:, :, ::res_stride, ::res_stride][:, :, :y.shape[2], :y.shape[3]]
+    if act == 1:
+        y = y.clamp(min=0)
+    elif act == 2:
+        y = y.clamp(min=0, max=6)
+    return y.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad(t,b,l,r), act, residual(res_stride or 0), bias
+    (1, 38, 63, 64, 256, 1, 1, (0, 0, 0, 0), 1, 0, True),        # 1x1, 64x64 tile path
+    (1, 38, 63, 256, 64, 1, 1, (0, 0, 0, 0), 1, 1, True),         # 1x1 + residual, Cout 64
+    (1, 19, 23, 64, 64, 3, 1, (1, 1, 1, 1), 1, 0, True),          # 3x3 SAME
+    (1, 21, 25, 64, 96, 3, 2, (1, 1, 1, 1), 0, 0, False),         # conv2d_same stride 2 (odd size)
+    (1, 20, 24, 32, 128, 3, 2, (1, 1, 1, 1), 1, 2, True),         # stride 2 + subsample residual
+    (300, 7, 7, 128, 128, 3, 1, (1, 1, 1, 1), 1, 0, True),        # per-RoI 3x3, big tile path (M=14700)
+    (300, 7, 7, 64, 256, 1, 1, (0, 0, 0, 0), 1, 1, True),         # per-RoI 1x1 + residual, big tile
+    (1, 38, 63, 512, 54, 1, 1, (0, 0, 0, 0), 0, 0, True),         # RPN heads (Cout not a tile multiple)
+    (1, 1, 300, 2048, 105, 1, 1, (0, 0, 0, 0), 0, 0, True),       # fc heads as 1x1 (M=300)
+    (1, 13, 17, 32, 20, 3, 1, (1, 1, 1, 1), 2, 0, True),          # Cout <= 32 path, relu6
+    (2, 9, 11, 96, 160, 3, 1, (0, 0, 0, 0), 1, 0, True),          # VALID, batch 2
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(i) for i in range(len(CASES))])
+def test_conv2d_igemm(dev, case):
+    from frcnn_hip import ops
+    N, H, W, Cin, Cout, k, stride, pad, act, res, has_bias = case
+    rng = np.random.RandomState(hash(case) % (2 ** 31))
+    x = rng.randn(N, H, W, Cin).astype(np.float32)
+    w = (rng.randn(k, k, Cin, Cout) / np.sqrt(k * k * Cin)).astype(np.float32)
+    b = rng.randn(Cout).astype(np.float32) if has_bias else None
+    OH = (H + pad[0] + pad[1] - k) // stride + 1
+    OW = (W + pad[2] + pad[3] - k) // stride + 1
+    r = None
+    if res:
+        r = rng.randn(N, (OH - 1) * res + 1 + (res - 1), (OW - 1) * res + 1 + (res - 1), Cout).astype(np.float32)
+    want = ref_conv(x, w, b, stride, pad, act, r, max(res, 1))
+    wp = torch.from_numpy(ops.pack_filter_hwio(w)).to(dev)
+    got = ops.conv2d(torch.from_numpy(x).to(dev), wp, None if b is None else torch.from_numpy(b).to(dev), k, k, stride, pad,
+                     act, None if r is None else torch.from_numpy(r).to(dev), max(res, 1)).cpu().numpy()
+    assert got.shape == want.shape
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 2e-5 * max(scale, 1.0), np.abs(got - want).max()
+
+
+def test_conv2d_is_transpose_detecting(dev):
+    # A = I-like check with an ASYMMETRIC filter: catches a swapped row/col in the MFMA C/D map
+    from frcnn_hip import ops
+    x = np.zeros((1, 8, 8, 32), dtype=np.float32)
+    x[0, 3, 5, 7] = 1.0
+    w = np.arange(32 * 40, dtype=np.float32).reshape(1, 1, 32, 40)
+    got = ops.conv2d(torch.from_numpy(x).to(dev), torch.from_numpy(ops.pack_filter_hwio(w)).to(dev), None, 1, 1).cpu().numpy()
+    want = np.zeros((1, 8, 8, 40), dtype=np.float32)
+    want[0, 3, 5, :] = w[0, 0, 7, :]
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("H,W", [(64, 96), (61, 93)])
+def test_stem_conv_fold_w(dev, H, W):
+    # 7x7/2 conv2d_same on a 3-channel image (lib/nets/resnet_v1.py:82), image padded to 4 channels
+    from frcnn_hip import ops
+    rng = np.random.RandomState(1)
+    img = (rng.rand(1, H, W, 3) * 255 - 110).astype(np.float32)
+    w = (rng.randn(7, 7, 3, 64) * 0.05).astype(np.float32)
+    b = rng.randn(64).astype(np.float32)
+    want = ref_conv(img, w, b, 2, (3, 3, 3, 3), 1)          # pad_beg = 3, pad_end = 3 (k-1 = 6)
+    x4 = np.zeros((1, H, W, 4), dtype=np.float32)
+    x4[..., :3] = img
+    wp = torch.from_numpy(ops.pack_filter_foldw(w)).to(dev)
+    got = ops.conv2d(torch.from_numpy(x4).to(dev), wp, torch.from_numpy(b).to(dev), 7, 7, 2, (3, 3, 3, 3), 1, fold_w=True).cpu().numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+
+
+def test_maxpool_mean_softmax(dev):
+    from frcnn_hip import ops
+    rng = np.random.RandomState(3)
+    x = np.maximum(rng.randn(1, 31, 45, 64), 0).astype(np.float32)       # post-ReLU like the stem
+    xt = torch.from_numpy(x).to(dev)
+    # ResNet pool1: zero pad 1 then 3x3/2 VALID (resnet_v1.py:83-84)
+    want = F.max_pool2d(F.pad(torch.from_numpy(x).permute(0, 3, 1, 2), (1, 1, 1, 1)), 3, 2).permute(0, 2, 3, 1).numpy()
+    assert np.array_equal(ops.maxpool(xt, 3, 2, (1, 1, 1, 1)).cpu().numpy(), want)
+    # VGG 2x2/2 SAME on odd sizes (vgg16.py:30): pad on bottom/right, ignored
+    xn = rng.randn(1, 31, 45, 64).astype(np.float32)
+    want = F.max_pool2d(torch.from_numpy(xn).permute(0, 3, 1, 2), 2, 2, ceil_mode=True).permute(0, 2, 3, 1).numpy()
+    assert np.array_equal(ops.maxpool(torch.from_numpy(xn).to(dev), 2, 2, (0, 1, 0, 1)).cpu().numpy(), want)
+    t = rng.randn(30, 7, 7, 256).astype(np.float32)
+    got = ops.spatial_mean(torch.from_numpy(t).to(dev)).cpu().numpy()
+    assert np.allclose(got, t.astype(np.float64).mean(axis=(1, 2)), rtol=0, atol=2e-6)
+    s = (rng.randn(300, 128) * 3).astype(np.float32)
+    got = ops.softmax_rows(torch.from_numpy(s).to(dev), C=21).cpu().numpy()
+    want = torch.softmax(torch.from_numpy(s[:, :21]).double(), dim=1).numpy()
+    assert np.allclose(got, want, rtol=0, atol=2e-7)
+    sc = rng.randn(1, 38, 63, 64).astype(np.float32)
+    got = ops.rpn_softmax(torch.from_numpy(sc).to(dev), 9).cpu().numpy()
+    pair = torch.softmax(torch.stack([torch.from_numpy(sc[..., :9]).double(), torch.from_numpy(sc[..., 9:18]).double()]), dim=0)
+    assert np.allclose(got[..., :9], pair[0].numpy(), atol=2e-7) and np.allclose(got[..., 9:], pair[1].numpy(), atol=2e-7)
+    assert np.array_equal(ops.copy_cols(torch.from_numpy(sc).to(dev), 18, 36).cpu().numpy(), sc[..., 18:54])
+
+
+def test_dwconv3x3(dev):
+    from frcnn_hip import ops
+    rng = np.random.RandomState(4)
+    x = rng.randn(1, 21, 33, 64).astype(np.float32)
+    w = rng.randn(3, 3, 64).astype(np.float32)
+    b = rng.randn(64).astype(np.float32)
+    for stride in (1, 2):
+        want = F.conv2d(F.pad(torch.from_numpy(x).double().permute(0, 3, 1, 2), (1, 1, 1, 1)),
+                        torch.from_numpy(w).double().permute(2, 0, 1)[:, None], torch.from_numpy(b).double(), stride=stride, groups=64)
+        want = want.clamp(0, 6).permute(0, 2, 3, 1).numpy()
+        got = ops.dwconv3x3(torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev), stride, (1, 1, 1, 1), 2).cpu().numpy()
+        assert np.abs(got - want).max() < 1e-5
+
+
+def test_graph_capture_replay(dev):
+    from frcnn_hip import ops
+    x = torch.randn(1, 16, 16, 32, device=dev)
+    w = torch.randn(64, 1, 1, 32, device=dev)
+    out = torch.empty(1, 16, 16, 64, device=dev)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ops.conv2d(x, w, None, 1, 1, out=out)            # warm-up (sets func attributes)
+        st.synchronize()
+        g = ops.Graph().capture(lambda: ops.conv2d(x, w, None, 1, 1, out=out))
+        out.zero_()
+        g.launch()
+        st.synchronize()
+    want = torch.einsum("nhwc,oc->nhwo", x.double(), w[:, 0, 0, :].double())
+    assert (out.double() - want).abs().max().item() < 1e-4

@@ -1,0 +1,190 @@
+"""GPU parity: HIP detection kernels (through the C ABI) vs the oracle and the golden vectors.
+Bit-exact for indices / keep lists on identical inputs; 1e-4 on coordinates where a device expf
+feeds the value (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+import frcnn_oracle as ora
+import synth
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def T(a, dev, dtype=None):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev) if dtype is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype)
+
+
+@pytest.mark.parametrize("scales,H,W", [((8, 16, 32), 38, 63), ((4, 8, 16, 32), 38, 63), ((2, 4, 8, 16, 32), 50, 84)])
+def test_anchors_device_bit_exact(dev, scales, H, W):
+    from frcnn_hip import ops
+    base = ops.generate_anchors(16, (0.5, 1, 2), scales)
+    got = ops.generate_anchors_pre(H, W, 16, T(base, dev)).cpu().numpy()
+    want, _ = ora.generate_anchors_pre(H, W, 16, scales, (0.5, 1, 2))
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("tag,k,thr,cl", [("u3000_t07", 3000, 0.7, 0), ("c3000_t03", 3000, 0.3, 12),
+                                          ("c6000_t07", 6000, 0.7, 40), ("c700_t05", 700, 0.5, 5), ("one", 1, 0.3, 0)])
+def test_nms_keep_bit_exact_vs_golden(dev, golden, tag, k, thr, cl):
+    from frcnn_hip import ops
+    d = synth.random_dets(k, seed=11, cluster=cl)
+    keep, num = ops.nms(T(d, dev), thr)
+    n = int(num.item())
+    got = keep[:n].cpu().numpy()
+    assert np.array_equal(got, golden["nms"][tag + "_keep"])          # the reference's own cpu_nms output
+    assert got.tolist() == ora.cpu_nms(d, thr)
+
+
+@pytest.mark.parametrize("k,thr,cl,seed", [(12000, 0.7, 200, 5), (16384, 0.5, 0, 6), (65, 0.3, 2, 7), (64, 0.3, 2, 8),
+                                           (129, 0.9, 1, 9), (4097, 0.1, 30, 10)])
+def test_nms_keep_bit_exact_vs_oracle(dev, k, thr, cl, seed):
+    from frcnn_hip import ops
+    d = synth.random_dets(k, seed=seed, cluster=cl)
+    keep, num = ops.nms(T(d, dev), thr)
+    assert keep[:int(num.item())].cpu().numpy().tolist() == ora.cpu_nms(d, thr)
+
+
+def test_nms_max_keep_truncates_like_slicing(dev):
+    from frcnn_hip import ops
+    d = synth.random_dets(6000, seed=21, cluster=60)
+    full = ora.cpu_nms(d, 0.7)
+    for mk in (1, 63, 64, 65, 300):
+        keep, num = ops.nms(T(d, dev), 0.7, max_keep=mk)
+        assert keep[:int(num.item())].cpu().numpy().tolist() == full[:mk]
+
+
+def test_nms_threshold_compared_in_double(dev):
+    from frcnn_hip import ops
+    d = np.array([[0, 0, 9, 9, 0.9], [0, 0, 9, 4, 0.8]], dtype=f32)        # IoU exactly 0.5
+    for thr, want in ((0.5, [0]), (0.5000001, [0, 1]), (0.49999999, [0])):
+        keep, num = ops.nms(T(d, dev), thr)
+        assert keep[:int(num.item())].cpu().numpy().tolist() == want == ora.cpu_nms(d, thr)
+
+
+def test_nms_ties_are_index_ascending_and_empty(dev):
+    from frcnn_hip import ops
+    d = synth.random_dets(500, seed=3, cluster=4)
+    d[:, 4] = np.round(d[:, 4] * 8) / 8                                      # heavy ties
+    keep, num = ops.nms(T(d, dev), 0.5)
+    assert keep[:int(num.item())].cpu().numpy().tolist() == ora.cpu_nms(d, 0.5)   # oracle: (score desc, index asc)
+    keep, num = ops.nms(torch.zeros((0, 5), device=dev), 0.3)
+    assert int(num.item()) == 0                                                # nms_wrapper.py:18-19
+
+
+def test_nms_sorted_and_host_compat__nms(dev):
+    import ctypes
+    import frcnn_hip
+    from frcnn_hip import ops
+    d = synth.random_dets(3000, seed=11, cluster=12)
+    order = ora.order_desc(d[:, 4])
+    ds = np.ascontiguousarray(d[order])
+    want = ora.cpu_nms(ds, 0.3)                                                # indices into the sorted array
+    keep, num = ops.nms_sorted(T(ds, dev), 0.3)
+    assert keep[:int(num.item())].cpu().numpy().tolist() == want
+    # `_nms` (lib/nms/gpu_nms.hpp:1-2): host pointers, float threshold
+    keep_h = np.zeros(3000, dtype=np.int32)
+    n_h = ctypes.c_int(0)
+    frcnn_hip.lib()._nms(keep_h.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n_h), ds.ctypes.data_as(ctypes.c_void_p),
+                         3000, 5, ctypes.c_float(0.3), 0)
+    assert keep_h[:n_h.value].tolist() == ora.cpu_nms(ds, float(np.float32(0.3)))
+
+
+def _proposal_case(dev, H, W, scales, key, post, info, seed=3):
+    from frcnn_hip import ops
+    A = 3 * len(scales)
+    prob, dl = synth.rpn_outputs(H, W, A, seed=seed)
+    base = ops.generate_anchors(16, (0.5, 1, 2), scales)
+    pre = {"TEST": 6000, "TRAIN": 12000}[key]
+    rois, scores, num = ops.proposal_layer(T(prob, dev), T(dl, dev), info[0], info[1], 16, T(base, dev), pre, post, 0.7)
+    return prob, dl, rois.cpu().numpy(), scores.cpu().numpy(), int(num.item())
+
+
+@pytest.mark.parametrize("tag,H,W,scales,key,post,info", [
+    ("test_38x63_a9", 38, 63, (8, 16, 32), "TEST", 300, (600, 1000, 1.6)),
+    ("train_38x63_a9", 38, 63, (8, 16, 32), "TRAIN", 2000, (600, 1000, 1.6)),
+    ("test_10x14_a9", 10, 14, (8, 16, 32), "TEST", 300, (160, 224, 1.0)),
+    ("test_50x84_a15", 50, 84, (2, 4, 8, 16, 32), "TEST", 1000, (800, 1333, 1.6))])
+def test_proposal_layer_vs_reference_golden(dev, golden, tag, H, W, scales, key, post, info):
+    g = golden["proposal"]
+    _, _, rois, scores, n = _proposal_case(dev, H, W, scales, key, post, info)
+    want_r, want_s = g[tag + "_rois"], g[tag + "_scores"]
+    assert n == want_r.shape[0]
+    # scores are copied (bit-exact); boxes pass through the device expf: 1e-4
+    # a 1-ulp decode difference may flip an IoU that sits on the threshold; such a flip would
+    # change the kept set and show up as a score mismatch, so exact score equality is the
+    # index-parity check.
+    assert np.array_equal(scores[:n], want_s)
+    assert np.allclose(rois[:n], want_r, rtol=0, atol=1e-4 * max(1.0, float(np.abs(want_r).max()) / 1000.0 * 10))
+    assert np.all(rois[n:] == 0) and np.all(scores[n:] == 0)
+
+
+def test_proposal_top_layer_vs_reference_golden(dev, golden):
+    from frcnn_hip import ops
+    g = golden["proposal"]
+    prob, dl = synth.rpn_outputs(38, 63, 9, seed=3)
+    base = ops.generate_anchors(16)
+    rois, scores = ops.proposal_top_layer(T(prob, dev), T(dl, dev), 600, 1000, 16, T(base, dev), 5000)
+    assert np.array_equal(scores.cpu().numpy(), g["top_38x63_a9_scores"])
+    assert np.allclose(rois.cpu().numpy(), g["top_38x63_a9_rois"], rtol=0, atol=1e-3)
+
+
+def test_proposal_layer_other_seeds_vs_oracle(dev):
+    for seed in (4, 5):
+        prob, dl, rois, scores, n = _proposal_case(dev, 38, 63, (8, 16, 32), "TEST", 300, (600, 1000, 1.6), seed=seed)
+        anc, _ = ora.generate_anchors_pre(38, 63, 16)
+        wr, ws = ora.proposal_layer(prob, dl, np.array([600, 1000, 1.6], dtype=f32), "TEST", [16], anc, 9)
+        assert n == wr.shape[0] and np.array_equal(scores[:n], ws) and np.allclose(rois[:n], wr, rtol=0, atol=1e-3)
+
+
+@pytest.mark.parametrize("H,W,C,R,pool,mp", [(38, 63, 1024, 300, 7, False), (38, 63, 512, 64, 7, True), (50, 84, 256, 100, 7, False),
+                                             (5, 6, 8, 9, 3, False)])
+def test_crop_and_resize_vs_oracle(dev, H, W, C, R, pool, mp):
+    from frcnn_hip import ops
+    rng = np.random.RandomState(2)
+    feat = rng.randn(H, W, C).astype(f32)
+    d = synth.random_dets(R, seed=4, im_w=W * 16.0, im_h=H * 16.0)
+    d[: R // 4, 2] = W * 16.0 - 1      # border-touching RoIs sample beyond the map -> zeros
+    d[R // 4: R // 2, 3] = H * 16.0 - 1
+    rois = np.hstack([np.zeros((R, 1), dtype=f32), d[:, :4]]).astype(f32)
+    got = ops.crop_and_resize(T(feat, dev), T(rois, dev), 16.0, pool, max_pool=mp).cpu().numpy()
+    want = ora.crop_and_resize(feat, rois, 16.0, pool, max_pool=mp)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)                                   # same f32 op order, no contraction
+    assert (want == 0).any() and (want != 0).any()
+
+
+@pytest.mark.parametrize("tag,R,C,W,H", [("voc_300x21", 300, 21, 1000.0, 600.0), ("coco_1000x81", 1000, 81, 1333.0, 800.0)])
+def test_detect_post_vs_reference_golden(dev, golden, tag, R, C, W, H):
+    from frcnn_hip import ops
+    prob, bp, rois = synth.rcnn_outputs(R, C, seed=7, im_w=W, im_h=H)
+    im_h, im_w = int(H / 1.6), int(W / 1.6)
+    dets, cnt = ops.detect_post(T(prob, dev), T(bp, dev), T(rois, dev), None, 1.6, im_h, im_w)
+    n = int(cnt.item())
+    want = golden["perclass"][tag + "_records"]
+    got = dets[:n].cpu().numpy()
+    assert n == want.shape[0]
+    assert np.array_equal(got[:, 4:], want[:, 4:])                    # scores + classes: bit-exact => same keep sets
+    assert np.allclose(got[:, :4], want[:, :4], rtol=0, atol=1e-3)
+
+
+def test_detect_post_num_rois_and_no_cap(dev):
+    from frcnn_hip import ops
+    R, C = 300, 21
+    prob, bp, rois = synth.rcnn_outputs(R, C, seed=9)
+    nr = torch.tensor([120], dtype=torch.int32, device=dev)
+    dets, cnt = ops.detect_post(T(prob, dev), T(bp, dev), T(rois, dev), nr, 1.6, 375, 625, max_per_image=0, max_out=4096)
+    sc, boxes = ora.im_detect_post(prob[:120], bp[:120], rois[:120], 1.6, (375, 625, 3))
+    want = ora.detections_to_records(ora.test_net_post(sc, boxes, C, max_per_image=0))
+    n = int(cnt.item())
+    got = dets[:n].cpu().numpy()
+    assert n == want.shape[0] and np.array_equal(got[:, 4:], want[:, 4:]) and np.allclose(got[:, :4], want[:, :4], atol=1e-3)
+
+
+def test_bbox_overlaps_bit_exact(dev, golden):
+    from frcnn_hip import ops
+    d = synth.random_dets(600, seed=13)[:, :4].astype(np.float64)
+    q = synth.gt_boxes(12, 21, seed=14).astype(np.float64)[:, :4]
+    got = ops.bbox_overlaps(T(d, dev), T(q, dev)).cpu().numpy()
+    assert np.array_equal(got, golden["targets"]["overlaps"])

@@ -1,0 +1,86 @@
+// Shared helpers for the libfrcnn_hip.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "frcnn_hip.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+#define HIP_TRY(expr)                                  \
+  do {                                                 \
+    hipError_t _e = (expr);                            \
+    if (_e != hipSuccess) return FRCNN_E_HIP(_e);      \
+  } while (0)
+
+#define LAUNCH_CHECK()                                 \
+  do {                                                 \
+    hipError_t _e = hipGetLastError();                 \
+    if (_e != hipSuccess) return FRCNN_E_HIP(_e);      \
+  } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Smallest float32 f with (double)f >= thresh: `(double)ovr >= thresh` (lib/nms/cpu_nms.c:2239-2241)
+// is then equivalent to the all-f32 test `ovr >= f`.
+static inline float thresh_to_f32(double thresh) {
+  float f = (float)thresh;
+  if ((double)f < thresh) f = nextafterf(f, INFINITY);
+  return f;
+}
+
+// Monotone float -> uint32 map (larger float <=> larger uint).
+__device__ __forceinline__ u32 sortable_u32(float f) {
+  u32 b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+// 64-bit sort key: (score descending, index ascending) <=> key descending.  Keys are unique.
+__device__ __forceinline__ u64 make_key(float score, u32 index) {
+  return ((u64)sortable_u32(score) << 32) | (u64)(0xffffffffu - index);
+}
+
+// a if a >= b else b  /  a if a <= b else b   (lib/nms/cpu_nms.pyx:11-15)
+__device__ __forceinline__ float rmax(float a, float b) { return a >= b ? a : b; }
+__device__ __forceinline__ float rmin(float a, float b) { return a <= b ? a : b; }
+
+__device__ __forceinline__ float box_area(const float4 b) {       // cpu_nms.pyx:24
+  return ((b.z - b.x) + 1.0f) * ((b.w - b.y) + 1.0f);
+}
+// cpu_nms.pyx:57-65 with the threshold pre-rounded by thresh_to_f32().  Separate roundings
+// (this TU is compiled with -ffp-contract=off), IEEE division.
+__device__ __forceinline__ bool iou_suppresses(const float4 a, float aa, const float4 b, float ab, float thr) {
+  const float xx1 = rmax(a.x, b.x), yy1 = rmax(a.y, b.y);
+  const float xx2 = rmin(a.z, b.z), yy2 = rmin(a.w, b.w);
+  const float w = rmax(0.0f, (xx2 - xx1) + 1.0f);
+  const float h = rmax(0.0f, (yy2 - yy1) + 1.0f);
+  const float inter = w * h;
+  const float ovr = inter / ((aa + ab) - inter);
+  return ovr >= thr;
+}
+
+// bbox_transform_inv for one box / one delta quadruple (lib/model/bbox_transform.py:35-65), f32.
+__device__ __forceinline__ float4 decode_box(const float4 b, const float4 d) {
+  const float w = (b.z - b.x) + 1.0f;
+  const float h = (b.w - b.y) + 1.0f;
+  const float cx = b.x + 0.5f * w;
+  const float cy = b.y + 0.5f * h;
+  const float pcx = d.x * w + cx;
+  const float pcy = d.y * h + cy;
+  const float pw = expf(d.z) * w;
+  const float ph = expf(d.w) * h;
+  return make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph);
+}
+
+__device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
+  const u32 lo = __shfl((u32)v, src, 64), hi = __shfl((u32)(v >> 32), src, 64);
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 readlane_u64(u64 v, int lane_const) {
+  const u32 lo = __builtin_amdgcn_readlane((u32)v, lane_const);
+  const u32 hi = __builtin_amdgcn_readlane((u32)(v >> 32), lane_const);
+  return ((u64)hi << 32) | lo;
+}

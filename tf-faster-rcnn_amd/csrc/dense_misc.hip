@@ -1,0 +1,205 @@
+// Bandwidth-bound dense helpers (NHWC f32, float4 along the channel axis) + stream-capture glue.
+// Citations relative to /root/reference/lib.
+#include "common.h"
+
+extern "C" int frcnn_abi_version(void) { return 1; }
+extern "C" const char* frcnn_build_info(void) { return "libfrcnn_hip gfx950 (CDNA4, wave64, f32 MFMA 32x32x2) abi 1"; }
+
+// ---- max pool (nets/resnet_v1.py:83-84 pool1: pad 1 + 3x3/2 VALID; nets/vgg16.py:30-39 2x2/2 SAME;
+//      nets/network.py:157).  Out-of-image taps are skipped, which equals TF's SAME behaviour and,
+//      for the post-ReLU ResNet stem, the explicit zero pad.  ZERO_PAD makes the zero explicit.
+template <bool ZERO_PAD>
+__global__ void k_maxpool(const float4* __restrict__ x, int N, int H, int W, int C4, int k, int stride, int pt, int pl,
+                          float4* __restrict__ y, int OH, int OW) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long tot = (long long)N * OH * OW * C4;
+  if (t >= tot) return;
+  const int c4 = (int)(t % C4);
+  long long pix = t / C4;
+  const int ow = (int)(pix % OW); pix /= OW;
+  const int oh = (int)(pix % OH);
+  const int img = (int)(pix / OH);
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  bool any_oob = false;
+  for (int dy = 0; dy < k; ++dy) {
+    const int ih = oh * stride - pt + dy;
+    for (int dx = 0; dx < k; ++dx) {
+      const int iw = ow * stride - pl + dx;
+      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+        const float4 v = x[((size_t)(img * H + ih) * W + iw) * C4 + c4];
+        m = make_float4(fmaxf(m.x, v.x), fmaxf(m.y, v.y), fmaxf(m.z, v.z), fmaxf(m.w, v.w));
+      } else {
+        any_oob = true;
+      }
+    }
+  }
+  if (ZERO_PAD && any_oob) m = make_float4(fmaxf(m.x, 0.f), fmaxf(m.y, 0.f), fmaxf(m.z, 0.f), fmaxf(m.w, 0.f));
+  y[t] = m;
+}
+
+extern "C" int frcnn_maxpool_nhwc(const float* x_d, int N, int H, int W, int C, int k, int stride, int pad_top,
+                                  int pad_left, float* y_d, int OH, int OW, void* stream) {
+  if (!x_d || !y_d || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || stride <= 0 || OH <= 0 || OW <= 0) return FRCNN_E_ARG;
+  if (C % 4) return FRCNN_E_UNSUPPORTED;
+  const long long tot = (long long)N * OH * OW * (C / 4);
+  const bool zero_pad = (pad_top > 0 || pad_left > 0);   // explicit tf.pad zeros (resnet_v1.py:83)
+  if (zero_pad)
+    hipLaunchKernelGGL(k_maxpool<true>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)x_d, N, H, W, C / 4, k, stride, pad_top, pad_left, (float4*)y_d, OH, OW);
+  else
+    hipLaunchKernelGGL(k_maxpool<false>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)x_d, N, H, W, C / 4, k, stride, pad_top, pad_left, (float4*)y_d, OH, OW);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// ---- depthwise 3x3 (nets/mobilenet_v1.py:21-49): VALU / bandwidth bound by nature.
+__global__ void k_dwconv3x3(const float4* __restrict__ x, int N, int H, int W, int C4, const float4* __restrict__ w,
+                            const float4* __restrict__ bias, float4* __restrict__ y, int OH, int OW, int stride, int pt,
+                            int pl, int act) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long tot = (long long)N * OH * OW * C4;
+  if (t >= tot) return;
+  const int c4 = (int)(t % C4);
+  long long pix = t / C4;
+  const int ow = (int)(pix % OW); pix /= OW;
+  const int oh = (int)(pix % OH);
+  const int img = (int)(pix / OH);
+  float4 a = bias ? bias[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int dy = 0; dy < 3; ++dy) {
+    const int ih = oh * stride - pt + dy;
+    if ((unsigned)ih >= (unsigned)H) continue;
+    for (int dx = 0; dx < 3; ++dx) {
+      const int iw = ow * stride - pl + dx;
+      if ((unsigned)iw >= (unsigned)W) continue;
+      const float4 v = x[((size_t)(img * H + ih) * W + iw) * C4 + c4];
+      const float4 f = w[(dy * 3 + dx) * C4 + c4];
+      a.x = fmaf(v.x, f.x, a.x); a.y = fmaf(v.y, f.y, a.y); a.z = fmaf(v.z, f.z, a.z); a.w = fmaf(v.w, f.w, a.w);
+    }
+  }
+  if (act == FRCNN_ACT_RELU) a = make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f));
+  else if (act == FRCNN_ACT_RELU6)
+    a = make_float4(fminf(fmaxf(a.x, 0.f), 6.f), fminf(fmaxf(a.y, 0.f), 6.f), fminf(fmaxf(a.z, 0.f), 6.f), fminf(fmaxf(a.w, 0.f), 6.f));
+  y[t] = a;
+}
+
+extern "C" int frcnn_dwconv3x3_nhwc(const float* x_d, int N, int H, int W, int C, const float* w_d, const float* bias_d,
+                                    float* y_d, int OH, int OW, int stride, int pad_top, int pad_left, int act, void* stream) {
+  if (!x_d || !w_d || !y_d || N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || stride <= 0) return FRCNN_E_ARG;
+  if (C % 4) return FRCNN_E_UNSUPPORTED;
+  const long long tot = (long long)N * OH * OW * (C / 4);
+  hipLaunchKernelGGL(k_dwconv3x3, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x_d,
+                     N, H, W, C / 4, (const float4*)w_d, (const float4*)bias_d, (float4*)y_d, OH, OW, stride, pad_top, pad_left, act);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// ---- spatial mean [N,HW,C] -> [N,C] (nets/resnet_v1.py:124).  One thread per (n, c4): the HW
+//      loop strides by C so a wave reads 1 KiB contiguous runs.
+__global__ void k_spatial_mean(const float4* __restrict__ x, int N, int HW, int C4, float4* __restrict__ y) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * C4) return;
+  const int n = t / C4, c4 = t % C4;
+  const float4* p = x + (size_t)n * HW * C4 + c4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < HW; ++i) {
+    const float4 v = p[(size_t)i * C4];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const float inv = 1.0f / (float)HW;
+  y[t] = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+}
+
+extern "C" int frcnn_spatial_mean(const float* x_d, int N, int HW, int C, float* y_d, void* stream) {
+  if (!x_d || !y_d || N <= 0 || HW <= 0 || C <= 0) return FRCNN_E_ARG;
+  if (C % 4) return FRCNN_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_spatial_mean, dim3(cdiv(N * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x_d, N,
+                     HW, C / 4, (float4*)y_d);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// ---- row softmax [R,C] with leading dimension ld (nets/network.py:80-86): one wave per row.
+__global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ x, int R, int C, int ld, float* __restrict__ y) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const float* p = x + (size_t)row * ld;
+  float m = -INFINITY;
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, p[c]);
+  for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += expf(p[c] - m);
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o, 64);
+  for (int c = lane; c < C; c += 64) y[(size_t)row * C + c] = expf(p[c] - m) / s;
+}
+
+extern "C" int frcnn_softmax_rows(const float* x_d, int R, int C, int ld, float* y_d, void* stream) {
+  if (!x_d || !y_d || R <= 0 || C <= 0 || ld < C) return FRCNN_E_ARG;
+  hipLaunchKernelGGL(k_softmax_rows, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, x_d, R, C, ld, y_d);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// ---- RPN pairwise softmax (nets/network.py:68-86,331-334): the reshape-to-2-channels trick pairs
+//      channel a (bg) with channel A+a (fg) at every position.
+__global__ void k_rpn_softmax(const float* __restrict__ score, int HW, int A, int ld, float* __restrict__ prob) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= HW * A) return;
+  const int pix = t / A, a = t % A;
+  const float bg = score[(size_t)pix * ld + a], fg = score[(size_t)pix * ld + A + a];
+  const float m = fmaxf(bg, fg);
+  const float e0 = expf(bg - m), e1 = expf(fg - m);
+  const float s = e0 + e1;
+  prob[(size_t)pix * 2 * A + a] = e0 / s;
+  prob[(size_t)pix * 2 * A + A + a] = e1 / s;
+}
+
+extern "C" int frcnn_rpn_softmax(const float* score_d, int HW, int A, int ld, float* prob_d, void* stream) {
+  if (!score_d || !prob_d || HW <= 0 || A <= 0 || ld < 2 * A) return FRCNN_E_ARG;
+  hipLaunchKernelGGL(k_rpn_softmax, dim3(cdiv(HW * A, 256)), dim3(256), 0, (hipStream_t)stream, score_d, HW, A, ld, prob_d);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+__global__ void k_copy_cols(const float* __restrict__ src, int R, int ld_src, int col0, int cols, float* __restrict__ dst, int ld_dst) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= R * cols) return;
+  const int r = t / cols, c = t % cols;
+  dst[(size_t)r * ld_dst + c] = src[(size_t)r * ld_src + col0 + c];
+}
+
+extern "C" int frcnn_copy_cols(const float* src_d, int R, int ld_src, int col0, int cols, float* dst_d, int ld_dst, void* stream) {
+  if (!src_d || !dst_d || R <= 0 || cols <= 0 || col0 < 0 || ld_src < col0 + cols || ld_dst < cols) return FRCNN_E_ARG;
+  hipLaunchKernelGGL(k_copy_cols, dim3(cdiv(R * cols, 256)), dim3(256), 0, (hipStream_t)stream, src_d, R, ld_src, col0, cols, dst_d, ld_dst);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// ---- stream capture: the whole per-image chain (about 150 launches) becomes one hipGraph, the
+//      MI355X replacement for the reference's one-sess.run-per-image (nets/network.py:470-479).
+extern "C" int frcnn_graph_begin(void* stream) {
+  if (!stream) return FRCNN_E_ARG;       // the legacy default stream cannot be captured
+  HIP_TRY(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+  return FRCNN_OK;
+}
+extern "C" int frcnn_graph_end(void* stream, void** graph_exec_out) {
+  if (!stream || !graph_exec_out) return FRCNN_E_ARG;
+  hipGraph_t g = nullptr;
+  HIP_TRY(hipStreamEndCapture((hipStream_t)stream, &g));
+  hipGraphExec_t ge = nullptr;
+  hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) return FRCNN_E_HIP(e);
+  *graph_exec_out = (void*)ge;
+  return FRCNN_OK;
+}
+extern "C" int frcnn_graph_launch(void* graph_exec, void* stream) {
+  if (!graph_exec) return FRCNN_E_ARG;
+  HIP_TRY(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+  return FRCNN_OK;
+}
+extern "C" int frcnn_graph_destroy(void* graph_exec) {
+  if (!graph_exec) return FRCNN_E_ARG;
+  HIP_TRY(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  return FRCNN_OK;
+}

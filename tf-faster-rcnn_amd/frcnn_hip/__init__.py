@@ -1,0 +1,82 @@
+"""frcnn_hip -- ctypes binding of libfrcnn_hip.so (include/frcnn_hip.h), the MI355X hot path.
+
+PyTorch-ROCm tensors are used for device storage and streams only: every op below hands raw
+device pointers + the current hipStream_t to the C ABI.  There is NO CPU / eager fallback: if the
+library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+from ctypes import c_double, c_float, c_int, c_size_t, c_void_p
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libfrcnn_hip.so")
+_lib = None
+
+ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+
+# name -> (restype, argtypes); must list every symbol include/frcnn_hip.h declares
+_P = c_void_p
+SIGNATURES = {
+    "frcnn_abi_version": (c_int, []),
+    "frcnn_build_info": (ctypes.c_char_p, []),
+    "_nms": (None, [_P, _P, _P, c_int, c_int, c_float, c_int]),
+    "frcnn_nms_workspace_bytes": (c_size_t, [c_int]),
+    "frcnn_nms": (c_int, [_P, c_int, c_double, c_int, _P, _P, _P, c_size_t, _P]),
+    "frcnn_nms_sorted": (c_int, [_P, c_int, c_int, c_double, c_int, _P, _P, _P, c_size_t, _P]),
+    "frcnn_generate_anchors": (c_int, [c_int, _P, c_int, _P, c_int, _P]),
+    "frcnn_generate_anchors_pre": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P]),
+    "frcnn_proposal_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "frcnn_proposal_layer": (c_int, [_P, _P, c_float, c_float, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_double,
+                                     _P, _P, _P, _P, c_size_t, _P]),
+    "frcnn_proposal_top_layer": (c_int, [_P, _P, c_float, c_float, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P,
+                                         c_size_t, _P]),
+    "frcnn_crop_and_resize": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_float, c_int, c_int, _P, _P]),
+    "frcnn_detect_post_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "frcnn_detect_post": (c_int, [_P, _P, _P, _P, c_int, c_int, c_double, c_int, c_int, c_double, c_float, c_int, _P, _P,
+                                  c_int, _P, c_size_t, _P]),
+    "frcnn_bbox_overlaps": (c_int, [_P, c_int, _P, c_int, _P, _P]),
+    "frcnn_conv2d_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int,
+                                  c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "frcnn_pack_filter_hwio": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "frcnn_maxpool_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
+    "frcnn_dwconv3x3_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "frcnn_spatial_mean": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    "frcnn_softmax_rows": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    "frcnn_rpn_softmax": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    "frcnn_copy_cols": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    "frcnn_graph_begin": (c_int, [_P]),
+    "frcnn_graph_end": (c_int, [_P, ctypes.POINTER(c_void_p)]),
+    "frcnn_graph_launch": (c_int, [_P, _P]),
+    "frcnn_graph_destroy": (c_int, [_P]),
+}
+
+
+class FrcnnHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libfrcnn_hip.so (once).  Raises ImportError loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libfrcnn_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(or python tf-faster-rcnn_amd/frcnn_hip/build.py); there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is missing: loud by design
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        if rc <= -1000:
+            raise FrcnnHipError("%s: HIP error %d" % (what, -rc - 1000))
+        raise FrcnnHipError("%s: %s" % (what, {-1: "bad argument", -2: "workspace too small",
+                                               -3: "shape not supported by the kernels"}.get(rc, "error %d" % rc)))
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args), name)

@@ -1,0 +1,296 @@
+"""Tensor-level wrappers over the C ABI.  torch is plumbing here: device buffers, streams.
+
+Every function takes/returns torch CUDA tensors (float32, contiguous, NHWC) and launches on the
+CURRENT torch stream (so torch.cuda.Event / torch.cuda.synchronize see the work).  Outputs may be
+passed in (`out=`) so a captured hipGraph can reuse static buffers.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import ACT_NONE, call, lib
+
+_ws_cache = {}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _chk(t, dtype=torch.float32):
+    if not (t.is_cuda and t.is_contiguous() and t.dtype == dtype):
+        raise ValueError("expected a contiguous CUDA %s tensor, got %s %s contiguous=%s" %
+                         (dtype, t.device, t.dtype, t.is_contiguous()))
+    return t
+
+
+def workspace(nbytes, device, tag="default"):
+    """Grow-only scratch buffer per (device, tag); never reallocated inside a captured region
+    as long as the first (warm-up) call already saw the largest request."""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------------------------------ anchors
+def generate_anchors(base_size=16, ratios=(0.5, 1, 2), scales=(8, 16, 32)):
+    """HOST float64 [A,4] base anchors (lib/layer_utils/generate_anchors.py:41-52)."""
+    r = np.ascontiguousarray(ratios, dtype=np.float64)
+    s = np.ascontiguousarray(scales, dtype=np.float64)
+    out = np.empty((r.size * s.size, 4), dtype=np.float64)
+    call("frcnn_generate_anchors", int(base_size), r.ctypes.data_as(ctypes.c_void_p), r.size,
+         s.ctypes.data_as(ctypes.c_void_p), s.size, out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def generate_anchors_pre(height, width, feat_stride, base_d, out=None):
+    """DEVICE f32 [H*W*A,4] (lib/layer_utils/snippets.py:14-30).  base_d: float64 CUDA [A,4]."""
+    A = base_d.shape[0]
+    _chk(base_d, torch.float64)
+    if out is None:
+        out = torch.empty((height * width * A, 4), dtype=torch.float32, device=base_d.device)
+    call("frcnn_generate_anchors_pre", height, width, int(feat_stride), _ptr(base_d), A, _ptr(out), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------ NMS
+def nms(dets, thresh, max_keep=None, keep=None, num=None):
+    """cpu_nms semantics on device.  dets f32 [k,5] any order -> (keep int32 [max_keep], num int32 [1])."""
+    _chk(dets)
+    k = dets.shape[0]
+    max_keep = k if max_keep is None else min(max_keep, k)
+    dev = dets.device
+    keep = torch.empty((max(max_keep, 1),), dtype=torch.int32, device=dev) if keep is None else keep
+    num = torch.zeros((1,), dtype=torch.int32, device=dev) if num is None else num
+    nb = lib().frcnn_nms_workspace_bytes(max(k, 1))
+    ws = workspace(nb, dev, "nms")
+    call("frcnn_nms", _ptr(dets), k, float(thresh), max_keep, _ptr(keep), _ptr(num), _ptr(ws), ws.numel(), _stream())
+    return keep, num
+
+
+def nms_sorted(boxes, thresh, max_keep=None):
+    """Device-pointer form of `_nms`: boxes f32 [k, >=4] sorted by descending score."""
+    _chk(boxes)
+    k, stride = boxes.shape
+    max_keep = k if max_keep is None else min(max_keep, k)
+    dev = boxes.device
+    keep = torch.empty((max(max_keep, 1),), dtype=torch.int32, device=dev)
+    num = torch.zeros((1,), dtype=torch.int32, device=dev)
+    nb = lib().frcnn_nms_workspace_bytes(max(k, 1))
+    ws = workspace(nb, dev, "nms")
+    call("frcnn_nms_sorted", _ptr(boxes), k, stride, float(thresh), max_keep, _ptr(keep), _ptr(num), _ptr(ws),
+         ws.numel(), _stream())
+    return keep, num
+
+
+def bbox_overlaps(boxes, query):
+    _chk(boxes, torch.float64), _chk(query, torch.float64)
+    out = torch.empty((boxes.shape[0], query.shape[0]), dtype=torch.float64, device=boxes.device)
+    call("frcnn_bbox_overlaps", _ptr(boxes), boxes.shape[0], _ptr(query), query.shape[0], _ptr(out), _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------ proposals
+def proposal_layer(rpn_cls_prob, rpn_bbox_pred, im_h, im_w, feat_stride, base_d, pre_nms_topn, post_nms_topn,
+                   nms_thresh, rois=None, scores=None, num=None):
+    """lib/layer_utils/proposal_layer.py:16-53 on device.  Returns (rois [post,5], scores [post,1], num [1])."""
+    _chk(rpn_cls_prob), _chk(rpn_bbox_pred), _chk(base_d, torch.float64)
+    _, H, W, A2 = rpn_cls_prob.shape
+    A = A2 // 2
+    dev = rpn_cls_prob.device
+    rois = torch.empty((post_nms_topn, 5), dtype=torch.float32, device=dev) if rois is None else rois
+    scores = torch.empty((post_nms_topn, 1), dtype=torch.float32, device=dev) if scores is None else scores
+    num = torch.zeros((1,), dtype=torch.int32, device=dev) if num is None else num
+    nb = lib().frcnn_proposal_workspace_bytes(H, W, A, int(pre_nms_topn))
+    ws = workspace(nb, dev, "proposal")
+    call("frcnn_proposal_layer", _ptr(rpn_cls_prob), _ptr(rpn_bbox_pred), float(im_h), float(im_w), H, W, A,
+         int(feat_stride), _ptr(base_d), int(pre_nms_topn), int(post_nms_topn), float(nms_thresh), _ptr(rois),
+         _ptr(scores), _ptr(num), _ptr(ws), ws.numel(), _stream())
+    return rois, scores, num
+
+
+def proposal_top_layer(rpn_cls_prob, rpn_bbox_pred, im_h, im_w, feat_stride, base_d, rpn_top_n):
+    _chk(rpn_cls_prob), _chk(rpn_bbox_pred), _chk(base_d, torch.float64)
+    _, H, W, A2 = rpn_cls_prob.shape
+    A = A2 // 2
+    dev = rpn_cls_prob.device
+    rois = torch.empty((rpn_top_n, 5), dtype=torch.float32, device=dev)
+    scores = torch.empty((rpn_top_n, 1), dtype=torch.float32, device=dev)
+    nb = lib().frcnn_proposal_workspace_bytes(H, W, A, int(rpn_top_n))
+    ws = workspace(nb, dev, "proposal")
+    call("frcnn_proposal_top_layer", _ptr(rpn_cls_prob), _ptr(rpn_bbox_pred), float(im_h), float(im_w), H, W, A,
+         int(feat_stride), _ptr(base_d), int(rpn_top_n), _ptr(rois), _ptr(scores), _ptr(ws), ws.numel(), _stream())
+    return rois, scores
+
+
+def crop_and_resize(feat, rois, feat_stride, pool, max_pool=False, out=None):
+    """feat [1,H,W,C] or [H,W,C]; rois [R,5] -> [R,pool,pool,C] (TF crop_and_resize semantics)."""
+    _chk(feat), _chk(rois)
+    H, W, C = feat.shape[-3:]
+    R = rois.shape[0]
+    out = torch.empty((R, pool, pool, C), dtype=torch.float32, device=feat.device) if out is None else out
+    call("frcnn_crop_and_resize", _ptr(feat), H, W, C, _ptr(rois), R, float(feat_stride), int(pool),
+         1 if max_pool else 0, _ptr(out), _stream())
+    return out
+
+
+def detect_post(cls_prob, bbox_pred, rois, num_rois, im_scale, im_h, im_w, nms_thresh=0.3, score_thresh=0.0,
+                max_per_image=100, max_out=None, out=None, count=None):
+    """lib/model/test.py:95-102 + :162-180 on device -> (dets [max_out,6], count [1])."""
+    _chk(cls_prob), _chk(bbox_pred), _chk(rois)
+    R, C = cls_prob.shape
+    dev = cls_prob.device
+    max_out = (max_per_image + 28 if max_per_image > 0 else R * (C - 1)) if max_out is None else max_out
+    out = torch.empty((max_out, 6), dtype=torch.float32, device=dev) if out is None else out
+    count = torch.zeros((1,), dtype=torch.int32, device=dev) if count is None else count
+    nb = lib().frcnn_detect_post_workspace_bytes(R, C)
+    ws = workspace(nb, dev, "detect_post")
+    call("frcnn_detect_post", _ptr(cls_prob), _ptr(bbox_pred), _ptr(rois), _ptr(num_rois), R, C, float(im_scale),
+         int(im_h), int(im_w), float(nms_thresh), float(score_thresh), int(max_per_image), _ptr(out), _ptr(count),
+         int(max_out), _ptr(ws), ws.numel(), _stream())
+    return out, count
+
+
+# ------------------------------------------------------------------------------------------ dense
+def pack_filter_hwio(w_hwio, scale=None):
+    """HOST numpy HWIO -> packed [Cout][KH][KW][Cin] (folding a per-output-channel scale)."""
+    w = np.ascontiguousarray(w_hwio, dtype=np.float32)
+    KH, KW, Cin, Cout = w.shape
+    out = np.empty((Cout, KH, KW, Cin), dtype=np.float32)
+    sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float32)
+    call("frcnn_pack_filter_hwio", w.ctypes.data_as(ctypes.c_void_p), KH, KW, Cin, Cout,
+         None if sc is None else sc.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def pack_filter_foldw(w_hwio, scale=None):
+    """HOST: stem filter HWIO [KH,KW<=8,Cin<=4,Cout] -> [Cout][KH][8][4] (zero padded) for the
+    fold_w mode of frcnn_conv2d_nhwc: the kw taps become part of the contiguous channel run of the
+    4-channel-padded image, so the 7x7x3 stem runs on the MFMA pipe with K = KH*32."""
+    w = np.asarray(w_hwio, dtype=np.float32)
+    KH, KW, Cin, Cout = w.shape
+    assert KW <= 8 and Cin <= 4
+    if scale is not None:
+        w = w * np.asarray(scale, dtype=np.float32)[None, None, None, :]
+    out = np.zeros((Cout, KH, 8, 4), dtype=np.float32)
+    out[:, :, :KW, :Cin] = np.transpose(w, (3, 0, 1, 2))
+    return out
+
+
+def conv_out_size(n, k, stride, pad_lo, pad_hi):
+    return (n + pad_lo + pad_hi - k) // stride + 1
+
+
+def conv2d(x, w_packed, bias, KH, KW, stride=1, pad=(0, 0, 0, 0), act=ACT_NONE, residual=None, res_stride=1,
+           fold_w=False, out=None):
+    """x [N,H,W,Cin]; w_packed [Cout,KH,KW,Cin] (fold_w: [Cout,KH,8,4]); pad = (top, bottom, left, right)."""
+    _chk(x), _chk(w_packed)
+    N, H, W, Cin = x.shape
+    Cout = w_packed.shape[0]
+    OH = conv_out_size(H, KH, stride, pad[0], pad[1])
+    OW = conv_out_size(W, KW, stride, pad[2], pad[3])
+    out = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=x.device) if out is None else out
+    RH = RW = 0
+    if residual is not None:
+        _chk(residual)
+        RH, RW = residual.shape[1], residual.shape[2]
+    call("frcnn_conv2d_nhwc", _ptr(x), N, H, W, Cin, _ptr(w_packed), _ptr(bias), _ptr(residual), RH, RW,
+         int(res_stride), _ptr(out), OH, OW, Cout, KH, KW, int(stride), int(pad[0]), int(pad[2]), int(act),
+         1 if fold_w else 0, _stream())
+    return out
+
+
+def maxpool(x, k, stride, pad=(0, 0, 0, 0), out=None):
+    _chk(x)
+    N, H, W, C = x.shape
+    OH = conv_out_size(H, k, stride, pad[0], pad[1])
+    OW = conv_out_size(W, k, stride, pad[2], pad[3])
+    out = torch.empty((N, OH, OW, C), dtype=torch.float32, device=x.device) if out is None else out
+    call("frcnn_maxpool_nhwc", _ptr(x), N, H, W, C, int(k), int(stride), int(pad[0]), int(pad[2]), _ptr(out), OH, OW,
+         _stream())
+    return out
+
+
+def dwconv3x3(x, w, bias, stride=1, pad=(1, 1, 1, 1), act=ACT_NONE, out=None):
+    _chk(x), _chk(w)
+    N, H, W, C = x.shape
+    OH = conv_out_size(H, 3, stride, pad[0], pad[1])
+    OW = conv_out_size(W, 3, stride, pad[2], pad[3])
+    out = torch.empty((N, OH, OW, C), dtype=torch.float32, device=x.device) if out is None else out
+    call("frcnn_dwconv3x3_nhwc", _ptr(x), N, H, W, C, _ptr(w), _ptr(bias), _ptr(out), OH, OW, int(stride),
+         int(pad[0]), int(pad[2]), int(act), _stream())
+    return out
+
+
+def spatial_mean(x, out=None):
+    _chk(x)
+    N, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (N * C)
+    out = torch.empty((N, C), dtype=torch.float32, device=x.device) if out is None else out
+    call("frcnn_spatial_mean", _ptr(x), N, HW, C, _ptr(out), _stream())
+    return out
+
+
+def softmax_rows(x, C=None, out=None):
+    _chk(x)
+    R, ld = x.shape
+    C = ld if C is None else C
+    out = torch.empty((R, C), dtype=torch.float32, device=x.device) if out is None else out
+    call("frcnn_softmax_rows", _ptr(x), R, C, ld, _ptr(out), _stream())
+    return out
+
+
+def rpn_softmax(score, A, out=None):
+    """score [1,H,W,ld] (first 2A channels = bg|fg scores) -> prob [1,H,W,2A]."""
+    _chk(score)
+    _, H, W, ld = score.shape
+    out = torch.empty((1, H, W, 2 * A), dtype=torch.float32, device=score.device) if out is None else out
+    call("frcnn_rpn_softmax", _ptr(score), H * W, A, ld, _ptr(out), _stream())
+    return out
+
+
+def copy_cols(src, col0, cols, out=None):
+    _chk(src)
+    ld = src.shape[-1]
+    R = src.numel() // ld
+    out = torch.empty(tuple(src.shape[:-1]) + (cols,), dtype=torch.float32, device=src.device) if out is None else out
+    call("frcnn_copy_cols", _ptr(src), R, ld, int(col0), int(cols), _ptr(out), cols, _stream())
+    return out
+
+
+class Graph:
+    """One captured hipGraph (frcnn_graph_* in the C ABI)."""
+
+    def __init__(self):
+        self.handle = None
+
+    def capture(self, fn):
+        st = torch.cuda.current_stream()
+        if st.cuda_stream == 0:
+            raise RuntimeError("capture needs a non-default stream (use torch.cuda.stream(torch.cuda.Stream()))")
+        call("frcnn_graph_begin", ctypes.c_void_p(st.cuda_stream))
+        try:
+            fn()
+        finally:
+            h = ctypes.c_void_p()
+            call("frcnn_graph_end", ctypes.c_void_p(st.cuda_stream), ctypes.byref(h))
+        self.handle = h
+        return self
+
+    def launch(self):
+        call("frcnn_graph_launch", self.handle, _stream())
+
+    def __del__(self):
+        try:
+            if self.handle:
+                call("frcnn_graph_destroy", self.handle)
+        except Exception:
+            pass
