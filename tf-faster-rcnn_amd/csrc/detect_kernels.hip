@@ -188,7 +188,10 @@ __device__ __forceinline__ int greedy_reduce_wave(const u64* __restrict__ mask, 
     if (slot == 2) sel = remv2;
     if (slot == 3) sel = remv3;
     sel = shfl_u64(sel, c & 63);
-    u64 cur = ((u64)__builtin_amdgcn_readfirstlane((u32)(sel >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)sel);
+    // readfirstlane returns a (signed) int: go through u32 or the low word sign-extends into the high one
+    const u32 cur_lo = (u32)__builtin_amdgcn_readfirstlane((u32)sel);
+    const u32 cur_hi = (u32)__builtin_amdgcn_readfirstlane((u32)(sel >> 32));
+    u64 cur = ((u64)cur_hi << 32) | (u64)cur_lo;
     const int nvalid = min(64, K - c * 64);
     if (nvalid < 64) cur |= (~0ull) << nvalid;
     u64 kept = 0;

@@ -1,0 +1,154 @@
+"""Session -- the opaque runtime handle that replaces `tf.Session` in the host-side mirror
+(SURVEY.md 8b "Model-level seam"): device + stream + variables (host numpy, TF layouts and names)
++ their packed device images + static activation buffers + captured hipGraphs.
+
+torch is used for device memory and streams only.
+"""
+import collections
+import time
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+class VarSpec(object):
+    __slots__ = ("shape", "init", "arg")
+
+    def __init__(self, shape, init, arg=None):
+        self.shape, self.init, self.arg = tuple(int(s) for s in shape), init, arg
+
+
+class Session(object):
+    def __init__(self, device=None, seed=3):
+        if not torch.cuda.is_available():
+            raise RuntimeError("frcnn_hip.Session needs a GPU: the product path has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.variables = collections.OrderedDict()     # TF name -> numpy (HWIO conv, [in,out] fc)
+        self.packed = {}                                # layer key -> device tensors
+        self.buffers = {}
+        self.graphs = {}
+        self.seed = seed
+        self.profile = None                             # list of (tag, flops, ev0, ev1) when profiling
+        self.flops_last_forward = 0
+
+    # ---- variables ---------------------------------------------------------------------------
+    def init_variables(self, specs, seed=None):
+        """Random-init weights of the reference architecture (no checkpoints exist offline):
+        He/variance-scaling for backbone convs (lib/nets/resnet_v1.py:38), N(0,0.01)/N(0,0.001)
+        for RPN/cls/bbox (lib/nets/network.py:239-240), zero biases (:420), synthetic frozen-BN
+        statistics."""
+        rng = np.random.RandomState(self.seed if seed is None else seed)
+        for name, sp in specs.items():
+            if sp.init == "he":
+                fan_in = int(np.prod(sp.shape[:-1]))
+                v = rng.randn(*sp.shape) * np.sqrt(2.0 / fan_in)
+            elif sp.init == "normal":
+                v = rng.randn(*sp.shape) * sp.arg
+            elif sp.init == "zeros":
+                v = np.zeros(sp.shape)
+            elif sp.init == "bn_gamma":
+                v = rng.uniform(0.5, 1.5, size=sp.shape)
+            elif sp.init == "bn_var":
+                v = rng.uniform(0.5, 1.5, size=sp.shape)
+            elif sp.init == "bn_beta" or sp.init == "bn_mean":
+                v = rng.randn(*sp.shape) * 0.1
+            else:
+                raise ValueError(sp.init)
+            self.variables[name] = v.astype(np.float32)
+        self.packed.clear()
+        self.graphs.clear()
+
+    def load_variables(self, values):
+        for k, v in values.items():
+            self.variables[k] = np.asarray(v, dtype=np.float32)
+        self.packed.clear()
+        self.graphs.clear()
+
+    # ---- device-side images of the variables ----------------------------------------------------
+    def to_device(self, a, dtype=torch.float32):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device, dtype)
+
+    def fold_bn(self, scope, eps):
+        v = self.variables
+        g, b = v[scope + "/BatchNorm/gamma"], v[scope + "/BatchNorm/beta"]
+        m, var = v[scope + "/BatchNorm/moving_mean"], v[scope + "/BatchNorm/moving_variance"]
+        scale = (g.astype(np.float64) / np.sqrt(var.astype(np.float64) + eps))
+        bias = b.astype(np.float64) - m.astype(np.float64) * scale
+        return scale.astype(np.float32), bias.astype(np.float32)
+
+    def conv_params(self, scope, bn_eps=None, fold_w=False, out_scale=None, out_shift=None):
+        """(w_packed_d, bias_d) for a conv / fc scope.  bn_eps: fold the frozen batch norm
+        gamma*(x-mean)/sqrt(var+eps)+beta into (w*scale, bias).  out_scale/out_shift: extra affine
+        on the outputs (test-time bbox de-normalisation, lib/nets/network.py:428-432)."""
+        key = (scope, bn_eps, fold_w, None if out_scale is None else tuple(out_scale))
+        if key in self.packed:
+            return self.packed[key]
+        w = self.variables[scope + "/weights"]
+        if w.ndim == 2:
+            w = w[None, None, :, :]
+        scale, bias = None, None
+        if bn_eps is not None:
+            scale, bias = self.fold_bn(scope, bn_eps)
+        elif (scope + "/biases") in self.variables:
+            bias = self.variables[scope + "/biases"]
+        if out_scale is not None:
+            osc = np.asarray(out_scale, dtype=np.float32)
+            scale = osc if scale is None else scale * osc
+            bias = (np.zeros_like(osc) if bias is None else bias) * osc + np.asarray(out_shift, dtype=np.float32)
+        wp = ops.pack_filter_foldw(w, scale) if fold_w else ops.pack_filter_hwio(w, scale)
+        res = (self.to_device(wp), None if bias is None else self.to_device(bias))
+        self.packed[key] = res
+        return res
+
+    # ---- static activation buffers ----------------------------------------------------------------
+    def buf(self, name, shape, dtype=torch.float32, zero=False):
+        key = (name, tuple(shape), dtype)
+        t = self.buffers.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(tuple(shape), dtype=dtype, device=self.device)
+            self.buffers[key] = t
+        return t
+
+    # ---- profiling hook: HIP events around selected launches, on the stream they run on ----------
+    def mark(self, tag, flops, fn):
+        self.flops_last_forward += flops
+        if self.profile is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self.profile.append((tag, flops, e0, e1))
+        return r
+
+    def synchronize(self):
+        torch.cuda.current_stream(self.device).synchronize()
+
+    def close(self):
+        self.graphs.clear()
+        self.buffers.clear()
+        self.packed.clear()
+
+
+class Timer(object):
+    """tic/toc wall-clock timer with the interface of lib/utils/timer.py:10-32."""
+
+    def __init__(self):
+        self.total_time = 0.
+        self.calls = 0
+        self.start_time = 0.
+        self.diff = 0.
+        self.average_time = 0.
+
+    def tic(self):
+        self.start_time = time.time()
+
+    def toc(self, average=True):
+        self.diff = time.time() - self.start_time
+        self.total_time += self.diff
+        self.calls += 1
+        self.average_time = self.total_time / self.calls
+        return self.average_time if average else self.diff

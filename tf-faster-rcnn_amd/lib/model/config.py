@@ -1,0 +1,139 @@
+"""cfg -- the reference's global configuration object, re-hosted without easydict/TensorFlow.
+
+Same keys, defaults and helper functions as /root/reference/lib/model/config.py:14-387
+(cfg, cfg_from_file, cfg_from_list, get_output_dir, get_output_tb_dir) so that the tools/ entry
+points and `--set KEY VALUE` overrides behave identically.  Differences, on purpose:
+  * yaml.safe_load instead of the Loader-less yaml.load (config.py:362 raises under PyYAML >= 6);
+  * USE_GPU_NMS keeps its meaning "use the accelerator NMS" -- which is now the HIP kernel with
+    the CPU/Cython suppression rule (`>=`), the path BASELINE.json names;
+  * USE_E2E_TF defaults to False: there is no TF graph; the py_func seam functions ARE the path.
+"""
+import ast
+import os
+import os.path as osp
+
+import numpy as np
+
+
+class AttrDict(dict):
+    """dict with attribute access, recursive on assignment (what the reference uses easydict for)."""
+
+    def __init__(self, d=None, **kw):
+        super().__init__()
+        for k, v in dict(d or {}, **kw).items():
+            self[k] = v
+
+    def __setitem__(self, k, v):
+        if isinstance(v, dict) and not isinstance(v, AttrDict):
+            v = AttrDict(v)
+        super().__setitem__(k, v)
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    __setattr__ = __setitem__
+
+
+_TRAIN = dict(
+    LEARNING_RATE=0.001, MOMENTUM=0.9, WEIGHT_DECAY=0.0001, GAMMA=0.1, STEPSIZE=[30000], DISPLAY=10,
+    DOUBLE_BIAS=True, TRUNCATED=False, BIAS_DECAY=False, USE_GT=False, ASPECT_GROUPING=False,
+    SNAPSHOT_KEPT=3, SUMMARY_INTERVAL=180, SCALES=(600,), MAX_SIZE=1000, IMS_PER_BATCH=1, BATCH_SIZE=128,
+    FG_FRACTION=0.25, FG_THRESH=0.5, BG_THRESH_HI=0.5, BG_THRESH_LO=0.1, USE_FLIPPED=True, BBOX_REG=True,
+    BBOX_THRESH=0.5, SNAPSHOT_ITERS=5000, SNAPSHOT_PREFIX='res101_faster_rcnn', BBOX_NORMALIZE_TARGETS=True,
+    BBOX_INSIDE_WEIGHTS=(1.0, 1.0, 1.0, 1.0), BBOX_NORMALIZE_TARGETS_PRECOMPUTED=True,
+    BBOX_NORMALIZE_MEANS=(0.0, 0.0, 0.0, 0.0), BBOX_NORMALIZE_STDS=(0.1, 0.1, 0.2, 0.2), PROPOSAL_METHOD='gt',
+    HAS_RPN=True, RPN_POSITIVE_OVERLAP=0.7, RPN_NEGATIVE_OVERLAP=0.3, RPN_CLOBBER_POSITIVES=False,
+    RPN_FG_FRACTION=0.5, RPN_BATCHSIZE=256, RPN_NMS_THRESH=0.7, RPN_PRE_NMS_TOP_N=12000,
+    RPN_POST_NMS_TOP_N=2000, RPN_BBOX_INSIDE_WEIGHTS=(1.0, 1.0, 1.0, 1.0), RPN_POSITIVE_WEIGHT=-1.0,
+    USE_ALL_GT=True)
+
+_TEST = dict(
+    SCALES=(600,), MAX_SIZE=1000, NMS=0.3, SVM=False, BBOX_REG=True, HAS_RPN=False, PROPOSAL_METHOD='gt',
+    RPN_NMS_THRESH=0.7, RPN_PRE_NMS_TOP_N=6000, RPN_POST_NMS_TOP_N=300, MODE='nms', RPN_TOP_N=5000)
+
+__C = AttrDict(
+    TRAIN=_TRAIN, TEST=_TEST,
+    RESNET=dict(MAX_POOL=False, FIXED_BLOCKS=1),
+    MOBILENET=dict(REGU_DEPTH=False, FIXED_LAYERS=5, WEIGHT_DECAY=0.00004, DEPTH_MULTIPLIER=1.),
+    PIXEL_MEANS=np.array([[[102.9801, 115.9465, 122.7717]]]), RNG_SEED=3,
+    ROOT_DIR=osp.abspath(osp.join(osp.dirname(__file__), '..', '..')),
+    MATLAB='matlab', EXP_DIR='default', USE_GPU_NMS=True, USE_E2E_TF=False, POOLING_MODE='crop', POOLING_SIZE=7,
+    ANCHOR_SCALES=[8, 16, 32], ANCHOR_RATIOS=[0.5, 1, 2], RPN_CHANNELS=512)
+__C.DATA_DIR = osp.abspath(osp.join(__C.ROOT_DIR, 'data'))
+cfg = __C
+
+
+def get_output_dir(imdb, weights_filename):
+    """output/<EXP_DIR>/<imdb.name>[/<weights_filename>]  (reference config.py:293-306)."""
+    outdir = osp.abspath(osp.join(__C.ROOT_DIR, 'output', __C.EXP_DIR, imdb.name))
+    outdir = osp.join(outdir, 'default' if weights_filename is None else weights_filename)
+    os.makedirs(outdir, exist_ok=True)
+    return outdir
+
+
+def get_output_tb_dir(imdb, weights_filename):
+    outdir = osp.abspath(osp.join(__C.ROOT_DIR, 'tensorboard', __C.EXP_DIR, imdb.name))
+    outdir = osp.join(outdir, 'default' if weights_filename is None else weights_filename)
+    os.makedirs(outdir, exist_ok=True)
+    return outdir
+
+
+def _merge_a_into_b(a, b):
+    """Recursive merge with the reference's type checks (config.py:325-356)."""
+    if not isinstance(a, dict):
+        return
+    for k, v in a.items():
+        if k not in b:
+            raise KeyError('{} is not a valid config key'.format(k))
+        old = b[k]
+        if type(old) is not type(v) and not (isinstance(old, dict) and isinstance(v, dict)):
+            if isinstance(old, np.ndarray):
+                v = np.array(v, dtype=old.dtype)
+            elif isinstance(old, tuple) and isinstance(v, list):
+                v = tuple(v)
+            elif isinstance(old, list) and isinstance(v, tuple):
+                v = list(v)
+            else:
+                raise ValueError('Type mismatch ({} vs. {}) for config key: {}'.format(type(old), type(v), k))
+        if isinstance(v, dict):
+            try:
+                _merge_a_into_b(v, b[k])
+            except Exception:
+                print('Error under config key: {}'.format(k))
+                raise
+        else:
+            b[k] = v
+
+
+def cfg_from_file(filename):
+    """Load a YAML config file and merge it into the defaults."""
+    import yaml
+    with open(filename, 'r') as f:
+        _merge_a_into_b(AttrDict(yaml.safe_load(f) or {}), __C)
+
+
+def cfg_from_list(cfg_list):
+    """`--set K1 V1 K2 V2 ...` (dotted keys; values parsed as Python literals when possible)."""
+    assert len(cfg_list) % 2 == 0
+    for k, v in zip(cfg_list[0::2], cfg_list[1::2]):
+        path = k.split('.')
+        d = __C
+        for sub in path[:-1]:
+            assert sub in d
+            d = d[sub]
+        leaf = path[-1]
+        assert leaf in d
+        try:
+            value = ast.literal_eval(v)
+        except Exception:
+            value = v
+        old = d[leaf]
+        if isinstance(old, tuple) and isinstance(value, list):
+            value = tuple(value)
+        if isinstance(old, list) and isinstance(value, tuple):
+            value = list(value)
+        assert type(value) == type(old), 'type {} does not match original type {}'.format(type(value), type(old))
+        d[leaf] = value
