@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the MI355X Faster R-CNN hot path (BASELINE.json metric).
+
+One "step" = one 600x1000 image per GPU through the whole device chain: image (already in HBM) ->
+ResNet-101 head (f32 MFMA implicit-GEMM convs) -> RPN -> proposal layer (decode/clip/sort/NMS) ->
+crop_and_resize -> block4 per RoI -> cls/bbox -> per-class NMS + top-100 -> detection record in HBM.
+N > 1: one process per GPU (torchrun), one image per rank per step, fixed-size detection records
+all-gathered over RCCL/xGMI every step (north_star); weak scaling.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement; extra objects `roofline`,
+`cpu_baseline`).  /root/reference is never read here.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "tf-faster-rcnn_amd")
+for p in (ROOT, os.path.join(ROOT, "oracle"), PKG, os.path.join(PKG, "lib")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+METRIC = "images/sec (600×1000) ResNet-101 Faster R-CNN at 1/2/4/8 MI355X"
+F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+IM_H, IM_W, IM_SCALE = 600, 1000, 1.6
+NUM_CLASSES = 21
+ANCHOR_SCALES, ANCHOR_RATIOS = (8, 16, 32), (0.5, 1, 2)
+
+
+def synth_image(seed):
+    from model.config import cfg
+    rng = np.random.RandomState(seed)
+    return (rng.rand(1, IM_H, IM_W, 3) * 255.0).astype(np.float32) - cfg.PIXEL_MEANS.astype(np.float32)
+
+
+def cpu_baseline(variables, image, rois_hint):
+    """Host-CPU number beside the GPU one: the oracle's restatement of the SAME workload (one image),
+    dense part = torch-CPU float32 on all host cores (TensorFlow-CPU is not installable offline),
+    detection part = the pinned numpy/C oracle (single thread, like the reference under the GIL)."""
+    import frcnn_oracle as ora
+    from dense_ref import DenseRef
+    cores = torch.get_num_threads()
+    ref = DenseRef(variables, 101, NUM_CLASSES, ANCHOR_SCALES, ANCHOR_RATIOS, dtype=torch.float32)
+    im_info = np.array([IM_H, IM_W, IM_SCALE], dtype=np.float32)
+    t0 = time.time()
+    with torch.no_grad():
+        out = ref.test_image(image, im_info)
+    t_fwd = time.time() - t0
+    t1 = time.time()
+    sc, boxes = ora.im_detect_post(out["cls_prob"].astype(np.float32), out["bbox_pred"].astype(np.float32),
+                                   out["rois"].astype(np.float32), IM_SCALE, (int(IM_H / IM_SCALE), int(IM_W / IM_SCALE), 3))
+    ora.test_net_post(sc, boxes, NUM_CLASSES)
+    t_post = time.time() - t1
+    total = t_fwd + t_post
+    return {"value": round(1.0 / total, 4), "unit": "images/sec", "cores": int(cores), "kind": "port",
+            "sample": "1 image 600x1000 ResNet-101 (300 RoIs): torch-CPU f32 dense restatement on %d threads %.2fs "
+                      "(incl. numpy/C proposal_layer) + per-class NMS %.3fs" % (cores, t_fwd, t_post)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--profile-steps", type=int, default=3, help="steps of the HIP-event pass that feeds `roofline`")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("N>1 must be launched with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    import frcnn_hip
+    frcnn_hip.lib()
+    from frcnn_hip.runtime import Session
+    from model.config import cfg
+    from nets.resnet_v1 import resnetv1
+
+    sess = Session(device=dev, seed=cfg.RNG_SEED)
+    net = resnetv1(num_layers=101)
+    net.create_architecture("TEST", NUM_CLASSES, tag="default", anchor_scales=ANCHOR_SCALES, anchor_ratios=ANCHOR_RATIOS)
+    sess.init_variables(net.variable_specs())
+    image = synth_image(cfg.RNG_SEED + rank)            # every rank its own image
+    im_info = np.array([IM_H, IM_W, IM_SCALE], dtype=np.float32)
+    orig_shape = (int(IM_H / IM_SCALE), int(IM_W / IM_SCALE))
+
+    run_stream = torch.cuda.Stream(device=dev)
+    from frcnn_hip import parallel
+    rec, dets_view = parallel.new_record(dev)              # fixed-size detection record [dets | count]
+    count_i32 = torch.zeros((1,), dtype=torch.int32, device=dev)
+    gathered = torch.zeros((world, rec.numel()), dtype=torch.float32, device=dev) if world > 1 else None
+
+    with torch.cuda.stream(run_stream):
+        img_d = net._stage_image(sess, image)              # input resident in HBM before the timed region
+        run_stream.synchronize()
+
+        def step():
+            net.detect_device(sess, img_d, im_info, orig_shape, out=dets_view, count=count_i32)
+            if world > 1:
+                parallel.set_count(rec, count_i32)
+                parallel.all_gather_records(rec, gathered)
+
+        if args.no_graph:
+            sess.profile = []                                # forward_device runs eagerly while profile is not None
+        for _ in range(max(args.warmup, 1)):
+            step()
+            if args.no_graph:
+                sess.profile = []
+        run_stream.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            if args.no_graph:
+                sess.profile = []
+        run_stream.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        n_det = int(count_i32.item())
+        n_rois = int(net._num_rois.item())
+        flops_per_image = sess.flops_last_forward
+
+        # ---- roofline of the dominant kernel (k_conv_igemm): HIP events around every conv launch, on
+        #      the stream the kernels run on, over `profile_steps` further steps of the same workload
+        conv_ms, conv_flops, conv_launches = 0.0, 0, 0
+        if rank == 0 and args.profile_steps > 0:
+            sess.profile = []
+            for _ in range(args.profile_steps):       # no collective here: only rank 0 runs this pass
+                net.detect_device(sess, img_d, im_info, orig_shape, out=dets_view, count=count_i32)
+            run_stream.synchronize()
+            for tag, fl, e0, e1 in sess.profile:
+                if tag.startswith("conv:"):
+                    conv_ms += e0.elapsed_time(e1)
+                    conv_flops += fl
+                    conv_launches += 1
+            sess.profile = None
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        value = world * args.steps / elapsed
+        out = {
+            "metric": METRIC, "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: ResNet-101 VOC 600x1000, 300 proposals, 21 classes, A=9, TEST.MODE nms; "
+                                   "image in HBM -> <=100 detections in HBM", "images_per_gpu_per_step": 1,
+                       "parallelism": "dp%d (one image per GPU, all-gather of detection records)" % world,
+                       "launch": "eager" if args.no_graph else "hipGraph replay", "rois": n_rois, "detections": n_det,
+                       "gflop_per_image": round(flops_per_image / 1e9, 2)},
+        }
+        if conv_launches:
+            ach = conv_flops / (conv_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "kernel": "k_conv_igemm (f32 MFMA 32x32x2 implicit GEMM, all tile shapes)",
+                               "launches_per_image": conv_launches // args.profile_steps,
+                               "avg_launch_us": round(1000.0 * conv_ms / conv_launches, 2),
+                               "conv_ms_per_image": round(conv_ms / args.profile_steps, 3),
+                               "whole_image_frac_of_mfma_roofline": round(flops_per_image * value / world / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sess.variables, image, None)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

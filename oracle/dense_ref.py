@@ -1,0 +1,129 @@
+"""TEST INFRASTRUCTURE ONLY -- torch-CPU restatement of the dense (TensorFlow/slim) part of the
+reference graph for ResNet-v1 Faster R-CNN.  PARITY UNPINNED for these ops: TensorFlow r1.2 +
+tf.contrib.slim (README.md:56; pip-unpinned in docker/Dockerfile.cuda-8.0) is a third-party
+dependency that is neither vendored in /root/reference nor installable here, and the reference has
+no test that pins its arithmetic.  This file restates the published semantics of the
+call sites:
+
+  lib/nets/resnet_v1.py:80-86   conv1 = conv2d_same(64,7,stride 2) + BN + ReLU, pad 1, 3x3/2 VALID pool
+  lib/nets/resnet_v1.py:88-125  blocks 1-3 (head, block3 stride 1), block4 per RoI + reduce_mean
+  slim bottleneck_v1            shortcut 1x1 conv(BN, no act) if depth changes else subsample;
+                                conv1 1x1 -> conv2 3x3 conv2d_same(stride) -> conv3 1x1 (no act); relu(sum)
+  slim batch_norm (frozen)      gamma * (x - moving_mean) / sqrt(moving_variance + 1e-5) + beta
+  lib/nets/network.py:323-378   RPN 3x3 (SAME, bias, ReLU), 1x1 heads, pair softmax; fc cls/bbox heads
+  lib/nets/network.py:428-432   test-time bbox_pred * stds + means
+
+It is the reference for the HIP dense kernels (float64 mode) and the host-CPU baseline that
+bench.py times (float32 mode, all cores): used ONLY by tests/, smoke() and bench.py's cpu_baseline.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import frcnn_oracle as ora
+
+UNITS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+
+def _t(a, dtype):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
+
+
+class DenseRef(object):
+    def __init__(self, variables, num_layers=101, num_classes=21, anchor_scales=(8, 16, 32), anchor_ratios=(0.5, 1, 2),
+                 dtype=torch.float64):
+        self.v = variables
+        self.scope = "resnet_v1_%d" % num_layers
+        u = UNITS[num_layers]
+        self.blocks = [("block1", 64, u[0], 2), ("block2", 128, u[1], 2), ("block3", 256, u[2], 1), ("block4", 512, u[3], 1)]
+        self.C = num_classes
+        self.scales, self.ratios = tuple(anchor_scales), tuple(anchor_ratios)
+        self.A = len(anchor_scales) * len(anchor_ratios)
+        self.dtype = dtype
+        self._cache = {}
+
+    # weights as torch OIHW, cached
+    def w(self, name):
+        if name not in self._cache:
+            a = self.v[name]
+            if a.ndim == 4:
+                a = np.transpose(a, (3, 2, 0, 1))
+            self._cache[name] = _t(a, self.dtype)
+        return self._cache[name]
+
+    def conv_same(self, x, scope, k, stride):
+        """slim conv2d SAME for stride 1; resnet_utils.conv2d_same (explicit pad + VALID) otherwise."""
+        total = k - 1
+        beg = total // 2
+        x = F.pad(x, (beg, total - beg, beg, total - beg))
+        return F.conv2d(x, self.w(scope + "/weights"), stride=stride)
+
+    def bn(self, x, scope, eps=1e-5):
+        g, b = self.w(scope + "/BatchNorm/gamma"), self.w(scope + "/BatchNorm/beta")
+        m, var = self.w(scope + "/BatchNorm/moving_mean"), self.w(scope + "/BatchNorm/moving_variance")
+        return (x - m[None, :, None, None]) * (g / torch.sqrt(var + eps))[None, :, None, None] + b[None, :, None, None]
+
+    def bottleneck(self, x, p, base, stride):
+        depth = base * 4
+        if x.shape[1] != depth:
+            sc = self.bn(F.conv2d(x, self.w(p + "/shortcut/weights"), stride=stride), p + "/shortcut")
+        else:
+            sc = x if stride == 1 else x[:, :, ::stride, ::stride]          # slim subsample (1x1 max pool, stride)
+        r = F.relu(self.bn(F.conv2d(x, self.w(p + "/conv1/weights")), p + "/conv1"))
+        r = F.relu(self.bn(self.conv_same(r, p + "/conv2", 3, stride), p + "/conv2"))
+        r = self.bn(F.conv2d(r, self.w(p + "/conv3/weights")), p + "/conv3")
+        return F.relu(sc + r)
+
+    def run_blocks(self, x, blocks):
+        for name, base, n, stride in blocks:
+            for u in range(1, n + 1):
+                x = self.bottleneck(x, "%s/%s/unit_%d/bottleneck_v1" % (self.scope, name, u), base, stride if u == n else 1)
+        return x
+
+    def head(self, image_nhwc):
+        x = _t(image_nhwc, self.dtype).permute(0, 3, 1, 2)
+        x = F.relu(self.bn(self.conv_same(x, self.scope + "/conv1", 7, 2), self.scope + "/conv1"))
+        x = F.max_pool2d(F.pad(x, (1, 1, 1, 1)), 3, 2)
+        return self.run_blocks(x, self.blocks[:3])                            # NCHW
+
+    def rpn(self, feat):
+        s = self.scope
+        r = F.relu(F.conv2d(feat, self.w(s + "/rpn_conv/3x3/weights"), self.w(s + "/rpn_conv/3x3/biases"), padding=1))
+        score = F.conv2d(r, self.w(s + "/rpn_cls_score/weights"), self.w(s + "/rpn_cls_score/biases"))
+        bbox = F.conv2d(r, self.w(s + "/rpn_bbox_pred/weights"), self.w(s + "/rpn_bbox_pred/biases"))
+        A = self.A
+        pair = torch.softmax(torch.stack([score[:, :A], score[:, A:]]), dim=0)  # channels (a, A+a) (network.py:68-86)
+        prob = torch.cat([pair[0], pair[1]], dim=1)
+        to_nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().numpy()
+        return to_nhwc(score), to_nhwc(prob), to_nhwc(bbox)
+
+    def tail(self, pool5_nhwc):
+        x = _t(pool5_nhwc, self.dtype).permute(0, 3, 1, 2)
+        return self.run_blocks(x, self.blocks[3:]).mean(dim=(2, 3))           # fc7 [R, 2048]
+
+    def classify(self, fc7, test_mode=True):
+        s = self.scope
+        cls_score = fc7 @ self.w(s + "/cls_score/weights") + self.w(s + "/cls_score/biases")
+        cls_prob = torch.softmax(cls_score, dim=1)
+        bbox = fc7 @ self.w(s + "/bbox_pred/weights") + self.w(s + "/bbox_pred/biases")
+        if test_mode:
+            bbox = bbox * _t(np.tile((0.1, 0.1, 0.2, 0.2), self.C), self.dtype) + _t(np.tile((0.0,) * 4, self.C), self.dtype)
+        return cls_score.numpy(), cls_prob.numpy(), bbox.numpy()
+
+    def test_image(self, image_nhwc, im_info, rois=None, pre=6000, post=300, thr=0.7, pool=7):
+        """Full reference forward (network.py:233-262, TEST, MODE nms).  If `rois` is given the RoI
+        stage uses THEM (so a tail comparison is not confounded by a proposal that flipped on a
+        1e-7 score difference)."""
+        feat = self.head(image_nhwc)
+        score, prob, bbox = self.rpn(feat)
+        H, W = feat.shape[2], feat.shape[3]
+        if rois is None:
+            anchors, _ = ora.generate_anchors_pre(H, W, 16, self.scales, self.ratios)
+            rois, _ = ora.proposal_layer(prob.astype(np.float32), bbox.astype(np.float32), np.asarray(im_info, dtype=np.float32),
+                                         "TEST", [16], anchors, self.A, pre_nms_topN=pre, post_nms_topN=post, nms_thresh=thr)
+        feat_nhwc = feat.permute(0, 2, 3, 1).contiguous().numpy()
+        pool5 = ora.crop_and_resize(feat_nhwc[0].astype(np.float32), rois.astype(np.float32), 16.0, pool)
+        fc7 = self.tail(pool5)
+        cls_score, cls_prob, bbox_pred = self.classify(fc7)
+        return dict(head=feat_nhwc, rpn_cls_score=score, rpn_cls_prob=prob, rpn_bbox_pred=bbox, rois=rois, pool5=pool5,
+                    fc7=fc7.numpy(), cls_score=cls_score, cls_prob=cls_prob, bbox_pred=bbox_pred)

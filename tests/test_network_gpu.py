@@ -1,0 +1,104 @@
+"""GPU end-to-end parity of the re-hosted Network (ResNet-v1 Faster R-CNN, TEST mode) against the
+oracle: dense part vs the torch-CPU float64 restatement (1e-4, BASELINE.json), detection stages vs
+the pinned numpy/C oracle on identical inputs (bit-exact keep sets)."""
+import numpy as np
+import pytest
+import torch
+
+import frcnn_oracle as ora
+from dense_ref import DenseRef
+
+pytestmark = pytest.mark.gpu
+SCALES, RATIOS = (4, 8, 16), (0.5, 1, 2)
+
+
+@pytest.fixture(scope="module")
+def small_net(dev):
+    from frcnn_hip.runtime import Session
+    from model.config import cfg
+    from nets.resnet_v1 import resnetv1
+    cfg.TEST.RPN_POST_NMS_TOP_N = 48
+    sess = Session(device=dev, seed=3)
+    net = resnetv1(num_layers=50)
+    net.create_architecture("TEST", 21, tag="default", anchor_scales=SCALES, anchor_ratios=RATIOS)
+    sess.init_variables(net.variable_specs())
+    for k in list(sess.variables):
+        if ("/rpn_" in k or "cls_score" in k or "bbox_pred" in k) and k.endswith("weights"):
+            sess.variables[k] *= 5.0            # well separated scores: no near-ties at the decision boundaries
+    rng = np.random.RandomState(5)
+    H, W = 150, 200                              # odd intermediate sizes: 75x100 -> 38x50 -> 19x25 -> 10x13
+    image = (rng.rand(1, H, W, 3) * 255.0).astype(np.float32) - cfg.PIXEL_MEANS.astype(np.float32)
+    im_info = np.array([H, W, 1.0], dtype=np.float32)
+    yield sess, net, image, im_info
+    cfg.TEST.RPN_POST_NMS_TOP_N = 300
+    cfg.TEST.MODE = "nms"
+
+
+def rel_err(got, want):
+    return float(np.abs(got - want).max()) / max(1.0, float(np.abs(want).max()))
+
+
+def test_test_image_matches_dense_oracle(small_net):
+    sess, net, image, im_info = small_net
+    cls_score, cls_prob, bbox_pred, rois = net.test_image(sess, image, im_info)
+    assert rois.shape[1] == 5 and 0 < rois.shape[0] <= 48 and cls_prob.shape == (rois.shape[0], 21)
+    ref = DenseRef(sess.variables, 50, 21, SCALES, RATIOS).test_image(image, im_info, rois=rois, post=48)
+    head = net._layers["head"].cpu().numpy()
+    assert head.shape == ref["head"].shape == (1, 10, 13, 1024)
+    assert rel_err(head, ref["head"]) <= 1e-4
+    for name in ("rpn_cls_score", "rpn_cls_prob", "rpn_bbox_pred"):
+        assert rel_err(net._predictions[name].cpu().numpy(), ref[name]) <= 1e-4, name
+    n = rois.shape[0]
+    assert np.array_equal(net._layers["pool5"][:n].cpu().numpy(), ora.crop_and_resize(head[0], rois, 16.0, 7))
+    assert rel_err(net._layers["fc7"][:n].cpu().numpy(), ref["fc7"]) <= 1e-4
+    assert rel_err(cls_score, ref["cls_score"]) <= 1e-4
+    assert np.abs(cls_prob - ref["cls_prob"]).max() <= 1e-4
+    assert np.abs(bbox_pred - ref["bbox_pred"]).max() <= 1e-4
+    assert abs(cls_prob.sum(axis=1) - 1).max() < 1e-5
+
+
+def test_proposals_match_oracle_on_identical_rpn_outputs(small_net):
+    sess, net, image, im_info = small_net
+    _, _, _, rois = net.test_image(sess, image, im_info)
+    prob = net._predictions["rpn_cls_prob"].cpu().numpy()
+    dl = net._predictions["rpn_bbox_pred"].cpu().numpy()
+    anchors, _ = ora.generate_anchors_pre(prob.shape[1], prob.shape[2], 16, SCALES, RATIOS)
+    want, _ = ora.proposal_layer(prob, dl, im_info, "TEST", [16], anchors, 9, post_nms_topN=48)
+    assert want.shape == rois.shape and np.allclose(rois, want, rtol=0, atol=1e-3)
+
+
+def test_graph_replay_is_deterministic_and_device_post_matches(small_net):
+    sess, net, image, im_info = small_net
+    a = net.test_image(sess, image, im_info)
+    b = net.test_image(sess, image, im_info)             # second call = pure hipGraph replay
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    img_d = net._stage_image(sess, image)
+    dets, cnt = net.detect_device(sess, img_d, im_info, (150, 200))
+    n = int(cnt.item())
+    sc, boxes = ora.im_detect_post(a[1], a[2], a[3], 1.0, (150, 200, 3))
+    want = ora.detections_to_records(ora.test_net_post(sc, boxes, 21))
+    got = dets[:n].cpu().numpy()
+    assert n == want.shape[0] > 0
+    assert np.array_equal(got[:, 4:], want[:, 4:]) and np.allclose(got[:, :4], want[:, :4], rtol=0, atol=1e-3)
+
+
+def test_eager_equals_graph_and_top_mode(small_net):
+    from model.config import cfg
+    sess, net, image, im_info = small_net
+    g = net.test_image(sess, image, im_info)
+    img_d = net._stage_image(sess, image)
+    p = net.forward_device(sess, img_d, im_info, use_graph=False)
+    n = int(net._num_rois.item())
+    assert np.array_equal(p["cls_prob"][:n].cpu().numpy(), g[1])
+    cfg.TEST.MODE, cfg.TEST.RPN_TOP_N = "top", 200
+    try:
+        _, cls_prob, _, rois = net.test_image(sess, image, im_info)
+        assert rois.shape == (200, 5) and cls_prob.shape == (200, 21)
+        prob = net._predictions["rpn_cls_prob"].cpu().numpy()
+        dl = net._predictions["rpn_bbox_pred"].cpu().numpy()
+        anchors, _ = ora.generate_anchors_pre(prob.shape[1], prob.shape[2], 16, SCALES, RATIOS)
+        want, _ = ora.proposal_top_layer(prob, dl, im_info, [16], anchors, 9, rpn_top_n=200)
+        assert np.allclose(rois, want, rtol=0, atol=1e-3)
+    finally:
+        cfg.TEST.MODE, cfg.TEST.RPN_TOP_N = "nms", 5000

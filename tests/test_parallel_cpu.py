@@ -1,0 +1,58 @@
+"""CPU, world_size 2, gloo: the N>1 path of bench.py -- image sharding + the single all-gather of
+fixed-size detection records (frcnn_hip/parallel.py)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tf-faster-rcnn_amd"))
+    from frcnn_hip import parallel
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = parallel.shard_images(5, rank, world)
+        rng = np.random.RandomState(100 + rank)
+        n = 3 + 4 * rank
+        dets = rng.rand(n, 6).astype(np.float32)
+        rec, view = parallel.new_record("cpu")
+        view[:n] = torch.from_numpy(dets)
+        parallel.set_count(rec, torch.tensor([n], dtype=torch.int32))
+        out = parallel.unpack_records(parallel.all_gather_records(rec))
+        q.put((rank, mine, [o.tolist() for o in out], dets.tolist()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_gather_detection_records_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 2, 4] and res[1][1] == [1, 3]          # image i -> rank i % world
+    sent = [res[0][3], res[1][3]]
+    for rank, _, gathered, _ in res:                                 # every rank holds every rank's detections
+        assert len(gathered) == 2
+        for r in range(2):
+            assert np.array_equal(np.array(gathered[r], dtype=np.float32), np.array(sent[r], dtype=np.float32))

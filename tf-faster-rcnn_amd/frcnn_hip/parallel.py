@@ -1,0 +1,51 @@
+"""Data-parallel inference: one process per GPU, one image per rank, and ONE collective per batch --
+an all-gather of a fixed-size padded detection record (new relative to the reference,
+which is strictly single-GPU / batch-1: lib/model/test.py:88).
+
+Record layout (float32, REC_FLOATS long): rows [0, REC_ROWS) = (x1,y1,x2,y2,score,class) padded with
+zeros, then the detection count as a float32 (exact below 2**24), then padding to a 32-byte multiple.
+The same code runs over RCCL/xGMI (backend "nccl", GPU tensors) and over gloo (CPU tensors, tests).
+"""
+import torch
+
+REC_ROWS = 128
+REC_FLOATS = REC_ROWS * 6 + 8
+
+
+def new_record(device):
+    rec = torch.zeros((REC_FLOATS,), dtype=torch.float32, device=device)
+    return rec, rec[:REC_ROWS * 6].view(REC_ROWS, 6)
+
+
+def set_count(rec, count_i32):
+    """count_i32: int32 tensor [1] on the same device (written by frcnn_detect_post)."""
+    rec[REC_ROWS * 6] = count_i32[0].to(torch.float32)
+
+
+def shard_images(num_images, rank, world):
+    """Image i goes to rank i % world (weights replicated, nothing couples two images)."""
+    return list(range(rank, num_images, world))
+
+
+def all_gather_records(rec, gathered=None, group=None):
+    """-> tensor [world, REC_FLOATS]; one all_gather_into_tensor call (latency bound, 3 KB/rank)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if gathered is None:
+        gathered = torch.empty((world, REC_FLOATS), dtype=torch.float32, device=rec.device)
+    if dist.get_backend(group) == "gloo":
+        parts = list(gathered.unbind(0))
+        dist.all_gather(parts, rec, group=group)
+    else:
+        dist.all_gather_into_tensor(gathered, rec, group=group)
+    return gathered
+
+
+def unpack_records(gathered):
+    """-> list over ranks of float32 [n_i, 6] detection arrays (host)."""
+    g = gathered.detach().cpu()
+    out = []
+    for r in range(g.shape[0]):
+        n = min(int(g[r, REC_ROWS * 6].item()), REC_ROWS)
+        out.append(g[r, :REC_ROWS * 6].view(REC_ROWS, 6)[:n].clone().numpy())
+    return out

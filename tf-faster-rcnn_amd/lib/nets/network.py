@@ -1,0 +1,281 @@
+"""Network -- the Faster R-CNN graph of the reference (lib/nets/network.py), re-hosted on
+libfrcnn_hip.so.  No TensorFlow: `sess` is a frcnn_hip.runtime.Session (device + stream + weights),
+`create_architecture` declares the variables (TF/slim names and layouts), and one call of
+`test_image` runs image -> backbone -> RPN -> proposals -> RoI crop -> tail -> cls/bbox entirely
+on the GPU -- the py_func host hops of network.py:100-126 and the per-image sess.run (:470-479)
+are gone; the chain is captured once per image shape into a hipGraph and replayed.
+
+Public surface kept from the reference (file:line = /root/reference/lib/nets/network.py):
+  create_architecture (386), test_image (470), extract_head (464), hooks _image_to_head /
+  _head_to_tail (380-384), _anchor_component (210), _region_proposal (323), _crop_pool_layer (141),
+  _region_classification (361), self._predictions keys (348-353, 373-376).
+"""
+import collections
+
+import numpy as np
+import torch
+
+from frcnn_hip import ACT_NONE, ACT_RELU, ops
+from frcnn_hip.runtime import VarSpec
+from model.config import cfg
+
+
+class Network(object):
+    def __init__(self):
+        self._predictions = {}
+        self._losses = {}
+        self._anchor_targets = {}
+        self._proposal_targets = {}
+        self._layers = {}
+        self._gt_image = None
+        self._act_summaries = []
+        self._score_summaries = {}
+        self._train_summaries = []
+        self._event_summaries = {}
+        self._variables_to_fix = {}
+        self._feat_stride = [16, ]
+        self._scope = "network"
+        self._sess = None
+        self._image = None
+        self._im_info = None
+        self._var_specs = collections.OrderedDict()
+
+    # ------------------------------------------------------------------ variable declaration
+    def _var(self, name, shape, init, arg=None):
+        self._var_specs[name] = VarSpec(shape, init, arg)
+
+    def _declare_conv_bn(self, scope, kh, kw, cin, cout):
+        self._var(scope + "/weights", (kh, kw, cin, cout), "he")
+        self._var(scope + "/BatchNorm/gamma", (cout,), "bn_gamma")
+        self._var(scope + "/BatchNorm/beta", (cout,), "bn_beta")
+        self._var(scope + "/BatchNorm/moving_mean", (cout,), "bn_mean")
+        self._var(scope + "/BatchNorm/moving_variance", (cout,), "bn_var")
+
+    def _declare_conv_bias(self, scope, kh, kw, cin, cout, std):
+        self._var(scope + "/weights", (kh, kw, cin, cout), "normal", std)
+        self._var(scope + "/biases", (cout,), "zeros")
+
+    def _declare_backbone(self):
+        raise NotImplementedError
+
+    def _head_channels(self):
+        raise NotImplementedError
+
+    def _tail_channels(self):
+        raise NotImplementedError
+
+    def variable_specs(self):
+        return self._var_specs
+
+    # ------------------------------------------------------------------ building blocks
+    def _conv(self, x, scope, k, stride=1, pad=(0, 0, 0, 0), act=ACT_RELU, bn_eps=None, residual=None,
+              res_stride=1, fold_w=False, out_affine=None, real_cin=None):
+        sess = self._sess
+        w, b = sess.conv_params(scope, bn_eps=bn_eps, fold_w=fold_w,
+                                out_scale=None if out_affine is None else out_affine[0],
+                                out_shift=None if out_affine is None else out_affine[1])
+        N, H, W, Cin = x.shape
+        OH = ops.conv_out_size(H, k, stride, pad[0], pad[1])
+        OW = ops.conv_out_size(W, k, stride, pad[2], pad[3])
+        Cout = w.shape[0]
+        out = sess.buf(self._tag + "/" + scope, (N, OH, OW, Cout))
+        flops = 2 * N * OH * OW * Cout * k * k * (Cin if real_cin is None else real_cin)
+        sess.mark("conv:" + scope, flops,
+                  lambda: ops.conv2d(x, w, b, k, k, stride, pad, act, residual, res_stride, fold_w, out=out))
+        return out
+
+    def _reshape_layer(self, bottom, num_dim, name):
+        raise NotImplementedError("folded into frcnn_rpn_softmax (network.py:68-78 only served the pair softmax)")
+
+    def _softmax_layer(self, bottom, name):
+        if name.startswith("rpn_cls_prob"):
+            A = self._num_anchors
+            return ops.rpn_softmax(bottom, A, out=self._sess.buf(self._tag + "/" + name, bottom.shape[:3] + (2 * A,)))
+        return ops.softmax_rows(bottom, out=self._sess.buf(self._tag + "/" + name, bottom.shape))
+
+    # ------------------------------------------------------------------ graph pieces (same names as the reference)
+    def _anchor_component(self):
+        # network.py:210-231: feature-map size from im_info; anchors are regenerated in-kernel by the
+        # proposal layer, so only the float64 base anchors [A,4] live on the device.
+        h = int(np.ceil(self._im_info[0] / np.float32(self._feat_stride[0])))
+        w = int(np.ceil(self._im_info[1] / np.float32(self._feat_stride[0])))
+        base = ops.generate_anchors(16, self._anchor_ratios, self._anchor_scales)
+        key = ("base_anchors", tuple(self._anchor_ratios), tuple(self._anchor_scales))
+        if key not in self._sess.packed:
+            self._sess.packed[key] = self._sess.to_device(base, torch.float64)
+        self._base_anchors = self._sess.packed[key]
+        self._anchor_length = h * w * self._num_anchors
+        self._anchors = None      # materialise on demand with ops.generate_anchors_pre
+
+    def _proposal_layer(self, rpn_cls_prob, rpn_bbox_pred, name):
+        c = cfg[self._mode]
+        post = int(c.RPN_POST_NMS_TOP_N)
+        s = self._sess
+        rois, scores, num = ops.proposal_layer(
+            rpn_cls_prob, rpn_bbox_pred, self._im_info[0], self._im_info[1], self._feat_stride[0], self._base_anchors,
+            int(c.RPN_PRE_NMS_TOP_N), post, float(c.RPN_NMS_THRESH),
+            rois=s.buf(self._tag + "/rois", (post, 5)), scores=s.buf(self._tag + "/roi_scores", (post, 1)),
+            num=s.buf(self._tag + "/num_rois", (1,), torch.int32))
+        self._num_rois = num
+        return rois, scores
+
+    def _proposal_top_layer(self, rpn_cls_prob, rpn_bbox_pred, name):
+        rois, scores = ops.proposal_top_layer(rpn_cls_prob, rpn_bbox_pred, self._im_info[0], self._im_info[1],
+                                              self._feat_stride[0], self._base_anchors, int(cfg.TEST.RPN_TOP_N))
+        self._num_rois = None
+        return rois, scores
+
+    def _crop_pool_layer(self, bottom, rois, name):
+        # network.py:141-157: 14x14 crop + 2x2 max pool (fused in the kernel)
+        return ops.crop_and_resize(bottom, rois, float(self._feat_stride[0]), cfg.POOLING_SIZE, max_pool=True,
+                                   out=self._sess.buf(self._tag + "/" + name, (rois.shape[0], cfg.POOLING_SIZE, cfg.POOLING_SIZE, bottom.shape[-1])))
+
+    def _region_proposal(self, net_conv, is_training, initializer=None):
+        A = self._num_anchors
+        rpn = self._conv(net_conv, self._scope + "/rpn_conv/3x3", 3, 1, (1, 1, 1, 1), ACT_RELU)          # :324-325
+        self._act_summaries.append(rpn)
+        rpn_cls_score = self._conv(rpn, self._scope + "/rpn_cls_score", 1, act=ACT_NONE)                   # :327-329
+        rpn_cls_prob = self._softmax_layer(rpn_cls_score, "rpn_cls_prob")                                   # :331-334
+        rpn_bbox_pred = self._conv(rpn, self._scope + "/rpn_bbox_pred", 1, act=ACT_NONE)                   # :335-337
+        if is_training:
+            raise NotImplementedError("TRAIN branch (anchor/proposal targets, network.py:338-343): SURVEY.md 8a rows 14-17, next rounds")
+        if cfg.TEST.MODE == "nms":
+            rois, _ = self._proposal_layer(rpn_cls_prob, rpn_bbox_pred, "rois")
+        elif cfg.TEST.MODE == "top":
+            rois, _ = self._proposal_top_layer(rpn_cls_prob, rpn_bbox_pred, "rois")
+        else:
+            raise NotImplementedError
+        self._predictions["rpn_cls_score"] = rpn_cls_score
+        self._predictions["rpn_cls_prob"] = rpn_cls_prob
+        self._predictions["rpn_bbox_pred"] = rpn_bbox_pred
+        self._predictions["rois"] = rois
+        return rois
+
+    def _region_classification(self, fc7, is_training, initializer=None, initializer_bbox=None):
+        R = fc7.shape[0]
+        x = fc7.view(1, 1, R, fc7.shape[1])
+        cls_score = self._conv(x, self._scope + "/cls_score", 1, act=ACT_NONE).view(R, self._num_classes)   # :362-366
+        cls_prob = self._softmax_layer(cls_score, "cls_prob")
+        affine = None
+        if self._mode == "TEST":      # network.py:428-432: bbox_pred * stds + means, folded into the fc
+            affine = (np.tile(np.array(cfg.TRAIN.BBOX_NORMALIZE_STDS), self._num_classes),
+                      np.tile(np.array(cfg.TRAIN.BBOX_NORMALIZE_MEANS), self._num_classes))
+        bbox_pred = self._conv(x, self._scope + "/bbox_pred", 1, act=ACT_NONE, out_affine=affine).view(R, 4 * self._num_classes)
+        self._predictions["cls_score"] = cls_score
+        self._predictions["cls_prob"] = cls_prob
+        self._predictions["bbox_pred"] = bbox_pred
+        return cls_prob, bbox_pred
+
+    def _image_to_head(self, is_training, reuse=None):
+        raise NotImplementedError
+
+    def _head_to_tail(self, pool5, is_training, reuse=None):
+        raise NotImplementedError
+
+    def _build_network(self, is_training=True):
+        net_conv = self._image_to_head(is_training)
+        self._anchor_component()
+        rois = self._region_proposal(net_conv, is_training)
+        if cfg.POOLING_MODE == "crop":
+            pool5 = self._crop_pool_layer(net_conv, rois, "pool5")
+        else:
+            raise NotImplementedError
+        self._layers["pool5"] = pool5
+        fc7 = self._head_to_tail(pool5, is_training)
+        self._layers["fc7"] = fc7
+        cls_prob, bbox_pred = self._region_classification(fc7, is_training)
+        return rois, cls_prob, bbox_pred
+
+    def create_architecture(self, mode, num_classes, tag=None, anchor_scales=(8, 16, 32), anchor_ratios=(0.5, 1, 2)):
+        assert tag is not None
+        self._tag = tag
+        self._num_classes = num_classes
+        self._mode = mode
+        self._anchor_scales = tuple(anchor_scales)
+        self._num_scales = len(anchor_scales)
+        self._anchor_ratios = tuple(anchor_ratios)
+        self._num_ratios = len(anchor_ratios)
+        self._num_anchors = self._num_scales * self._num_ratios
+        A = self._num_anchors
+        self._var_specs.clear()
+        self._declare_backbone()
+        hc = self._head_channels()
+        self._declare_conv_bias(self._scope + "/rpn_conv/3x3", 3, 3, hc, cfg.RPN_CHANNELS, 0.01)           # :239-240,324
+        self._declare_conv_bias(self._scope + "/rpn_cls_score", 1, 1, cfg.RPN_CHANNELS, 2 * A, 0.01)
+        self._declare_conv_bias(self._scope + "/rpn_bbox_pred", 1, 1, cfg.RPN_CHANNELS, 4 * A, 0.01)
+        tc = self._tail_channels()
+        self._var(self._scope + "/cls_score/weights", (tc, num_classes), "normal", 0.01)
+        self._var(self._scope + "/cls_score/biases", (num_classes,), "zeros")
+        self._var(self._scope + "/bbox_pred/weights", (tc, 4 * num_classes), "normal", 0.001)
+        self._var(self._scope + "/bbox_pred/biases", (4 * num_classes,), "zeros")
+        names = ["rois", "rpn_cls_score", "rpn_cls_prob", "rpn_bbox_pred", "cls_score", "cls_prob", "bbox_pred"]
+        return {k: k for k in names}
+
+    def get_variables_to_restore(self, variables, var_keep_dic):
+        raise NotImplementedError
+
+    def fix_variables(self, sess, pretrained_model):
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ execution
+    def _stage_image(self, sess, image):
+        """[1,H,W,3] (BGR - PIXEL_MEANS, like blobs['data']) -> static device buffer [1,H,W,4]; the
+        zero 4th channel lets the 7x7/3x3 stem run as a channel-folded MFMA GEMM."""
+        if isinstance(image, np.ndarray):
+            image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32))
+        _, H, W, C = image.shape
+        buf = sess.buf(self._tag + "/image", (1, H, W, 4), zero=True)
+        buf[..., :C].copy_(image, non_blocking=True)
+        return buf
+
+    def forward_device(self, sess, image_d, im_info, use_graph=True):
+        """Runs the network on a staged device image; fills self._predictions with DEVICE tensors.
+        The whole chain is captured into one hipGraph per (tag, image shape) and replayed."""
+        self._sess = sess
+        self._image = image_d
+        self._im_info = (float(im_info[0]), float(im_info[1]), float(im_info[2]))
+        key = (self._tag, tuple(image_d.shape), self._im_info[:2], self._mode, cfg.TEST.MODE)
+        cur = torch.cuda.current_stream(sess.device)
+        if not use_graph or sess.profile is not None:
+            sess.flops_last_forward = 0
+            self._build_network(self._mode == "TRAIN")
+            return self._predictions
+        if key not in sess.graphs:
+            with torch.cuda.stream(sess.stream):
+                sess.stream.wait_stream(cur)
+                sess.flops_last_forward = 0
+                self._build_network(False)                   # warm-up: allocates buffers, packs weights
+                sess.stream.synchronize()
+                flops = sess.flops_last_forward
+                g = ops.Graph().capture(lambda: self._build_network(False))
+                sess.stream.synchronize()
+            sess.graphs[key] = (g, dict(self._predictions), self._num_rois, flops)
+        g, preds, num, flops = sess.graphs[key]
+        self._predictions, self._num_rois, sess.flops_last_forward = dict(preds), num, flops
+        g.launch()
+        return self._predictions
+
+    # only useful during testing mode
+    def extract_head(self, sess, image):
+        self._sess = sess
+        self._image = self._stage_image(sess, image)
+        feat = self._image_to_head(False)
+        return feat.cpu().numpy()
+
+    # only useful during testing mode
+    def test_image(self, sess, image, im_info):
+        """network.py:470-479: returns cls_score, cls_prob, bbox_pred, rois as numpy arrays (rows of
+        the `num_rois` proposals that survived NMS)."""
+        img = self._stage_image(sess, image)
+        p = self.forward_device(sess, img, im_info)
+        n = p["rois"].shape[0] if self._num_rois is None else int(self._num_rois.item())
+        return (p["cls_score"][:n].cpu().numpy(), p["cls_prob"][:n].cpu().numpy(), p["bbox_pred"][:n].cpu().numpy(),
+                p["rois"][:n].cpu().numpy())
+
+    def detect_device(self, sess, image_d, im_info, im_shape, max_per_image=100, thresh=0.0, out=None, count=None):
+        """image (already in HBM) -> final detections in HBM: forward + the whole of
+        lib/model/test.py:95-102,162-180 on device.  Returns (dets [max_out,6], count [1])."""
+        p = self.forward_device(sess, image_d, im_info)
+        return ops.detect_post(p["cls_prob"], p["bbox_pred"], p["rois"], self._num_rois, float(im_info[2]),
+                               int(im_shape[0]), int(im_shape[1]), float(cfg.TEST.NMS), float(thresh), int(max_per_image),
+                               out=out, count=count)

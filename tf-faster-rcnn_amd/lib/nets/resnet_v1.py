@@ -1,0 +1,115 @@
+"""resnetv1 -- ResNet-50/101/152 Faster R-CNN backbone of the reference (lib/nets/resnet_v1.py) on
+libfrcnn_hip.so: every convolution is an implicit-GEMM launch on the f32 MFMA pipe with the frozen
+batch norm (resnet_v1.py:22-44: is_training False, trainable False) folded into filter + bias, and
+ReLU / residual add / `subsample` shortcut fused into the epilogue.
+
+slim semantics restated (third-party):
+  * conv1 = resnet_utils.conv2d_same(64, 7, stride 2) (pad 3/3 then VALID), pad 1 + 3x3/2 VALID pool
+    (resnet_v1.py:80-86);
+  * bottleneck_v1: shortcut = 1x1 conv (BN, no activation) when depth changes, else
+    subsample(inputs, stride) (= every stride-th pixel); conv1 1x1 -> conv2 3x3 conv2d_same(stride)
+    -> conv3 1x1 (BN, no activation); out = relu(shortcut + residual);
+  * resnet_v1_block: the stride sits on the LAST unit of a block;
+  * blocks 1-3 form the stride-16 head (block3 stride 1), block4 (stride 1) runs per RoI on the
+    7x7 crops followed by a spatial mean (resnet_v1.py:88-125).
+"""
+from frcnn_hip import ACT_NONE, ACT_RELU, ops
+from model.config import cfg
+from nets.network import Network
+
+BN_EPS = 1e-5      # resnet_v1.py:24
+
+
+def _same_pad(k, stride):
+    """resnet_utils.conv2d_same: stride 1 -> 'SAME'; stride > 1 -> explicit pad (k-1)//2, rest."""
+    total = k - 1
+    beg = total // 2
+    return (beg, total - beg, beg, total - beg)
+
+
+class resnetv1(Network):
+    def __init__(self, num_layers=50):
+        Network.__init__(self)
+        self._feat_stride = [16, ]
+        self._feat_compress = [1. / float(self._feat_stride[0]), ]
+        self._num_layers = num_layers
+        self._scope = 'resnet_v1_%d' % num_layers
+        self._decide_blocks()
+
+    def _decide_blocks(self):
+        # (name, base_depth, num_units, stride)  (resnet_v1.py:127-152)
+        units = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}.get(self._num_layers)
+        if units is None:
+            raise NotImplementedError
+        self._blocks = [("block1", 64, units[0], 2), ("block2", 128, units[1], 2),
+                        ("block3", 256, units[2], 1),          # stride 1 for the last conv4 layer
+                        ("block4", 512, units[3], 1)]
+
+    # ---- variables (slim names) ------------------------------------------------------------------
+    def _declare_backbone(self):
+        s = self._scope
+        self._declare_conv_bn(s + "/conv1", 7, 7, 3, 64)
+        cin = 64
+        for name, base, n_units, _ in self._blocks:
+            depth = base * 4
+            for u in range(1, n_units + 1):
+                p = "%s/%s/unit_%d/bottleneck_v1" % (s, name, u)
+                if cin != depth:
+                    self._declare_conv_bn(p + "/shortcut", 1, 1, cin, depth)
+                self._declare_conv_bn(p + "/conv1", 1, 1, cin, base)
+                self._declare_conv_bn(p + "/conv2", 3, 3, base, base)
+                self._declare_conv_bn(p + "/conv3", 1, 1, base, depth)
+                cin = depth
+
+    def _head_channels(self):
+        return self._blocks[2][1] * 4
+
+    def _tail_channels(self):
+        return self._blocks[3][1] * 4
+
+    # ---- graph -----------------------------------------------------------------------------------
+    def _bottleneck(self, x, prefix, base, stride):
+        depth = base * 4
+        cin = x.shape[-1]
+        if cin != depth:
+            shortcut = self._conv(x, prefix + "/shortcut", 1, stride, act=ACT_NONE, bn_eps=BN_EPS)
+            res_stride = 1
+        else:
+            shortcut, res_stride = x, stride                # slim `subsample`: fused into conv3's epilogue
+        r = self._conv(x, prefix + "/conv1", 1, 1, act=ACT_RELU, bn_eps=BN_EPS)
+        pad = (1, 1, 1, 1) if stride == 1 else _same_pad(3, stride)
+        r = self._conv(r, prefix + "/conv2", 3, stride, pad, act=ACT_RELU, bn_eps=BN_EPS)
+        return self._conv(r, prefix + "/conv3", 1, 1, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut, res_stride=res_stride)
+
+    def _run_blocks(self, x, blocks):
+        for name, base, n_units, stride in blocks:
+            for u in range(1, n_units + 1):
+                x = self._bottleneck(x, "%s/%s/unit_%d/bottleneck_v1" % (self._scope, name, u), base,
+                                     stride if u == n_units else 1)
+        return x
+
+    def _crop_pool_layer(self, bottom, rois, name):
+        # resnet_v1.py:55-76: direct 7x7 crop unless RESNET.MAX_POOL
+        P = cfg.POOLING_SIZE
+        out = self._sess.buf(self._tag + "/" + name, (rois.shape[0], P, P, bottom.shape[-1]))
+        return ops.crop_and_resize(bottom, rois, float(self._feat_stride[0]), P, max_pool=bool(cfg.RESNET.MAX_POOL), out=out)
+
+    def _build_base(self):
+        # resnet_v1.py:80-86.  The image buffer is [1,H,W,4]: 7x7x3 stem as a channel-folded GEMM.
+        net = self._conv(self._image, self._scope + "/conv1", 7, 2, _same_pad(7, 2), act=ACT_RELU, bn_eps=BN_EPS,
+                         fold_w=True, real_cin=3)
+        N, H, W, C = net.shape
+        out = self._sess.buf(self._tag + "/pool1", (N, ops.conv_out_size(H, 3, 2, 1, 1), ops.conv_out_size(W, 3, 2, 1, 1), C))
+        return ops.maxpool(net, 3, 2, (1, 1, 1, 1), out=out)
+
+    def _image_to_head(self, is_training, reuse=None):
+        assert (0 <= cfg.RESNET.FIXED_BLOCKS <= 3)
+        net_conv = self._run_blocks(self._build_base(), self._blocks[0:3])
+        self._act_summaries.append(net_conv)
+        self._layers['head'] = net_conv
+        return net_conv
+
+    def _head_to_tail(self, pool5, is_training, reuse=None):
+        fc7 = self._run_blocks(pool5, self._blocks[-1:])
+        # average pooling done by reduce_mean (resnet_v1.py:124)
+        return ops.spatial_mean(fc7, out=self._sess.buf(self._tag + "/fc7", (fc7.shape[0], fc7.shape[-1])))
