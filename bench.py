@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--profile-steps", type=int, default=3, help="steps of the HIP-event pass that feeds `roofline`")
+    ap.add_argument("--layer-report", default=None, help="write a per-layer table of the event pass to this file")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,12 +154,21 @@ def main():
             for _ in range(args.profile_steps):       # no collective here: only rank 0 runs this pass
                 net.detect_device(sess, img_d, im_info, orig_shape, out=dets_view, count=count_i32)
             run_stream.synchronize()
+            per_layer = {}
             for tag, fl, e0, e1 in sess.profile:
+                ms = e0.elapsed_time(e1)
+                a = per_layer.setdefault(tag, [0.0, 0, 0])
+                a[0] += ms; a[1] += fl; a[2] += 1
                 if tag.startswith("conv:"):
-                    conv_ms += e0.elapsed_time(e1)
+                    conv_ms += ms
                     conv_flops += fl
                     conv_launches += 1
             sess.profile = None
+            if args.layer_report:
+                with open(args.layer_report, "w") as f:
+                    f.write("# tag  launches  us/launch  GFLOP/launch  TFLOP/s\n")
+                    for tag, (ms, fl, n) in per_layer.items():
+                        f.write("%-70s %3d %9.1f %9.3f %8.1f\n" % (tag, n, 1000 * ms / n, fl / n / 1e9, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0))
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)

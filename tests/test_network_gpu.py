@@ -22,9 +22,8 @@ def small_net(dev):
     net = resnetv1(num_layers=50)
     net.create_architecture("TEST", 21, tag="default", anchor_scales=SCALES, anchor_ratios=RATIOS)
     sess.init_variables(net.variable_specs())
-    for k in list(sess.variables):
-        if ("/rpn_" in k or "cls_score" in k or "bbox_pred" in k) and k.endswith("weights"):
-            sess.variables[k] *= 5.0            # well separated scores: no near-ties at the decision boundaries
+    # reference initialisers (network.py:239-240).  Near-ties between scores are harmless here: every
+    # decision stage is compared against the oracle on IDENTICAL inputs (the HIP tensors).
     rng = np.random.RandomState(5)
     H, W = 150, 200                              # odd intermediate sizes: 75x100 -> 38x50 -> 19x25 -> 10x13
     image = (rng.rand(1, H, W, 3) * 255.0).astype(np.float32) - cfg.PIXEL_MEANS.astype(np.float32)
@@ -43,6 +42,12 @@ def test_test_image_matches_dense_oracle(small_net):
     cls_score, cls_prob, bbox_pred, rois = net.test_image(sess, image, im_info)
     assert rois.shape[1] == 5 and 0 < rois.shape[0] <= 48 and cls_prob.shape == (rois.shape[0], 21)
     ref = DenseRef(sess.variables, 50, 21, SCALES, RATIOS).test_image(image, im_info, rois=rois, post=48)
+    # what plain float32 arithmetic costs on this graph (torch-CPU f32 vs f64): the HIP f32-MFMA path
+    # must be in the same class, not merely under the absolute 1e-4 budget
+    ref32 = DenseRef(sess.variables, 50, 21, SCALES, RATIOS, dtype=torch.float32).test_image(image, im_info, rois=rois, post=48)
+    for name in ("rpn_cls_score", "rpn_bbox_pred", "cls_score", "bbox_pred"):
+        got = net._predictions[name].cpu().numpy()[:ref[name].shape[0]]
+        assert rel_err(got, ref[name]) <= 4 * rel_err(ref32[name], ref[name]) + 2e-6, name
     head = net._layers["head"].cpu().numpy()
     assert head.shape == ref["head"].shape == (1, 10, 13, 1024)
     assert rel_err(head, ref["head"]) <= 1e-4
@@ -53,7 +58,7 @@ def test_test_image_matches_dense_oracle(small_net):
     assert rel_err(net._layers["fc7"][:n].cpu().numpy(), ref["fc7"]) <= 1e-4
     assert rel_err(cls_score, ref["cls_score"]) <= 1e-4
     assert np.abs(cls_prob - ref["cls_prob"]).max() <= 1e-4
-    assert np.abs(bbox_pred - ref["bbox_pred"]).max() <= 1e-4
+    assert rel_err(bbox_pred, ref["bbox_pred"]) <= 1e-4
     assert abs(cls_prob.sum(axis=1) - 1).max() < 1e-5
 
 

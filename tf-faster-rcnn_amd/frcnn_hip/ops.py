@@ -117,13 +117,13 @@ def proposal_layer(rpn_cls_prob, rpn_bbox_pred, im_h, im_w, feat_stride, base_d,
     return rois, scores, num
 
 
-def proposal_top_layer(rpn_cls_prob, rpn_bbox_pred, im_h, im_w, feat_stride, base_d, rpn_top_n):
+def proposal_top_layer(rpn_cls_prob, rpn_bbox_pred, im_h, im_w, feat_stride, base_d, rpn_top_n, rois=None, scores=None):
     _chk(rpn_cls_prob), _chk(rpn_bbox_pred), _chk(base_d, torch.float64)
     _, H, W, A2 = rpn_cls_prob.shape
     A = A2 // 2
     dev = rpn_cls_prob.device
-    rois = torch.empty((rpn_top_n, 5), dtype=torch.float32, device=dev)
-    scores = torch.empty((rpn_top_n, 1), dtype=torch.float32, device=dev)
+    rois = torch.empty((rpn_top_n, 5), dtype=torch.float32, device=dev) if rois is None else rois
+    scores = torch.empty((rpn_top_n, 1), dtype=torch.float32, device=dev) if scores is None else scores
     nb = lib().frcnn_proposal_workspace_bytes(H, W, A, int(rpn_top_n))
     ws = workspace(nb, dev, "proposal")
     call("frcnn_proposal_top_layer", _ptr(rpn_cls_prob), _ptr(rpn_bbox_pred), float(im_h), float(im_w), H, W, A,

@@ -51,6 +51,10 @@ class Session(object):
                 v = np.zeros(sp.shape)
             elif sp.init == "bn_gamma":
                 v = rng.uniform(0.5, 1.5, size=sp.shape)
+            elif sp.init == "bn_gamma_res":
+                # last BN of a residual branch: small gain, otherwise 33 stacked units with
+                # un-matched synthetic statistics double the activation variance per unit
+                v = rng.uniform(0.1, 0.3, size=sp.shape)
             elif sp.init == "bn_var":
                 v = rng.uniform(0.5, 1.5, size=sp.shape)
             elif sp.init == "bn_beta" or sp.init == "bn_mean":

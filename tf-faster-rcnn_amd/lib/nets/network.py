@@ -44,9 +44,9 @@ class Network(object):
     def _var(self, name, shape, init, arg=None):
         self._var_specs[name] = VarSpec(shape, init, arg)
 
-    def _declare_conv_bn(self, scope, kh, kw, cin, cout):
+    def _declare_conv_bn(self, scope, kh, kw, cin, cout, residual_branch_end=False):
         self._var(scope + "/weights", (kh, kw, cin, cout), "he")
-        self._var(scope + "/BatchNorm/gamma", (cout,), "bn_gamma")
+        self._var(scope + "/BatchNorm/gamma", (cout,), "bn_gamma_res" if residual_branch_end else "bn_gamma")
         self._var(scope + "/BatchNorm/beta", (cout,), "bn_beta")
         self._var(scope + "/BatchNorm/moving_mean", (cout,), "bn_mean")
         self._var(scope + "/BatchNorm/moving_variance", (cout,), "bn_var")
@@ -90,8 +90,10 @@ class Network(object):
     def _softmax_layer(self, bottom, name):
         if name.startswith("rpn_cls_prob"):
             A = self._num_anchors
-            return ops.rpn_softmax(bottom, A, out=self._sess.buf(self._tag + "/" + name, bottom.shape[:3] + (2 * A,)))
-        return ops.softmax_rows(bottom, out=self._sess.buf(self._tag + "/" + name, bottom.shape))
+            out = self._sess.buf(self._tag + "/" + name, bottom.shape[:3] + (2 * A,))
+            return self._sess.mark("op:rpn_softmax", 0, lambda: ops.rpn_softmax(bottom, A, out=out))
+        out = self._sess.buf(self._tag + "/" + name, bottom.shape)
+        return self._sess.mark("op:softmax_rows", 0, lambda: ops.softmax_rows(bottom, out=out))
 
     # ------------------------------------------------------------------ graph pieces (same names as the reference)
     def _anchor_component(self):
@@ -111,17 +113,20 @@ class Network(object):
         c = cfg[self._mode]
         post = int(c.RPN_POST_NMS_TOP_N)
         s = self._sess
-        rois, scores, num = ops.proposal_layer(
+        rois, scores, num = s.mark("op:proposal_layer", 0, lambda: ops.proposal_layer(
             rpn_cls_prob, rpn_bbox_pred, self._im_info[0], self._im_info[1], self._feat_stride[0], self._base_anchors,
             int(c.RPN_PRE_NMS_TOP_N), post, float(c.RPN_NMS_THRESH),
             rois=s.buf(self._tag + "/rois", (post, 5)), scores=s.buf(self._tag + "/roi_scores", (post, 1)),
-            num=s.buf(self._tag + "/num_rois", (1,), torch.int32))
+            num=s.buf(self._tag + "/num_rois", (1,), torch.int32)))
         self._num_rois = num
         return rois, scores
 
     def _proposal_top_layer(self, rpn_cls_prob, rpn_bbox_pred, name):
+        n, s = int(cfg.TEST.RPN_TOP_N), self._sess
         rois, scores = ops.proposal_top_layer(rpn_cls_prob, rpn_bbox_pred, self._im_info[0], self._im_info[1],
-                                              self._feat_stride[0], self._base_anchors, int(cfg.TEST.RPN_TOP_N))
+                                              self._feat_stride[0], self._base_anchors, n,
+                                              rois=s.buf(self._tag + "/top_rois", (n, 5)),
+                                              scores=s.buf(self._tag + "/top_scores", (n, 1)))
         self._num_rois = None
         return rois, scores
 
@@ -276,6 +281,6 @@ class Network(object):
         """image (already in HBM) -> final detections in HBM: forward + the whole of
         lib/model/test.py:95-102,162-180 on device.  Returns (dets [max_out,6], count [1])."""
         p = self.forward_device(sess, image_d, im_info)
-        return ops.detect_post(p["cls_prob"], p["bbox_pred"], p["rois"], self._num_rois, float(im_info[2]),
-                               int(im_shape[0]), int(im_shape[1]), float(cfg.TEST.NMS), float(thresh), int(max_per_image),
-                               out=out, count=count)
+        return sess.mark("op:detect_post", 0, lambda: ops.detect_post(
+            p["cls_prob"], p["bbox_pred"], p["rois"], self._num_rois, float(im_info[2]), int(im_shape[0]),
+            int(im_shape[1]), float(cfg.TEST.NMS), float(thresh), int(max_per_image), out=out, count=count))

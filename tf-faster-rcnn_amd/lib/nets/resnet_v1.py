@@ -58,7 +58,7 @@ class resnetv1(Network):
                     self._declare_conv_bn(p + "/shortcut", 1, 1, cin, depth)
                 self._declare_conv_bn(p + "/conv1", 1, 1, cin, base)
                 self._declare_conv_bn(p + "/conv2", 3, 3, base, base)
-                self._declare_conv_bn(p + "/conv3", 1, 1, base, depth)
+                self._declare_conv_bn(p + "/conv3", 1, 1, base, depth, residual_branch_end=True)
                 cin = depth
 
     def _head_channels(self):
@@ -92,7 +92,8 @@ class resnetv1(Network):
         # resnet_v1.py:55-76: direct 7x7 crop unless RESNET.MAX_POOL
         P = cfg.POOLING_SIZE
         out = self._sess.buf(self._tag + "/" + name, (rois.shape[0], P, P, bottom.shape[-1]))
-        return ops.crop_and_resize(bottom, rois, float(self._feat_stride[0]), P, max_pool=bool(cfg.RESNET.MAX_POOL), out=out)
+        return self._sess.mark("op:crop_and_resize", 0, lambda: ops.crop_and_resize(
+            bottom, rois, float(self._feat_stride[0]), P, max_pool=bool(cfg.RESNET.MAX_POOL), out=out))
 
     def _build_base(self):
         # resnet_v1.py:80-86.  The image buffer is [1,H,W,4]: 7x7x3 stem as a channel-folded GEMM.
@@ -100,7 +101,7 @@ class resnetv1(Network):
                          fold_w=True, real_cin=3)
         N, H, W, C = net.shape
         out = self._sess.buf(self._tag + "/pool1", (N, ops.conv_out_size(H, 3, 2, 1, 1), ops.conv_out_size(W, 3, 2, 1, 1), C))
-        return ops.maxpool(net, 3, 2, (1, 1, 1, 1), out=out)
+        return self._sess.mark("op:maxpool", 0, lambda: ops.maxpool(net, 3, 2, (1, 1, 1, 1), out=out))
 
     def _image_to_head(self, is_training, reuse=None):
         assert (0 <= cfg.RESNET.FIXED_BLOCKS <= 3)
@@ -112,4 +113,5 @@ class resnetv1(Network):
     def _head_to_tail(self, pool5, is_training, reuse=None):
         fc7 = self._run_blocks(pool5, self._blocks[-1:])
         # average pooling done by reduce_mean (resnet_v1.py:124)
-        return ops.spatial_mean(fc7, out=self._sess.buf(self._tag + "/fc7", (fc7.shape[0], fc7.shape[-1])))
+        out = self._sess.buf(self._tag + "/fc7", (fc7.shape[0], fc7.shape[-1]))
+        return self._sess.mark("op:spatial_mean", 0, lambda: ops.spatial_mean(fc7, out=out))
