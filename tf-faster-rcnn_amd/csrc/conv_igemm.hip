@@ -2,55 +2,91 @@
 //
 //   Y[m, n] = act( sum_k A[m, k] * Wt[n, k] + bias[n] (+ residual) )
 //   m = output pixel (img, oh, ow) flattened, n = output channel, k = (kh, kw, c) flattened.
-//   A is never materialised: each workgroup gathers its BM x 32 activation slab straight from the
-//   NHWC tensor (a (kh,kw) tap is a contiguous Cin run per pixel -> float4, fully coalesced loads),
-//   stages it and the matching BN x 32 filter slab through LDS (double buffered, register
-//   prefetch of the next slab while the MFMAs of the current one run), and every wave owns a
-//   WM x WN sub-tile made of 32x32 MFMA accumulators.
+//
+// A is never materialised: a (kh,kw) tap of an NHWC tensor is a contiguous Cin run per pixel, so a
+// BM x 32 activation slab is BM 128-byte rows.  Slabs (activation rows + filter rows) travel
+// HBM/L2 -> LDS with direct-to-LDS loads (global_load_lds_dwordx4: no VGPR round trip, no
+// ds_write pass) into an NS-deep ring; NS-1 slabs are in flight while the MFMAs of the current
+// one run (counted s_waitcnt vmcnt + one raw s_barrier per slab).  Padding taps / tile tails read a
+// 16-byte zero page instead of being predicated (direct-to-LDS loads cannot write zeros).
+//
+// LDS image: a slab row is 8 chunks of 16 B; chunk q of row r is stored at position
+// q ^ ((r >> 1) & 7).  Direct-to-LDS loads write lane-linear (wave base + lane*16), so the swizzle is
+// applied to the per-lane GLOBAL source chunk and again on the fragment read; the ds_read_b128
+// fragment reads (lane&31 = row, lane>>5 = k half) then hit 16 distinct 16-byte slots per 16-lane
+// group: conflict free without padding.
 //
 // Why f32 MFMA: BASELINE.json asks for 1e-4 on scores/boxes through a 100-layer backbone; the
-// f32-input MFMA is bit-equivalent to an fmaf chain (exact f32 products, f32 accumulate) and runs
-// at the 157.3 TFLOP/s matrix peak of the chip.  One wave per SIMD with one accumulator already
-// saturates the pipe (64-cycle issue == dependent latency), so LDS traffic is tiny:
-// per 8 k-values a wave reads (WM+WN)/32 ds_read_b128 and issues 4*(WM/32)*(WN/32) MFMAs.
+// f32-input MFMA is an exact-product f32 fmaf chain and runs at the 157.3 TFLOP/s matrix peak.  One
+// accumulator per wave already saturates a SIMD's matrix pipe (64-cycle issue == dependent latency).
 //
-// LDS image: rows of 32 k-values padded to 36 floats (144 B) -> the ds_read_b128 fragment reads
-// (lane&31 = row, lane>>5 selects k 0-3 / 4-7) hit 16 distinct 16-B slots per 16-lane group:
-// conflict free.  k is consumed in the permuted order (e, e+4) per MFMA; A and B use the same
-// permutation so the contraction is unchanged.
+// Epilogue: accumulators -> LDS tile -> float4 rows: bias + residual (`subsample` stride) + ReLU
+// fused, 16-byte coalesced global stores.
 //
 // Covers the slim call sites of lib/nets/network.py:323-378 (RPN 3x3/1x1, fc heads as 1x1),
 // lib/nets/resnet_v1.py:80-125 (7x7/2 stem via fold_w, bottleneck 1x1 / 3x3 / conv2d_same
-// stride 2, projection and subsample shortcuts fused in the epilogue), vgg16.py:26-60.
+// stride 2, projection and subsample shortcuts), vgg16.py:26-60.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ float4 g_zero_page[4];     // 64 zero bytes (static device memory, zero-initialised)
 
 struct ConvParams {
   const float* x; const float* w; const float* bias; const float* res; float* y;
   int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad_top, pad_left, act;
   int RH, RW, res_stride;
-  int M, Ktot, nsteps, csteps;     // M = N*OH*OW, Ktot = KH*KW*Cin, csteps = Cin/32 (1 for fold_w)
+  int M, Ktot, nsteps;             // M = N*OH*OW, Ktot = KH*KW*Cin (fold_w: KH*32)
   int mtiles, ntiles;
+  int dbg;                         // experiments only: bit0 skip MFMAs, bit1 skip slab loads after the prologue
 };
 
-constexpr int BK = 32;
-constexpr int LDK = BK + 4;
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
 
-template <int BM, int BN, int WM, int WN, bool FOLDW>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// One direct-to-LDS load: 64 lanes x 16 B from per-lane global addresses to LDS [lds_base, +1 KiB),
+// lane-linear.  Issued from inline asm on purpose: hipcc tracks builtin LDS-DMA conservatively and
+// puts `s_waitcnt vmcnt(0)` in front of the first ds_read of every k-step (it cannot prove the ring
+// slots disjoint), which would drain the NS-deep pipeline; asm loads are invisible to its scoreboard,
+// so the counted waits below are the only ones.  M0 (LDS base) is saved/restored inside the statement.
+__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_base)
+      : "memory");
+}
+
+template <int BM, int BN, int WM, int WN, int NS, bool FOLDW>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const ConvParams p) {
   constexpr int NW = (BM / WM) * (BN / WN);
   constexpr int NT = NW * 64;
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int LA = (BM * 8) / NT, LB = (BN * 8) / NT;       // float4 loads per thread per slab
-  static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile/threads mismatch");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                                  // [2][BM][LDK]
-  float* Bs = smem + 2 * BM * LDK;                   // [2][BN][LDK]
+  constexpr int LA = BM / 8 / NW, LB = BN / 8 / NW;       // direct-to-LDS wave-instructions per wave per slab
+  constexpr int G = LA + LB;
+  constexpr int P = NS - 1;                               // slabs in flight ahead of the MFMAs
+  constexpr int SLAB = (BM + BN) * 32;                    // floats per slab
+  constexpr int EPI_LD = BN;                              // epilogue tile row stride (floats): b32 writes are per
+                                                          // 32-lane half, float4 reads are lane-linear -> no padding needed
+  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile/wave mismatch");
+  static_assert((P - 1) * G <= 63, "vmcnt range");
+  static_assert(NS * SLAB >= BM * EPI_LD, "epilogue tile must fit in the slab ring");
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // [NS][BM+BN][32]; reused by the epilogue
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // XCD-aware tile order: consecutive tiles of one XCD (observed placement: block b -> XCD b % 8)
-  // share the activation slab; bijective for any grid size.
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware tile order (observed placement: block b -> XCD b % 8): consecutive tiles of one XCD
+  // share an activation slab; bijective for any grid size.
   const int nwg = p.mtiles * p.ntiles;
   int bid = blockIdx.x;
   {
@@ -61,58 +97,59 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
   const int bm0 = mt * BM, bn0 = nt * BN;
   const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
 
-  // per-thread gather descriptors of the A rows this thread stages
-  int a_base[LA], a_ih0[LA], a_iw0[LA];
+  // ---- per-lane source descriptors of the rows this lane stages -------------------------------
+  const int lrow = lane >> 3, lpos = lane & 7;
+  int a_base[LA], a_ih0[LA], a_iw0[LA], a_q4[LA];
 #pragma unroll
-  for (int l = 0; l < LA; ++l) {
-    const int row = (tid + l * NT) >> 3;
+  for (int t = 0; t < LA; ++t) {
+    const int row = (wave * LA + t) * 8 + lrow;                 // slab row in [0, BM)
+    a_q4[t] = (lpos ^ ((row >> 1) & 7)) * 4;                    // swizzled source chunk (float offset)
     const int m = bm0 + row;
     if (m < p.M) {
       const int img = m / (p.OH * p.OW), rem = m % (p.OH * p.OW);
       const int oh = rem / p.OW, ow = rem % p.OW;
-      a_base[l] = img * p.H * p.W * p.Cin;
-      a_ih0[l] = oh * p.stride - p.pad_top;
-      a_iw0[l] = ow * p.stride - p.pad_left;
+      a_base[t] = img * p.H * p.W * p.Cin;
+      a_ih0[t] = oh * p.stride - p.pad_top;
+      a_iw0[t] = ow * p.stride - p.pad_left;
     } else {
-      a_base[l] = 0; a_ih0[l] = -(1 << 28); a_iw0[l] = -(1 << 28);
+      a_base[t] = 0; a_ih0[t] = -(1 << 28); a_iw0[t] = -(1 << 28);
     }
   }
-  const int q4 = (tid & 7) * 4;                      // float offset of this thread's 16-B chunk in the 32-wide slab
-  float4 ra[LA], rb[LB];
-  int kh = 0, kw = 0, c0 = 0, kflat = 0;
+  long long b_off[LB];                                          // float offset of (row n, swizzled chunk) or -1
+#pragma unroll
+  for (int t = 0; t < LB; ++t) {
+    const int row = BM + (wave * LB + t) * 8 + lrow;
+    const int n = bn0 + row - BM;
+    const int q4 = (lpos ^ ((row >> 1) & 7)) * 4;
+    b_off[t] = (n < p.Cout) ? ((long long)n * p.Ktot + q4) : -1;
+  }
+  const float* zero = (const float*)g_zero_page;
+  int kh = 0, kw = 0, c0 = 0, kflat = 0;                        // k position of the NEXT slab to issue
 
-  auto load_slab = [&]() {
+  const unsigned lds0 = (unsigned)(size_t)(LDS_AS float*)smem;       // LDS byte address of the ring
+  auto issue_slab = [&](int buf) {
+    const unsigned sb = lds0 + (unsigned)(buf * SLAB * 4);
 #pragma unroll
-    for (int l = 0; l < LA; ++l) {
-      const int ih = a_ih0[l] + kh, iw = a_iw0[l] + kw;
+    for (int t = 0; t < LA; ++t) {
+      const int ih = a_ih0[t] + kh, iw = a_iw0[t] + kw;
       bool ok = (unsigned)ih < (unsigned)p.H;
-      if (FOLDW) ok = ok && ((unsigned)(iw + (q4 >> 2)) < (unsigned)p.W);
+      if (FOLDW) ok = ok && ((unsigned)(iw + (a_q4[t] >> 2)) < (unsigned)p.W);
       else ok = ok && ((unsigned)iw < (unsigned)p.W);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) v = *(const float4*)(p.x + (size_t)(a_base[l] + (ih * p.W + iw) * p.Cin + c0 + q4));
-      ra[l] = v;
+      const float* src = ok ? p.x + (size_t)(a_base[t] + (ih * p.W + iw) * p.Cin + c0 + a_q4[t]) : zero;
+      glds16(src, __builtin_amdgcn_readfirstlane(sb + (wave * LA + t) * 1024));
     }
 #pragma unroll
-    for (int l = 0; l < LB; ++l) {
-      const int n = bn0 + ((tid + l * NT) >> 3);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < p.Cout) v = *(const float4*)(p.w + (size_t)n * p.Ktot + kflat + q4);
-      rb[l] = v;
+    for (int t = 0; t < LB; ++t) {
+      const float* src = (b_off[t] >= 0) ? p.w + b_off[t] + kflat : zero;
+      glds16(src, __builtin_amdgcn_readfirstlane(sb + BM * 128 + (wave * LB + t) * 1024));
     }
-  };
-  auto store_slab = [&](int buf) {
-#pragma unroll
-    for (int l = 0; l < LA; ++l)
-      *(float4*)(As + ((size_t)buf * BM + ((tid + l * NT) >> 3)) * LDK + q4) = ra[l];
-#pragma unroll
-    for (int l = 0; l < LB; ++l)
-      *(float4*)(Bs + ((size_t)buf * BN + ((tid + l * NT) >> 3)) * LDK + q4) = rb[l];
-  };
-  auto advance = [&]() {
-    kflat += BK;
-    if (FOLDW) { ++kh; return; }
-    c0 += BK;
-    if (c0 == p.Cin) { c0 = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+    // advance to the following slab
+    kflat += 32;
+    if (FOLDW) { ++kh; }
+    else {
+      c0 += 32;
+      if (c0 == p.Cin) { c0 = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -123,77 +160,118 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_slab();
-  store_slab(0);
-  __syncthreads();
+  // fragment read offsets: row (lane&31) of the wave's 32-row groups, k chunk 2s + (lane>>5), swizzled
+  const int frow = lane & 31, khalf = lane >> 5;
+  int koff[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) koff[s] = ((2 * s + khalf) ^ ((frow >> 1) & 7)) * 4;
+  const int a_row0 = (wm0 + frow) * 32, b_row0 = (BM + wn0 + frow) * 32;
 
-  const int frow = lane & 31, fk = (lane >> 5) * 4;
-  int buf = 0;
+  // ---- prologue: P slabs in flight ---------------------------------------------------------------
+#pragma unroll
+  for (int s = 0; s < P; ++s)
+    if (s < p.nsteps) issue_slab(s);
+
   for (int step = 0; step < p.nsteps; ++step) {
-    const bool more = step + 1 < p.nsteps;
-    if (more) { advance(); load_slab(); }
-    const float* Ab = As + ((size_t)buf * BM + wm0 + frow) * LDK + fk;
-    const float* Bb = Bs + ((size_t)buf * BN + wn0 + frow) * LDK + fk;
+    // slab `step` must have landed: at most the P-1 younger slabs may still be in flight
+    if (step + P <= p.nsteps) wait_vmcnt<(P - 1) * G>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();          // every wave finished slab step-1 and sees slab step
+    if (step + P < p.nsteps && !(p.dbg & 2)) issue_slab((step + P) % NS);
+    const float* sb = smem + (step % NS) * SLAB;
+    // all fragment reads of the slab first (the MFMAs below then run back to back; the compiler
+    // staggers them with partial lgkmcnt waits), then 16 x TM x TN MFMAs
+    float4 a[4][TM], b[4][TN];
 #pragma unroll
-    for (int s = 0; s < BK / 8; ++s) {
-      float4 a[TM], b[TN];
+    for (int s = 0; s < 4; ++s) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *(const float4*)(Ab + (size_t)i * 32 * LDK + s * 8);
+      for (int i = 0; i < TM; ++i) a[s][i] = *(const float4*)(sb + a_row0 + i * 1024 + koff[s]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *(const float4*)(Bb + (size_t)j * 32 * LDK + s * 8);
+      for (int j = 0; j < TN; ++j) b[s][j] = *(const float4*)(sb + b_row0 + j * 1024 + koff[s]);
+    }
+    if (!(p.dbg & 1))
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i].x, b[s][j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i].y, b[s][j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i].z, b[s][j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i].w, b[s][j].w, acc[i][j], 0, 0, 0);
         }
     }
-    if (more) store_slab(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
   }
 
-  // epilogue: D[i][j] of a 32x32 tile sits in lane (j = lane&31), reg r -> i = (r&3) + 8*(r>>2) + 4*(lane>>5):
-  // per register the two half-waves each write one 128-B contiguous run of the NHWC row.
-  const int ohow = p.OH * p.OW;
+  // ---- epilogue: accumulators -> LDS tile [BM][BN] -> float4 rows ---------------------------------
+  __syncthreads();                         // all slab reads done; the ring is free
+  // D[i][j] of a 32x32 MFMA tile: lane holds column j = lane&31, register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = bn0 + wn0 + j * 32 + (lane & 31);
-    if (n >= p.Cout) continue;
-    const float bv = p.bias ? p.bias[n] : 0.f;
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = bm0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m >= p.M) continue;
-        float v = acc[i][j][r] + bv;
-        if (p.res) {
-          size_t ro;
-          if (p.res_stride == 1) ro = (size_t)m * p.Cout + n;
-          else {
-            const int img = m / ohow, rem = m % ohow, oh = rem / p.OW, ow = rem % p.OW;
-            ro = ((size_t)(img * p.RH + oh * p.res_stride) * p.RW + ow * p.res_stride) * p.Cout + n;
-          }
-          v += p.res[ro];
-        }
-        if (p.act == FRCNN_ACT_RELU) v = fmaxf(v, 0.f);
-        else if (p.act == FRCNN_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
-        p.y[(size_t)m * p.Cout + n] = v;
+        const int ml = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        smem[ml * EPI_LD + wn0 + j * 32 + frow] = acc[i][j][r];
       }
+  __syncthreads();
+  const int ohow = p.OH * p.OW;
+  if ((p.Cout & 3) == 0) {
+    constexpr int C4 = BN / 4;
+    for (int t = tid; t < BM * C4; t += NT) {
+      const int ml = t / C4, nl = (t % C4) * 4;
+      const int m = bm0 + ml, n = bn0 + nl;
+      if (m >= p.M || n >= p.Cout) continue;
+      float4 v = *(const float4*)(smem + ml * EPI_LD + nl);
+      if (p.bias) {
+        const float4 bv = *(const float4*)(p.bias + n);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+      }
+      if (p.res) {
+        size_t ro;
+        if (p.res_stride == 1) ro = (size_t)m * p.Cout + n;
+        else {
+          const int img = m / ohow, rem = m % ohow, oh = rem / p.OW, ow = rem % p.OW;
+          ro = ((size_t)(img * p.RH + oh * p.res_stride) * p.RW + ow * p.res_stride) * p.Cout + n;
+        }
+        const float4 rv = *(const float4*)(p.res + ro);
+        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+      }
+      if (p.act == FRCNN_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      else if (p.act == FRCNN_ACT_RELU6)
+        v = make_float4(fminf(fmaxf(v.x, 0.f), 6.f), fminf(fmaxf(v.y, 0.f), 6.f), fminf(fmaxf(v.z, 0.f), 6.f), fminf(fmaxf(v.w, 0.f), 6.f));
+      *(float4*)(p.y + (size_t)m * p.Cout + n) = v;
+    }
+  } else {          // Cout not a multiple of 4 (RPN / fc heads): scalar path
+    for (int t = tid; t < BM * BN; t += NT) {
+      const int ml = t / BN, nl = t % BN;
+      const int m = bm0 + ml, n = bn0 + nl;
+      if (m >= p.M || n >= p.Cout) continue;
+      float v = smem[ml * EPI_LD + nl] + (p.bias ? p.bias[n] : 0.f);
+      if (p.res) {
+        size_t ro;
+        if (p.res_stride == 1) ro = (size_t)m * p.Cout + n;
+        else {
+          const int img = m / ohow, rem = m % ohow, oh = rem / p.OW, ow = rem % p.OW;
+          ro = ((size_t)(img * p.RH + oh * p.res_stride) * p.RW + ow * p.res_stride) * p.Cout + n;
+        }
+        v += p.res[ro];
+      }
+      if (p.act == FRCNN_ACT_RELU) v = fmaxf(v, 0.f);
+      else if (p.act == FRCNN_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+      p.y[(size_t)m * p.Cout + n] = v;
     }
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool FOLDW>
+template <int BM, int BN, int WM, int WN, int NS, bool FOLDW>
 static int launch_conv(ConvParams p, hipStream_t st) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
-  constexpr size_t lds = sizeof(float) * 2 * (BM + BN) * LDK;
+  constexpr size_t lds = sizeof(float) * NS * (BM + BN) * 32;
   static bool attr_set = false;
-  auto kern = k_conv_igemm<BM, BN, WM, WN, FOLDW>;
+  auto kern = k_conv_igemm<BM, BN, WM, WN, NS, FOLDW>;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
@@ -203,6 +281,32 @@ static int launch_conv(ConvParams p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles), dim3(NT), lds, st, p);
   LAUNCH_CHECK();
   return FRCNN_OK;
+}
+
+// tuning knob (experiments / A-B runs): key 0 = force a tile configuration id for every non-stem conv
+// (-1 = automatic choice).
+static int g_force_cfg = -1, g_dbg = 0;
+extern "C" int frcnn_set_tuning(int key, int value) {
+  if (key == 0) { g_force_cfg = value; return FRCNN_OK; }
+  if (key == 1) { g_dbg = value; return FRCNN_OK; }
+  return FRCNN_E_ARG;
+}
+
+static int launch_cfg(int id, const ConvParams& p, hipStream_t st) {
+  switch (id) {
+    case 0: return launch_conv<128, 128, 64, 64, 2, false>(p, st);   // 64 KB LDS: 2 workgroups / CU
+    case 1: return launch_conv<128, 128, 64, 64, 3, false>(p, st);   // 96 KB: 1 workgroup / CU, 2 slabs ahead
+    case 2: return launch_conv<64, 64, 32, 32, 4, false>(p, st);
+    case 3: return launch_conv<32, 64, 32, 32, 4, false>(p, st);
+    case 4: return launch_conv<64, 32, 32, 32, 4, false>(p, st);
+    case 5: return launch_conv<128, 64, 64, 32, 3, false>(p, st);
+    case 6: return launch_conv<64, 128, 32, 64, 3, false>(p, st);
+    case 7: return launch_conv<64, 64, 32, 32, 2, false>(p, st);
+    case 8: return launch_conv<32, 64, 32, 32, 2, false>(p, st);
+    case 9: return launch_conv<32, 32, 32, 32, 4, false>(p, st);
+    case 10: return launch_conv<128, 128, 32, 64, 2, false>(p, st);  // 8 waves, 2 accumulators each
+    default: return FRCNN_E_ARG;
+  }
 }
 
 extern "C" int frcnn_conv2d_nhwc(const float* x_d, int N, int H, int W, int Cin, const float* w_d, const float* bias_d,
@@ -227,22 +331,21 @@ extern "C" int frcnn_conv2d_nhwc(const float* x_d, int N, int H, int W, int Cin,
   p.RH = RH; p.RW = RW; p.res_stride = residual_d ? res_stride : 1;
   p.M = N * OH * OW;
   p.Ktot = fold_w ? KH * 32 : KH * KW * Cin;
-  p.csteps = fold_w ? 1 : Cin / 32;
-  p.nsteps = fold_w ? KH : KH * KW * p.csteps;
+  p.nsteps = fold_w ? KH : KH * KW * (Cin / 32);
   p.mtiles = p.ntiles = 0;
+  p.dbg = g_dbg;
   hipStream_t st = (hipStream_t)stream;
-  if (fold_w) return launch_conv<128, 64, 32, 64, true>(p, st);
-  // tile choice: fill >= ~2 waves of work per SIMD when possible (256 CUs); the big 128x128 tile
-  // (64x64 per wave, 4 accumulators) is the efficient one, the smaller tiles exist for the
-  // small-M (38x63 feature map) and small-Cout (RPN/fc heads) layers.
+  if (fold_w) return launch_conv<128, 64, 32, 64, 3, true>(p, st);
+  if (g_force_cfg >= 0) return launch_cfg(g_force_cfg, p, st);
+  // Tile choice, from the measured sweep (profiles/r01_conv_tile_sweep.txt).  f32 MFMA needs few
+  // bytes per FLOP, so the limiter is never LDS or HBM but (a) how many of the 1024 SIMDs get a wave
+  // and (b) the per-slab barrier/ds_read overhead: 128x128 tiles with 8 waves (2 accumulators each)
+  // for the per-RoI tail (M = 14700), 64x64 tiles with a shallow ring (32 KB LDS -> up to 5
+  // workgroups per CU) for the 38x63 / 75x125 / 150x250 feature maps.
   const long long big = (long long)cdiv(p.M, 128) * cdiv(Cout, 128);
-  if (Cout >= 96 && big >= 384) return launch_conv<128, 128, 64, 64, false>(p, st);
-  if (Cout > 32) {
-    const long long mid = (long long)cdiv(p.M, 64) * cdiv(Cout, 64);
-    if (mid >= 512) return launch_conv<64, 64, 32, 32, false>(p, st);
-    return launch_conv<32, 64, 32, 32, false>(p, st);
-  }
-  return launch_conv<64, 32, 32, 32, false>(p, st);
+  if (Cout >= 96 && big >= 384 && p.nsteps >= 8) return launch_cfg(10, p, st);
+  if (Cout > 32) return launch_cfg(7, p, st);
+  return launch_cfg(4, p, st);
 }
 
 // HOST: HWIO -> [Cout][KH][KW][Cin] with optional per-output-channel scale (folded frozen BN).
