@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--profile-steps", type=int, default=3, help="steps of the HIP-event pass that feeds `roofline`")
+    ap.add_argument("--streams", type=int, default=2, help="images in flight per GPU (independent HIP streams + graphs)")
     ap.add_argument("--layer-report", default=None, help="write a per-layer table of the event pass to this file")
     args = ap.parse_args()
 
@@ -99,45 +100,57 @@ def main():
     from nets.resnet_v1 import resnetv1
 
     sess = Session(device=dev, seed=cfg.RNG_SEED)
-    net = resnetv1(num_layers=101)
-    net.create_architecture("TEST", NUM_CLASSES, tag="default", anchor_scales=ANCHOR_SCALES, anchor_ratios=ANCHOR_RATIOS)
-    sess.init_variables(net.variable_specs())
-    image = synth_image(cfg.RNG_SEED + rank)            # every rank its own image
+    S = max(1, args.streams)
+    nets = []
+    for i in range(S):                                   # one Network (= one set of static buffers + one hipGraph) per stream
+        n_ = resnetv1(num_layers=101)
+        n_.create_architecture("TEST", NUM_CLASSES, tag="s%d" % i, anchor_scales=ANCHOR_SCALES, anchor_ratios=ANCHOR_RATIOS)
+        nets.append(n_)
+    net = nets[0]
+    sess.init_variables(net.variable_specs())            # weights are shared by all streams
     im_info = np.array([IM_H, IM_W, IM_SCALE], dtype=np.float32)
     orig_shape = (int(IM_H / IM_SCALE), int(IM_W / IM_SCALE))
+    image = synth_image(cfg.RNG_SEED + rank)             # every rank its own image
 
-    run_stream = torch.cuda.Stream(device=dev)
     from frcnn_hip import parallel
-    rec, dets_view = parallel.new_record(dev)              # fixed-size detection record [dets | count]
-    count_i32 = torch.zeros((1,), dtype=torch.int32, device=dev)
-    gathered = torch.zeros((world, rec.numel()), dtype=torch.float32, device=dev) if world > 1 else None
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    recs, views, counts, gathered, imgs = [], [], [], [], []
+    for i in range(S):
+        r_, v_ = parallel.new_record(dev)                # fixed-size detection record [dets | count]
+        recs.append(r_); views.append(v_)
+        counts.append(torch.zeros((1,), dtype=torch.int32, device=dev))
+        gathered.append(torch.zeros((world, r_.numel()), dtype=torch.float32, device=dev) if world > 1 else None)
+        with torch.cuda.stream(streams[i]):
+            imgs.append(nets[i]._stage_image(sess, synth_image(cfg.RNG_SEED + rank + 1000 * i)))   # resident in HBM
+    torch.cuda.synchronize()
+    run_stream = streams[0]
+    img_d, dets_view, count_i32 = imgs[0], views[0], counts[0]
 
-    with torch.cuda.stream(run_stream):
-        img_d = net._stage_image(sess, image)              # input resident in HBM before the timed region
-        run_stream.synchronize()
-
-        def step():
-            net.detect_device(sess, img_d, im_info, orig_shape, out=dets_view, count=count_i32)
+    def step(k):
+        i = k % S
+        with torch.cuda.stream(streams[i]):
+            nets[i].detect_device(sess, imgs[i], im_info, orig_shape, out=views[i], count=counts[i])
             if world > 1:
-                parallel.set_count(rec, count_i32)
-                parallel.all_gather_records(rec, gathered)
+                parallel.set_count(recs[i], counts[i])
+                parallel.all_gather_records(recs[i], gathered[i])
 
+    if True:
         if args.no_graph:
             sess.profile = []                                # forward_device runs eagerly while profile is not None
-        for _ in range(max(args.warmup, 1)):
-            step()
+        for k in range(max(args.warmup, S)):
+            step(k)
             if args.no_graph:
                 sess.profile = []
-        run_stream.synchronize()
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        for k in range(args.steps):
+            step(k)
             if args.no_graph:
                 sess.profile = []
-        run_stream.synchronize()
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -150,6 +163,7 @@ def main():
         #      the stream the kernels run on, over `profile_steps` further steps of the same workload
         conv_ms, conv_flops, conv_launches = 0.0, 0, 0
         if rank == 0 and args.profile_steps > 0:
+          with torch.cuda.stream(run_stream):
             sess.profile = []
             for _ in range(args.profile_steps):       # no collective here: only rank 0 runs this pass
                 net.detect_device(sess, img_d, im_info, orig_shape, out=dets_view, count=count_i32)
@@ -182,7 +196,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: ResNet-101 VOC 600x1000, 300 proposals, 21 classes, A=9, TEST.MODE nms; "
-                                   "image in HBM -> <=100 detections in HBM", "images_per_gpu_per_step": 1,
+                                   "image in HBM -> <=100 detections in HBM", "images_per_gpu_per_step": 1, "images_in_flight_per_gpu": S,
                        "parallelism": "dp%d (one image per GPU, all-gather of detection records)" % world,
                        "launch": "eager" if args.no_graph else "hipGraph replay", "rois": n_rois, "detections": n_det,
                        "gflop_per_image": round(flops_per_image / 1e9, 2)},

@@ -10,7 +10,7 @@ for k, thr, cl in [(2, 0.5, 0), (64, 0.3, 2), (65, 0.3, 2), (200, 0.5, 3), (3000
     keep, num = ops.nms(torch.from_numpy(d).to(dev), thr)
     torch.cuda.synchronize()
     n = int(num.item()); got = keep[:n].cpu().numpy().tolist(); want = ora.cpu_nms(d, thr)
-    ws = ops._ws_cache[(str(dev), "nms")].cpu().numpy()
+    ws = ops._ws_cache[(str(dev), "nms", "default")].cpu().numpy()
     off = 0
     def take(nb):
         global off

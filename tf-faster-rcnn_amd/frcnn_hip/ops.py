@@ -12,6 +12,7 @@ import torch
 from . import ACT_NONE, call, lib
 
 _ws_cache = {}
+ws_scope = "default"     # set by callers that run several independent chains concurrently (one scope per stream)
 
 
 def _stream():
@@ -32,7 +33,7 @@ def _chk(t, dtype=torch.float32):
 def workspace(nbytes, device, tag="default"):
     """Grow-only scratch buffer per (device, tag); never reallocated inside a captured region
     as long as the first (warm-up) call already saw the largest request."""
-    key = (str(device), tag)
+    key = (str(device), tag, ws_scope)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)

@@ -239,6 +239,7 @@ class Network(object):
         self._sess = sess
         self._image = image_d
         self._im_info = (float(im_info[0]), float(im_info[1]), float(im_info[2]))
+        ops.ws_scope = self._tag                       # scratch buffers are per network tag (= per stream)
         key = (self._tag, tuple(image_d.shape), self._im_info[:2], self._mode, cfg.TEST.MODE)
         cur = torch.cuda.current_stream(sess.device)
         if not use_graph or sess.profile is not None:
@@ -281,6 +282,7 @@ class Network(object):
         """image (already in HBM) -> final detections in HBM: forward + the whole of
         lib/model/test.py:95-102,162-180 on device.  Returns (dets [max_out,6], count [1])."""
         p = self.forward_device(sess, image_d, im_info)
+        ops.ws_scope = self._tag
         return sess.mark("op:detect_post", 0, lambda: ops.detect_post(
             p["cls_prob"], p["bbox_pred"], p["rois"], self._num_rois, float(im_info[2]), int(im_shape[0]),
             int(im_shape[1]), float(cfg.TEST.NMS), float(thresh), int(max_per_image), out=out, count=count))
