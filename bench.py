@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--profile-steps", type=int, default=3, help="steps of the HIP-event pass that feeds `roofline`")
-    ap.add_argument("--streams", type=int, default=2, help="images in flight per GPU (independent HIP streams + graphs)")
+    ap.add_argument("--streams", type=int, default=3, help="images in flight per GPU (independent HIP streams + graphs)")
     ap.add_argument("--layer-report", default=None, help="write a per-layer table of the event pass to this file")
     args = ap.parse_args()
 

@@ -1,5 +1,5 @@
 import sys, os, itertools
-sys.path[:0] = ["tf-faster-rcnn_amd"]
+sys.path[:0] = [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tf-faster-rcnn_amd")]
 import numpy as np, torch
 from frcnn_hip import ops, lib
 dev = torch.device("cuda:0")

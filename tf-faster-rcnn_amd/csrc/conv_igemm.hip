@@ -115,36 +115,49 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
       a_base[t] = 0; a_ih0[t] = -(1 << 28); a_iw0[t] = -(1 << 28);
     }
   }
-  long long b_off[LB];                                          // float offset of (row n, swizzled chunk) or -1
+  // Per-lane running source pointers.  Within one (kh,kw) tap consecutive slabs are 128 B apart, so a
+  // slab issue is one 64-bit add per load; pointers are rebuilt only at tap boundaries (wave-uniform
+  // branch).  Padding taps / tile-tail rows point at the zero page with increment 0.
+  const float* zero = (const float*)g_zero_page;
+  const float* a_ptr[LA]; int a_inc[LA];
+  const float* b_ptr[LB]; int b_inc[LB];
 #pragma unroll
   for (int t = 0; t < LB; ++t) {
     const int row = BM + (wave * LB + t) * 8 + lrow;
     const int n = bn0 + row - BM;
     const int q4 = (lpos ^ ((row >> 1) & 7)) * 4;
-    b_off[t] = (n < p.Cout) ? ((long long)n * p.Ktot + q4) : -1;
+    const bool ok = n < p.Cout;
+    b_ptr[t] = ok ? p.w + (size_t)n * p.Ktot + q4 : zero;
+    b_inc[t] = ok ? 32 : 0;
   }
-  const float* zero = (const float*)g_zero_page;
-  int kh = 0, kw = 0, c0 = 0, kflat = 0;                        // k position of the NEXT slab to issue
+  int kh = 0, kw = 0, c0 = 0;                                   // k position of the NEXT slab to issue
 
-  const unsigned lds0 = (unsigned)(size_t)(LDS_AS float*)smem;       // LDS byte address of the ring
-  auto issue_slab = [&](int buf) {
-    const unsigned sb = lds0 + (unsigned)(buf * SLAB * 4);
+  auto set_tap = [&]() {
 #pragma unroll
     for (int t = 0; t < LA; ++t) {
       const int ih = a_ih0[t] + kh, iw = a_iw0[t] + kw;
       bool ok = (unsigned)ih < (unsigned)p.H;
       if (FOLDW) ok = ok && ((unsigned)(iw + (a_q4[t] >> 2)) < (unsigned)p.W);
       else ok = ok && ((unsigned)iw < (unsigned)p.W);
-      const float* src = ok ? p.x + (size_t)(a_base[t] + (ih * p.W + iw) * p.Cin + c0 + a_q4[t]) : zero;
-      glds16(src, __builtin_amdgcn_readfirstlane(sb + (wave * LA + t) * 1024));
+      a_ptr[t] = ok ? p.x + (size_t)(a_base[t] + (ih * p.W + iw) * p.Cin + a_q4[t]) : zero;
+      a_inc[t] = ok ? 32 : 0;
+    }
+  };
+  const unsigned lds0 = (unsigned)(size_t)(LDS_AS float*)smem;       // LDS byte address of the ring
+  auto issue_slab = [&](int buf) {
+    const unsigned sb = lds0 + (unsigned)(buf * SLAB * 4);
+    if (c0 == 0) set_tap();
+#pragma unroll
+    for (int t = 0; t < LA; ++t) {
+      glds16(a_ptr[t], __builtin_amdgcn_readfirstlane(sb + (wave * LA + t) * 1024));
+      a_ptr[t] += a_inc[t];
     }
 #pragma unroll
     for (int t = 0; t < LB; ++t) {
-      const float* src = (b_off[t] >= 0) ? p.w + b_off[t] + kflat : zero;
-      glds16(src, __builtin_amdgcn_readfirstlane(sb + BM * 128 + (wave * LB + t) * 1024));
+      glds16(b_ptr[t], __builtin_amdgcn_readfirstlane(sb + BM * 128 + (wave * LB + t) * 1024));
+      b_ptr[t] += b_inc[t];
     }
     // advance to the following slab
-    kflat += 32;
     if (FOLDW) { ++kh; }
     else {
       c0 += 32;
@@ -152,13 +165,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
     }
   };
 
-  f32x16 acc[TM][TN];
+  constexpr bool KSPLIT = (TM * TN == 1);                 // second accumulator for odd k of single-tile waves
+  f32x16 acc[TM][TN], acc2[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acc2[i][j][r] = 0.f; }
 
   // fragment read offsets: row (lane&31) of the wave's 32-row groups, k chunk 2s + (lane>>5), swizzled
   const int frow = lane & 31, khalf = lane >> 5;
@@ -189,19 +203,32 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
 #pragma unroll
       for (int j = 0; j < TN; ++j) b[s][j] = *(const float4*)(sb + b_row0 + j * 1024 + koff[s]);
     }
+    // MFMA order: consecutive instructions always target DIFFERENT accumulators (the dependent
+    // latency of v_mfma_f32_32x32x2_f32 is not shorter than its issue interval, so chains of
+    // dependent MFMAs leave bubbles).  Single-tile waves split k over two accumulators (KSPLIT).
     if (!(p.dbg & 1))
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i].x, b[s][j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i].y, b[s][j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i].z, b[s][j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][i].w, b[s][j].w, acc[i][j], 0, 0, 0);
-        }
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float av = e == 0 ? a[s][i].x : e == 1 ? a[s][i].y : e == 2 ? a[s][i].z : a[s][i].w;
+            const float bv = e == 0 ? b[s][j].x : e == 1 ? b[s][j].y : e == 2 ? b[s][j].z : b[s][j].w;
+            if (KSPLIT && (e & 1)) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc2[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+          }
     }
+  }
+  if (KSPLIT) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[i][j][r];
   }
 
   // ---- epilogue: accumulators -> LDS tile [BM][BN] -> float4 rows ---------------------------------
