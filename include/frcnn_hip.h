@@ -104,6 +104,11 @@ int frcnn_detect_post(const float* cls_prob_d, const float* bbox_pred_d, const f
                       double nms_thresh, float score_thresh, int max_per_image, float* out_dets_d,
                       int* out_count_d, int max_out, void* ws, size_t ws_bytes, void* stream);
 
+/* The box stage of im_detect alone (lib/model/test.py:95-102): pred_boxes [R,4C] = clip(decode(rois/scale,
+ * bbox_pred)) for every class, for callers that want the reference's (scores, pred_boxes) pair. */
+int frcnn_im_detect_boxes(const float* rois_d, const float* bbox_pred_d, int R, int C, double im_scale,
+                          int im_h, int im_w, float* boxes_d, void* stream);
+
 /* ---- IoU matrix: replaces lib/utils/bbox.pyx:15-55 ------------------------------------------ */
 /* boxes_d [n,4] f64, query_d [k,4] f64 -> out_d [n,k] f64. */
 int frcnn_bbox_overlaps(const double* boxes_d, int n, const double* query_d, int k, double* out_d, void* stream);

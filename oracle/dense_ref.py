@@ -110,6 +110,8 @@ class DenseRef(object):
             bbox = bbox * _t(np.tile((0.1, 0.1, 0.2, 0.2), self.C), self.dtype) + _t(np.tile((0.0,) * 4, self.C), self.dtype)
         return cls_score.numpy(), cls_prob.numpy(), bbox.numpy()
 
+    max_pool_crop = False          # resnet: direct 7x7 crop (resnet_v1.py:55-76); vgg/mobilenet: 14x14 + 2x2 max
+
     def test_image(self, image_nhwc, im_info, rois=None, pre=6000, post=300, thr=0.7, pool=7):
         """Full reference forward (network.py:233-262, TEST, MODE nms).  If `rois` is given the RoI
         stage uses THEM (so a tail comparison is not confounded by a proposal that flipped on a
@@ -122,8 +124,68 @@ class DenseRef(object):
             rois, _ = ora.proposal_layer(prob.astype(np.float32), bbox.astype(np.float32), np.asarray(im_info, dtype=np.float32),
                                          "TEST", [16], anchors, self.A, pre_nms_topN=pre, post_nms_topN=post, nms_thresh=thr)
         feat_nhwc = feat.permute(0, 2, 3, 1).contiguous().numpy()
-        pool5 = ora.crop_and_resize(feat_nhwc[0].astype(np.float32), rois.astype(np.float32), 16.0, pool)
+        pool5 = ora.crop_and_resize(feat_nhwc[0].astype(np.float32), rois.astype(np.float32), 16.0, pool,
+                                    max_pool=self.max_pool_crop)
         fc7 = self.tail(pool5)
         cls_score, cls_prob, bbox_pred = self.classify(fc7)
         return dict(head=feat_nhwc, rpn_cls_score=score, rpn_cls_prob=prob, rpn_bbox_pred=bbox, rois=rois, pool5=pool5,
                     fc7=fc7.numpy(), cls_score=cls_score, cls_prob=cls_prob, bbox_pred=bbox_pred)
+
+
+class VGG16Ref(DenseRef):
+    """lib/nets/vgg16.py:26-60 (TEST): conv+bias+ReLU x13, 2x2/2 SAME max pools, fc6/fc7 on the
+    NHWC-flattened 7x7x512 crop."""
+    max_pool_crop = True
+    CFG = [("conv1", 2), ("conv2", 2), ("conv3", 3), ("conv4", 3), ("conv5", 3)]
+
+    def __init__(self, variables, num_classes=21, anchor_scales=(8, 16, 32), anchor_ratios=(0.5, 1, 2), dtype=torch.float64):
+        DenseRef.__init__(self, variables, 50, num_classes, anchor_scales, anchor_ratios, dtype)
+        self.scope = "vgg_16"
+
+    def head(self, image_nhwc):
+        x = _t(image_nhwc, self.dtype).permute(0, 3, 1, 2)
+        for bi, (name, reps) in enumerate(self.CFG):
+            for r in range(1, reps + 1):
+                sc = "%s/%s/%s_%d" % (self.scope, name, name, r)
+                x = F.relu(F.conv2d(x, self.w(sc + "/weights"), self.w(sc + "/biases"), padding=1))
+            if bi < 4:
+                x = F.max_pool2d(x, 2, 2, ceil_mode=True)          # 'SAME': pad bottom/right, ignored
+        return x
+
+    def tail(self, pool5_nhwc):
+        x = _t(pool5_nhwc, self.dtype).reshape(pool5_nhwc.shape[0], -1)        # slim.flatten: (h, w, c)
+        w6 = _t(np.asarray(self.v[self.scope + "/fc6/weights"]).reshape(-1, 4096), self.dtype)
+        x = F.relu(x @ w6 + self.w(self.scope + "/fc6/biases"))
+        return F.relu(x @ self.w(self.scope + "/fc7/weights") + self.w(self.scope + "/fc7/biases"))
+
+
+class MobileNetRef(DenseRef):
+    """lib/nets/mobilenet_v1.py:63-79,114-172,214-250 (TEST), depth multiplier 1.0."""
+    max_pool_crop = True
+    SEP = [(1, 64), (2, 128), (1, 128), (2, 256), (1, 256), (2, 512), (1, 512), (1, 512), (1, 512), (1, 512), (1, 512),
+           (1, 1024), (1, 1024)]
+
+    def __init__(self, variables, num_classes=21, anchor_scales=(8, 16, 32), anchor_ratios=(0.5, 1, 2), dtype=torch.float64):
+        DenseRef.__init__(self, variables, 50, num_classes, anchor_scales, anchor_ratios, dtype)
+        self.scope = "MobilenetV1"
+
+    def sep(self, x, i, stride):
+        dw = "%s/Conv2d_%d_depthwise" % (self.scope, i)
+        w = _t(np.transpose(self.v[dw + "/depthwise_weights"], (2, 3, 0, 1)), self.dtype)      # [C,1,3,3]
+        x = F.conv2d(F.pad(x, (1, 1, 1, 1)), w, stride=stride, groups=x.shape[1])
+        x = self.bn(x, dw, eps=1e-3).clamp(0, 6)
+        pw = "%s/Conv2d_%d_pointwise" % (self.scope, i)
+        return self.bn(F.conv2d(x, self.w(pw + "/weights")), pw, eps=1e-3).clamp(0, 6)
+
+    def head(self, image_nhwc):
+        x = _t(image_nhwc, self.dtype).permute(0, 3, 1, 2)
+        x = self.bn(self.conv_same(x, self.scope + "/Conv2d_0", 3, 2), self.scope + "/Conv2d_0", eps=1e-3).clamp(0, 6)
+        for i in range(1, 12):
+            x = self.sep(x, i, self.SEP[i - 1][0])
+        return x
+
+    def tail(self, pool5_nhwc):
+        x = _t(pool5_nhwc, self.dtype).permute(0, 3, 1, 2)
+        for i in (12, 13):
+            x = self.sep(x, i, self.SEP[i - 1][0])
+        return x.mean(dim=(2, 3))

@@ -188,3 +188,38 @@ def test_bbox_overlaps_bit_exact(dev, golden):
     q = synth.gt_boxes(12, 21, seed=14).astype(np.float64)[:, :4]
     got = ops.bbox_overlaps(T(d, dev), T(q, dev)).cpu().numpy()
     assert np.array_equal(got, golden["targets"]["overlaps"])
+
+
+def test_im_detect_boxes_vs_reference_golden(dev, golden):
+    import hashlib
+    from frcnn_hip import ops
+    for tag, (R, C, W, H) in {"voc_300x21": (300, 21, 1000.0, 600.0), "coco_1000x81": (1000, 81, 1333.0, 800.0)}.items():
+        prob, bp, rois = synth.rcnn_outputs(R, C, seed=7, im_w=W, im_h=H)
+        got = ops.im_detect_boxes(T(rois, dev), T(bp, dev), 1.6, int(H / 1.6), int(W / 1.6)).cpu().numpy()
+        _, want = ora.im_detect_post(prob, bp, rois, 1.6, (int(H / 1.6), int(W / 1.6), 3))
+        # `want` is pinned to the reference through its sha in the golden file (test_oracle_golden.py)
+        assert np.array_equal(np.frombuffer(hashlib.sha256(want.tobytes()).digest(), dtype=np.uint8), golden["perclass"][tag + "_boxes_sha"])
+        assert np.allclose(got, want, rtol=0, atol=1e-3)     # device expf vs np.exp: 1e-4 relative budget
+
+
+def test_host_mirror_seams_numpy_in_numpy_out(dev, golden):
+    """The reference-named modules (nms.gpu_nms, model.nms_wrapper, utils.cython_bbox, layer_utils.*) are
+    drop-ins: numpy in, numpy out, reference results."""
+    from layer_utils.generate_anchors import generate_anchors
+    from layer_utils.proposal_layer import proposal_layer
+    from layer_utils.snippets import generate_anchors_pre
+    from model.nms_wrapper import nms
+    from utils.cython_bbox import bbox_overlaps
+    d = synth.random_dets(3000, seed=11, cluster=12)
+    assert np.array_equal(np.array(nms(d, 0.3), dtype=np.int32), golden["nms"]["c3000_t03_keep"])
+    assert nms(np.zeros((0, 5), dtype=f32), 0.3) == []
+    assert np.array_equal(generate_anchors(), ora.generate_anchors())
+    anc, n = generate_anchors_pre(38, 63, [16, ], (8, 16, 32), (0.5, 1, 2))
+    assert n == 21546 and np.array_equal(anc, ora.generate_anchors_pre(38, 63, 16)[0])
+    q = synth.gt_boxes(12, 21, seed=14).astype(np.float64)
+    bx = synth.random_dets(600, seed=13)[:, :4].astype(np.float64)
+    assert np.array_equal(bbox_overlaps(bx, q), golden["targets"]["overlaps"])
+    prob, dl = synth.rpn_outputs(38, 63, 9, seed=3)
+    blob, sc = proposal_layer(prob, dl, np.array([600, 1000, 1.6], dtype=f32), b"TEST", [16, ], anc, 9)
+    assert np.array_equal(sc, golden["proposal"]["test_38x63_a9_scores"])
+    assert np.allclose(blob, golden["proposal"]["test_38x63_a9_rois"], rtol=0, atol=1e-3)

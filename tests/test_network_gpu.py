@@ -107,3 +107,54 @@ def test_eager_equals_graph_and_top_mode(small_net):
         assert np.allclose(rois, want, rtol=0, atol=1e-3)
     finally:
         cfg.TEST.MODE, cfg.TEST.RPN_TOP_N = "nms", 5000
+
+
+@pytest.mark.parametrize("arch", ["vgg16", "mobile"])
+def test_vgg16_and_mobilenet_match_dense_oracle(dev, arch):
+    """SURVEY.md 8a rows 2/10 (VGG16, MobileNet-v1 backbones + tails): same parity bar as ResNet."""
+    from dense_ref import VGG16Ref, MobileNetRef
+    from frcnn_hip.runtime import Session
+    from model.config import cfg
+    from nets.mobilenet_v1 import mobilenetv1
+    from nets.vgg16 import vgg16
+    cfg.TEST.RPN_POST_NMS_TOP_N = 24
+    try:
+        sess = Session(device=dev, seed=7)
+        net = vgg16() if arch == "vgg16" else mobilenetv1()
+        net.create_architecture("TEST", 21, tag=arch, anchor_scales=SCALES, anchor_ratios=RATIOS)
+        sess.init_variables(net.variable_specs())
+        rng = np.random.RandomState(11)
+        H, W = 121, 170                                      # odd sizes exercise the SAME / conv2d_same rules
+        image = ((rng.rand(1, H, W, 3) * 255.0).astype(np.float32) - cfg.PIXEL_MEANS.astype(np.float32)) * np.float32(1 / 64.0 if arch == "vgg16" else 1.0)
+        im_info = np.array([H, W, 1.0], dtype=np.float32)
+        cls_score, cls_prob, bbox_pred, rois = net.test_image(sess, image, im_info)
+        Ref = VGG16Ref if arch == "vgg16" else MobileNetRef
+        ref = Ref(sess.variables, 21, SCALES, RATIOS).test_image(image, im_info, rois=rois, post=24)
+        ref32 = Ref(sess.variables, 21, SCALES, RATIOS, dtype=torch.float32).test_image(image, im_info, rois=rois, post=24)
+        head = net._layers["head"].cpu().numpy()
+        assert head.shape == ref["head"].shape
+        assert rel_err(head, ref["head"]) <= 1e-4
+        n = rois.shape[0]
+        assert n > 0
+        assert np.array_equal(net._layers["pool5"][:n].cpu().numpy(), ora.crop_and_resize(head[0], rois, 16.0, 7, max_pool=True))
+        for name, got in (("rpn_cls_prob", net._predictions["rpn_cls_prob"].cpu().numpy()), ("rpn_bbox_pred", net._predictions["rpn_bbox_pred"].cpu().numpy()),
+                          ("cls_score", cls_score), ("bbox_pred", bbox_pred)):
+            assert rel_err(got, ref[name][:got.shape[0]]) <= max(1e-4, 4 * rel_err(ref32[name][:got.shape[0]], ref[name][:got.shape[0]])), name
+        assert np.abs(cls_prob - ref["cls_prob"]).max() <= 1e-4
+    finally:
+        cfg.TEST.RPN_POST_NMS_TOP_N = 300
+
+
+def test_model_test_module_matches_reference_loop(small_net):
+    """model.test.im_detect / detect (lib/model/test.py:86-107,156-180) vs the oracle on identical inputs."""
+    from model.test import detect, im_detect
+    sess, net, image, im_info = small_net
+    scores, pred_boxes = im_detect(sess, net, image, 1.0, (150, 200, 3))
+    _, cls_prob, bbox_pred, rois = net.test_image(sess, image, im_info)
+    want_s, want_b = ora.im_detect_post(cls_prob, bbox_pred, rois, 1.0, (150, 200, 3))
+    assert np.array_equal(scores, want_s) and np.allclose(pred_boxes, want_b, rtol=0, atol=1e-3)
+    per_class = detect(sess, net, image, 1.0, (150, 200))
+    want = ora.test_net_post(want_s, want_b, 21)
+    for j in range(1, 21):
+        assert per_class[j].shape == want[j].shape
+        assert np.array_equal(per_class[j][:, 4], want[j][:, 4]) and np.allclose(per_class[j][:, :4], want[j][:, :4], atol=1e-3)

@@ -576,6 +576,32 @@ extern "C" int frcnn_bbox_overlaps(const double* boxes_d, int n, const double* q
 // kernel B: one workgroup: exact max_per_image-th score by 4-pass radix select, then an
 //           order-preserving compaction (wave ballot + popcount prefix) into the record list.
 // ------------------------------------------------------------------------------------------------
+// im_detect's box stage alone (model/test.py:95-102): rois/scale, decode for EVERY class, final clip.
+__global__ void k_im_detect_boxes(const float* __restrict__ rois, const float* __restrict__ bbox_pred, int R, int C,
+                                  double im_scale, float hi_x, float hi_y, float4* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= R * C) return;
+  const int r = t / C;
+  const float* ro = rois + 5 * (size_t)r;
+  const float4 box = make_float4((float)((double)ro[1] / im_scale), (float)((double)ro[2] / im_scale),
+                                 (float)((double)ro[3] / im_scale), (float)((double)ro[4] / im_scale));
+  float4 b = decode_box(box, ((const float4*)bbox_pred)[t]);
+  b.x = rmax(b.x, 0.0f); b.y = rmax(b.y, 0.0f);
+  b.z = rmin(b.z, hi_x); b.w = rmin(b.w, hi_y);
+  out[t] = b;
+}
+
+extern "C" int frcnn_im_detect_boxes(const float* rois_d, const float* bbox_pred_d, int R, int C, double im_scale, int im_h,
+                                     int im_w, float* boxes_d, void* stream) {
+  if (R < 0 || C <= 0 || !(im_scale > 0)) return FRCNN_E_ARG;
+  if (R == 0) return FRCNN_OK;
+  if (!rois_d || !bbox_pred_d || !boxes_d) return FRCNN_E_ARG;
+  hipLaunchKernelGGL(k_im_detect_boxes, dim3(cdiv(R * C, 256)), dim3(256), 0, (hipStream_t)stream, rois_d, bbox_pred_d, R, C,
+                     im_scale, (float)(im_w - 1), (float)(im_h - 1), (float4*)boxes_d);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
 #define PC_MAXR 1024
 #define PC_WORDS (PC_MAXR / 64)
 

@@ -34,6 +34,7 @@ SIGNATURES = {
     "frcnn_detect_post_workspace_bytes": (c_size_t, [c_int, c_int]),
     "frcnn_detect_post": (c_int, [_P, _P, _P, _P, c_int, c_int, c_double, c_int, c_int, c_double, c_float, c_int, _P, _P,
                                   c_int, _P, c_size_t, _P]),
+    "frcnn_im_detect_boxes": (c_int, [_P, _P, c_int, c_int, c_double, c_int, c_int, _P, _P]),
     "frcnn_bbox_overlaps": (c_int, [_P, c_int, _P, c_int, _P, _P]),
     "frcnn_conv2d_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

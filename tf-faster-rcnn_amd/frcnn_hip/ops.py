@@ -160,6 +160,16 @@ def detect_post(cls_prob, bbox_pred, rois, num_rois, im_scale, im_h, im_w, nms_t
     return out, count
 
 
+def im_detect_boxes(rois, bbox_pred, im_scale, im_h, im_w):
+    """lib/model/test.py:95-102 on device: -> pred_boxes [R,4C]."""
+    _chk(rois), _chk(bbox_pred)
+    R, C4 = bbox_pred.shape
+    out = torch.empty((R, C4), dtype=torch.float32, device=rois.device)
+    call("frcnn_im_detect_boxes", _ptr(rois), _ptr(bbox_pred), R, C4 // 4, float(im_scale), int(im_h), int(im_w), _ptr(out),
+         _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------------ dense
 def pack_filter_hwio(w_hwio, scale=None):
     """HOST numpy HWIO -> packed [Cout][KH][KW][Cin] (folding a per-output-channel scale)."""

@@ -1,0 +1,59 @@
+"""model.test -- the test loop of the reference (lib/model/test.py) on the device chain.
+
+`im_detect` / `test_net` keep the reference's names and return conventions; image decoding and the
+cv2 resize of `_get_image_blob` (test.py:26-58) are host preprocessing outside the hot path (SURVEY.md
+8f row 2), so `im_detect` takes the ALREADY SCALED, mean-subtracted blob plus its scale."""
+import numpy as np
+import torch
+
+from frcnn_hip import ops
+from frcnn_hip.runtime import Timer
+from model.config import cfg
+
+
+def im_detect(sess, net, blob, im_scale, im_shape):
+    """blob [1,H,W,3] f32 (BGR - PIXEL_MEANS, scaled by im_scale), im_shape = original (h, w[, c]).
+    Returns (scores [R,C], pred_boxes [R,4C]) like lib/model/test.py:86-107 -- decode + clip of the
+    per-class boxes included -- computed from the device tensors."""
+    im_info = np.array([blob.shape[1], blob.shape[2], im_scale], dtype=np.float32)
+    img = net._stage_image(sess, blob)
+    p = net.forward_device(sess, img, im_info)
+    n = p["rois"].shape[0] if net._num_rois is None else int(net._num_rois.item())
+    rois, bbox_pred = p["rois"][:n].contiguous(), p["bbox_pred"][:n].contiguous()
+    pred_boxes = ops.im_detect_boxes(rois, bbox_pred, im_scale, im_shape[0], im_shape[1])      # test.py:95-102
+    return p["cls_prob"][:n].cpu().numpy(), pred_boxes.cpu().numpy()
+
+
+def detect(sess, net, blob, im_scale, im_shape, max_per_image=100, thresh=0.):
+    """Whole per-image body of test_net (test.py:156-180) on the GPU -> all_boxes-style list over
+    classes of [n,5] arrays (x1,y1,x2,y2,score)."""
+    im_info = np.array([blob.shape[1], blob.shape[2], im_scale], dtype=np.float32)
+    img = net._stage_image(sess, blob)
+    dets, cnt = net.detect_device(sess, img, im_info, im_shape, max_per_image=max_per_image, thresh=thresh)
+    n = min(int(cnt.item()), dets.shape[0])
+    rec = dets[:n].cpu().numpy()
+    out = [np.zeros((0, 5), dtype=np.float32) for _ in range(net._num_classes)]
+    for j in range(1, net._num_classes):
+        out[j] = rec[rec[:, 5] == j, :5]
+    return out
+
+
+def test_net(sess, net, images, num_classes=None, max_per_image=100, thresh=0.):
+    """images: iterable of (blob, im_scale, im_shape).  Returns all_boxes[cls][image] like the
+    reference; prints the same per-image timing line (test.py:183-185)."""
+    images = list(images)
+    num_classes = net._num_classes if num_classes is None else num_classes
+    all_boxes = [[[] for _ in range(len(images))] for _ in range(num_classes)]
+    _t = {'im_detect': Timer(), 'misc': Timer()}
+    for i, (blob, im_scale, im_shape) in enumerate(images):
+        _t['im_detect'].tic()
+        per_class = detect(sess, net, blob, im_scale, im_shape, max_per_image, thresh)
+        torch.cuda.synchronize()
+        _t['im_detect'].toc()
+        _t['misc'].tic()
+        for j in range(1, num_classes):
+            all_boxes[j][i] = per_class[j]
+        _t['misc'].toc()
+        print('im_detect: {:d}/{:d} {:.3f}s {:.3f}s'.format(i + 1, len(images), _t['im_detect'].average_time,
+                                                            _t['misc'].average_time))
+    return all_boxes
