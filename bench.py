@@ -42,6 +42,23 @@ def synth_image(seed):
     return (rng.rand(1, IM_H, IM_W, 3) * 255.0).astype(np.float32) - cfg.PIXEL_MEANS.astype(np.float32)
 
 
+def calibrate_rpn(sess, net, img_d, im_info):
+    """Random-init RPN heads give near-constant scores and ~0 deltas, so NMS collapses the 6000 candidates
+    to ~140 boxes.  Rescale the two 1x1 RPN heads so the proposal stage sees the statistics SURVEY.md 8d
+    prescribes (logit spread ~1, deltas ~N(0,0.2^2)) and the full 300 proposals survive, as they do with a
+    trained model.  Weights only; the architecture and every shape stay those of the reference."""
+    with torch.cuda.stream(sess.stream):
+        p = net.forward_device(sess, img_d, im_info, use_graph=False)
+        sess.stream.synchronize()
+        s_cls = float(p["rpn_cls_score"].std().item())
+        s_box = float(p["rpn_bbox_pred"].std().item())
+    scope = net._scope
+    sess.variables[scope + "/rpn_cls_score/weights"] *= np.float32(1.0 / max(s_cls, 1e-12))
+    sess.variables[scope + "/rpn_bbox_pred/weights"] *= np.float32(0.2 / max(s_box, 1e-12))
+    sess.packed.clear()
+    sess.graphs.clear()
+
+
 def cpu_baseline(variables, image, rois_hint):
     """Host-CPU number beside the GPU one: the oracle's restatement of the SAME workload (one image),
     dense part = torch-CPU float32 on all host cores (TensorFlow-CPU is not installable offline),
@@ -123,6 +140,7 @@ def main():
         with torch.cuda.stream(streams[i]):
             imgs.append(nets[i]._stage_image(sess, synth_image(cfg.RNG_SEED + rank + 1000 * i)))   # resident in HBM
     torch.cuda.synchronize()
+    calibrate_rpn(sess, nets[0], imgs[0], im_info)          # synthetic-data preparation, outside any timed region
     run_stream = streams[0]
     img_d, dets_view, count_i32 = imgs[0], views[0], counts[0]
 
