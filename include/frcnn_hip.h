@@ -150,6 +150,39 @@ int frcnn_rpn_softmax(const float* score_d, int HW, int A, int ld, float* prob_d
 /* strided 2-D copy  dst[r, 0:cols] = src[r, col0:col0+cols]  (splits fused head outputs). */
 int frcnn_copy_cols(const float* src_d, int R, int ld_src, int col0, int cols, float* dst_d, int ld_dst, void* stream);
 
+/* ---- training targets + losses ---------------------------------------- */
+/* anchor_target_layer (lib/layer_utils/anchor_target_layer.py:18-138).  gt_boxes_d [G,5] f32; anchors are
+ * regenerated from base_d (float64 [A,4]).  Outputs in the reference layouts: labels_d [1,1,A*H,W],
+ * bbox_targets_d / inside_w_d / outside_w_d [1,H,W,4A].  seed >= 0: fg/bg subsampling to rpn_batchsize with a
+ * counter-based hash (same distribution as npr.choice without replacement, not the same stream);
+ * seed < 0: no subsampling (every fg/bg anchor keeps its label) -- the deterministic part, used for parity. */
+size_t frcnn_anchor_target_workspace_bytes(int H, int W, int A, int max_gt);
+int frcnn_anchor_target_layer(const float* gt_boxes_d, int G, float im_h, float im_w, int H, int W, int A,
+                              int feat_stride, const double* base_d, int rpn_batchsize, double fg_fraction,
+                              double pos_overlap, double neg_overlap, long long seed, float* labels_d,
+                              float* bbox_targets_d, float* inside_w_d, float* outside_w_d, void* ws,
+                              size_t ws_bytes, void* stream);
+/* proposal_target_layer (lib/layer_utils/proposal_target_layer.py:18-152, USE_GT False).  rpn_rois_d [N,5],
+ * rpn_scores_d [N], N <= 3072.  Outputs: rois_d [B,5], roi_scores_d [B], labels_d [B], bbox_targets_d /
+ * inside_w_d / outside_w_d [B,4*num_classes], counts_d[4] = {fg sampled, bg sampled, fg candidates, bg candidates}.
+ * fg rows first, then bg rows (np.append(fg_inds, bg_inds), :138). */
+int frcnn_proposal_target_layer(const float* rpn_rois_d, const float* rpn_scores_d, int N, const float* gt_boxes_d,
+                                int G, int num_classes, int batch_size, double fg_fraction, double fg_thresh,
+                                double bg_thresh_hi, double bg_thresh_lo, const double* means4, const double* stds4,
+                                long long seed, float* rois_d, float* roi_scores_d, float* labels_d,
+                                float* bbox_targets_d, float* inside_w_d, float* outside_w_d, int* counts_d,
+                                void* stream);
+/* Losses of lib/nets/network.py:264-321, value + gradient w.r.t. the logits / predictions in one call.
+ * softmax CE: logits [R,C] rows (rpn_A = 0) or the RPN pair layout (rpn_A = A: logits [H*W,2A], element
+ * r = (a*H+h)*W+w pairs channels (a, A+a), labels_d in the [1,1,A*H,W] layout); label < 0 is ignored;
+ * loss = mean over the selected rows.  SmoothL1: loss = sum(out_w * f(in_w*(pred-tgt))) / mean_divisor. */
+size_t frcnn_loss_workspace_bytes(long long elements);
+int frcnn_softmax_ce_loss(const float* logits_d, const float* labels_d, int R, int C, int rpn_A, int rpn_H, int rpn_W,
+                          float* loss_d, float* dlogits_d, void* ws, size_t ws_bytes, void* stream);
+int frcnn_smooth_l1_loss(const float* pred_d, const float* targets_d, const float* inside_w_d, const float* outside_w_d,
+                         long long n, float sigma, float mean_divisor, float* loss_d, float* dpred_d, void* ws,
+                         size_t ws_bytes, void* stream);
+
 /* ---- stream capture (one hipGraph per image-shape; replaces the per-image sess.run) ---------- */
 int frcnn_graph_begin(void* stream);
 int frcnn_graph_end(void* stream, void** graph_exec_out);

@@ -1,0 +1,136 @@
+"""GPU parity of the training-side kernels through the C ABI.
+Deterministic parts vs the pinned oracle / the reference goldens; random subsampling vs its contract
+(uniform k-subset of the candidates, counts as in the reference); losses vs torch float64 autograd."""
+import numpy as np
+import pytest
+import torch
+
+import frcnn_oracle as ora
+import synth
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+IM_INFO = np.array([600, 1000, 1.6], dtype=f32)
+
+
+def T(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(dev) if dtype is None else t.to(dev, dtype)
+
+
+def _at_inputs(dev, golden):
+    from frcnn_hip import ops
+    gt = golden["targets"]["gt"]
+    base = ops.generate_anchors(16)
+    anc, _ = ora.generate_anchors_pre(38, 63, 16)
+    return gt, base, anc
+
+
+def test_anchor_target_layer_deterministic_part_vs_oracle_and_reference(dev, golden):
+    from frcnn_hip import ops
+    gt, base, anc = _at_inputs(dev, golden)
+    lab, tg, iw, ow = [t.cpu().numpy() for t in ops.anchor_target_layer(T(gt, dev), 600, 1000, 38, 63, T(base, dev), seed=-1)]
+    want = ora.anchor_target_layer(np.zeros((1, 38, 63, 18), dtype=f32), gt, IM_INFO, [16], anc, 9, rng=np.random.RandomState(0),
+                                   batchsize=10 ** 9)                  # batch so large that nothing is subsampled
+    assert np.array_equal(lab, want[0])                                # labels: bit-exact (f64 IoU, thresholds, gt-argmax ties)
+    assert np.allclose(tg, want[1], rtol=0, atol=2e-6)                 # bbox_transform: device logf vs np.log
+    assert np.array_equal(iw, want[2]) and np.array_equal(ow, want[3])
+    # regression targets do not depend on the sampling: compare with the REFERENCE's own output too
+    assert np.allclose(tg, golden["targets"]["at_targets"], rtol=0, atol=2e-6)
+    assert (lab == 1).sum() > 0 and (lab == 0).sum() > 1000
+
+
+def test_anchor_target_layer_subsampling_contract(dev, golden):
+    from frcnn_hip import ops
+    gt, base, anc = _at_inputs(dev, golden)
+    full = ops.anchor_target_layer(T(gt, dev), 600, 1000, 38, 63, T(base, dev), seed=-1)[0].cpu().numpy().ravel()
+    outs = []
+    for seed in (3, 3, 4):
+        lab, tg, iw, ow = [t.cpu().numpy() for t in ops.anchor_target_layer(T(gt, dev), 600, 1000, 38, 63, T(base, dev), seed=seed)]
+        l = lab.ravel()
+        nfg, nbg = int((l == 1).sum()), int((l == 0).sum())
+        assert nfg == min(int((full == 1).sum()), 128) and nfg + nbg == 256        # anchor_target_layer.py:72-86
+        assert np.all(full[l == 1] == 1) and np.all(full[l == 0] == 0)             # subsets of the candidates
+        assert np.allclose(ow[ow > 0], 1.0 / 256) and int((ow > 0).sum()) == 4 * 256
+        assert int((iw > 0).sum()) == 4 * nfg
+        outs.append(l)
+    assert np.array_equal(outs[0], outs[1]) and not np.array_equal(outs[0], outs[2])  # deterministic per seed
+    # the reference's sampled output has the same counts
+    ref = golden["targets"]["at_labels"].ravel()
+    assert int((ref == 1).sum()) == int((outs[0] == 1).sum()) and int((ref == 0).sum()) == int((outs[0] == 0).sum())
+
+
+def test_proposal_target_layer_contract_and_values(dev, golden):
+    from frcnn_hip import ops
+    gt = golden["targets"]["gt"]
+    prob, dl = synth.rpn_outputs(38, 63, 9, seed=3)
+    anc, _ = ora.generate_anchors_pre(38, 63, 16)
+    rois_in, sc_in = ora.proposal_layer(prob, dl, IM_INFO, "TRAIN", [16], anc, 9)
+    out = ops.proposal_target_layer(T(rois_in, dev), T(sc_in.ravel(), dev), T(gt, dev), 21, seed=5)
+    rois, sc, labels, tg, iw, ow, counts = [t.cpu().numpy() for t in out]
+    nfg_s, nbg_s, nfg_c, nbg_c = counts.tolist()
+    ov = ora.bbox_overlaps(rois_in[:, 1:5], gt[:, :4])
+    mx, am = ov.max(axis=1), ov.argmax(axis=1)
+    assert nfg_c == int((mx >= 0.5).sum()) and nbg_c == int(((mx < 0.5) & (mx >= 0.0)).sum())
+    assert nfg_s == min(64, nfg_c) and nfg_s + nbg_s == 256                              # proposal_target_layer.py:119-127
+    # every output row is one of the input rois, fg rows first
+    idx = [int(np.where((rois_in == r).all(axis=1))[0][0]) for r in rois]
+    assert np.all(mx[idx[:nfg_s]] >= 0.5) and np.all(mx[idx[nfg_s:]] < 0.5)
+    assert len(set(idx[:nfg_s])) == nfg_s                                                # fg without replacement
+    assert np.array_equal(sc, sc_in.ravel()[idx])
+    want_labels = gt[am[idx], 4].copy()
+    want_labels[nfg_s:] = 0
+    assert np.array_equal(labels.ravel(), want_labels)
+    # regression targets / weights: the oracle's formulas on the rows the kernel picked
+    t = ora.bbox_transform(rois[:, 1:5], gt[am[idx], :4])
+    t = ((t - np.array((0.0, 0.0, 0.0, 0.0))) / np.array((0.1, 0.1, 0.2, 0.2))).astype(f32)
+    want_t = np.zeros((256, 84), dtype=f32)
+    want_i = np.zeros((256, 84), dtype=f32)
+    for i in np.where(want_labels > 0)[0]:
+        c = int(4 * want_labels[i])
+        want_t[i, c:c + 4] = t[i]
+        want_i[i, c:c + 4] = 1
+    assert np.allclose(tg, want_t, rtol=0, atol=2e-5) and np.array_equal(iw, want_i) and np.array_equal(ow, want_i)
+    # same seed -> same sample; the reference's own sample has the same fg/bg split
+    again = ops.proposal_target_layer(T(rois_in, dev), T(sc_in.ravel(), dev), T(gt, dev), 21, seed=5)[0].cpu().numpy()
+    assert np.array_equal(again, rois)
+    assert int((golden["targets"]["pt_labels"] > 0).sum()) == nfg_s
+
+
+def test_losses_value_and_gradient_vs_torch_float64(dev, golden):
+    from frcnn_hip import ops
+    rng = np.random.RandomState(0)
+    A, H, W = 9, 38, 63
+    score = rng.randn(1, H, W, 2 * A).astype(f32)
+    labels = golden["targets"]["at_labels"]                                           # [1,1,A*H,W] in {-1,0,1}
+    loss, grad = ops.softmax_ce_loss(T(score, dev), T(labels, dev), rpn_shape=(A, H, W))
+    s = torch.from_numpy(score).double().requires_grad_(True)
+    # network.py:68-78,282-288: pair (a, A+a), element order (a, h, w)
+    pair = torch.stack([s[0, :, :, :A].permute(2, 0, 1).reshape(-1), s[0, :, :, A:].permute(2, 0, 1).reshape(-1)], dim=1)
+    lab = torch.from_numpy(labels.ravel()).long()
+    sel = lab >= 0
+    ref = torch.nn.functional.cross_entropy(pair[sel], lab[sel])
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-6 and np.allclose(grad.cpu().numpy(), s.grad.numpy(), rtol=0, atol=1e-8)
+    # RCNN class loss (network.py:299-301)
+    cs = (rng.randn(256, 21) * 2).astype(f32)
+    lb = golden["targets"]["pt_labels"].ravel().astype(f32)
+    loss, grad = ops.softmax_ce_loss(T(cs, dev), T(lb, dev))
+    c = torch.from_numpy(cs).double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(c, torch.from_numpy(lb).long())
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-6 and np.allclose(grad.cpu().numpy(), c.grad.numpy(), rtol=0, atol=1e-8)
+    # SmoothL1 (network.py:264-277): RPN sigma 3 / sum over (H,W,4A) / mean over batch 1; RCNN sigma 1 / mean over 256
+    for pred_shape, tg, iw, ow, sigma, div in (
+            ((1, H, W, 4 * A), golden["targets"]["at_targets"], golden["targets"]["at_inside"], golden["targets"]["at_outside"], 3.0, 1.0),
+            ((256, 84), golden["targets"]["pt_targets"], golden["targets"]["pt_inside"], golden["targets"]["pt_outside"], 1.0, 256.0)):
+        pred = (rng.randn(*pred_shape) * 0.5).astype(f32)
+        loss, grad = ops.smooth_l1_loss(T(pred, dev), T(tg, dev), T(iw, dev), T(ow, dev), sigma, div)
+        p = torch.from_numpy(pred).double().requires_grad_(True)
+        d = torch.from_numpy(iw).double() * (p - torch.from_numpy(tg).double())
+        s2 = sigma ** 2
+        f = torch.where(d.abs() < 1.0 / s2, d * d * (s2 / 2.0), d.abs() - 0.5 / s2)
+        ref = (torch.from_numpy(ow).double() * f).sum() / div
+        ref.backward()
+        assert abs(loss.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
+        assert np.allclose(grad.cpu().numpy(), p.grad.numpy(), rtol=1e-5, atol=1e-9)

@@ -6,7 +6,7 @@ library is missing or a call fails, an exception is raised.
 """
 import ctypes
 import os
-from ctypes import c_double, c_float, c_int, c_size_t, c_void_p
+from ctypes import c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libfrcnn_hip.so")
@@ -46,6 +46,14 @@ SIGNATURES = {
     "frcnn_softmax_rows": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "frcnn_rpn_softmax": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "frcnn_copy_cols": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    "frcnn_anchor_target_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "frcnn_anchor_target_layer": (c_int, [_P, c_int, c_float, c_float, c_int, c_int, c_int, c_int, _P, c_int, c_double, c_double,
+                                          c_double, c_longlong, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "frcnn_proposal_target_layer": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_double, c_double, c_double, c_double, _P, _P,
+                                            c_longlong, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "frcnn_loss_workspace_bytes": (c_size_t, [c_longlong]),
+    "frcnn_softmax_ce_loss": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
+    "frcnn_smooth_l1_loss": (c_int, [_P, _P, _P, _P, c_longlong, c_float, c_float, _P, _P, _P, c_size_t, _P]),
     "frcnn_graph_begin": (c_int, [_P]),
     "frcnn_graph_end": (c_int, [_P, ctypes.POINTER(c_void_p)]),
     "frcnn_graph_launch": (c_int, [_P, _P]),

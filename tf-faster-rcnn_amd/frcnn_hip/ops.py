@@ -277,6 +277,66 @@ def copy_cols(src, col0, cols, out=None):
     return out
 
 
+# ------------------------------------------------------------------------------------------ training
+def anchor_target_layer(gt_boxes, im_h, im_w, H, W, base_d, feat_stride=16, rpn_batchsize=256, fg_fraction=0.5,
+                        pos_overlap=0.7, neg_overlap=0.3, seed=0):
+    """lib/layer_utils/anchor_target_layer.py:18-138 on device -> (labels [1,1,A*H,W], targets, inside, outside [1,H,W,4A])."""
+    _chk(gt_boxes), _chk(base_d, torch.float64)
+    A, G, dev = base_d.shape[0], gt_boxes.shape[0], gt_boxes.device
+    labels = torch.empty((1, 1, A * H, W), dtype=torch.float32, device=dev)
+    tg, iw, ow = (torch.empty((1, H, W, 4 * A), dtype=torch.float32, device=dev) for _ in range(3))
+    ws = workspace(lib().frcnn_anchor_target_workspace_bytes(H, W, A, G), dev, "anchor_target")
+    call("frcnn_anchor_target_layer", _ptr(gt_boxes), G, float(im_h), float(im_w), H, W, A, int(feat_stride), _ptr(base_d),
+         int(rpn_batchsize), float(fg_fraction), float(pos_overlap), float(neg_overlap), int(seed), _ptr(labels), _ptr(tg),
+         _ptr(iw), _ptr(ow), _ptr(ws), ws.numel(), _stream())
+    return labels, tg, iw, ow
+
+
+def proposal_target_layer(rpn_rois, rpn_scores, gt_boxes, num_classes, batch_size=256, fg_fraction=0.25, fg_thresh=0.5,
+                          bg_hi=0.5, bg_lo=0.0, means=(0.0, 0.0, 0.0, 0.0), stds=(0.1, 0.1, 0.2, 0.2), seed=0):
+    """lib/layer_utils/proposal_target_layer.py:18-152 on device."""
+    _chk(rpn_rois), _chk(rpn_scores), _chk(gt_boxes)
+    dev, N, G, B, C = rpn_rois.device, rpn_rois.shape[0], gt_boxes.shape[0], int(batch_size), int(num_classes)
+    rois = torch.empty((B, 5), dtype=torch.float32, device=dev)
+    sc = torch.empty((B,), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, 1), dtype=torch.float32, device=dev)
+    tg, iw, ow = (torch.empty((B, 4 * C), dtype=torch.float32, device=dev) for _ in range(3))
+    counts = torch.zeros((4,), dtype=torch.int32, device=dev)
+    m = np.ascontiguousarray(means, dtype=np.float64)
+    s = np.ascontiguousarray(stds, dtype=np.float64)
+    call("frcnn_proposal_target_layer", _ptr(rpn_rois), _ptr(rpn_scores), N, _ptr(gt_boxes), G, C, B, float(fg_fraction),
+         float(fg_thresh), float(bg_hi), float(bg_lo), m.ctypes.data_as(ctypes.c_void_p), s.ctypes.data_as(ctypes.c_void_p),
+         int(seed), _ptr(rois), _ptr(sc), _ptr(labels), _ptr(tg), _ptr(iw), _ptr(ow), _ptr(counts), _stream())
+    return rois, sc, labels, tg, iw, ow, counts
+
+
+def softmax_ce_loss(logits, labels, rpn_shape=None):
+    """-> (loss [1], dlogits like logits).  rpn_shape=(A,H,W): logits [1,H,W,2A] with labels [1,1,A*H,W]."""
+    _chk(logits), _chk(labels)
+    dev = logits.device
+    if rpn_shape is None:
+        R, C, A, H, W = logits.shape[0], logits.shape[1], 0, 0, 0
+    else:
+        A, H, W = rpn_shape
+        R, C = A * H * W, 2
+    loss = torch.zeros((1,), dtype=torch.float32, device=dev)
+    grad = torch.zeros_like(logits)
+    ws = workspace(lib().frcnn_loss_workspace_bytes(R), dev, "loss")
+    call("frcnn_softmax_ce_loss", _ptr(logits), _ptr(labels), R, C, A, H, W, _ptr(loss), _ptr(grad), _ptr(ws), ws.numel(), _stream())
+    return loss, grad
+
+
+def smooth_l1_loss(pred, targets, inside_w, outside_w, sigma, mean_divisor):
+    _chk(pred), _chk(targets), _chk(inside_w), _chk(outside_w)
+    dev, n = pred.device, pred.numel()
+    loss = torch.zeros((1,), dtype=torch.float32, device=dev)
+    grad = torch.empty_like(pred)
+    ws = workspace(lib().frcnn_loss_workspace_bytes(n), dev, "loss")
+    call("frcnn_smooth_l1_loss", _ptr(pred), _ptr(targets), _ptr(inside_w), _ptr(outside_w), n, float(sigma), float(mean_divisor),
+         _ptr(loss), _ptr(grad), _ptr(ws), ws.numel(), _stream())
+    return loss, grad
+
+
 class Graph:
     """One captured hipGraph (frcnn_graph_* in the C ABI)."""
 
