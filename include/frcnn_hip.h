@@ -183,6 +183,36 @@ int frcnn_smooth_l1_loss(const float* pred_d, const float* targets_d, const floa
                          long long n, float sigma, float mean_divisor, float* loss_d, float* dpred_d, void* ws,
                          size_t ws_bytes, void* stream);
 
+/* ---- backward pass + solver (lib/model/train_val.py:116-153) ------------------ */
+/* Operand re-layouts that let frcnn_conv2d_nhwc compute conv gradients (see csrc/backward_kernels.hip):
+ *   frcnn_transpose_pad:         out[c][m] = in[m][c], rows zero-padded to Mp (Mp % 32 == 0 for use as a GEMM K axis)
+ *   frcnn_im2col_t:              out[(kh*KW+kw)*Cin + c][m] = x[img, oh*s-pt+kh, ow*s-pl+kw, c]  (transposed im2col)
+ *   frcnn_flip_transpose_filter: out[c][KH-1-kh][KW-1-kw][n] = w[n][kh][kw][c]                    (dgrad filter) */
+int frcnn_transpose_pad(const float* in_d, int M, int C, float* out_d, int Mp, void* stream);
+int frcnn_im2col_t(const float* x_d, int N, int H, int W, int Cin, int OH, int OW, int KH, int KW, int stride,
+                   int pad_top, int pad_left, float* out_d, int Mp, void* stream);
+int frcnn_flip_transpose_filter(const float* w_d, int Cout, int KH, int KW, int Cin, float* out_d, void* stream);
+/* dX of a strided convolution (gather form; the ResNet head has two stride-2 3x3 convs). */
+int frcnn_conv2d_dgrad_strided(const float* dy_d, int N, int OH, int OW, int Cout, const float* w_d, int KH, int KW,
+                               int Cin, int stride, int pad_top, int pad_left, float* dx_d, int H, int W,
+                               int accumulate, void* stream);
+int frcnn_relu_bwd(float* grad_d, const float* y_d, long long n, void* stream);              /* grad *= (y > 0) */
+int frcnn_add_strided(const float* src_d, int N, int OH, int OW, int C, float* dst_d, int H, int W, int stride,
+                      int accumulate, void* stream);                                        /* skip / subsample gradient */
+int frcnn_spatial_mean_bwd(const float* dy_d, int N, int HW, int C, float* dx_d, void* stream);
+int frcnn_colsum(const float* dy_d, int M, int C, float* db_d, void* stream);                 /* bias gradient */
+/* Gradient of tf.image.crop_and_resize w.r.t. the feature map (scatter-add; dfeat_d must be zeroed or hold
+ * the gradient to accumulate into).  No max-pool variant (ResNet crops 7x7 directly). */
+int frcnn_crop_and_resize_bwd(const float* dout_d, int H, int W, int C, const float* rois_d, int R, float feat_stride,
+                              int pool, float* dfeat_d, void* stream);
+/* tf.train.MomentumOptimizer step on a packed master filter [Cout][K] (+ refresh of the BN-folded copy):
+ * g = grad_scale*grad*scale[n] + weight_decay*w ; acc = momentum*acc + g ; w -= lr*acc ; w_folded = w*scale[n].
+ * scale_d / w_folded_d may be NULL (biases, fc). */
+int frcnn_sgd_momentum(float* w_d, float* acc_d, float* w_folded_d, const float* grad_d, const float* scale_d,
+                       long long n, int K, float lr, float momentum, float weight_decay, float grad_scale, void* stream);
+/* out (+)= scale * sum(w^2)   (slim l2_regularizer value); ws >= 2 KiB. */
+int frcnn_sumsq(const float* w_d, long long n, double scale, float* out_d, int accumulate, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- stream capture (one hipGraph per image-shape; replaces the per-image sess.run) ---------- */
 int frcnn_graph_begin(void* stream);
 int frcnn_graph_end(void* stream, void** graph_exec_out);

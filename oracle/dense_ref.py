@@ -132,6 +132,84 @@ class DenseRef(object):
                     fc7=fc7.numpy(), cls_score=cls_score, cls_prob=cls_prob, bbox_pred=bbox_pred)
 
 
+def crop_and_resize_torch(feat, rois, stride, P):
+    """Differentiable (w.r.t. feat) torch statement of tf.image.crop_and_resize as the reference calls it
+    (nets/resnet_v1.py:55-76): sample positions in float32 exactly like oracle_c.c, bilinear taps by gather."""
+    _, C, H, W = feat.shape
+    r = np.asarray(rois, dtype=np.float32)
+    f32 = np.float32
+    height, width = (f32(H) - f32(1)) * f32(stride), (f32(W) - f32(1)) * f32(stride)
+    x1, y1, x2, y2 = r[:, 1] / width, r[:, 2] / height, r[:, 3] / width, r[:, 4] / height
+    hs = (y2 - y1) * f32(H - 1) / f32(P - 1)
+    ws = (x2 - x1) * f32(W - 1) / f32(P - 1)
+    g = np.arange(P, dtype=np.float32)
+    in_y = (y1 * f32(H - 1))[:, None] + g[None, :] * hs[:, None]             # [R,P]
+    in_x = (x1 * f32(W - 1))[:, None] + g[None, :] * ws[:, None]
+    vy = (in_y >= 0) & (in_y <= f32(H - 1))
+    vx = (in_x >= 0) & (in_x <= f32(W - 1))
+    top, bot = np.floor(in_y).astype(np.int64).clip(0, H - 1), np.ceil(in_y).astype(np.int64).clip(0, H - 1)
+    left, right = np.floor(in_x).astype(np.int64).clip(0, W - 1), np.ceil(in_x).astype(np.int64).clip(0, W - 1)
+    ly = torch.from_numpy((in_y - np.floor(in_y)).astype(np.float64)).to(feat.dtype)[None, :, :, None]
+    lx = torch.from_numpy((in_x - np.floor(in_x)).astype(np.float64)).to(feat.dtype)[None, :, None, :]
+    f = feat[0]
+    tt, bb, ll, rr = (torch.from_numpy(a) for a in (top, bot, left, right))
+    tl = f[:, tt[:, :, None], ll[:, None, :]]                                # [C,R,P,P]
+    tr = f[:, tt[:, :, None], rr[:, None, :]]
+    bl = f[:, bb[:, :, None], ll[:, None, :]]
+    br = f[:, bb[:, :, None], rr[:, None, :]]
+    t = tl + (tr - tl) * lx
+    b = bl + (br - bl) * lx
+    out = t + (b - t) * ly
+    mask = torch.from_numpy((vy[:, :, None] & vx[:, None, :]).astype(np.float64)).to(feat.dtype)[None]
+    return (out * mask).permute(1, 0, 2, 3)                                  # [R,C,P,P]
+
+
+class TrainRef(DenseRef):
+    """Reference TRAIN step (network.py:279-321 losses, train_val.py:128-145 solver) in torch float64 autograd,
+    given the sampled rois / targets as constants (they carry no gradient in the reference either: py_func,
+    tf.stop_gradient, network.py:153)."""
+
+    def __init__(self, variables, num_layers, num_classes, anchor_scales, anchor_ratios, trainable, dtype=torch.float64):
+        DenseRef.__init__(self, variables, num_layers, num_classes, anchor_scales, anchor_ratios, dtype)
+        self.trainable = trainable
+
+    def w(self, name):
+        if name not in self._cache:
+            a = self.v[name]
+            t = _t(a, self.dtype)
+            if name.endswith("/weights") or name.endswith("/biases"):
+                scope = name.rsplit("/", 1)[0]
+                if self.trainable(scope) and "BatchNorm" not in name:
+                    t.requires_grad_(True)
+            self._cache[name] = t
+        t = self._cache[name]
+        return t.permute(3, 2, 0, 1) if t.ndim == 4 else t
+
+    def losses(self, image_nhwc, rois, at, pt, sigma_rpn=3.0):
+        feat = self.head(image_nhwc)
+        s, A = self.scope, self.A
+        r = F.relu(F.conv2d(feat, self.w(s + "/rpn_conv/3x3/weights"), self.w(s + "/rpn_conv/3x3/biases"), padding=1))
+        score = F.conv2d(r, self.w(s + "/rpn_cls_score/weights"), self.w(s + "/rpn_cls_score/biases"))[0]     # [2A,H,W]
+        bbox = F.conv2d(r, self.w(s + "/rpn_bbox_pred/weights"), self.w(s + "/rpn_bbox_pred/biases"))
+        pair = torch.stack([score[:A].reshape(-1), score[A:].reshape(-1)], dim=1)                                # (a,h,w) order
+        lab = torch.from_numpy(np.asarray(at["rpn_labels"]).ravel()).long()
+        sel = lab >= 0
+        rpn_ce = F.cross_entropy(pair[sel], lab[sel])
+        sl1 = lambda pred, tg, iw, ow, sg: (ow * torch.where((iw * (pred - tg)).abs() < 1.0 / sg ** 2,
+                                                               (iw * (pred - tg)) ** 2 * (sg ** 2 / 2.0),
+                                                               (iw * (pred - tg)).abs() - 0.5 / sg ** 2)).sum()
+        d = lambda k, src: _t(np.asarray(src[k]), self.dtype)
+        rpn_box = sl1(bbox.permute(0, 2, 3, 1), d("rpn_bbox_targets", at), d("rpn_bbox_inside_weights", at),
+                      d("rpn_bbox_outside_weights", at), sigma_rpn)
+        pool5 = crop_and_resize_torch(feat, rois, 16.0, 7)
+        fc7 = self.run_blocks(pool5, self.blocks[3:]).mean(dim=(2, 3))
+        cls_score = fc7 @ self.w(s + "/cls_score/weights") + self.w(s + "/cls_score/biases")
+        bbox_pred = fc7 @ self.w(s + "/bbox_pred/weights") + self.w(s + "/bbox_pred/biases")
+        ce = F.cross_entropy(cls_score, torch.from_numpy(np.asarray(pt["labels"]).ravel()).long())
+        box = sl1(bbox_pred, d("bbox_targets", pt), d("bbox_inside_weights", pt), d("bbox_outside_weights", pt), 1.0) / bbox_pred.shape[0]
+        return dict(rpn_cross_entropy=rpn_ce, rpn_loss_box=rpn_box, cross_entropy=ce, loss_box=box)
+
+
 class VGG16Ref(DenseRef):
     """lib/nets/vgg16.py:26-60 (TEST): conv+bias+ReLU x13, 2x2/2 SAME max pools, fc6/fc7 on the
     NHWC-flattened 7x7x512 crop."""

@@ -134,3 +134,73 @@ def test_losses_value_and_gradient_vs_torch_float64(dev, golden):
         ref.backward()
         assert abs(loss.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
         assert np.allclose(grad.cpu().numpy(), p.grad.numpy(), rtol=1e-5, atol=1e-9)
+
+
+def test_full_train_step_matches_torch_autograd(dev):
+    """TRAIN forward + reverse sweep + momentum SGD on the device vs torch float64
+    autograd of the reference graph, with the device-sampled rois/targets fed to the reference as constants."""
+    from dense_ref import TrainRef
+    from frcnn_hip.runtime import Session
+    from frcnn_hip.train import TrainState
+    from model.config import cfg
+    from nets.resnet_v1 import resnetv1
+    SC, RT = (4, 8, 16), (0.5, 1, 2)
+    old = (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO)
+    cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO = 64, 0.0
+    try:
+        sess = Session(device=dev, seed=5)
+        net = resnetv1(num_layers=50)
+        net.create_architecture("TRAIN", 21, tag="train", anchor_scales=SC, anchor_ratios=RT)
+        sess.init_variables(net.variable_specs())
+        rng = np.random.RandomState(2)
+        H, W = 128, 160
+        image = ((rng.rand(1, H, W, 3) * 255.0).astype(np.float32) - cfg.PIXEL_MEANS.astype(np.float32)) * np.float32(1 / 256.0)
+        gt = np.array([[16, 16, 79, 79, 3], [60, 30, 150, 110, 7], [5, 70, 60, 120, 12]], dtype=np.float32)
+        blobs = dict(data=image, im_info=np.array([H, W, 1.0], dtype=np.float32), gt_boxes=gt)
+        losses = net.train_forward(sess, blobs)
+        pt, at = net._proposal_targets, net._anchor_targets
+        counts = pt["counts"].cpu().numpy()
+        assert counts[0] > 0 and counts[0] + counts[1] == 64
+        ts = TrainState(sess, net, momentum=0.9, weight_decay=1e-4).build()
+        ts.backward(net._loss_seeds)
+        torch.cuda.synchronize()
+        ref = TrainRef(sess.variables, 50, 21, SC, RT, net.trainable_scope)
+        to_np = lambda d_: {k: v.cpu().numpy() for k, v in d_.items()}
+        rl = ref.losses(image, pt["rois"].cpu().numpy(), to_np(at), to_np(pt))
+        for k in ("rpn_cross_entropy", "rpn_loss_box", "cross_entropy", "loss_box"):
+            assert abs(losses[k].item() - rl[k].item()) <= 1e-4 * max(1.0, abs(rl[k].item())), k
+        sum(rl.values()).backward()
+        checked = 0
+        for sc in ("/cls_score", "/bbox_pred", "/rpn_cls_score", "/rpn_conv/3x3", "/block4/unit_3/bottleneck_v1/conv2",
+                   "/block4/unit_1/bottleneck_v1/shortcut", "/block3/unit_6/bottleneck_v1/conv3", "/block3/unit_1/bottleneck_v1/conv1",
+                   "/block2/unit_4/bottleneck_v1/conv2", "/block2/unit_1/bottleneck_v1/conv1", "/block2/unit_1/bottleneck_v1/shortcut"):
+            scope = net._scope + sc
+            p = ts.params[scope]
+            g = ref._cache[scope + "/weights"].grad.numpy()                        # HWIO (or [in,out])
+            if g.ndim == 2:
+                g = g[None, None]
+            want = np.transpose(g, (3, 0, 1, 2))                                    # -> [Cout,KH,KW,Cin] (master filter)
+            got = p.grad_w.cpu().numpy()
+            if p.scale is not None:
+                got = got * p.scale.cpu().numpy()[:, None, None, None]              # chain rule through the BN fold
+            err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-12)
+            assert err <= 2e-3, (sc, err)
+            if p.bias is not None:
+                gb = ref._cache[scope + "/biases"].grad.numpy()
+                assert np.abs(p.grad_b.cpu().numpy() - gb).max() <= 2e-3 * max(np.abs(gb).max(), 1e-12), sc
+            checked += 1
+        assert checked == 11 and net._scope + "/conv1" not in ts.params and not any("/block1/" in s for s in ts.params)
+        # one solver step (train_val.py:128-145): acc = g + wd*w ; w -= lr*acc ; folded copy refreshed
+        sc = net._scope + "/block3/unit_1/bottleneck_v1/conv1"
+        p = ts.params[sc]
+        w0, g0 = p.w.cpu().numpy().copy(), (p.grad_w * p.scale.view(-1, 1, 1, 1)).cpu().numpy()
+        ts.apply(lr=0.01)
+        w1 = p.w.cpu().numpy()
+        assert np.allclose(w1, w0 - 0.01 * (g0 + 1e-4 * w0), rtol=1e-5, atol=1e-7)
+        assert np.allclose(p.wf.cpu().numpy(), w1 * p.scale.cpu().numpy()[:, None, None, None], rtol=1e-6, atol=1e-8)
+        # and the public API: a second full step runs and returns the five losses (network.py:488-498)
+        ts.lr = 0.001
+        out = net.train_step(sess, blobs, ts)
+        assert len(out) == 5 and all(np.isfinite(out)) and out[4] > sum(out[:4])   # total includes the L2 term
+    finally:
+        cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO = old

@@ -54,6 +54,18 @@ SIGNATURES = {
     "frcnn_loss_workspace_bytes": (c_size_t, [c_longlong]),
     "frcnn_softmax_ce_loss": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "frcnn_smooth_l1_loss": (c_int, [_P, _P, _P, _P, c_longlong, c_float, c_float, _P, _P, _P, c_size_t, _P]),
+    "frcnn_transpose_pad": (c_int, [_P, c_int, c_int, _P, c_int, _P]),
+    "frcnn_im2col_t": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    "frcnn_flip_transpose_filter": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "frcnn_conv2d_dgrad_strided": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int,
+                                           c_int, c_int, _P]),
+    "frcnn_relu_bwd": (c_int, [_P, _P, c_longlong, _P]),
+    "frcnn_add_strided": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "frcnn_spatial_mean_bwd": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    "frcnn_colsum": (c_int, [_P, c_int, c_int, _P, _P]),
+    "frcnn_crop_and_resize_bwd": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_float, c_int, _P, _P]),
+    "frcnn_sgd_momentum": (c_int, [_P, _P, _P, _P, _P, c_longlong, c_int, c_float, c_float, c_float, c_float, _P]),
+    "frcnn_sumsq": (c_int, [_P, c_longlong, c_double, _P, c_int, _P, c_size_t, _P]),
     "frcnn_graph_begin": (c_int, [_P]),
     "frcnn_graph_end": (c_int, [_P, ctypes.POINTER(c_void_p)]),
     "frcnn_graph_launch": (c_int, [_P, _P]),

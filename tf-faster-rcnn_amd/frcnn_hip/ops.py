@@ -337,6 +337,84 @@ def smooth_l1_loss(pred, targets, inside_w, outside_w, sigma, mean_divisor):
     return loss, grad
 
 
+# ------------------------------------------------------------------------------------------ backward
+def transpose_pad(x2d, Mp, out=None):
+    """x2d [M,C] -> [C,Mp] (zero padded)."""
+    _chk(x2d)
+    M, C = x2d.shape
+    out = torch.empty((C, Mp), dtype=torch.float32, device=x2d.device) if out is None else out
+    call("frcnn_transpose_pad", _ptr(x2d), M, C, _ptr(out), int(Mp), _stream())
+    return out
+
+
+def im2col_t(x, KH, KW, stride, pad, OH, OW, Mp, out=None):
+    _chk(x)
+    N, H, W, Cin = x.shape
+    out = torch.empty((KH * KW * Cin, Mp), dtype=torch.float32, device=x.device) if out is None else out
+    call("frcnn_im2col_t", _ptr(x), N, H, W, Cin, OH, OW, KH, KW, int(stride), int(pad[0]), int(pad[2]), _ptr(out), int(Mp), _stream())
+    return out
+
+
+def flip_transpose_filter(w_packed, out=None):
+    _chk(w_packed)
+    Cout, KH, KW, Cin = w_packed.shape
+    out = torch.empty((Cin, KH, KW, Cout), dtype=torch.float32, device=w_packed.device) if out is None else out
+    call("frcnn_flip_transpose_filter", _ptr(w_packed), Cout, KH, KW, Cin, _ptr(out), _stream())
+    return out
+
+
+def conv2d_dgrad_strided(dy, w_packed, stride, pad, H, W, dx, accumulate):
+    _chk(dy), _chk(w_packed), _chk(dx)
+    N, OH, OW, Cout = dy.shape
+    _, KH, KW, Cin = w_packed.shape
+    call("frcnn_conv2d_dgrad_strided", _ptr(dy), N, OH, OW, Cout, _ptr(w_packed), KH, KW, Cin, int(stride), int(pad[0]), int(pad[2]),
+         _ptr(dx), int(H), int(W), 1 if accumulate else 0, _stream())
+    return dx
+
+
+def relu_bwd(grad, y):
+    _chk(grad), _chk(y)
+    call("frcnn_relu_bwd", _ptr(grad), _ptr(y), grad.numel(), _stream())
+    return grad
+
+
+def add_strided(src, dst, stride, accumulate):
+    _chk(src), _chk(dst)
+    N, OH, OW, C = src.shape
+    call("frcnn_add_strided", _ptr(src), N, OH, OW, C, _ptr(dst), dst.shape[1], dst.shape[2], int(stride), 1 if accumulate else 0, _stream())
+    return dst
+
+
+def spatial_mean_bwd(dy, HW, out):
+    _chk(dy), _chk(out)
+    call("frcnn_spatial_mean_bwd", _ptr(dy), dy.shape[0], int(HW), dy.shape[1], _ptr(out), _stream())
+    return out
+
+
+def colsum(dy2d, out):
+    _chk(dy2d), _chk(out)
+    call("frcnn_colsum", _ptr(dy2d), dy2d.shape[0], dy2d.shape[1], _ptr(out), _stream())
+    return out
+
+
+def crop_and_resize_bwd(dout, rois, feat_stride, dfeat):
+    _chk(dout), _chk(rois), _chk(dfeat)
+    R, P, _, C = dout.shape
+    H, W = dfeat.shape[-3], dfeat.shape[-2]
+    call("frcnn_crop_and_resize_bwd", _ptr(dout), H, W, C, _ptr(rois), R, float(feat_stride), P, _ptr(dfeat), _stream())
+    return dfeat
+
+
+def sgd_momentum(w, acc, w_folded, grad, scale, K, lr, momentum, weight_decay, grad_scale=1.0):
+    call("frcnn_sgd_momentum", _ptr(w), _ptr(acc), _ptr(w_folded), _ptr(grad), _ptr(scale), w.numel(), int(K), float(lr),
+         float(momentum), float(weight_decay), float(grad_scale), _stream())
+
+
+def sumsq(w, scale, out, accumulate):
+    ws = workspace(4096, w.device, "sumsq")
+    call("frcnn_sumsq", _ptr(w), w.numel(), float(scale), _ptr(out), 1 if accumulate else 0, _ptr(ws), ws.numel(), _stream())
+
+
 class Graph:
     """One captured hipGraph (frcnn_graph_* in the C ABI)."""
 

@@ -28,6 +28,7 @@ class Session(object):
         self.stream = torch.cuda.Stream(device=self.device)
         self.variables = collections.OrderedDict()     # TF name -> numpy (HWIO conv, [in,out] fc)
         self.packed = {}                                # layer key -> device tensors
+        self.conv_info = {}                             # scope -> {w (folded, device), b, scale (np or None), bn}
         self.buffers = {}
         self.graphs = {}
         self.seed = seed
@@ -63,6 +64,7 @@ class Session(object):
                 raise ValueError(sp.init)
             self.variables[name] = v.astype(np.float32)
         self.packed.clear()
+        self.conv_info.clear()
         self.graphs.clear()
 
     def load_variables(self, values):
@@ -105,6 +107,7 @@ class Session(object):
         wp = ops.pack_filter_foldw(w, scale) if fold_w else ops.pack_filter_hwio(w, scale)
         res = (self.to_device(wp), None if bias is None else self.to_device(bias))
         self.packed[key] = res
+        self.conv_info[scope] = {"w": res[0], "b": res[1], "scale": scale if bn_eps is not None else None, "bn": bn_eps is not None}
         return res
 
     # ---- static activation buffers ----------------------------------------------------------------

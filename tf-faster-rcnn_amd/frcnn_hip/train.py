@@ -1,0 +1,185 @@
+"""Training step on the device chain (lib/model/train_val.py:116-153,
+lib/nets/network.py:488-516): reverse sweep over the tape the Network records in TRAIN mode, parameter
+gradients, momentum SGD with slim-style L2 regularisation, optional data-parallel gradient all-reduce.
+
+Convolution gradients run on the SAME f32-MFMA implicit-GEMM kernel as the forward pass, on re-laid-out
+operands (csrc/backward_kernels.hip).  BN is frozen in the reference (resnet_v1.py:22-44), so the
+forward pass uses BN-folded filters; the master copy of every filter is kept un-folded on the device in
+the packed layout [Cout][KH][KW][Cin], its gradient is dW_folded * scale[n] (chain rule through the
+fold) and the folded copy is refreshed inside the SGD kernel.
+"""
+import numpy as np
+import torch
+
+from . import ACT_NONE, ACT_RELU, ops
+
+
+class Param(object):
+    """One trainable filter (+ optional bias) on the device."""
+
+    def __init__(self, scope, wf, bias, scale_np, bias_trainable, flat_w, flat_b):
+        dev = wf.device
+        self.scope = scope
+        self.wf = wf                                            # folded filter used by the forward kernels
+        self.K = wf[0].numel()
+        self.scale = None if scale_np is None else torch.from_numpy(np.ascontiguousarray(scale_np, dtype=np.float32)).to(dev)
+        if self.scale is None:
+            self.w = wf                                         # no fold: master == forward filter
+        else:
+            self.w = (wf / self.scale.view(-1, 1, 1, 1)).contiguous()
+        self.acc_w = torch.zeros_like(self.w)
+        self.grad_w = flat_w.view(wf.shape)                     # view into the flat gradient buffer (one all-reduce)
+        self.bias = bias if bias_trainable else None
+        self.acc_b = torch.zeros_like(bias) if bias_trainable else None
+        self.grad_b = flat_b
+
+
+class TrainState(object):
+    """Owns the parameters, their momentum buffers and ONE flat gradient buffer (so data-parallel
+    training is a single RCCL all-reduce, or a few bucketed ones, over contiguous memory)."""
+
+    def __init__(self, sess, net, momentum=0.9, weight_decay=1e-4, double_bias=False, bias_decay=False):
+        self.sess, self.net = sess, net
+        self.momentum, self.weight_decay = momentum, weight_decay
+        self.double_bias, self.bias_decay = double_bias, bias_decay
+        self.params = {}
+        self.flat = None
+        self.reg_scopes = []
+
+    def build(self):
+        """Call after one TRAIN forward (which packs every filter and fills net._tape)."""
+        sess, net = self.sess, self.net
+        scopes = []
+        for rec in net._tape:
+            if rec["kind"] == "conv" and net.trainable_scope(rec["scope"]) and rec["scope"] not in scopes:
+                scopes.append(rec["scope"])
+        total = 0
+        sizes = []
+        for sc in scopes:
+            info = sess.conv_info[sc]
+            nb = info["b"].numel() if (info["b"] is not None and not info["bn"]) else 0
+            sizes.append((info["w"].numel(), nb))
+            total += info["w"].numel() + nb
+        self.flat = torch.zeros((total,), dtype=torch.float32, device=sess.device)
+        off = 0
+        for sc, (nw, nb) in zip(scopes, sizes):
+            info = sess.conv_info[sc]
+            fw = self.flat[off:off + nw]
+            off += nw
+            fb = self.flat[off:off + nb] if nb else None
+            off += nb
+            self.params[sc] = Param(sc, info["w"], info["b"], info["scale"], nb > 0, fw, fb)
+        self.reg_scopes = [sc for sc in sess.conv_info]            # slim regularises every conv/fc weight, frozen or not
+        return self
+
+    # ---- gradients -----------------------------------------------------------------------------------
+    def backward(self, seeds):
+        """seeds: list of (tensor, grad) for network outputs.  Fills every Param.grad_*."""
+        sess, net = self.sess, self.net
+        grads = {}
+        for t, g in seeds:
+            grads[t.data_ptr()] = g
+        needs = net._requires_grad
+
+        def accumulate_into(target, shape, name):
+            key = target.data_ptr()
+            if key in grads:
+                return grads[key], True
+            g = sess.buf("grad/" + name, shape)
+            grads[key] = g
+            return g, False
+
+        for rec in reversed(net._tape):
+            kind = rec["kind"]
+            if kind == "mean":
+                gy = grads.get(rec["y"].data_ptr())
+                if gy is None:
+                    continue
+                x = rec["x"]
+                gx, had = accumulate_into(x, x.shape, rec["name"] + "/in")
+                assert not had
+                ops.spatial_mean_bwd(gy.view(rec["y"].shape), x.shape[1] * x.shape[2], gx)
+                continue
+            if kind == "crop":
+                gy = grads.get(rec["y"].data_ptr())
+                if gy is None or rec["feat"].data_ptr() not in needs:
+                    continue
+                feat = rec["feat"]
+                gx, had = accumulate_into(feat, feat.shape, "feat")
+                if not had:
+                    gx.zero_()
+                ops.crop_and_resize_bwd(gy.view(rec["y"].shape), rec["rois"], rec["stride"], gx)
+                continue
+            # ---- convolution record -------------------------------------------------------------------
+            y, x, sc = rec["y"], rec["x"], rec["scope"]
+            gy = grads.get(y.data_ptr())
+            if gy is None:
+                continue
+            gy = gy.view(y.shape)
+            if rec["act"] == ACT_RELU:
+                ops.relu_bwd(gy, y)
+            res = rec["residual"]
+            if res is not None and res.data_ptr() in needs:
+                gr, had = accumulate_into(res, res.shape, sc + "/res")
+                if rec["res_stride"] == 1 and not had:
+                    gr.copy_(gy)
+                else:
+                    if not had:
+                        gr.zero_()
+                    ops.add_strided(gy, gr, rec["res_stride"], True)
+            k, stride, pad = rec["k"], rec["stride"], rec["pad"]
+            N, OH, OW, Cout = y.shape
+            M = N * OH * OW
+            p = self.params.get(sc)
+            if p is not None:
+                Mp = (M + 31) // 32 * 32
+                gyT = ops.transpose_pad(gy.view(M, Cout), Mp, out=sess.buf("bwd/gyT", (Cout, Mp)))
+                if k == 1 and stride == 1:
+                    xT = ops.transpose_pad(x.view(M, x.shape[-1]), Mp, out=sess.buf("bwd/xT", (x.shape[-1], Mp)))
+                else:
+                    xT = ops.im2col_t(x, k, k, stride, pad, OH, OW, Mp, out=sess.buf("bwd/xT", (k * k * x.shape[-1], Mp)))
+                # dW_folded[n][(kh,kw,c)] = sum_m gyT[n][m] * xT[(kh,kw,c)][m]   -- the forward MFMA kernel
+                ops.conv2d(gyT.view(1, 1, Cout, Mp), xT.view(xT.shape[0], 1, 1, Mp), None, 1, 1, out=p.grad_w.view(1, 1, Cout, p.K))
+                if p.bias is not None:
+                    ops.colsum(gy.view(M, Cout), p.grad_b)
+            if x.data_ptr() in needs:
+                gx, had = accumulate_into(x, x.shape, sc + "/in")
+                wf = sess.conv_info[sc]["w"]
+                if stride == 1 and Cout % 32 == 0:
+                    wd = ops.flip_transpose_filter(wf, out=sess.buf("bwd/wflip/" + sc, (wf.shape[3], k, k, Cout)))
+                    dpad = (k - 1 - pad[0], k - 1 - pad[1], k - 1 - pad[2], k - 1 - pad[3])
+                    ops.conv2d(gy, wd, None, k, k, 1, dpad, ACT_NONE, gx if had else None, 1, out=gx)
+                else:
+                    ops.conv2d_dgrad_strided(gy, wf, stride, pad, x.shape[1], x.shape[2], gx, had)
+        return grads
+
+    # ---- solver --------------------------------------------------------------------------------------
+    def apply(self, lr, world_size=1, all_reduce=None):
+        """acc = m*acc + g ; w -= lr*acc (train_val.py:128-145).  all_reduce: callable(flat_tensor) summing the
+        flat gradient over the ranks (RCCL); the mean over replicas is folded into the SGD kernel."""
+        if all_reduce is not None and world_size > 1:
+            all_reduce(self.flat)
+        gs = 1.0 / float(world_size)
+        for p in self.params.values():
+            ops.sgd_momentum(p.w, p.acc_w, p.wf if p.scale is not None else None, p.grad_w, p.scale, p.K, lr, self.momentum,
+                             self.weight_decay, gs)
+            if p.bias is not None:
+                ops.sgd_momentum(p.bias, p.acc_b, None, p.grad_b, None, p.bias.numel(), lr * (2.0 if self.double_bias else 1.0),
+                                 self.momentum, self.weight_decay if self.bias_decay else 0.0, gs)
+
+    def regularization_loss(self, out):
+        """slim l2_regularizer(WEIGHT_DECAY): wd * sum(w^2)/2 over every conv / fc weight (network.py:315-317)."""
+        first = True
+        for sc in self.reg_scopes:
+            p = self.params.get(sc)
+            if p is not None:
+                w = p.w
+            else:
+                info = self.sess.conv_info[sc]
+                if "w_master" not in info:
+                    info["w_master"] = info["w"] if info["scale"] is None else \
+                        (info["w"] / torch.from_numpy(info["scale"]).to(info["w"].device).view(-1, 1, 1, 1)).contiguous()
+                w = info["w_master"]
+            ops.sumsq(w, 0.5 * self.weight_decay, out, not first)
+            first = False
+        return out

@@ -39,6 +39,11 @@ class Network(object):
         self._image = None
         self._im_info = None
         self._var_specs = collections.OrderedDict()
+        self._tape = []
+        self._requires_grad = set()
+        self._gt_boxes = None
+        self._sample_seed = 0
+        self._train_state = None
 
     # ------------------------------------------------------------------ variable declaration
     def _var(self, name, shape, init, arg=None):
@@ -82,7 +87,18 @@ class Network(object):
         flops = 2 * N * OH * OW * Cout * k * k * (Cin if real_cin is None else real_cin)
         sess.mark("conv:" + scope, flops,
                   lambda: ops.conv2d(x, w, b, k, k, stride, pad, act, residual, res_stride, fold_w, out=out))
+        if self._mode == "TRAIN":
+            self._tape.append(dict(kind="conv", scope=scope, x=x, y=out, k=k, stride=stride, pad=tuple(pad), act=act,
+                                   residual=residual, res_stride=res_stride))
+            if self.trainable_scope(scope) or x.data_ptr() in self._requires_grad:
+                self._requires_grad.add(out.data_ptr())
+            if residual is not None and residual.data_ptr() in self._requires_grad:
+                self._requires_grad.add(out.data_ptr())
         return out
+
+    def trainable_scope(self, scope):
+        """Which filters the solver updates (reference: `trainable=` flags of the slim layers)."""
+        return True
 
     def _reshape_layer(self, bottom, num_dim, name):
         raise NotImplementedError("folded into frcnn_rpn_softmax (network.py:68-78 only served the pair softmax)")
@@ -130,6 +146,49 @@ class Network(object):
         self._num_rois = None
         return rois, scores
 
+    def _anchor_target_layer(self, rpn_cls_score, name):
+        # network.py:162-183 -> lib/layer_utils/anchor_target_layer.py, on device
+        _, H, W, _ = rpn_cls_score.shape
+        t = cfg.TRAIN
+        labels, tg, iw, ow = ops.anchor_target_layer(self._gt_boxes, self._im_info[0], self._im_info[1], H, W, self._base_anchors,
+                                                     self._feat_stride[0], t.RPN_BATCHSIZE, t.RPN_FG_FRACTION, t.RPN_POSITIVE_OVERLAP,
+                                                     t.RPN_NEGATIVE_OVERLAP, seed=self._sample_seed)
+        self._anchor_targets = dict(rpn_labels=labels, rpn_bbox_targets=tg, rpn_bbox_inside_weights=iw, rpn_bbox_outside_weights=ow)
+        return labels
+
+    def _proposal_target_layer(self, rois, roi_scores, name):
+        # network.py:185-208 -> lib/layer_utils/proposal_target_layer.py, on device
+        t = cfg.TRAIN
+        n = int(self._num_rois.item())                    # rows of the padded proposal buffer that are real
+        out = ops.proposal_target_layer(rois[:n].contiguous(), roi_scores[:n, 0].contiguous(), self._gt_boxes, self._num_classes,
+                                        t.BATCH_SIZE, t.FG_FRACTION, t.FG_THRESH, t.BG_THRESH_HI, t.BG_THRESH_LO,
+                                        t.BBOX_NORMALIZE_MEANS, t.BBOX_NORMALIZE_STDS, seed=self._sample_seed + 1)
+        rois, roi_scores, labels, tg, iw, ow, counts = out
+        self._proposal_targets = dict(rois=rois, labels=labels, bbox_targets=tg, bbox_inside_weights=iw, bbox_outside_weights=ow,
+                                      counts=counts)
+        self._num_rois = None
+        return rois, roi_scores
+
+    def _smooth_l1_loss(self, bbox_pred, bbox_targets, bbox_inside_weights, bbox_outside_weights, sigma=1.0, dim=[1]):
+        """network.py:264-277 -> (loss [1], d loss / d bbox_pred).  dim=[1]: mean over rows; dim=[1,2,3]: batch of 1."""
+        div = float(bbox_pred.shape[0]) if list(dim) == [1] else 1.0
+        return ops.smooth_l1_loss(bbox_pred, bbox_targets, bbox_inside_weights, bbox_outside_weights, sigma, div)
+
+    def _add_losses(self, sigma_rpn=3.0):
+        """network.py:279-321.  Returns the loss tensors and the seed gradients of the four network outputs."""
+        A = self._num_anchors
+        p, at, pt = self._predictions, self._anchor_targets, self._proposal_targets
+        _, H, W, _ = p["rpn_cls_score"].shape
+        rpn_ce, g_rpn_cls = ops.softmax_ce_loss(p["rpn_cls_score"], at["rpn_labels"], rpn_shape=(A, H, W))
+        rpn_box, g_rpn_box = self._smooth_l1_loss(p["rpn_bbox_pred"], at["rpn_bbox_targets"], at["rpn_bbox_inside_weights"],
+                                                  at["rpn_bbox_outside_weights"], sigma=sigma_rpn, dim=[1, 2, 3])
+        ce, g_cls = ops.softmax_ce_loss(p["cls_score"], pt["labels"].view(-1))
+        box, g_box = self._smooth_l1_loss(p["bbox_pred"], pt["bbox_targets"], pt["bbox_inside_weights"], pt["bbox_outside_weights"])
+        self._losses = dict(cross_entropy=ce, loss_box=box, rpn_cross_entropy=rpn_ce, rpn_loss_box=rpn_box)
+        self._loss_seeds = [(p["rpn_cls_score"], g_rpn_cls), (p["rpn_bbox_pred"], g_rpn_box), (p["cls_score"], g_cls),
+                            (p["bbox_pred"], g_box)]
+        return self._losses
+
     def _crop_pool_layer(self, bottom, rois, name):
         # network.py:141-157: 14x14 crop + 2x2 max pool (fused in the kernel)
         return ops.crop_and_resize(bottom, rois, float(self._feat_stride[0]), cfg.POOLING_SIZE, max_pool=True,
@@ -142,9 +201,11 @@ class Network(object):
         rpn_cls_score = self._conv(rpn, self._scope + "/rpn_cls_score", 1, act=ACT_NONE)                   # :327-329
         rpn_cls_prob = self._softmax_layer(rpn_cls_score, "rpn_cls_prob")                                   # :331-334
         rpn_bbox_pred = self._conv(rpn, self._scope + "/rpn_bbox_pred", 1, act=ACT_NONE)                   # :335-337
-        if is_training:
-            raise NotImplementedError("TRAIN branch (anchor/proposal targets, network.py:338-343): SURVEY.md 8a rows 14-17, next rounds")
-        if cfg.TEST.MODE == "nms":
+        if is_training:                                                                                    # :338-343
+            rois, roi_scores = self._proposal_layer(rpn_cls_prob, rpn_bbox_pred, "rois")
+            self._anchor_target_layer(rpn_cls_score, "anchor")
+            rois, _ = self._proposal_target_layer(rois, roi_scores, "rpn_rois")
+        elif cfg.TEST.MODE == "nms":
             rois, _ = self._proposal_layer(rpn_cls_prob, rpn_bbox_pred, "rois")
         elif cfg.TEST.MODE == "top":
             rois, _ = self._proposal_top_layer(rpn_cls_prob, rpn_bbox_pred, "rois")
@@ -178,6 +239,8 @@ class Network(object):
         raise NotImplementedError
 
     def _build_network(self, is_training=True):
+        self._tape = []
+        self._requires_grad = set()
         net_conv = self._image_to_head(is_training)
         self._anchor_component()
         rois = self._region_proposal(net_conv, is_training)
@@ -277,6 +340,39 @@ class Network(object):
         n = p["rois"].shape[0] if self._num_rois is None else int(self._num_rois.item())
         return (p["cls_score"][:n].cpu().numpy(), p["cls_prob"][:n].cpu().numpy(), p["bbox_pred"][:n].cpu().numpy(),
                 p["rois"][:n].cpu().numpy())
+
+    # ------------------------------------------------------------------ training (network.py:488-516)
+    def train_forward(self, sess, blobs):
+        """TRAIN-mode forward + losses on the device (eager; the tape for the reverse sweep is recorded)."""
+        assert self._mode == "TRAIN"
+        self._sess = sess
+        self._image = self._stage_image(sess, blobs["data"])
+        info = blobs["im_info"]
+        self._im_info = (float(info[0]), float(info[1]), float(info[2]))
+        gt = blobs["gt_boxes"]
+        self._gt_boxes = gt if torch.is_tensor(gt) else sess.to_device(np.ascontiguousarray(gt, dtype=np.float32))
+        ops.ws_scope = self._tag
+        sess.flops_last_forward = 0
+        self._build_network(True)
+        return self._add_losses()
+
+    def train_step(self, sess, blobs, train_op):
+        """One SGD step.  `train_op` is the solver handle (frcnn_hip.train.TrainState with .lr set), the stand-in
+        for the reference's TF train op.  Returns the five losses like network.py:488-498."""
+        losses = self.train_forward(sess, blobs)
+        if not train_op.params:
+            train_op.build()
+        train_op.backward(self._loss_seeds)
+        total = sess.buf(self._tag + "/total_loss", (1,))
+        train_op.regularization_loss(total)
+        total += losses["rpn_cross_entropy"] + losses["rpn_loss_box"] + losses["cross_entropy"] + losses["loss_box"]
+        out = [float(losses[k].item()) for k in ("rpn_cross_entropy", "rpn_loss_box", "cross_entropy", "loss_box")] + [float(total.item())]
+        train_op.apply(train_op.lr, getattr(train_op, "world_size", 1), getattr(train_op, "all_reduce", None))
+        self._sample_seed += 2
+        return tuple(out)
+
+    def train_step_no_return(self, sess, blobs, train_op):
+        self.train_step(sess, blobs, train_op)
 
     def detect_device(self, sess, image_d, im_info, im_shape, max_per_image=100, thresh=0.0, out=None, count=None):
         """image (already in HBM) -> final detections in HBM: forward + the whole of

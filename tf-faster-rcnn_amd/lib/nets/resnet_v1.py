@@ -92,8 +92,13 @@ class resnetv1(Network):
         # resnet_v1.py:55-76: direct 7x7 crop unless RESNET.MAX_POOL
         P = cfg.POOLING_SIZE
         out = self._sess.buf(self._tag + "/" + name, (rois.shape[0], P, P, bottom.shape[-1]))
-        return self._sess.mark("op:crop_and_resize", 0, lambda: ops.crop_and_resize(
+        res = self._sess.mark("op:crop_and_resize", 0, lambda: ops.crop_and_resize(
             bottom, rois, float(self._feat_stride[0]), P, max_pool=bool(cfg.RESNET.MAX_POOL), out=out))
+        if self._mode == "TRAIN":
+            self._tape.append(dict(kind="crop", feat=bottom, rois=rois, y=res, stride=float(self._feat_stride[0])))
+            if bottom.data_ptr() in self._requires_grad:
+                self._requires_grad.add(res.data_ptr())
+        return res
 
     def _build_base(self):
         # resnet_v1.py:80-86.  The image buffer is [1,H,W,4]: 7x7x3 stem as a channel-folded GEMM.
@@ -114,4 +119,16 @@ class resnetv1(Network):
         fc7 = self._run_blocks(pool5, self._blocks[-1:])
         # average pooling done by reduce_mean (resnet_v1.py:124)
         out = self._sess.buf(self._tag + "/fc7", (fc7.shape[0], fc7.shape[-1]))
-        return self._sess.mark("op:spatial_mean", 0, lambda: ops.spatial_mean(fc7, out=out))
+        res = self._sess.mark("op:spatial_mean", 0, lambda: ops.spatial_mean(fc7, out=out))
+        if self._mode == "TRAIN":
+            self._tape.append(dict(kind="mean", x=fc7, y=res, name=self._scope + "/fc7_mean"))
+            if fc7.data_ptr() in self._requires_grad:
+                self._requires_grad.add(res.data_ptr())
+        return res
+
+    def trainable_scope(self, scope):
+        """resnet_v1.py:88-113: conv1 and the first cfg.RESNET.FIXED_BLOCKS blocks are frozen; everything else trains
+        (BN statistics and affine parameters are always frozen)."""
+        fixed = ["/conv1"] + ["/block%d/" % b for b in range(1, cfg.RESNET.FIXED_BLOCKS + 1)]
+        tail = scope[len(self._scope):]
+        return not any(tail.startswith(f) for f in fixed)
