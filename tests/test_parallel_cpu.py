@@ -33,6 +33,9 @@ def _worker(rank, world, port, q):
         view[:n] = torch.from_numpy(dets)
         parallel.set_count(rec, torch.tensor([n], dtype=torch.int32))
         out = parallel.unpack_records(parallel.all_gather_records(rec))
+        flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)          # training exchange: bucketed gradient sum
+        parallel.make_grad_all_reduce(bucket_bytes=1024)(flat)
+        assert torch.equal(flat, torch.arange(1000, dtype=torch.float32) * 3)
         q.put((rank, mine, [o.tolist() for o in out], dets.tolist()))
         dist.barrier()
     finally:

@@ -49,3 +49,21 @@ def unpack_records(gathered):
         n = min(int(g[r, REC_ROWS * 6].item()), REC_ROWS)
         out.append(g[r, :REC_ROWS * 6].view(REC_ROWS, 6)[:n].clone().numpy())
     return out
+
+
+def make_grad_all_reduce(group=None, bucket_bytes=64 << 20):
+    """Data-parallel training exchange: returns f(flat) that sums the flat f32 gradient buffer
+    over the ranks in place, in contiguous buckets (default 64 MiB: large enough that the xGMI ring is
+    bandwidth- not latency-bound, small enough that a later round can overlap them with the remaining
+    backward sweep).  The mean over replicas is applied inside the SGD kernel (grad_scale = 1/world)."""
+    import torch.distributed as dist
+
+    def all_reduce(flat):
+        n = flat.numel()
+        step = max(1, bucket_bytes // 4)
+        handles = [dist.all_reduce(flat[o:min(n, o + step)], op=dist.ReduceOp.SUM, group=group, async_op=True)
+                   for o in range(0, n, step)]
+        for h in handles:
+            h.wait()
+        return flat
+    return all_reduce
