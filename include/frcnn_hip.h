@@ -90,6 +90,14 @@ int frcnn_proposal_top_layer(const float* rpn_cls_prob_d, const float* rpn_bbox_
 int frcnn_crop_and_resize(const float* feat_d, int H, int W, int C, const float* rois_d, int R,
                           float feat_stride, int pool, int fuse_max2x2, float* out_d, void* stream);
 
+/* out = act(crop_and_resize(feat) + bias[c]).  A 1x1 convolution commutes with the (linear) bilinear crop,
+ * so the two 1x1 convs that consume the RoI crops (block4/unit_1 shortcut and conv1, lib/nets/resnet_v1.py:
+ * 115-125) can run once on the H x W map (2 394 pixels) instead of on R x 7 x 7 crops (14 700 pixels);
+ * bias and ReLU are applied here, after the crop, because out-of-range samples are zeros. */
+int frcnn_crop_and_resize_bias_act(const float* feat_d, int H, int W, int C, const float* rois_d, int R,
+                                   float feat_stride, int pool, const float* bias_d, int act, float* out_d,
+                                   void* stream);
+
 /* ---- test-time post-processing: replaces lib/model/test.py:95-102 (im_detect) and :162-180
  * (test_net per-class NMS + max_per_image cut) ----------------------------------------------- */
 size_t frcnn_detect_post_workspace_bytes(int R, int C);

@@ -158,3 +158,21 @@ def test_model_test_module_matches_reference_loop(small_net):
     for j in range(1, 21):
         assert per_class[j].shape == want[j].shape
         assert np.array_equal(per_class[j][:, 4], want[j][:, 4]) and np.allclose(per_class[j][:, :4], want[j][:, :4], atol=1e-3)
+
+
+def test_fused_tail_entry_equals_reference_order(small_net):
+    """resnetv1._fused_tail_entry: crop commuted past block4/unit_1's 1x1 convs == the reference op order
+    (up to f32 rounding) and within the same 1e-4 budget against the float64 oracle."""
+    sess, net, image, im_info = small_net
+    base = net.test_image(sess, image, im_info)
+    net._fuse_tail_entry = True
+    try:
+        fused = net.test_image(sess, image, im_info)
+    finally:
+        net._fuse_tail_entry = False
+    assert np.array_equal(base[3], fused[3])                                     # same rois
+    for a, b in zip(base[:3], fused[:3]):
+        assert rel_err(b, a) <= 2e-5
+    ref = DenseRef(sess.variables, 50, 21, SCALES, RATIOS).test_image(image, im_info, rois=fused[3], post=48)
+    assert rel_err(fused[0], ref["cls_score"]) <= 1e-4 and np.abs(fused[1] - ref["cls_prob"]).max() <= 1e-4
+    assert rel_err(fused[2], ref["bbox_pred"]) <= 1e-4

@@ -495,7 +495,7 @@ __device__ __forceinline__ float4 crop_sample(const float4* __restrict__ feat, i
 template <bool MAX2>
 __global__ __launch_bounds__(256) void k_crop_and_resize(const float4* __restrict__ feat, int H, int W, int C4,
                                                          const float* __restrict__ rois, float stride, int pool,
-                                                         float4* __restrict__ out) {
+                                                         const float4* __restrict__ bias, int act, float4* __restrict__ out) {
   const int r = blockIdx.x / pool, py = blockIdx.x % pool;
   const float height = ((float)H - 1.0f) * stride, width = ((float)W - 1.0f) * stride;   // network.py:146-147
   const float* roi = rois + 5 * (size_t)r;
@@ -515,24 +515,45 @@ __global__ __launch_bounds__(256) void k_crop_and_resize(const float4* __restric
     } else {
       v = crop_sample(feat, H, W, C4, c4, y1, x1, hs, ws, py, px);
     }
+    if (bias) {                       // optional fused epilogue (see frcnn_crop_and_resize_bias_act)
+      const float4 b = bias[c4];
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (act == FRCNN_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
     orow[(size_t)px * C4 + c4] = v;
   }
 }
 
-extern "C" int frcnn_crop_and_resize(const float* feat_d, int H, int W, int C, const float* rois_d, int R,
-                                     float feat_stride, int pool, int fuse_max2x2, float* out_d, void* stream) {
+static int launch_crop(const float* feat_d, int H, int W, int C, const float* rois_d, int R, float feat_stride, int pool,
+                       int fuse_max2x2, const float* bias_d, int act, float* out_d, void* stream) {
   if (!feat_d || !rois_d || !out_d || H < 2 || W < 2 || C <= 0 || R < 0 || pool < 2) return FRCNN_E_ARG;
   if (C % 4) return FRCNN_E_UNSUPPORTED;
   if (R == 0) return FRCNN_OK;
   hipStream_t st = (hipStream_t)stream;
   if (fuse_max2x2)
     hipLaunchKernelGGL(k_crop_and_resize<true>, dim3(R * pool), dim3(256), 0, st, (const float4*)feat_d, H, W, C / 4,
-                       rois_d, feat_stride, pool, (float4*)out_d);
+                       rois_d, feat_stride, pool, (const float4*)bias_d, act, (float4*)out_d);
   else
     hipLaunchKernelGGL(k_crop_and_resize<false>, dim3(R * pool), dim3(256), 0, st, (const float4*)feat_d, H, W, C / 4,
-                       rois_d, feat_stride, pool, (float4*)out_d);
+                       rois_d, feat_stride, pool, (const float4*)bias_d, act, (float4*)out_d);
   LAUNCH_CHECK();
   return FRCNN_OK;
+}
+
+extern "C" int frcnn_crop_and_resize(const float* feat_d, int H, int W, int C, const float* rois_d, int R,
+                                     float feat_stride, int pool, int fuse_max2x2, float* out_d, void* stream) {
+  return launch_crop(feat_d, H, W, C, rois_d, R, feat_stride, pool, fuse_max2x2, nullptr, FRCNN_ACT_NONE, out_d, stream);
+}
+
+// crop_and_resize followed by (+ bias[c], activation).  Lets a 1x1 convolution that consumes a RoI crop
+// run on the H x W feature map instead of on the R x pool x pool crops: conv1x1 and the bilinear crop are
+// both linear, so  conv1x1(crop(F)) + b == crop(conv1x1(F)) + b  (the bias must be added AFTER the crop
+// because out-of-range samples are zeros).
+extern "C" int frcnn_crop_and_resize_bias_act(const float* feat_d, int H, int W, int C, const float* rois_d, int R,
+                                              float feat_stride, int pool, const float* bias_d, int act, float* out_d,
+                                              void* stream) {
+  if (act != FRCNN_ACT_NONE && act != FRCNN_ACT_RELU) return FRCNN_E_ARG;
+  return launch_crop(feat_d, H, W, C, rois_d, R, feat_stride, pool, 0, bias_d, act, out_d, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

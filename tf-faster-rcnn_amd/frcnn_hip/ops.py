@@ -143,6 +143,17 @@ def crop_and_resize(feat, rois, feat_stride, pool, max_pool=False, out=None):
     return out
 
 
+def crop_and_resize_bias_act(feat, rois, feat_stride, pool, bias, act, out=None):
+    """act(crop_and_resize(feat) + bias): see frcnn_crop_and_resize_bias_act."""
+    _chk(feat), _chk(rois)
+    H, W, C = feat.shape[-3:]
+    R = rois.shape[0]
+    out = torch.empty((R, pool, pool, C), dtype=torch.float32, device=feat.device) if out is None else out
+    call("frcnn_crop_and_resize_bias_act", _ptr(feat), H, W, C, _ptr(rois), R, float(feat_stride), int(pool), _ptr(bias),
+         int(act), _ptr(out), _stream())
+    return out
+
+
 def detect_post(cls_prob, bbox_pred, rois, num_rois, im_scale, im_h, im_w, nms_thresh=0.3, score_thresh=0.0,
                 max_per_image=100, max_out=None, out=None, count=None):
     """lib/model/test.py:95-102 + :162-180 on device -> (dets [max_out,6], count [1])."""

@@ -44,6 +44,7 @@ class Network(object):
         self._gt_boxes = None
         self._sample_seed = 0
         self._train_state = None
+        self._fuse_tail_entry = False          # TEST-only graph restructuring, see resnetv1._fused_tail_entry
 
     # ------------------------------------------------------------------ variable declaration
     def _var(self, name, shape, init, arg=None):
@@ -74,11 +75,13 @@ class Network(object):
 
     # ------------------------------------------------------------------ building blocks
     def _conv(self, x, scope, k, stride=1, pad=(0, 0, 0, 0), act=ACT_RELU, bn_eps=None, residual=None,
-              res_stride=1, fold_w=False, out_affine=None, real_cin=None):
+              res_stride=1, fold_w=False, out_affine=None, real_cin=None, no_bias=False):
         sess = self._sess
         w, b = sess.conv_params(scope, bn_eps=bn_eps, fold_w=fold_w,
                                 out_scale=None if out_affine is None else out_affine[0],
                                 out_shift=None if out_affine is None else out_affine[1])
+        if no_bias:
+            b = None
         N, H, W, Cin = x.shape
         OH = ops.conv_out_size(H, k, stride, pad[0], pad[1])
         OW = ops.conv_out_size(W, k, stride, pad[2], pad[3])
@@ -244,12 +247,14 @@ class Network(object):
         net_conv = self._image_to_head(is_training)
         self._anchor_component()
         rois = self._region_proposal(net_conv, is_training)
-        if cfg.POOLING_MODE == "crop":
-            pool5 = self._crop_pool_layer(net_conv, rois, "pool5")
-        else:
+        if cfg.POOLING_MODE != "crop":
             raise NotImplementedError
-        self._layers["pool5"] = pool5
-        fc7 = self._head_to_tail(pool5, is_training)
+        if self._fuse_tail_entry and not is_training and hasattr(self, "_fused_tail_entry"):
+            fc7 = self._fused_tail_entry(net_conv, rois)          # crop commuted past the first 1x1 convs (exact algebra)
+        else:
+            pool5 = self._crop_pool_layer(net_conv, rois, "pool5")
+            self._layers["pool5"] = pool5
+            fc7 = self._head_to_tail(pool5, is_training)
         self._layers["fc7"] = fc7
         cls_prob, bbox_pred = self._region_classification(fc7, is_training)
         return rois, cls_prob, bbox_pred
@@ -303,7 +308,7 @@ class Network(object):
         self._image = image_d
         self._im_info = (float(im_info[0]), float(im_info[1]), float(im_info[2]))
         ops.ws_scope = self._tag                       # scratch buffers are per network tag (= per stream)
-        key = (self._tag, tuple(image_d.shape), self._im_info[:2], self._mode, cfg.TEST.MODE)
+        key = (self._tag, tuple(image_d.shape), self._im_info[:2], self._mode, cfg.TEST.MODE, self._fuse_tail_entry)
         cur = torch.cuda.current_stream(sess.device)
         if not use_graph or sess.profile is not None:
             sess.flops_last_forward = 0

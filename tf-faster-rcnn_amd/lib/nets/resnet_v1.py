@@ -115,6 +115,32 @@ class resnetv1(Network):
         self._layers['head'] = net_conv
         return net_conv
 
+    def _fused_tail_entry(self, net_conv, rois):
+        """TEST-mode restructuring of the entry of block4/unit_1 (same result up to f32 rounding): the two 1x1
+        convolutions that read the RoI crops (projection shortcut, conv1) are linear per pixel and the bilinear
+        crop is linear too, so they run ONCE on the 38x63 map and their outputs are cropped, instead of cropping
+        first and convolving 14 700 RoI pixels:  conv1x1(crop(F)) + b == crop(conv1x1(F)) + b.
+        Saves 64.5 of the 622.3 GFLOP per image (shortcut 61.7 -> 10.0, conv1 15.4 -> 2.5) and the pool5 tensor."""
+        sess, P = self._sess, cfg.POOLING_SIZE
+        name, base, n_units, stride = self._blocks[-1]
+        prefix = "%s/%s/unit_1/bottleneck_v1" % (self._scope, name)
+        R = rois.shape[0]
+        sc_map = self._conv(net_conv, prefix + "/shortcut", 1, 1, act=ACT_NONE, bn_eps=BN_EPS, no_bias=True)
+        c1_map = self._conv(net_conv, prefix + "/conv1", 1, 1, act=ACT_NONE, bn_eps=BN_EPS, no_bias=True)
+        b_sc = sess.conv_info[prefix + "/shortcut"]["b"]
+        b_c1 = sess.conv_info[prefix + "/conv1"]["b"]
+        fs = float(self._feat_stride[0])
+        sc_out = sess.buf(self._tag + "/" + prefix + "/shortcut_crop", (R, P, P, sc_map.shape[-1]))
+        c1_out = sess.buf(self._tag + "/" + prefix + "/conv1_crop", (R, P, P, c1_map.shape[-1]))
+        shortcut = sess.mark("op:crop_and_resize", 0, lambda: ops.crop_and_resize_bias_act(sc_map, rois, fs, P, b_sc, ACT_NONE, out=sc_out))
+        r = sess.mark("op:crop_and_resize", 0, lambda: ops.crop_and_resize_bias_act(c1_map, rois, fs, P, b_c1, ACT_RELU, out=c1_out))
+        r = self._conv(r, prefix + "/conv2", 3, 1, (1, 1, 1, 1), act=ACT_RELU, bn_eps=BN_EPS)
+        x = self._conv(r, prefix + "/conv3", 1, 1, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut, res_stride=1)
+        for u in range(2, n_units + 1):
+            x = self._bottleneck(x, "%s/%s/unit_%d/bottleneck_v1" % (self._scope, name, u), base, stride if u == n_units else 1)
+        out = sess.buf(self._tag + "/fc7", (x.shape[0], x.shape[-1]))
+        return sess.mark("op:spatial_mean", 0, lambda: ops.spatial_mean(x, out=out))
+
     def _head_to_tail(self, pool5, is_training, reuse=None):
         fc7 = self._run_blocks(pool5, self._blocks[-1:])
         # average pooling done by reduce_mean (resnet_v1.py:124)
