@@ -1,3 +1,4 @@
+"""A/B harness: configurations interleaved in rounds inside one process, median over rounds."""
 import sys, os, itertools
 sys.path[:0] = [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tf-faster-rcnn_amd")]
 import numpy as np, torch
@@ -10,27 +11,28 @@ shapes = {  # name: (N,H,W,Cin,Cout,k,pad)
  "b1c2": (1,150,250,64,64,3,1), "b1c3": (1,150,250,64,256,1,0),
  "b4c1": (300,7,7,2048,512,1,0), "b4c2": (300,7,7,512,512,3,1), "b4c3": (300,7,7,512,2048,1,0),
 }
-cfgs = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0,1,2,3,5,6,7,8,9,10]
+cfgs = [int(c) for c in sys.argv[1].split(",")]
 dbgs = [int(c) for c in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
 only = sys.argv[3].split(",") if len(sys.argv) > 3 else list(shapes)
-print("%-6s %4s %3s %9s %8s" % ("shape", "cfg", "dbg", "us", "TFLOP/s"))
+rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+print("%-6s %4s %3s %9s %9s %8s" % ("shape", "cfg", "dbg", "med_us", "min_us", "TFLOP/s"))
 for name in only:
     N,H,W,Cin,Cout,k,pad = shapes[name]
     x = torch.randn(N,H,W,Cin, device=dev); w = torch.randn(Cout,k,k,Cin, device=dev) * 0.05; b = torch.randn(Cout, device=dev)
     res = torch.randn(N,H,W,Cout, device=dev) if name.endswith("c3") else None
     out = torch.empty(N,H,W,Cout, device=dev)
     flops = 2.0*N*H*W*Cout*k*k*Cin
-    for cfg, dbg in itertools.product(cfgs, dbgs):
-        L.frcnn_set_tuning(0, cfg); L.frcnn_set_tuning(1, dbg)
-        try:
-            for _ in range(3): ops.conv2d(x, w, b, k, k, 1, (pad,)*4, 1, res, 1, out=out)
-        except Exception as e:
-            print(name, cfg, "ERR", e); continue
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20): ops.conv2d(x, w, b, k, k, 1, (pad,)*4, 1, res, 1, out=out)
-        e1.record(); torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1000 / 20
-        print("%-6s %4d %3d %9.1f %8.1f" % (name, cfg, dbg, us, flops / us / 1e6))
+    combos = list(itertools.product(cfgs, dbgs))
+    times = {c: [] for c in combos}
+    for r in range(rounds + 1):
+        for cfg, dbg in combos:
+            L.frcnn_set_tuning(0, cfg); L.frcnn_set_tuning(1, dbg)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(8): ops.conv2d(x, w, b, k, k, 1, (pad,)*4, 1, res, 1, out=out)
+            e1.record(); torch.cuda.synchronize()
+            if r: times[(cfg, dbg)].append(e0.elapsed_time(e1) * 1000 / 8)
+    for (cfg, dbg), ts in times.items():
+        med = float(np.median(ts))
+        print("%-6s %4d %3d %9.1f %9.1f %8.1f" % (name, cfg, dbg, med, min(ts), flops / med / 1e6))
 L.frcnn_set_tuning(0, -1); L.frcnn_set_tuning(1, 0)

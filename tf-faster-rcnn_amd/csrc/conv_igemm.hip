@@ -67,7 +67,7 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_base) {
       : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool FOLDW>
+template <int BM, int BN, int WM, int WN, int NS, bool FOLDW, bool ILV = false>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const ConvParams p) {
   constexpr int NW = (BM / WM) * (BN / WN);
   constexpr int NT = NW * 64;
@@ -80,7 +80,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
                                                           // 32-lane half, float4 reads are lane-linear -> no padding needed
   static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile/wave mismatch");
   static_assert((P - 1) * G <= 63, "vmcnt range");
-  static_assert(NS * SLAB >= BM * EPI_LD, "epilogue tile must fit in the slab ring");
   extern __shared__ __attribute__((aligned(16))) float smem[];     // [NS][BM+BN][32]; reused by the epilogue
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -144,25 +143,30 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
     }
   };
   const unsigned lds0 = (unsigned)(size_t)(LDS_AS float*)smem;       // LDS byte address of the ring
-  auto issue_slab = [&](int buf) {
+  // one direct-to-LDS load (t-th of the G = LA + LB a wave owns) of the slab going into ring slot `buf`
+  auto issue_one = [&](int buf, int t) {
     const unsigned sb = lds0 + (unsigned)(buf * SLAB * 4);
-    if (c0 == 0) set_tap();
-#pragma unroll
-    for (int t = 0; t < LA; ++t) {
+    if (t < LA) {
       glds16(a_ptr[t], __builtin_amdgcn_readfirstlane(sb + (wave * LA + t) * 1024));
       a_ptr[t] += a_inc[t];
+    } else {
+      const int u = t - LA;
+      glds16(b_ptr[u], __builtin_amdgcn_readfirstlane(sb + BM * 128 + (wave * LB + u) * 1024));
+      b_ptr[u] += b_inc[u];
     }
-#pragma unroll
-    for (int t = 0; t < LB; ++t) {
-      glds16(b_ptr[t], __builtin_amdgcn_readfirstlane(sb + BM * 128 + (wave * LB + t) * 1024));
-      b_ptr[t] += b_inc[t];
-    }
-    // advance to the following slab
+  };
+  auto advance_k = [&]() {
     if (FOLDW) { ++kh; }
     else {
       c0 += 32;
       if (c0 == p.Cin) { c0 = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
     }
+  };
+  auto issue_slab = [&](int buf) {
+    if (c0 == 0) set_tap();
+#pragma unroll
+    for (int t = 0; t < G; ++t) issue_one(buf, t);
+    advance_k();
   };
 
   constexpr bool KSPLIT = (TM * TN == 1);                 // second accumulator for odd k of single-tile waves
@@ -191,36 +195,51 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
     if (step + P <= p.nsteps) wait_vmcnt<(P - 1) * G>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();          // every wave finished slab step-1 and sees slab step
-    if (step + P < p.nsteps && !(p.dbg & 2)) issue_slab((step + P) % NS);
+    const bool more = (step + P < p.nsteps) && !(p.dbg & 2);
+    const int nbuf = (step + P) % NS;
+    if (!ILV) { if (more) issue_slab(nbuf); }
+    else if (more && c0 == 0) set_tap();
     const float* sb = smem + (step % NS) * SLAB;
-    // all fragment reads of the slab first (the MFMAs below then run back to back; the compiler
-    // staggers them with partial lgkmcnt waits), then 16 x TM x TN MFMAs
+    // MFMA order: consecutive instructions always target DIFFERENT accumulators; single-tile waves split k
+    // over two accumulators (KSPLIT).  ILV: the wave's G slab loads are spread between the four k-groups
+    // so their issue slots hide behind MFMAs instead of delaying the first MFMA after the barrier.
     float4 a[4][TM], b[4][TN];
+    if (!ILV) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[s][i] = *(const float4*)(sb + a_row0 + i * 1024 + koff[s]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[s][j] = *(const float4*)(sb + b_row0 + j * 1024 + koff[s]);
+      }
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
+      if (ILV) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[s][i] = *(const float4*)(sb + a_row0 + i * 1024 + koff[s]);
+        for (int i = 0; i < TM; ++i) a[s][i] = *(const float4*)(sb + a_row0 + i * 1024 + koff[s]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[s][j] = *(const float4*)(sb + b_row0 + j * 1024 + koff[s]);
+        for (int j = 0; j < TN; ++j) b[s][j] = *(const float4*)(sb + b_row0 + j * 1024 + koff[s]);
+        if (more) {
+#pragma unroll
+          for (int t = (s * G) / 4; t < ((s + 1) * G) / 4; ++t) issue_one(nbuf, t);
+        }
+      }
+      if (!(p.dbg & 1)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const float av = e == 0 ? a[s][i].x : e == 1 ? a[s][i].y : e == 2 ? a[s][i].z : a[s][i].w;
+              const float bv = e == 0 ? b[s][j].x : e == 1 ? b[s][j].y : e == 2 ? b[s][j].z : b[s][j].w;
+              if (KSPLIT && (e & 1)) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc2[i][j], 0, 0, 0);
+              else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+            }
+      }
     }
-    // MFMA order: consecutive instructions always target DIFFERENT accumulators (the dependent
-    // latency of v_mfma_f32_32x32x2_f32 is not shorter than its issue interval, so chains of
-    // dependent MFMAs leave bubbles).  Single-tile waves split k over two accumulators (KSPLIT).
-    if (!(p.dbg & 1))
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const float av = e == 0 ? a[s][i].x : e == 1 ? a[s][i].y : e == 2 ? a[s][i].z : a[s][i].w;
-            const float bv = e == 0 ? b[s][j].x : e == 1 ? b[s][j].y : e == 2 ? b[s][j].z : b[s][j].w;
-            if (KSPLIT && (e & 1)) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc2[i][j], 0, 0, 0);
-            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
-          }
-    }
+    if (ILV && more) advance_k();
   }
   if (KSPLIT) {
 #pragma unroll
@@ -293,12 +312,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool FOLDW>
+template <int BM, int BN, int WM, int WN, int NS, bool FOLDW, bool ILV = false>
 static int launch_conv(ConvParams p, hipStream_t st) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
-  constexpr size_t lds = sizeof(float) * NS * (BM + BN) * 32;
+  constexpr size_t ring = sizeof(float) * NS * (BM + BN) * 32, epi = sizeof(float) * BM * BN;
+  constexpr size_t lds = ring > epi ? ring : epi;     // the epilogue tile reuses the ring memory
   static bool attr_set = false;
-  auto kern = k_conv_igemm<BM, BN, WM, WN, NS, FOLDW>;
+  auto kern = k_conv_igemm<BM, BN, WM, WN, NS, FOLDW, ILV>;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
@@ -332,6 +352,12 @@ static int launch_cfg(int id, const ConvParams& p, hipStream_t st) {
     case 8: return launch_conv<32, 64, 32, 32, 2, false>(p, st);
     case 9: return launch_conv<32, 32, 32, 32, 4, false>(p, st);
     case 10: return launch_conv<128, 128, 32, 64, 2, false>(p, st);  // 8 waves, 2 accumulators each
+    case 11: return launch_conv<128, 128, 32, 64, 3, false, true>(p, st);   // 96 KB ring, loads interleaved with MFMAs
+    case 12: return launch_conv<128, 128, 32, 64, 2, false, true>(p, st);
+    case 13: return launch_conv<128, 256, 64, 64, 2, false>(p, st);         // 8 waves x 64x64, 96 KB, 1 workgroup / CU
+    case 14: return launch_conv<128, 256, 64, 64, 2, false, true>(p, st);
+    case 15: return launch_conv<64, 64, 32, 32, 2, false, true>(p, st);
+    case 16: return launch_conv<128, 128, 64, 64, 2, false, true>(p, st);
     default: return FRCNN_E_ARG;
   }
 }
@@ -370,7 +396,7 @@ extern "C" int frcnn_conv2d_nhwc(const float* x_d, int N, int H, int W, int Cin,
   // for the per-RoI tail (M = 14700), 64x64 tiles with a shallow ring (32 KB LDS -> up to 5
   // workgroups per CU) for the 38x63 / 75x125 / 150x250 feature maps.
   const long long big = (long long)cdiv(p.M, 128) * cdiv(Cout, 128);
-  if (Cout >= 96 && big >= 384 && p.nsteps >= 8) return launch_cfg(10, p, st);
+  if (Cout >= 96 && big >= 384 && p.nsteps >= 8) return launch_cfg(Cout >= 1024 ? 10 : 0, p, st);   // 8 waves help the residual epilogue
   if (Cout > 32) return launch_cfg(7, p, st);
   return launch_cfg(4, p, st);
 }
