@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--profile-steps", type=int, default=3, help="steps of the HIP-event pass that feeds `roofline`")
+    ap.add_argument("--batch", type=int, default=4, help="images per launch chain: the dense layers of B images share launches "
+                    "(fills the 256 CUs on the 38x63 layers); a step still counts images")
     ap.add_argument("--streams", type=int, default=3, help="images in flight per GPU (independent HIP streams + graphs)")
     ap.add_argument("--reference-order", action="store_true",
                     help="keep the reference op order crop -> 1x1 convs at the block4 entry (default: the 1x1 convs run on the "
@@ -134,17 +136,19 @@ def main():
     image = synth_image(cfg.RNG_SEED + rank)             # every rank its own image
 
     from frcnn_hip import parallel
+    B = max(1, args.batch)
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     recs, views, counts, gathered, imgs = [], [], [], [], []
     for i in range(S):
-        r_, v_ = parallel.new_record(dev)                # fixed-size detection record [dets | count]
+        r_, v_ = parallel.new_record(dev, batch=B)       # fixed-size detection records [B][dets | count]
         recs.append(r_); views.append(v_)
-        counts.append(torch.zeros((1,), dtype=torch.int32, device=dev))
-        gathered.append(torch.zeros((world, r_.numel()), dtype=torch.float32, device=dev) if world > 1 else None)
-        with torch.cuda.stream(streams[i]):
-            imgs.append(nets[i]._stage_image(sess, synth_image(cfg.RNG_SEED + rank + 1000 * i)))   # resident in HBM
+        counts.append(torch.zeros((B,), dtype=torch.int32, device=dev))
+        gathered.append(torch.zeros((world,) + tuple(r_.shape), dtype=torch.float32, device=dev) if world > 1 else None)
+        with torch.cuda.stream(streams[i]):                 # every (rank, stream, slot) its own image, resident in HBM
+            batch_np = np.concatenate([synth_image(cfg.RNG_SEED + rank + 1000 * i + 100000 * b) for b in range(B)], axis=0)
+            imgs.append(nets[i]._stage_image(sess, batch_np))
     torch.cuda.synchronize()
-    calibrate_rpn(sess, nets[0], imgs[0], im_info)          # synthetic-data preparation, outside any timed region
+    calibrate_rpn(sess, nets[0], imgs[0][:1].contiguous(), im_info)   # synthetic-data preparation, outside any timed region
     run_stream = streams[0]
     img_d, dets_view, count_i32 = imgs[0], views[0], counts[0]
 
@@ -177,8 +181,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        n_det = int(count_i32.item())
-        n_rois = int(net._num_rois.item())
+        n_det = int(count_i32[0].item())
+        n_rois = int(net._num_rois[0].item())
         flops_per_image = sess.flops_last_forward
 
         # ---- roofline of the dominant kernel (k_conv_igemm): HIP events around every conv launch, on
@@ -191,6 +195,7 @@ def main():
                 net.detect_device(sess, img_d, im_info, orig_shape, out=dets_view, count=count_i32)
             run_stream.synchronize()
             per_layer = {}
+            per_image_scale = 1.0 / B
             for tag, fl, e0, e1 in sess.profile:
                 ms = e0.elapsed_time(e1)
                 a = per_layer.setdefault(tag, [0.0, 0, 0])
@@ -212,29 +217,29 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        value = world * args.steps / elapsed
+        value = world * args.steps * B / elapsed
         out = {
             "metric": METRIC, "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: ResNet-101 VOC 600x1000, 300 proposals, 21 classes, A=9, TEST.MODE nms; "
-                                   "image in HBM -> <=100 detections in HBM", "images_per_gpu_per_step": 1, "images_in_flight_per_gpu": S,
+                                   "image in HBM -> <=100 detections in HBM", "images_per_gpu_per_step": B, "chains_in_flight_per_gpu": S,
                        "parallelism": "dp%d (one image per GPU, all-gather of detection records)" % world,
                        "launch": "eager" if args.no_graph else "hipGraph replay", "rois": n_rois, "detections": n_det,
                        "graph": "reference op order" if args.reference_order else
                                 "block4/unit_1 1x1 convs commuted past the bilinear crop (exact algebra, same outputs to f32 rounding; "
                                 "--reference-order keeps crop -> conv)",
-                       "gflop_per_image_launched": round(flops_per_image / 1e9, 2), "gflop_per_image_reference_graph": 622.29},
+                       "gflop_per_image_launched": round(flops_per_image / B / 1e9, 2), "gflop_per_image_reference_graph": 622.29},
         }
         if conv_launches:
             ach = conv_flops / (conv_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                                "kernel": "k_conv_igemm (f32 MFMA 32x32x2 implicit GEMM, all tile shapes)",
-                               "launches_per_image": conv_launches // args.profile_steps,
+                               "launches_per_step": conv_launches // args.profile_steps,
                                "avg_launch_us": round(1000.0 * conv_ms / conv_launches, 2),
-                               "conv_ms_per_image": round(conv_ms / args.profile_steps, 3),
-                               "whole_image_frac_of_mfma_roofline": round(flops_per_image * value / world / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
+                               "conv_ms_per_image": round(conv_ms / args.profile_steps / B, 3),
+                               "whole_image_frac_of_mfma_roofline": round(flops_per_image / B * value / world / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sess.variables, image, None)
         print(json.dumps(out), flush=True)

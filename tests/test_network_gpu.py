@@ -117,6 +117,7 @@ def test_vgg16_and_mobilenet_match_dense_oracle(dev, arch):
     from model.config import cfg
     from nets.mobilenet_v1 import mobilenetv1
     from nets.vgg16 import vgg16
+    prev_post = cfg.TEST.RPN_POST_NMS_TOP_N
     cfg.TEST.RPN_POST_NMS_TOP_N = 24
     try:
         sess = Session(device=dev, seed=7)
@@ -142,7 +143,7 @@ def test_vgg16_and_mobilenet_match_dense_oracle(dev, arch):
             assert rel_err(got, ref[name][:got.shape[0]]) <= max(1e-4, 4 * rel_err(ref32[name][:got.shape[0]], ref[name][:got.shape[0]])), name
         assert np.abs(cls_prob - ref["cls_prob"]).max() <= 1e-4
     finally:
-        cfg.TEST.RPN_POST_NMS_TOP_N = 300
+        cfg.TEST.RPN_POST_NMS_TOP_N = prev_post
 
 
 def test_model_test_module_matches_reference_loop(small_net):
@@ -176,3 +177,31 @@ def test_fused_tail_entry_equals_reference_order(small_net):
     ref = DenseRef(sess.variables, 50, 21, SCALES, RATIOS).test_image(image, im_info, rois=fused[3], post=48)
     assert rel_err(fused[0], ref["cls_score"]) <= 1e-4 and np.abs(fused[1] - ref["cls_prob"]).max() <= 1e-4
     assert rel_err(fused[2], ref["bbox_pred"]) <= 1e-4
+
+
+def test_batched_forward_equals_single_image_forward(small_net):
+    """A batch is B independent images whose dense layers share launches.  Tile shapes (hence f32 summation
+    order) depend on the launch size, so batch vs single agree to f32 rounding, not bitwise."""
+    sess, net, image, im_info = small_net
+    rng = np.random.RandomState(9)
+    from model.config import cfg
+    img2 = (rng.rand(1, 150, 200, 3) * 255.0).astype(np.float32) - cfg.PIXEL_MEANS.astype(np.float32)
+    singles = []
+    for im in (image, img2):
+        p = net.forward_device(sess, net._stage_image(sess, im), im_info)
+        torch.cuda.synchronize()
+        singles.append({k: p[k].cpu().numpy().copy() for k in ("rois", "cls_score", "bbox_pred", "rpn_cls_prob")})
+    batch = net._stage_image(sess, np.concatenate([image, img2, image], axis=0))
+    p = net.forward_device(sess, batch, im_info)
+    per = net._rois_per_image
+    assert p["rois"].shape[0] == 3 * per and net._num_rois.shape[0] == 3
+    for b, want in enumerate((singles[0], singles[1], singles[0])):
+        assert rel_err(p["rpn_cls_prob"][b:b + 1].cpu().numpy(), want["rpn_cls_prob"]) <= 1e-5
+        sl = slice(b * per, (b + 1) * per)
+        assert np.allclose(p["rois"][sl].cpu().numpy(), want["rois"], rtol=0, atol=1e-3)
+        assert rel_err(p["cls_score"][sl].cpu().numpy(), want["cls_score"]) <= 2e-5      # logits (this fixture's are O(1e3))
+        assert rel_err(p["bbox_pred"][sl].cpu().numpy(), want["bbox_pred"]) <= 2e-5
+    d, c = net.detect_device(sess, batch, im_info, (150, 200))
+    c = c.cpu().numpy()
+    assert d.shape[0] == 3 and np.all(c > 0) and c[0] == c[2]
+    assert np.array_equal(d[0, :c[0]].cpu().numpy(), d[2, :c[2]].cpu().numpy())      # same image, same batch -> identical

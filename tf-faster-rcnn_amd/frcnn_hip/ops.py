@@ -273,9 +273,9 @@ def softmax_rows(x, C=None, out=None):
 def rpn_softmax(score, A, out=None):
     """score [1,H,W,ld] (first 2A channels = bg|fg scores) -> prob [1,H,W,2A]."""
     _chk(score)
-    _, H, W, ld = score.shape
-    out = torch.empty((1, H, W, 2 * A), dtype=torch.float32, device=score.device) if out is None else out
-    call("frcnn_rpn_softmax", _ptr(score), H * W, A, ld, _ptr(out), _stream())
+    N, H, W, ld = score.shape
+    out = torch.empty((N, H, W, 2 * A), dtype=torch.float32, device=score.device) if out is None else out
+    call("frcnn_rpn_softmax", _ptr(score), N * H * W, A, ld, _ptr(out), _stream())
     return out
 
 

@@ -12,14 +12,22 @@ REC_ROWS = 128
 REC_FLOATS = REC_ROWS * 6 + 8
 
 
-def new_record(device):
-    rec = torch.zeros((REC_FLOATS,), dtype=torch.float32, device=device)
-    return rec, rec[:REC_ROWS * 6].view(REC_ROWS, 6)
+def new_record(device, batch=None):
+    """-> (record, detection view).  batch=None: one image ([REC_FLOATS], [REC_ROWS,6]); batch=B: B images
+    ([B,REC_FLOATS], [B,REC_ROWS,6] strided view whose per-image slices are contiguous)."""
+    if batch is None:
+        rec = torch.zeros((REC_FLOATS,), dtype=torch.float32, device=device)
+        return rec, rec[:REC_ROWS * 6].view(REC_ROWS, 6)
+    rec = torch.zeros((batch, REC_FLOATS), dtype=torch.float32, device=device)
+    return rec, rec[:, :REC_ROWS * 6].unflatten(1, (REC_ROWS, 6))
 
 
 def set_count(rec, count_i32):
-    """count_i32: int32 tensor [1] on the same device (written by frcnn_detect_post)."""
-    rec[REC_ROWS * 6] = count_i32[0].to(torch.float32)
+    """count_i32: int32 tensor [1] (or [B] for a batched record) written by frcnn_detect_post."""
+    if rec.dim() == 1:
+        rec[REC_ROWS * 6] = count_i32[0].to(torch.float32)
+    else:
+        rec[:, REC_ROWS * 6] = count_i32.to(torch.float32)
 
 
 def shard_images(num_images, rank, world):
@@ -32,7 +40,7 @@ def all_gather_records(rec, gathered=None, group=None):
     import torch.distributed as dist
     world = dist.get_world_size(group)
     if gathered is None:
-        gathered = torch.empty((world, REC_FLOATS), dtype=torch.float32, device=rec.device)
+        gathered = torch.empty((world,) + tuple(rec.shape), dtype=torch.float32, device=rec.device)
     if dist.get_backend(group) == "gloo":
         parts = list(gathered.unbind(0))
         dist.all_gather(parts, rec, group=group)
@@ -43,7 +51,7 @@ def all_gather_records(rec, gathered=None, group=None):
 
 def unpack_records(gathered):
     """-> list over ranks of float32 [n_i, 6] detection arrays (host)."""
-    g = gathered.detach().cpu()
+    g = gathered.detach().cpu().reshape(-1, REC_FLOATS)      # [world(*batch), REC_FLOATS]
     out = []
     for r in range(g.shape[0]):
         n = min(int(g[r, REC_ROWS * 6].item()), REC_ROWS)

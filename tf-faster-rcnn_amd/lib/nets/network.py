@@ -129,19 +129,28 @@ class Network(object):
         self._anchors = None      # materialise on demand with ops.generate_anchors_pre
 
     def _proposal_layer(self, rpn_cls_prob, rpn_bbox_pred, name):
+        """network.py:110-131 -> frcnn_proposal_layer, once per image of the batch (the reference graph is
+        batch-1; a batch here is B independent images whose dense layers share launches)."""
         c = cfg[self._mode]
         post = int(c.RPN_POST_NMS_TOP_N)
         s = self._sess
-        rois, scores, num = s.mark("op:proposal_layer", 0, lambda: ops.proposal_layer(
-            rpn_cls_prob, rpn_bbox_pred, self._im_info[0], self._im_info[1], self._feat_stride[0], self._base_anchors,
-            int(c.RPN_PRE_NMS_TOP_N), post, float(c.RPN_NMS_THRESH),
-            rois=s.buf(self._tag + "/rois", (post, 5)), scores=s.buf(self._tag + "/roi_scores", (post, 1)),
-            num=s.buf(self._tag + "/num_rois", (1,), torch.int32)))
+        B = rpn_cls_prob.shape[0]
+        rois = s.buf(self._tag + "/rois", (B * post, 5))
+        scores = s.buf(self._tag + "/roi_scores", (B * post, 1))
+        num = s.buf(self._tag + "/num_rois", (B,), torch.int32)
+        for b in range(B):
+            s.mark("op:proposal_layer", 0, lambda: ops.proposal_layer(
+                rpn_cls_prob[b:b + 1], rpn_bbox_pred[b:b + 1], self._im_info[0], self._im_info[1], self._feat_stride[0],
+                self._base_anchors, int(c.RPN_PRE_NMS_TOP_N), post, float(c.RPN_NMS_THRESH),
+                rois=rois[b * post:(b + 1) * post], scores=scores[b * post:(b + 1) * post], num=num[b:b + 1]))
         self._num_rois = num
+        self._rois_per_image = post
         return rois, scores
 
     def _proposal_top_layer(self, rpn_cls_prob, rpn_bbox_pred, name):
         n, s = int(cfg.TEST.RPN_TOP_N), self._sess
+        assert rpn_cls_prob.shape[0] == 1, "TEST.MODE 'top' is provided for single images"
+        self._rois_per_image = n
         rois, scores = ops.proposal_top_layer(rpn_cls_prob, rpn_bbox_pred, self._im_info[0], self._im_info[1],
                                               self._feat_stride[0], self._base_anchors, n,
                                               rois=s.buf(self._tag + "/top_rois", (n, 5)),
@@ -192,10 +201,22 @@ class Network(object):
                             (p["bbox_pred"], g_box)]
         return self._losses
 
+    def _crop_images(self, bottom, rois, out, max_pool=False, bias=None, act=ACT_NONE):
+        """crop_and_resize of image b's RoI rows out of image b's feature map, for every image of the batch."""
+        B, per = bottom.shape[0], rois.shape[0] // bottom.shape[0]
+        fs, P = float(self._feat_stride[0]), cfg.POOLING_SIZE
+        for b in range(B):
+            r, o = rois[b * per:(b + 1) * per], out[b * per:(b + 1) * per]
+            if bias is None and act == ACT_NONE:
+                self._sess.mark("op:crop_and_resize", 0, lambda: ops.crop_and_resize(bottom[b], r, fs, P, max_pool=max_pool, out=o))
+            else:
+                self._sess.mark("op:crop_and_resize", 0, lambda: ops.crop_and_resize_bias_act(bottom[b], r, fs, P, bias, act, out=o))
+        return out
+
     def _crop_pool_layer(self, bottom, rois, name):
         # network.py:141-157: 14x14 crop + 2x2 max pool (fused in the kernel)
-        return ops.crop_and_resize(bottom, rois, float(self._feat_stride[0]), cfg.POOLING_SIZE, max_pool=True,
-                                   out=self._sess.buf(self._tag + "/" + name, (rois.shape[0], cfg.POOLING_SIZE, cfg.POOLING_SIZE, bottom.shape[-1])))
+        out = self._sess.buf(self._tag + "/" + name, (rois.shape[0], cfg.POOLING_SIZE, cfg.POOLING_SIZE, bottom.shape[-1]))
+        return self._crop_images(bottom, rois, out, max_pool=True)
 
     def _region_proposal(self, net_conv, is_training, initializer=None):
         A = self._num_anchors
@@ -296,8 +317,8 @@ class Network(object):
         zero 4th channel lets the 7x7/3x3 stem run as a channel-folded MFMA GEMM."""
         if isinstance(image, np.ndarray):
             image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32))
-        _, H, W, C = image.shape
-        buf = sess.buf(self._tag + "/image", (1, H, W, 4), zero=True)
+        B, H, W, C = image.shape
+        buf = sess.buf(self._tag + "/image", (B, H, W, 4), zero=True)
         buf[..., :C].copy_(image, non_blocking=True)
         return buf
 
@@ -308,7 +329,9 @@ class Network(object):
         self._image = image_d
         self._im_info = (float(im_info[0]), float(im_info[1]), float(im_info[2]))
         ops.ws_scope = self._tag                       # scratch buffers are per network tag (= per stream)
-        key = (self._tag, tuple(image_d.shape), self._im_info[:2], self._mode, cfg.TEST.MODE, self._fuse_tail_entry)
+        c = cfg[self._mode]
+        key = (self._tag, tuple(image_d.shape), self._im_info[:2], self._mode, cfg.TEST.MODE, self._fuse_tail_entry,
+               c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH, cfg.TEST.RPN_TOP_N, cfg.POOLING_SIZE)
         cur = torch.cuda.current_stream(sess.device)
         if not use_graph or sess.profile is not None:
             sess.flops_last_forward = 0
@@ -323,9 +346,9 @@ class Network(object):
                 flops = sess.flops_last_forward
                 g = ops.Graph().capture(lambda: self._build_network(False))
                 sess.stream.synchronize()
-            sess.graphs[key] = (g, dict(self._predictions), self._num_rois, flops)
-        g, preds, num, flops = sess.graphs[key]
-        self._predictions, self._num_rois, sess.flops_last_forward = dict(preds), num, flops
+            sess.graphs[key] = (g, dict(self._predictions), self._num_rois, flops, self._rois_per_image)
+        g, preds, num, flops, per = sess.graphs[key]
+        self._predictions, self._num_rois, sess.flops_last_forward, self._rois_per_image = dict(preds), num, flops, per
         g.launch()
         return self._predictions
 
@@ -342,6 +365,7 @@ class Network(object):
         the `num_rois` proposals that survived NMS)."""
         img = self._stage_image(sess, image)
         p = self.forward_device(sess, img, im_info)
+        assert img.shape[0] == 1, "test_image keeps the reference's single-image contract (network.py:388); use detect_device for batches"
         n = p["rois"].shape[0] if self._num_rois is None else int(self._num_rois.item())
         return (p["cls_score"][:n].cpu().numpy(), p["cls_prob"][:n].cpu().numpy(), p["bbox_pred"][:n].cpu().numpy(),
                 p["rois"][:n].cpu().numpy())
@@ -380,10 +404,24 @@ class Network(object):
         self.train_step(sess, blobs, train_op)
 
     def detect_device(self, sess, image_d, im_info, im_shape, max_per_image=100, thresh=0.0, out=None, count=None):
-        """image (already in HBM) -> final detections in HBM: forward + the whole of
-        lib/model/test.py:95-102,162-180 on device.  Returns (dets [max_out,6], count [1])."""
+        """image(s) already in HBM -> final detections in HBM: forward + the whole of lib/model/test.py:95-102,
+        162-180 on device.  One image: returns (dets [max_out,6], count [1]).  A batch [B,H,W,4] of same-size images:
+        dets [B,max_out,6], count [B] (the dense layers run once for the batch, the per-image stages once per image)."""
         p = self.forward_device(sess, image_d, im_info)
         ops.ws_scope = self._tag
-        return sess.mark("op:detect_post", 0, lambda: ops.detect_post(
-            p["cls_prob"], p["bbox_pred"], p["rois"], self._num_rois, float(im_info[2]), int(im_shape[0]),
-            int(im_shape[1]), float(cfg.TEST.NMS), float(thresh), int(max_per_image), out=out, count=count))
+        B = image_d.shape[0]
+        per = self._rois_per_image
+        if B == 1:
+            return sess.mark("op:detect_post", 0, lambda: ops.detect_post(
+                p["cls_prob"], p["bbox_pred"], p["rois"], self._num_rois, float(im_info[2]), int(im_shape[0]),
+                int(im_shape[1]), float(cfg.TEST.NMS), float(thresh), int(max_per_image), out=out, count=count))
+        max_out = (max_per_image + 28) if out is None else out.shape[1]
+        out = sess.buf(self._tag + "/dets", (B, max_out, 6)) if out is None else out
+        count = sess.buf(self._tag + "/det_count", (B,), torch.int32) if count is None else count
+        for b in range(B):
+            sl = slice(b * per, (b + 1) * per)
+            nr = None if self._num_rois is None else self._num_rois[b:b + 1]
+            sess.mark("op:detect_post", 0, lambda: ops.detect_post(
+                p["cls_prob"][sl], p["bbox_pred"][sl], p["rois"][sl], nr, float(im_info[2]), int(im_shape[0]), int(im_shape[1]),
+                float(cfg.TEST.NMS), float(thresh), int(max_per_image), out=out[b], count=count[b:b + 1], max_out=max_out))
+        return out, count

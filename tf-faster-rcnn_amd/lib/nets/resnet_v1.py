@@ -92,8 +92,7 @@ class resnetv1(Network):
         # resnet_v1.py:55-76: direct 7x7 crop unless RESNET.MAX_POOL
         P = cfg.POOLING_SIZE
         out = self._sess.buf(self._tag + "/" + name, (rois.shape[0], P, P, bottom.shape[-1]))
-        res = self._sess.mark("op:crop_and_resize", 0, lambda: ops.crop_and_resize(
-            bottom, rois, float(self._feat_stride[0]), P, max_pool=bool(cfg.RESNET.MAX_POOL), out=out))
+        res = self._crop_images(bottom, rois, out, max_pool=bool(cfg.RESNET.MAX_POOL))
         if self._mode == "TRAIN":
             self._tape.append(dict(kind="crop", feat=bottom, rois=rois, y=res, stride=float(self._feat_stride[0])))
             if bottom.data_ptr() in self._requires_grad:
@@ -132,8 +131,8 @@ class resnetv1(Network):
         fs = float(self._feat_stride[0])
         sc_out = sess.buf(self._tag + "/" + prefix + "/shortcut_crop", (R, P, P, sc_map.shape[-1]))
         c1_out = sess.buf(self._tag + "/" + prefix + "/conv1_crop", (R, P, P, c1_map.shape[-1]))
-        shortcut = sess.mark("op:crop_and_resize", 0, lambda: ops.crop_and_resize_bias_act(sc_map, rois, fs, P, b_sc, ACT_NONE, out=sc_out))
-        r = sess.mark("op:crop_and_resize", 0, lambda: ops.crop_and_resize_bias_act(c1_map, rois, fs, P, b_c1, ACT_RELU, out=c1_out))
+        shortcut = self._crop_images(sc_map, rois, sc_out, bias=b_sc, act=ACT_NONE)
+        r = self._crop_images(c1_map, rois, c1_out, bias=b_c1, act=ACT_RELU)
         r = self._conv(r, prefix + "/conv2", 3, 1, (1, 1, 1, 1), act=ACT_RELU, bn_eps=BN_EPS)
         x = self._conv(r, prefix + "/conv3", 1, 1, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut, res_stride=1)
         for u in range(2, n_units + 1):
