@@ -231,10 +231,17 @@ def main():
                                 "--reference-order keeps crop -> conv)",
                        "gflop_per_image_launched": round(flops_per_image / B / 1e9, 2), "gflop_per_image_reference_graph": 622.29},
         }
+        traffic = None      # HBM bytes per conv launch from the committed rocprofv3 PMC passes of this command (scratch/gpu_pmc2.sh)
+        tpath = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
+        if os.path.exists(tpath) and B == 4 and not args.reference_order:
+            try:
+                traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
+            except Exception:
+                traffic = None
         if conv_launches:
             ach = conv_flops / (conv_ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                               "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                                "kernel": "k_conv_igemm (f32 MFMA 32x32x2 implicit GEMM, all tile shapes)",
                                "launches_per_step": conv_launches // args.profile_steps,
                                "avg_launch_us": round(1000.0 * conv_ms / conv_launches, 2),

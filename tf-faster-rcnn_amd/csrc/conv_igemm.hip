@@ -358,6 +358,9 @@ static int launch_cfg(int id, const ConvParams& p, hipStream_t st) {
     case 14: return launch_conv<128, 256, 64, 64, 2, false, true>(p, st);
     case 15: return launch_conv<64, 64, 32, 32, 2, false, true>(p, st);
     case 16: return launch_conv<128, 128, 64, 64, 2, false, true>(p, st);
+    case 17: return launch_conv<128, 64, 64, 32, 2, false>(p, st);          // 48 KB: 3 workgroups / CU
+    case 18: return launch_conv<64, 128, 32, 64, 2, false>(p, st);
+    case 19: return launch_conv<128, 64, 32, 32, 2, false>(p, st);          // 8 single-tile waves
     default: return FRCNN_E_ARG;
   }
 }
