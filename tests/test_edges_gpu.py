@@ -1,0 +1,124 @@
+"""GPU edge cases through the C ABI: empty / tiny / maximum-size inputs and error codes (the reference's
+own guards: nms_wrapper.py:18-19 empty dets, proposal_layer.py:35,44 non-positive top-N, kernels' documented limits)."""
+import numpy as np
+import pytest
+import torch
+
+import frcnn_oracle as ora
+import synth
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def T(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(dev) if dtype is None else t.to(dev, dtype)
+
+
+def test_nms_limits_and_error_codes(dev):
+    import frcnn_hip
+    from frcnn_hip import ops
+    L = frcnn_hip.lib()
+    d = synth.random_dets(16384, seed=1, cluster=300)                      # documented maximum
+    keep, num = ops.nms(T(d, dev), 0.7, max_keep=2000)
+    assert keep[:int(num.item())].cpu().numpy().tolist() == ora.cpu_nms(d, 0.7)[:2000]
+    big = torch.zeros((16385, 5), device=dev)
+    with pytest.raises(frcnn_hip.FrcnnHipError, match="not supported"):
+        ops.nms(big, 0.7)
+    ws = torch.empty(16, dtype=torch.uint8, device=dev)                     # workspace too small -> FRCNN_E_WS
+    num = torch.zeros(1, dtype=torch.int32, device=dev)
+    keep = torch.zeros(8, dtype=torch.int32, device=dev)
+    rc = L.frcnn_nms(T(d[:8], dev).data_ptr(), 8, 0.5, 8, keep.data_ptr(), num.data_ptr(), ws.data_ptr(), 16, None)
+    assert rc == -2
+    # all boxes identical: only the best survives; all disjoint: everything survives
+    same = np.tile(np.array([[10, 10, 50, 50, 0]], dtype=f32), (200, 1)); same[:, 4] = synth.tie_free(np.random.RandomState(0).rand(200), np.random.RandomState(1))
+    keep, num = ops.nms(T(same, dev), 0.5)
+    assert int(num.item()) == 1 and int(keep[0].item()) == int(np.argmax(same[:, 4]))
+    grid = np.array([[x * 20, y * 20, x * 20 + 9, y * 20 + 9, 0] for x in range(20) for y in range(20)], dtype=f32)
+    grid[:, 4] = synth.tie_free(np.random.RandomState(2).rand(400), np.random.RandomState(3))
+    keep, num = ops.nms(T(grid, dev), 0.3)
+    assert int(num.item()) == 400
+
+
+def test_proposal_layer_small_maps_and_all_mode(dev):
+    from frcnn_hip import ops
+    base = ops.generate_anchors(16)
+    for H, W, pre, post in ((2, 3, 6000, 300), (1, 1, 6000, 300), (10, 14, -1, 50), (10, 14, 40, 300)):
+        prob, dl = synth.rpn_outputs(H, W, 9, seed=H * 100 + W)
+        info = np.array([H * 16, W * 16, 1.0], dtype=f32)
+        rois, scores, num = ops.proposal_layer(T(prob, dev), T(dl, dev), info[0], info[1], 16, T(base, dev), pre, post, 0.7)
+        anc, _ = ora.generate_anchors_pre(H, W, 16)
+        wr, ws = ora.proposal_layer(prob, dl, info, "TEST", [16], anc, 9, pre_nms_topN=pre, post_nms_topN=post)
+        n = int(num.item())
+        assert n == wr.shape[0] <= post
+        assert np.array_equal(scores[:n].cpu().numpy(), ws) and np.allclose(rois[:n].cpu().numpy(), wr, rtol=0, atol=1e-3)
+        assert np.all(rois[n:].cpu().numpy() == 0)
+
+
+def test_detect_post_empty_and_maximum(dev):
+    from frcnn_hip import ops
+    R, C = 1024, 21                                                          # documented maximum R
+    prob, bp, rois = synth.rcnn_outputs(R, C, seed=5)
+    dets, cnt = ops.detect_post(T(prob, dev), T(bp, dev), T(rois, dev), None, 1.6, 375, 625)
+    sc, boxes = ora.im_detect_post(prob, bp, rois, 1.6, (375, 625, 3))
+    want = ora.detections_to_records(ora.test_net_post(sc, boxes, C))
+    n = int(cnt.item())
+    got = dets[:n].cpu().numpy()
+    assert n == want.shape[0] and np.array_equal(got[:, 4:], want[:, 4:]) and np.allclose(got[:, :4], want[:, :4], atol=1e-3)
+    # nothing above the score threshold -> zero detections, zero-filled output
+    dets, cnt = ops.detect_post(T(prob, dev), T(bp, dev), T(rois, dev), None, 1.6, 375, 625, score_thresh=2.0)
+    assert int(cnt.item()) == 0 and float(dets.abs().sum().item()) == 0.0
+    # num_rois = 0 (an image whose proposal stage kept nothing)
+    zero = torch.zeros(1, dtype=torch.int32, device=dev)
+    dets, cnt = ops.detect_post(T(prob, dev), T(bp, dev), T(rois, dev), zero, 1.6, 375, 625)
+    assert int(cnt.item()) == 0
+    import frcnn_hip
+    with pytest.raises(frcnn_hip.FrcnnHipError, match="not supported"):
+        ops.detect_post(torch.zeros((1025, C), device=dev), torch.zeros((1025, 4 * C), device=dev), torch.zeros((1025, 5), device=dev), None, 1.0, 10, 10)
+
+
+def test_empty_inputs_are_no_ops(dev):
+    from frcnn_hip import ops
+    feat = torch.randn(8, 9, 16, device=dev)
+    out = ops.crop_and_resize(feat, torch.zeros((0, 5), device=dev), 16.0, 7)
+    assert out.shape == (0, 7, 7, 16)
+    ov = ops.bbox_overlaps(torch.zeros((0, 4), dtype=torch.float64, device=dev), torch.zeros((3, 4), dtype=torch.float64, device=dev))
+    assert ov.shape == (0, 3)
+    keep, num = ops.nms(torch.zeros((0, 5), device=dev), 0.5)
+    assert int(num.item()) == 0
+
+
+def test_conv_error_codes_and_ragged_tiles(dev):
+    import frcnn_hip
+    from frcnn_hip import ops
+    with pytest.raises(frcnn_hip.FrcnnHipError, match="not supported"):   # Cin must be a multiple of 32
+        ops.conv2d(torch.zeros((1, 4, 4, 24), device=dev), torch.zeros((8, 1, 1, 24), device=dev), None, 1, 1)
+    # ragged everything: M = 5 pixels, Cout = 3, one 32-wide k slab
+    rng = np.random.RandomState(0)
+    x = rng.randn(1, 1, 5, 32).astype(f32); w = rng.randn(1, 1, 32, 3).astype(f32); b = rng.randn(3).astype(f32)
+    got = ops.conv2d(T(x, dev), T(ops.pack_filter_hwio(w), dev), T(b, dev), 1, 1).cpu().numpy()
+    want = (x.reshape(5, 32).astype(np.float64) @ w.reshape(32, 3).astype(np.float64) + b).reshape(1, 1, 5, 3)
+    assert np.abs(got - want).max() < 1e-5
+
+
+def test_target_layers_degenerate_samples(dev):
+    from frcnn_hip import ops
+    base = ops.generate_anchors(16)
+    # a single tiny gt far from most anchors: few positives, bg fills the batch
+    gt = np.array([[300, 200, 330, 240, 5]], dtype=f32)
+    lab, tg, iw, ow = [t.cpu().numpy() for t in ops.anchor_target_layer(T(gt, dev), 600, 1000, 38, 63, T(base, dev), seed=1)]
+    l = lab.ravel()
+    assert (l == 1).sum() >= 1 and (l == 1).sum() + (l == 0).sum() == 256
+    # proposal targets: rois that never reach FG_THRESH -> bg only (proposal_target_layer.py:128-131)
+    rois = np.hstack([np.zeros((50, 1), dtype=f32), synth.random_dets(50, seed=3)[:, :4]]).astype(f32)
+    far = np.array([[900, 500, 999, 599, 2]], dtype=f32)
+    out = ops.proposal_target_layer(T(rois, dev), T(np.ones(50, dtype=f32), dev), T(far, dev), 21, batch_size=64, fg_thresh=0.99)
+    counts = out[6].cpu().numpy()
+    assert counts[0] == 0 and counts[1] == 64 and float(out[2].abs().sum().item()) == 0.0      # sampled with replacement, labels 0
+    # only fg candidates (gt == every roi) -> fg fills the batch
+    one = np.array([[0, 10, 10, 60, 60]], dtype=f32)
+    out = ops.proposal_target_layer(T(np.tile(one, (5, 1)), dev), T(np.ones(5, dtype=f32), dev), T(np.array([[10, 10, 60, 60, 4]], dtype=f32), dev),
+                                    21, batch_size=16, bg_lo=0.1)
+    counts = out[6].cpu().numpy()
+    assert counts[0] == 16 and counts[1] == 0 and np.all(out[2].cpu().numpy() == 4)

@@ -526,9 +526,9 @@ __global__ __launch_bounds__(256) void k_crop_and_resize(const float4* __restric
 
 static int launch_crop(const float* feat_d, int H, int W, int C, const float* rois_d, int R, float feat_stride, int pool,
                        int fuse_max2x2, const float* bias_d, int act, float* out_d, void* stream) {
+  if (R == 0) return FRCNN_OK;                          // empty in, empty out (pointers may be null)
   if (!feat_d || !rois_d || !out_d || H < 2 || W < 2 || C <= 0 || R < 0 || pool < 2) return FRCNN_E_ARG;
   if (C % 4) return FRCNN_E_UNSUPPORTED;
-  if (R == 0) return FRCNN_OK;
   hipStream_t st = (hipStream_t)stream;
   if (fuse_max2x2)
     hipLaunchKernelGGL(k_crop_and_resize<true>, dim3(R * pool), dim3(256), 0, st, (const float4*)feat_d, H, W, C / 4,
