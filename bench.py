@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--reference-order", action="store_true",
                     help="keep the reference op order crop -> 1x1 convs at the block4 entry (default: the 1x1 convs run on the "
                          "feature map and their outputs are cropped; same result up to f32 rounding, 64.5 GFLOP less)")
+    ap.add_argument("--mfma", choices=["f32", "bf16x3"], default="f32",
+                    help="f32: v_mfma_f32_32x32x2_f32 (default, the headline).  bf16x3: EXPERIMENTAL exact 3-way bf16 split of both "
+                         "operands, six bf16 MFMAs per f32 product, f32 accumulate (f32-class error, csrc/conv_igemm_b3.hip)")
     ap.add_argument("--layer-report", default=None, help="write a per-layer table of the event pass to this file")
     args = ap.parse_args()
 
@@ -117,6 +120,8 @@ def main():
 
     import frcnn_hip
     frcnn_hip.lib()
+    if args.mfma == "bf16x3":
+        frcnn_hip.lib().frcnn_set_tuning(2, 1)
     from frcnn_hip.runtime import Session
     from model.config import cfg
     from nets.resnet_v1 import resnetv1
@@ -221,7 +226,9 @@ def main():
         out = {
             "metric": METRIC, "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.mfma == "f32" else "f32 via exact bf16x3 operand split (6 bf16 MFMAs / product, f32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "configs[1]: ResNet-101 VOC 600x1000, 300 proposals, 21 classes, A=9, TEST.MODE nms; "
                                    "image in HBM -> <=100 detections in HBM", "images_per_gpu_per_step": B, "chains_in_flight_per_gpu": S,
                        "parallelism": "dp%d (one image per GPU, all-gather of detection records)" % world,

@@ -136,7 +136,9 @@ int frcnn_conv2d_nhwc(const float* x_d, int N, int H, int W, int Cin, const floa
                       const float* residual_d, int RH, int RW, int res_stride, float* y_d, int OH, int OW,
                       int Cout, int KH, int KW, int stride, int pad_top, int pad_left, int act, int fold_w,
                       void* stream);
-/* Tuning knob for A/B experiments: key 0 = force conv tile configuration id (-1 = automatic). */
+/* Tuning knobs for A/B experiments: key 0 = force conv tile configuration id (-1 = automatic); key 1 = ablation bits;
+ * key 2 = 1 enables the EXPERIMENTAL bf16x3 split-operand MFMA path for every non-stem conv (f32 in/out, f32-class
+ * accuracy, see csrc/conv_igemm_b3.hip); key 3 = force its tile configuration. */
 int frcnn_set_tuning(int key, int value);
 /* HOST helper: HWIO (TF layout, [KH][KW][Cin][Cout]) -> packed [Cout][KH][KW][Cin], optionally
  * multiplying output channel o by scale[o] (folded frozen batch-norm gamma/sqrt(var+eps)). */

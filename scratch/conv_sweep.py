@@ -29,7 +29,9 @@ for name in only:
     times = {c: [] for c in combos}
     for r in range(rounds + 1):
         for cfg, dbg in combos:
-            L.frcnn_set_tuning(0, cfg); L.frcnn_set_tuning(1, dbg)
+            if cfg >= 100: L.frcnn_set_tuning(2, 1); L.frcnn_set_tuning(3, cfg - 100)
+            else: L.frcnn_set_tuning(2, 0); L.frcnn_set_tuning(0, cfg)
+            L.frcnn_set_tuning(1, dbg)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(8): ops.conv2d(x, w, b, k, k, 1, (pad,)*4, 1, res, 1, out=out)
@@ -38,4 +40,4 @@ for name in only:
     for (cfg, dbg), ts in times.items():
         med = float(np.median(ts))
         print("%-6s %4d %3d %9.1f %9.1f %8.1f" % (name, cfg, dbg, med, min(ts), flops / med / 1e6))
-L.frcnn_set_tuning(0, -1); L.frcnn_set_tuning(1, 0)
+L.frcnn_set_tuning(0, -1); L.frcnn_set_tuning(1, 0); L.frcnn_set_tuning(2, 0); L.frcnn_set_tuning(3, -1)

@@ -205,3 +205,26 @@ def test_batched_forward_equals_single_image_forward(small_net):
     c = c.cpu().numpy()
     assert d.shape[0] == 3 and np.all(c > 0) and c[0] == c[2]
     assert np.array_equal(d[0, :c[0]].cpu().numpy(), d[2, :c[2]].cpu().numpy())      # same image, same batch -> identical
+
+
+def test_bf16x3_split_path_end_to_end_meets_the_f32_bounds(small_net):
+    """EXPERIMENTAL opt-in conv path (csrc/conv_igemm_b3.hip) through the whole network: same bounds vs the float64
+    oracle as the f32-MFMA path."""
+    import frcnn_hip
+    sess, net, image, im_info = small_net
+    L = frcnn_hip.lib()
+    L.frcnn_set_tuning(2, 1)
+    sess.graphs.clear()
+    try:
+        cls_score, cls_prob, bbox_pred, rois = net.test_image(sess, image, im_info)
+        head = net._layers["head"].cpu().numpy()
+        rpn = {k: net._predictions[k].cpu().numpy() for k in ("rpn_cls_score", "rpn_bbox_pred")}
+    finally:
+        L.frcnn_set_tuning(2, 0)
+        sess.graphs.clear()
+    ref = DenseRef(sess.variables, 50, 21, SCALES, RATIOS).test_image(image, im_info, rois=rois, post=48)
+    ref32 = DenseRef(sess.variables, 50, 21, SCALES, RATIOS, dtype=torch.float32).test_image(image, im_info, rois=rois, post=48)
+    assert rel_err(head, ref["head"]) <= 1e-4
+    for name, got in (("rpn_cls_score", rpn["rpn_cls_score"]), ("rpn_bbox_pred", rpn["rpn_bbox_pred"]), ("cls_score", cls_score), ("bbox_pred", bbox_pred)):
+        assert rel_err(got, ref[name]) <= max(1e-4 * 0 + 4 * rel_err(ref32[name], ref[name]) + 2e-6, 0), name
+    assert np.abs(cls_prob - ref["cls_prob"]).max() <= 1e-4

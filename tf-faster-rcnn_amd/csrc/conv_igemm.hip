@@ -332,10 +332,15 @@ static int launch_conv(ConvParams p, hipStream_t st) {
 
 // tuning knob (experiments / A-B runs): key 0 = force a tile configuration id for every non-stem conv
 // (-1 = automatic choice).
-static int g_force_cfg = -1, g_dbg = 0;
+static int g_force_cfg = -1, g_dbg = 0, g_b3 = 0, g_b3_cfg = -1;
+int frcnn_conv2d_b3_dispatch(const float* x_d, int N, int H, int W, int Cin, const float* w_d, const float* bias_d,
+                             const float* residual_d, int RH, int RW, int res_stride, float* y_d, int OH, int OW, int Cout,
+                             int KH, int KW, int stride, int pad_top, int pad_left, int act, int cfg, hipStream_t st);
 extern "C" int frcnn_set_tuning(int key, int value) {
   if (key == 0) { g_force_cfg = value; return FRCNN_OK; }
   if (key == 1) { g_dbg = value; return FRCNN_OK; }
+  if (key == 2) { g_b3 = value; return FRCNN_OK; }          // experimental bf16x3 split-operand path (conv_igemm_b3.hip)
+  if (key == 3) { g_b3_cfg = value; return FRCNN_OK; }
   return FRCNN_E_ARG;
 }
 
@@ -392,6 +397,8 @@ extern "C" int frcnn_conv2d_nhwc(const float* x_d, int N, int H, int W, int Cin,
   p.dbg = g_dbg;
   hipStream_t st = (hipStream_t)stream;
   if (fold_w) return launch_conv<128, 64, 32, 64, 3, true>(p, st);
+  if (g_b3) return frcnn_conv2d_b3_dispatch(x_d, N, H, W, Cin, w_d, bias_d, residual_d, RH, RW, res_stride, y_d, OH, OW, Cout, KH,
+                                            KW, stride, pad_top, pad_left, act, g_b3_cfg, st);
   if (g_force_cfg >= 0) return launch_cfg(g_force_cfg, p, st);
   // Tile choice, from the measured sweep (profiles/r01_conv_tile_sweep.txt).  f32 MFMA needs few
   // bytes per FLOP, so the limiter is never LDS or HBM but (a) how many of the 1024 SIMDs get a wave
