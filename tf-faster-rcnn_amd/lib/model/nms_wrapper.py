@@ -1,13 +1,25 @@
-"""model.nms_wrapper.nms -- same dispatcher as lib/model/nms_wrapper.py:15-23."""
+"""model.nms_wrapper -- the `nms(dets, thresh, force_cpu=False)` entry of the reference
+(/root/reference/lib/model/nms_wrapper.py:15-23), re-hosted on libfrcnn_hip.so.
+
+Contract kept: `dets` float32 [N,5] = (x1, y1, x2, y2, score); returns the list of kept ORIGINAL row indices in
+descending-score order; an empty input returns [] without touching the device.  `cfg.USE_GPU_NMS` and `force_cpu`
+still choose between the two module names the reference imports, but both are backed by the same HIP bitmask
+kernel with the CPU/Cython suppression rule (`ovr >= thresh`): there is no host implementation in the product."""
 from model.config import cfg
-from nms.gpu_nms import gpu_nms
-from nms.cpu_nms import cpu_nms
+import nms.cpu_nms as _cpu_mod
+import nms.gpu_nms as _gpu_mod
+
+
+def _pick_backend(force_cpu):
+    use_accel_name = bool(cfg.USE_GPU_NMS) and not force_cpu
+    if use_accel_name:
+        return lambda d, t: _gpu_mod.gpu_nms(d, t, device_id=0)
+    return _cpu_mod.cpu_nms
 
 
 def nms(dets, thresh, force_cpu=False):
-    """Dispatch to either CPU or GPU NMS implementations (both names run on the MI355X here)."""
-    if dets.shape[0] == 0:
+    n_boxes = int(dets.shape[0])
+    if n_boxes == 0:            # nothing to suppress: same early-out as the reference
         return []
-    if cfg.USE_GPU_NMS and not force_cpu:
-        return gpu_nms(dets, thresh, device_id=0)
-    return cpu_nms(dets, thresh)
+    run = _pick_backend(force_cpu)
+    return run(dets, thresh)
