@@ -173,3 +173,40 @@ def test_conv2d_bf16x3_split_path_is_f32_class(dev, case, b3cfg):
         L.frcnn_set_tuning(2, 0); L.frcnn_set_tuning(3, -1)
     assert got.shape == want.shape
     assert np.abs(got - want).max() <= 2e-5 * max(np.abs(want).max(), 1.0), np.abs(got - want).max()
+
+
+@pytest.mark.parametrize("G,M,N,K", [(16, 608, 512, 1024), (3, 77, 20, 32), (16, 4800, 128, 128), (1, 300, 1000, 64)])
+def test_gemm_batched_nt(dev, G, M, N, K):
+    from frcnn_hip import ops
+    rng = np.random.RandomState(G + M)
+    x = rng.randn(G, M, K).astype(np.float32)
+    w = rng.randn(G, N, K).astype(np.float32)
+    y = ops.gemm_batched_nt(torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev), torch.empty(G, M, N, device=dev)).cpu().numpy()
+    ref = np.einsum("gmk,gnk->gmn", x.astype(np.float64), w.astype(np.float64))
+    assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,act,bias", [
+    (1, 38, 63, 256, 256, 1, True),       # block3 conv2 (odd width: half tiles on the right edge)
+    (2, 7, 7, 512, 512, 1, True),         # per-RoI block4 conv2 (7x7 -> 4x4 tiles, last row/col half used)
+    (1, 19, 32, 1024, 512, 1, True),      # RPN 3x3
+    (1, 5, 9, 32, 20, 0, False),          # no bias, no activation, Cout not a tile multiple
+    (3, 1, 1, 64, 36, 1, True),           # single pixel: every tap but the centre is padding
+])
+def test_conv3x3_winograd(dev, N, H, W, Cin, Cout, act, bias):
+    """Winograd F(2x2,3x3) == the direct 3x3 SAME convolution to f32 rounding (exact algebra; same 2e-5 bound)."""
+    from frcnn_hip import ops
+    rng = np.random.RandomState(H * W + Cin)
+    x = np.maximum(rng.randn(N, H, W, Cin), 0).astype(np.float32)
+    w = (rng.randn(3, 3, Cin, Cout) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b = rng.randn(Cout).astype(np.float32) if bias else None
+    scale = (0.5 + rng.rand(Cout)).astype(np.float32)
+    u = torch.from_numpy(ops.winograd_filter_transform(w, scale)).to(dev)
+    y = ops.conv3x3_winograd(torch.from_numpy(x).to(dev), u, None if b is None else torch.from_numpy(b).to(dev), act).cpu().numpy()
+    ref = ref_conv(x, w * scale[None, None, None, :], b, 1, (1, 1, 1, 1), act)
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max()
+    # and against the direct kernel on the same operands (both are f32-class; they differ by rounding only)
+    wp = torch.from_numpy(ops.pack_filter_hwio(w, scale)).to(dev)
+    yd = ops.conv2d(torch.from_numpy(x).to(dev), wp, None if b is None else torch.from_numpy(b).to(dev), 3, 3, 1, (1, 1, 1, 1), act).cpu().numpy()
+    assert np.abs(y - yd).max() <= 4e-5 * np.abs(ref).max()

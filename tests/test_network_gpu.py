@@ -228,3 +228,30 @@ def test_bf16x3_split_path_end_to_end_meets_the_f32_bounds(small_net):
     for name, got in (("rpn_cls_score", rpn["rpn_cls_score"]), ("rpn_bbox_pred", rpn["rpn_bbox_pred"]), ("cls_score", cls_score), ("bbox_pred", bbox_pred)):
         assert rel_err(got, ref[name]) <= max(1e-4 * 0 + 4 * rel_err(ref32[name], ref[name]) + 2e-6, 0), name
     assert np.abs(cls_prob - ref["cls_prob"]).max() <= 1e-4
+
+
+def test_direct_conv_path_equals_winograd_path(small_net):
+    """cfg.HIP.WINOGRAD only changes HOW the 3x3 stride-1 convolutions are evaluated (F(2x2,3x3), exact algebra):
+    both settings meet the float64 oracle bound and agree with each other to f32 rounding."""
+    from model.config import cfg
+    sess, net, image, im_info = small_net
+    assert cfg.HIP.WINOGRAD
+    wino = net.test_image(sess, image, im_info)
+    wino_rpn = {k: net._predictions[k].cpu().numpy().copy() for k in ("rpn_cls_score", "rpn_bbox_pred")}
+    n_wino = sum(1 for k in sess.packed if isinstance(k, tuple) and k[0] == "wino")
+    assert n_wino > 0                                                             # the path really ran
+    cfg.HIP.WINOGRAD = False
+    try:
+        direct = net.test_image(sess, image, im_info)
+        direct_rpn = {k: net._predictions[k].cpu().numpy().copy() for k in wino_rpn}
+    finally:
+        cfg.HIP.WINOGRAD = True
+    for k in wino_rpn:
+        assert rel_err(wino_rpn[k], direct_rpn[k]) <= 2e-5, k
+    # this fixture's RPN deltas are large (exp() amplifies f32 rounding of the deltas into ~1e-2 px on the boxes)
+    assert np.allclose(direct[3], wino[3], rtol=0, atol=5e-2)
+    ref = DenseRef(sess.variables, 50, 21, SCALES, RATIOS).test_image(image, im_info, rois=direct[3], post=48)
+    assert rel_err(direct[0], ref["cls_score"]) <= 1e-4 and rel_err(direct[2], ref["bbox_pred"]) <= 1e-4
+    if np.array_equal(direct[3], wino[3]):
+        for a, b in zip(direct[:3], wino[:3]):
+            assert rel_err(b, a) <= 2e-5

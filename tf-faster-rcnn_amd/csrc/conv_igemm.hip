@@ -38,6 +38,8 @@ struct ConvParams {
   int RH, RW, res_stride;
   int M, Ktot, nsteps;             // M = N*OH*OW, Ktot = KH*KW*Cin (fold_w: KH*32)
   int mtiles, ntiles;
+  int batch;                       // grid.y (1 for convolutions)
+  long long gx, gw, gy;            // batched GEMM use (grid.y = batch index): element strides of x / w / y per batch
   int dbg;                         // experiments only: bit0 skip MFMAs, bit1 skip slab loads after the prologue
 };
 
@@ -95,6 +97,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
   const int mt = bid / p.ntiles, nt = bid % p.ntiles;
   const int bm0 = mt * BM, bn0 = nt * BN;
   const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
+  const float* const px = p.x + (size_t)blockIdx.y * p.gx;        // batched GEMM: independent problems along grid.y
+  const float* const pw = p.w + (size_t)blockIdx.y * p.gw;
+  float* const py = p.y + (size_t)blockIdx.y * p.gy;
 
   // ---- per-lane source descriptors of the rows this lane stages -------------------------------
   const int lrow = lane >> 3, lpos = lane & 7;
@@ -126,7 +131,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
     const int n = bn0 + row - BM;
     const int q4 = (lpos ^ ((row >> 1) & 7)) * 4;
     const bool ok = n < p.Cout;
-    b_ptr[t] = ok ? p.w + (size_t)n * p.Ktot + q4 : zero;
+    b_ptr[t] = ok ? pw + (size_t)n * p.Ktot + q4 : zero;
     b_inc[t] = ok ? 32 : 0;
   }
   int kh = 0, kw = 0, c0 = 0;                                   // k position of the NEXT slab to issue
@@ -138,7 +143,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
       bool ok = (unsigned)ih < (unsigned)p.H;
       if (FOLDW) ok = ok && ((unsigned)(iw + (a_q4[t] >> 2)) < (unsigned)p.W);
       else ok = ok && ((unsigned)iw < (unsigned)p.W);
-      a_ptr[t] = ok ? p.x + (size_t)(a_base[t] + (ih * p.W + iw) * p.Cin + a_q4[t]) : zero;
+      a_ptr[t] = ok ? px + (size_t)(a_base[t] + (ih * p.W + iw) * p.Cin + a_q4[t]) : zero;
       a_inc[t] = ok ? 32 : 0;
     }
   };
@@ -288,7 +293,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
       if (p.act == FRCNN_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
       else if (p.act == FRCNN_ACT_RELU6)
         v = make_float4(fminf(fmaxf(v.x, 0.f), 6.f), fminf(fmaxf(v.y, 0.f), 6.f), fminf(fmaxf(v.z, 0.f), 6.f), fminf(fmaxf(v.w, 0.f), 6.f));
-      *(float4*)(p.y + (size_t)m * p.Cout + n) = v;
+      *(float4*)(py + (size_t)m * p.Cout + n) = v;
     }
   } else {          // Cout not a multiple of 4 (RPN / fc heads): scalar path
     for (int t = tid; t < BM * BN; t += NT) {
@@ -307,7 +312,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
       }
       if (p.act == FRCNN_ACT_RELU) v = fmaxf(v, 0.f);
       else if (p.act == FRCNN_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
-      p.y[(size_t)m * p.Cout + n] = v;
+      py[(size_t)m * p.Cout + n] = v;
     }
   }
 }
@@ -325,7 +330,7 @@ static int launch_conv(ConvParams p, hipStream_t st) {
   }
   p.mtiles = cdiv(p.M, BM);
   p.ntiles = cdiv(p.Cout, BN);
-  hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles), dim3(NT), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles, p.batch), dim3(NT), lds, st, p);
   LAUNCH_CHECK();
   return FRCNN_OK;
 }
@@ -394,6 +399,8 @@ extern "C" int frcnn_conv2d_nhwc(const float* x_d, int N, int H, int W, int Cin,
   p.Ktot = fold_w ? KH * 32 : KH * KW * Cin;
   p.nsteps = fold_w ? KH : KH * KW * (Cin / 32);
   p.mtiles = p.ntiles = 0;
+  p.gx = p.gw = p.gy = 0;
+  p.batch = 1;
   p.dbg = g_dbg;
   hipStream_t st = (hipStream_t)stream;
   if (fold_w) return launch_conv<128, 64, 32, 64, 3, true>(p, st);
@@ -409,6 +416,26 @@ extern "C" int frcnn_conv2d_nhwc(const float* x_d, int N, int H, int W, int Cin,
   if (Cout >= 96 && big >= 384 && p.nsteps >= 8) return launch_cfg(Cout >= 1024 ? 10 : 0, p, st);   // 8 waves help the residual epilogue
   if (Cout > 32) return launch_cfg(7, p, st);
   return launch_cfg(4, p, st);
+}
+
+// G independent "NT" GEMMs in one launch: y[g][m][n] = sum_k x[g][m][k] * w[g][n][k]  (f32 MFMA, same kernel, grid.y = g).
+// Used by the Winograd path (16 transformed positions).  K % 32 == 0.
+extern "C" int frcnn_gemm_batched_nt(const float* x_d, const float* w_d, float* y_d, int G, int M, int N, int K, void* stream) {
+  if (!x_d || !w_d || !y_d || G <= 0 || M <= 0 || N <= 0 || K <= 0) return FRCNN_E_ARG;
+  if (K % 32 || G > 65535) return FRCNN_E_UNSUPPORTED;
+  ConvParams p;
+  p.x = x_d; p.w = w_d; p.bias = nullptr; p.res = nullptr; p.y = y_d;
+  p.N = 1; p.H = 1; p.W = M; p.Cin = K; p.OH = 1; p.OW = M; p.Cout = N; p.KH = 1; p.KW = 1;
+  p.stride = 1; p.pad_top = 0; p.pad_left = 0; p.act = FRCNN_ACT_NONE;
+  p.RH = p.RW = 0; p.res_stride = 1;
+  p.M = M; p.Ktot = K; p.nsteps = K / 32; p.mtiles = p.ntiles = 0;
+  p.gx = (long long)M * K; p.gw = (long long)N * K; p.gy = (long long)M * N;
+  p.dbg = 0;
+  p.batch = G;
+  const long long big = (long long)cdiv(M, 128) * cdiv(N, 128) * G;
+  if (g_force_cfg >= 0) return launch_cfg(g_force_cfg, p, (hipStream_t)stream);
+  return (N >= 96 && big >= 384 && p.nsteps >= 8) ? launch_cfg(N >= 1024 ? 10 : 0, p, (hipStream_t)stream)
+                                                 : launch_cfg(N > 32 ? 7 : 4, p, (hipStream_t)stream);
 }
 
 // HOST: HWIO -> [Cout][KH][KW][Cin] with optional per-output-channel scale (folded frozen BN).

@@ -1,0 +1,133 @@
+// Winograd F(2x2, 3x3) for the stride-1, pad-1 3x3 convolutions of the path (block conv2's, RPN 3x3;
+// lib/nets/resnet_v1.py bottleneck conv2, lib/nets/network.py:324): exact algebra, f32 throughout,
+// 2.25x fewer multiplications (16 per 2x2 outputs instead of 36).
+//
+//   U = G g G^T (per filter, host, once)    V = B^T d B (4x4 input tile)    M_xn = sum_c U_xn[o][c] V_xn[t][c]
+//   Y = A^T M A (2x2 outputs per tile), + bias, activation
+// The 16 element-wise products are 16 independent [T x Cin] x [Cin x Cout] GEMMs -> frcnn_gemm_batched_nt
+// (the same f32-MFMA kernel, grid.y = 16).  The two transforms below are bandwidth-bound float4 kernels.
+#include "common.h"
+
+// HOST: HWIO [3][3][Cin][Cout] (optionally * scale[o]) -> U [16][Cout][Cin]
+extern "C" int frcnn_winograd_filter_transform(const float* w_hwio, int Cin, int Cout, const float* scale, float* u_out) {
+  if (!w_hwio || !u_out || Cin <= 0 || Cout <= 0) return FRCNN_E_ARG;
+  static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  for (int c = 0; c < Cin; ++c)
+    for (int o = 0; o < Cout; ++o) {
+      double g[3][3], t[4][3];
+      const double sc = scale ? (double)scale[o] : 1.0;
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) g[i][j] = (double)w_hwio[((size_t)(i * 3 + j) * Cin + c) * Cout + o] * sc;
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * g[0][j] + G[i][1] * g[1][j] + G[i][2] * g[2][j];
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+          const double u = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+          u_out[((size_t)(i * 4 + j) * Cout + o) * Cin + c] = (float)u;
+        }
+    }
+  return FRCNN_OK;
+}
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+// V[xn][t][c] = (B^T d B)[xi][nu], tile t = (img, ty, tx), d[i][j] = x[img, 2ty-1+i, 2tx-1+j, c]
+__global__ void k_wino_input(const float4* __restrict__ x, int N, int H, int W, int C4, int TH, int TW, float4* __restrict__ V) {
+  const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long T = (long long)N * TH * TW;
+  if (id >= T * C4) return;
+  const int c4 = (int)(id % C4);
+  const long long t = id / C4;
+  const int tx = (int)(t % TW), ty = (int)((t / TW) % TH), img = (int)(t / ((long long)TW * TH));
+  float4 d[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ih = 2 * ty - 1 + i;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int iw = 2 * tx - 1 + j;
+      d[i][j] = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) ? x[((size_t)(img * H + ih) * W + iw) * C4 + c4]
+                                                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  float4 b[4][4];       // B^T d : rows (d0-d2, d1+d2, d2-d1, d1-d3)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    b[0][j] = f4sub(d[0][j], d[2][j]);
+    b[1][j] = f4add(d[1][j], d[2][j]);
+    b[2][j] = f4sub(d[2][j], d[1][j]);
+    b[3][j] = f4sub(d[1][j], d[3][j]);
+  }
+  const size_t plane = (size_t)T * C4;
+  float4* out = V + (size_t)t * C4 + c4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {     // (.. B): columns (b0-b2, b1+b2, b2-b1, b1-b3)
+    out[(size_t)(i * 4 + 0) * plane] = f4sub(b[i][0], b[i][2]);
+    out[(size_t)(i * 4 + 1) * plane] = f4add(b[i][1], b[i][2]);
+    out[(size_t)(i * 4 + 2) * plane] = f4sub(b[i][2], b[i][1]);
+    out[(size_t)(i * 4 + 3) * plane] = f4sub(b[i][1], b[i][3]);
+  }
+}
+
+extern "C" int frcnn_winograd_input_transform(const float* x_d, int N, int H, int W, int C, float* v_d, void* stream) {
+  if (!x_d || !v_d || N <= 0 || H <= 0 || W <= 0 || C <= 0) return FRCNN_E_ARG;
+  if (C % 4) return FRCNN_E_UNSUPPORTED;
+  const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+  const long long tot = (long long)N * TH * TW * (C / 4);
+  hipLaunchKernelGGL(k_wino_input, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x_d, N, H, W,
+                     C / 4, TH, TW, (float4*)v_d);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// y[img, 2ty+a, 2tx+b, o] = act( (A^T M A)[a][b] + bias[o] ),  M[xn][t][o]
+__global__ void k_wino_output(const float4* __restrict__ Mx, int N, int H, int W, int C4, int TH, int TW,
+                              const float4* __restrict__ bias, int act, float4* __restrict__ y) {
+  const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long T = (long long)N * TH * TW;
+  if (id >= T * C4) return;
+  const int c4 = (int)(id % C4);
+  const long long t = id / C4;
+  const int tx = (int)(t % TW), ty = (int)((t / TW) % TH), img = (int)(t / ((long long)TW * TH));
+  const size_t plane = (size_t)T * C4;
+  const float4* in = Mx + (size_t)t * C4 + c4;
+  float4 m[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[i][j] = in[(size_t)(i * 4 + j) * plane];
+  float4 s[2][4];       // A^T m : rows (m0+m1+m2, m1-m2-m3)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s[0][j] = f4add(f4add(m[0][j], m[1][j]), m[2][j]);
+    s[1][j] = f4sub(f4sub(m[1][j], m[2][j]), m[3][j]);
+  }
+  const float4 bv = bias ? bias[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int oh = 2 * ty + a;
+    if (oh >= H) continue;
+    float4 o0 = f4add(f4add(f4add(s[a][0], s[a][1]), s[a][2]), bv);
+    float4 o1 = f4add(f4sub(f4sub(s[a][1], s[a][2]), s[a][3]), bv);
+    if (act == FRCNN_ACT_RELU) {
+      o0 = make_float4(fmaxf(o0.x, 0.f), fmaxf(o0.y, 0.f), fmaxf(o0.z, 0.f), fmaxf(o0.w, 0.f));
+      o1 = make_float4(fmaxf(o1.x, 0.f), fmaxf(o1.y, 0.f), fmaxf(o1.z, 0.f), fmaxf(o1.w, 0.f));
+    }
+    float4* row = y + ((size_t)(img * H + oh) * W) * C4 + c4;
+    if (2 * tx < W) row[(size_t)(2 * tx) * C4] = o0;
+    if (2 * tx + 1 < W) row[(size_t)(2 * tx + 1) * C4] = o1;
+  }
+}
+
+extern "C" int frcnn_winograd_output_transform(const float* m_d, int N, int H, int W, int C, const float* bias_d, int act, float* y_d,
+                                               void* stream) {
+  if (!m_d || !y_d || N <= 0 || H <= 0 || W <= 0 || C <= 0) return FRCNN_E_ARG;
+  if (C % 4 || (act != FRCNN_ACT_NONE && act != FRCNN_ACT_RELU)) return FRCNN_E_UNSUPPORTED;
+  const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+  const long long tot = (long long)N * TH * TW * (C / 4);
+  hipLaunchKernelGGL(k_wino_output, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)m_d, N, H, W,
+                     C / 4, TH, TW, (const float4*)bias_d, act, (float4*)y_d);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}

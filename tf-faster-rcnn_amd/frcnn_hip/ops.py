@@ -230,6 +230,58 @@ def conv2d(x, w_packed, bias, KH, KW, stride=1, pad=(0, 0, 0, 0), act=ACT_NONE, 
     return out
 
 
+def winograd_filter_transform(w_hwio, scale=None):
+    """HOST: 3x3 HWIO filter -> U [16, Cout, Cin] (F(2x2,3x3), optional folded per-output scale)."""
+    w = np.ascontiguousarray(w_hwio, dtype=np.float32)
+    assert w.shape[0] == 3 and w.shape[1] == 3
+    Cin, Cout = w.shape[2], w.shape[3]
+    out = np.empty((16, Cout, Cin), dtype=np.float32)
+    sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float32)
+    call("frcnn_winograd_filter_transform", w.ctypes.data_as(ctypes.c_void_p), Cin, Cout,
+         None if sc is None else sc.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def winograd_input_transform(x, v):
+    _chk(x), _chk(v)
+    N, H, W, C = x.shape
+    assert v.numel() == 16 * N * ((H + 1) // 2) * ((W + 1) // 2) * C
+    call("frcnn_winograd_input_transform", _ptr(x), N, H, W, C, _ptr(v), _stream())
+    return v
+
+
+def gemm_batched_nt(x, w, y):
+    """y[g] = x[g] @ w[g]^T for x [G,M,K], w [G,N,K], y [G,M,N] in one launch of the f32-MFMA kernel."""
+    _chk(x), _chk(w), _chk(y)
+    G, M, K = x.shape
+    N = w.shape[1]
+    assert w.shape == (G, N, K) and y.shape == (G, M, N)
+    call("frcnn_gemm_batched_nt", _ptr(x), _ptr(w), _ptr(y), G, M, N, K, _stream())
+    return y
+
+
+def winograd_output_transform(m, bias, act, out):
+    _chk(m), _chk(out)
+    N, H, W, C = out.shape
+    assert m.numel() == 16 * N * ((H + 1) // 2) * ((W + 1) // 2) * C
+    call("frcnn_winograd_output_transform", _ptr(m), N, H, W, C, _ptr(bias), int(act), _ptr(out), _stream())
+    return out
+
+
+def conv3x3_winograd(x, u, bias, act=ACT_NONE, out=None, v_buf=None, m_buf=None):
+    """3x3 / stride 1 / pad 1 convolution as Winograd F(2x2,3x3): x [N,H,W,Cin], u [16,Cout,Cin] -> [N,H,W,Cout]."""
+    N, H, W, Cin = x.shape
+    Cout = u.shape[1]
+    T = N * ((H + 1) // 2) * ((W + 1) // 2)
+    dev = x.device
+    v = torch.empty((16, T, Cin), dtype=torch.float32, device=dev) if v_buf is None else v_buf
+    m = torch.empty((16, T, Cout), dtype=torch.float32, device=dev) if m_buf is None else m_buf
+    out = torch.empty((N, H, W, Cout), dtype=torch.float32, device=dev) if out is None else out
+    winograd_input_transform(x, v)
+    gemm_batched_nt(v, u, m)
+    return winograd_output_transform(m, bias, act, out)
+
+
 def maxpool(x, k, stride, pad=(0, 0, 0, 0), out=None):
     _chk(x)
     N, H, W, C = x.shape

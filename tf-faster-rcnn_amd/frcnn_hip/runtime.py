@@ -110,6 +110,21 @@ class Session(object):
         self.conv_info[scope] = {"w": res[0], "b": res[1], "scale": scale if bn_eps is not None else None, "bn": bn_eps is not None}
         return res
 
+    def winograd_params(self, scope, bn_eps=None):
+        """(U_d [16,Cout,Cin], bias_d) for a 3x3 stride-1 scope run as Winograd F(2x2,3x3) (TEST mode only)."""
+        key = ("wino", scope, bn_eps)
+        if key in self.packed:
+            return self.packed[key]
+        w = self.variables[scope + "/weights"]
+        scale, bias = None, None
+        if bn_eps is not None:
+            scale, bias = self.fold_bn(scope, bn_eps)
+        elif (scope + "/biases") in self.variables:
+            bias = self.variables[scope + "/biases"]
+        res = (self.to_device(ops.winograd_filter_transform(w, scale)), None if bias is None else self.to_device(bias))
+        self.packed[key] = res
+        return res
+
     # ---- static activation buffers ----------------------------------------------------------------
     def buf(self, name, shape, dtype=torch.float32, zero=False):
         key = (name, tuple(shape), dtype)

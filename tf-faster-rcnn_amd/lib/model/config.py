@@ -61,7 +61,9 @@ __C = AttrDict(
     PIXEL_MEANS=np.array([[[102.9801, 115.9465, 122.7717]]]), RNG_SEED=3,
     ROOT_DIR=osp.abspath(osp.join(osp.dirname(__file__), '..', '..')),
     MATLAB='matlab', EXP_DIR='default', USE_GPU_NMS=True, USE_E2E_TF=False, POOLING_MODE='crop', POOLING_SIZE=7,
-    ANCHOR_SCALES=[8, 16, 32], ANCHOR_RATIOS=[0.5, 1, 2], RPN_CHANNELS=512)
+    ANCHOR_SCALES=[8, 16, 32], ANCHOR_RATIOS=[0.5, 1, 2], RPN_CHANNELS=512,
+    # device-path switches (no reference counterpart): Winograd F(2x2,3x3) for the 3x3 stride-1 convolutions at test time
+    HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=128))
 __C.DATA_DIR = osp.abspath(osp.join(__C.ROOT_DIR, 'data'))
 cfg = __C
 

@@ -77,6 +77,11 @@ class Network(object):
     def _conv(self, x, scope, k, stride=1, pad=(0, 0, 0, 0), act=ACT_RELU, bn_eps=None, residual=None,
               res_stride=1, fold_w=False, out_affine=None, real_cin=None, no_bias=False):
         sess = self._sess
+        N, H, W, Cin = x.shape
+        if (self._mode == "TEST" and cfg.HIP.WINOGRAD and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1)
+                and residual is None and not fold_w and out_affine is None and not no_bias
+                and Cin % 32 == 0 and Cin >= cfg.HIP.WINOGRAD_MIN_CIN and act in (ACT_NONE, ACT_RELU)):
+            return self._conv_winograd(x, scope, act, bn_eps)
         w, b = sess.conv_params(scope, bn_eps=bn_eps, fold_w=fold_w,
                                 out_scale=None if out_affine is None else out_affine[0],
                                 out_shift=None if out_affine is None else out_affine[1])
@@ -97,6 +102,22 @@ class Network(object):
                 self._requires_grad.add(out.data_ptr())
             if residual is not None and residual.data_ptr() in self._requires_grad:
                 self._requires_grad.add(out.data_ptr())
+        return out
+
+    def _conv_winograd(self, x, scope, act, bn_eps):
+        """3x3 / stride 1 / SAME convolution as Winograd F(2x2,3x3): input transform -> 16 GEMMs in ONE launch of the
+        f32-MFMA kernel -> output transform with bias + ReLU.  Exact algebra (f32), 2.25x fewer multiplications."""
+        sess = self._sess
+        u, b = sess.winograd_params(scope, bn_eps=bn_eps)
+        N, H, W, Cin = x.shape
+        Cout = u.shape[1]
+        T = N * ((H + 1) // 2) * ((W + 1) // 2)
+        v = sess.buf(self._tag + "/wino_v", (16, T, Cin))
+        m = sess.buf(self._tag + "/wino_m", (16, T, Cout))
+        out = sess.buf(self._tag + "/" + scope, (N, H, W, Cout))
+        sess.mark("op:wino_in", 0, lambda: ops.winograd_input_transform(x, v))
+        sess.mark("conv:" + scope, 2 * 16 * T * Cout * Cin, lambda: ops.gemm_batched_nt(v, u, m))
+        sess.mark("op:wino_out", 0, lambda: ops.winograd_output_transform(m, b, act, out))
         return out
 
     def trainable_scope(self, scope):
@@ -331,7 +352,8 @@ class Network(object):
         ops.ws_scope = self._tag                       # scratch buffers are per network tag (= per stream)
         c = cfg[self._mode]
         key = (self._tag, tuple(image_d.shape), self._im_info[:2], self._mode, cfg.TEST.MODE, self._fuse_tail_entry,
-               c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH, cfg.TEST.RPN_TOP_N, cfg.POOLING_SIZE)
+               c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH, cfg.TEST.RPN_TOP_N, cfg.POOLING_SIZE,
+               bool(cfg.HIP.WINOGRAD), int(cfg.HIP.WINOGRAD_MIN_CIN))
         cur = torch.cuda.current_stream(sess.device)
         if not use_graph or sess.profile is not None:
             sess.flops_last_forward = 0
