@@ -142,12 +142,13 @@ int frcnn_conv2d_nhwc(const float* x_d, int N, int H, int W, int Cin, const floa
 int frcnn_set_tuning(int key, int value);
 /* G independent NT GEMMs in one launch (f32 MFMA): y[g][m][n] = sum_k x[g][m][k] * w[g][n][k];  K % 32 == 0. */
 int frcnn_gemm_batched_nt(const float* x_d, const float* w_d, float* y_d, int G, int M, int N, int K, void* stream);
-/* Winograd F(2x2,3x3) for stride-1 pad-1 3x3 convolutions (exact algebra, f32): filter transform on the host
- * (U [16][Cout][Cin], optional folded BN scale), input transform V [16][T][C] with T = N*ceil(H/2)*ceil(W/2), the 16
- * GEMMs via frcnn_gemm_batched_nt, output transform (+bias, ReLU) back to NHWC [N,H,W,Cout]. */
-int frcnn_winograd_filter_transform(const float* w_hwio, int Cin, int Cout, const float* scale, float* u_out);
-int frcnn_winograd_input_transform(const float* x_d, int N, int H, int W, int C, float* v_d, void* stream);
-int frcnn_winograd_output_transform(const float* m_d, int N, int H, int W, int C, const float* bias_d, int act, float* y_d,
+/* Winograd F(m x m, 3x3), m = 2 or 4, for stride-1 pad-1 3x3 convolutions (exact algebra, f32): filter transform on the
+ * host (U [(m+2)^2][Cout][Cin], optional folded BN scale), input transform V [(m+2)^2][T][C] with
+ * T = N*ceil(H/m)*ceil(W/m), the (m+2)^2 GEMMs via frcnn_gemm_batched_nt, output transform (+bias, ReLU) back to NHWC
+ * [N,H,W,Cout].  m = 4 does 4x fewer multiplications than direct but rounds ~10x worse (still f32-class). */
+int frcnn_winograd_filter_transform(const float* w_hwio, int Cin, int Cout, const float* scale, int m, float* u_out);
+int frcnn_winograd_input_transform(const float* x_d, int N, int H, int W, int C, int m, float* v_d, void* stream);
+int frcnn_winograd_output_transform(const float* m_d, int N, int H, int W, int C, int m, const float* bias_d, int act, float* y_d,
                                     void* stream);
 /* HOST helper: HWIO (TF layout, [KH][KW][Cin][Cout]) -> packed [Cout][KH][KW][Cin], optionally
  * multiplying output channel o by scale[o] (folded frozen batch-norm gamma/sqrt(var+eps)). */

@@ -238,7 +238,7 @@ def test_direct_conv_path_equals_winograd_path(small_net):
     assert cfg.HIP.WINOGRAD
     wino = net.test_image(sess, image, im_info)
     wino_rpn = {k: net._predictions[k].cpu().numpy().copy() for k in ("rpn_cls_score", "rpn_bbox_pred")}
-    n_wino = sum(1 for k in sess.packed if isinstance(k, tuple) and k[0] == "wino")
+    n_wino = sum(1 for k in sess.packed if isinstance(k, tuple) and k[0] == "wino" and k[-1] == cfg.HIP.WINOGRAD_M)
     assert n_wino > 0                                                             # the path really ran
     cfg.HIP.WINOGRAD = False
     try:

@@ -8,22 +8,32 @@
 // (the same f32-MFMA kernel, grid.y = 16).  The two transforms below are bandwidth-bound float4 kernels.
 #include "common.h"
 
-// HOST: HWIO [3][3][Cin][Cout] (optionally * scale[o]) -> U [16][Cout][Cin]
-extern "C" int frcnn_winograd_filter_transform(const float* w_hwio, int Cin, int Cout, const float* scale, float* u_out) {
+//
+// m = 2: F(2x2,3x3), 4x4 input tiles, 16 GEMMs.   m = 4: F(4x4,3x3) (Lavin & Gray points 0,+-1,+-2,inf), 6x6 input tiles,
+// 36 GEMMs, 4x fewer multiplications than direct; its f32 rounding error is ~10x the direct kernel's, so the network
+// only uses it where few such layers follow one another (block4's three conv2 on the 7x7 crops).
+
+// HOST: HWIO [3][3][Cin][Cout] (optionally * scale[o]) -> U [(m+2)^2][Cout][Cin]
+extern "C" int frcnn_winograd_filter_transform(const float* w_hwio, int Cin, int Cout, const float* scale, int m, float* u_out) {
   if (!w_hwio || !u_out || Cin <= 0 || Cout <= 0) return FRCNN_E_ARG;
-  static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  if (m != 2 && m != 4) return FRCNN_E_UNSUPPORTED;
+  static const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  static const double G4[6][3] = {{1.0 / 4, 0, 0},           {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                  {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+  const int a = m + 2;
+  const double(*G)[3] = m == 2 ? G2 : G4;
   for (int c = 0; c < Cin; ++c)
     for (int o = 0; o < Cout; ++o) {
-      double g[3][3], t[4][3];
+      double g[3][3], t[6][3];
       const double sc = scale ? (double)scale[o] : 1.0;
       for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) g[i][j] = (double)w_hwio[((size_t)(i * 3 + j) * Cin + c) * Cout + o] * sc;
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < a; ++i)
         for (int j = 0; j < 3; ++j) t[i][j] = G[i][0] * g[0][j] + G[i][1] * g[1][j] + G[i][2] * g[2][j];
-      for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) {
+      for (int i = 0; i < a; ++i)
+        for (int j = 0; j < a; ++j) {
           const double u = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
-          u_out[((size_t)(i * 4 + j) * Cout + o) * Cin + c] = (float)u;
+          u_out[((size_t)(i * a + j) * Cout + o) * Cin + c] = (float)u;
         }
     }
   return FRCNN_OK;
@@ -70,11 +80,118 @@ __global__ void k_wino_input(const float4* __restrict__ x, int N, int H, int W, 
   }
 }
 
-extern "C" int frcnn_winograd_input_transform(const float* x_d, int N, int H, int W, int C, float* v_d, void* stream) {
+// ---------------------------------------------------------------------------------------------------- F(4x4, 3x3)
+__device__ __forceinline__ float4 f4mad(float a, float4 x, float4 y) { return make_float4(a * x.x + y.x, a * x.y + y.y, a * x.z + y.z, a * x.w + y.w); }
+__device__ __forceinline__ float4 f4mul(float a, float4 x) { return make_float4(a * x.x, a * x.y, a * x.z, a * x.w); }
+
+// one application of B^T (6 -> 6) on a strided 6-vector held in registers
+#define WINO4_BT(v0, v1, v2, v3, v4, v5, o0, o1, o2, o3, o4, o5)                       \
+  {                                                                                    \
+    const float4 t0 = f4mad(-4.f, v2, v4), t1 = f4mad(-4.f, v1, v3);                   \
+    const float4 t2 = f4sub(v4, v2), t3 = f4mul(2.f, f4sub(v3, v1));                   \
+    const float4 r0 = f4add(f4mad(4.f, v0, f4mul(-5.f, v2)), v4);                      \
+    const float4 r5 = f4add(f4mad(4.f, v1, f4mul(-5.f, v3)), v5);                      \
+    o0 = r0;               /* outputs may alias the inputs: all reads are done */      \
+    o1 = f4add(t0, t1);                                                                \
+    o2 = f4sub(t0, t1);                                                                \
+    o3 = f4add(t2, t3);                                                                \
+    o4 = f4sub(t2, t3);                                                                \
+    o5 = r5;                                                                           \
+  }
+
+__global__ void __launch_bounds__(256) k_wino4_input(const float4* __restrict__ x, int N, int H, int W, int C4, int TH, int TW,
+                                                      float4* __restrict__ V) {
+  const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long T = (long long)N * TH * TW;
+  if (id >= T * C4) return;
+  const int c4 = (int)(id % C4);
+  const long long t = id / C4;
+  const int tx = (int)(t % TW), ty = (int)((t / TW) % TH), img = (int)(t / ((long long)TW * TH));
+  float4 d[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int ih = 4 * ty - 1 + i;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int iw = 4 * tx - 1 + j;
+      d[i][j] = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) ? x[((size_t)(img * H + ih) * W + iw) * C4 + c4]
+                                                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) WINO4_BT(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);
+  const size_t plane = (size_t)T * C4;
+  float4* out = V + (size_t)t * C4 + c4;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float4 o0, o1, o2, o3, o4, o5;
+    WINO4_BT(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], o0, o1, o2, o3, o4, o5);
+    out[(size_t)(i * 6 + 0) * plane] = o0;
+    out[(size_t)(i * 6 + 1) * plane] = o1;
+    out[(size_t)(i * 6 + 2) * plane] = o2;
+    out[(size_t)(i * 6 + 3) * plane] = o3;
+    out[(size_t)(i * 6 + 4) * plane] = o4;
+    out[(size_t)(i * 6 + 5) * plane] = o5;
+  }
+}
+
+// A^T (6 -> 4): rows (1 1 1 1 1 0), (0 1 -1 2 -2 0), (0 1 1 4 4 0), (0 1 -1 8 -8 1)
+#define WINO4_AT(v0, v1, v2, v3, v4, v5, o0, o1, o2, o3)                               \
+  {                                                                                    \
+    const float4 p = f4add(v1, v2), q = f4sub(v1, v2), r = f4add(v3, v4), u = f4sub(v3, v4); \
+    o0 = f4add(f4add(v0, p), r);                                                       \
+    o1 = f4mad(2.f, u, q);                                                             \
+    o2 = f4mad(4.f, r, p);                                                             \
+    o3 = f4add(f4mad(8.f, u, q), v5);                                                  \
+  }
+
+__global__ void __launch_bounds__(256) k_wino4_output(const float4* __restrict__ Mx, int N, int H, int W, int C4, int TH, int TW,
+                                                       const float4* __restrict__ bias, int act, float4* __restrict__ y) {
+  const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long T = (long long)N * TH * TW;
+  if (id >= T * C4) return;
+  const int c4 = (int)(id % C4);
+  const long long t = id / C4;
+  const int tx = (int)(t % TW), ty = (int)((t / TW) % TH), img = (int)(t / ((long long)TW * TH));
+  const size_t plane = (size_t)T * C4;
+  const float4* in = Mx + (size_t)t * C4 + c4;
+  float4 s[4][6];       // A^T m, one column j at a time
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const float4 m0 = in[(size_t)(0 * 6 + j) * plane], m1 = in[(size_t)(1 * 6 + j) * plane], m2 = in[(size_t)(2 * 6 + j) * plane];
+    const float4 m3 = in[(size_t)(3 * 6 + j) * plane], m4 = in[(size_t)(4 * 6 + j) * plane], m5 = in[(size_t)(5 * 6 + j) * plane];
+    WINO4_AT(m0, m1, m2, m3, m4, m5, s[0][j], s[1][j], s[2][j], s[3][j]);
+  }
+  const float4 bv = bias ? bias[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int oh = 4 * ty + a;
+    if (oh >= H) continue;
+    float4 o[4];
+    WINO4_AT(s[a][0], s[a][1], s[a][2], s[a][3], s[a][4], s[a][5], o[0], o[1], o[2], o[3]);
+    float4* row = y + ((size_t)(img * H + oh) * W) * C4 + c4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int ow = 4 * tx + b;
+      if (ow >= W) continue;
+      float4 v = f4add(o[b], bv);
+      if (act == FRCNN_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      row[(size_t)ow * C4] = v;
+    }
+  }
+}
+
+extern "C" int frcnn_winograd_input_transform(const float* x_d, int N, int H, int W, int C, int m, float* v_d, void* stream) {
   if (!x_d || !v_d || N <= 0 || H <= 0 || W <= 0 || C <= 0) return FRCNN_E_ARG;
-  if (C % 4) return FRCNN_E_UNSUPPORTED;
-  const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+  if (C % 4 || (m != 2 && m != 4)) return FRCNN_E_UNSUPPORTED;
+  const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
   const long long tot = (long long)N * TH * TW * (C / 4);
+  if (m == 4) {
+    hipLaunchKernelGGL(k_wino4_input, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x_d, N, H, W,
+                       C / 4, TH, TW, (float4*)v_d);
+    LAUNCH_CHECK();
+    return FRCNN_OK;
+  }
   hipLaunchKernelGGL(k_wino_input, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x_d, N, H, W,
                      C / 4, TH, TW, (float4*)v_d);
   LAUNCH_CHECK();
@@ -120,12 +237,18 @@ __global__ void k_wino_output(const float4* __restrict__ Mx, int N, int H, int W
   }
 }
 
-extern "C" int frcnn_winograd_output_transform(const float* m_d, int N, int H, int W, int C, const float* bias_d, int act, float* y_d,
-                                               void* stream) {
+extern "C" int frcnn_winograd_output_transform(const float* m_d, int N, int H, int W, int C, int m, const float* bias_d, int act,
+                                               float* y_d, void* stream) {
   if (!m_d || !y_d || N <= 0 || H <= 0 || W <= 0 || C <= 0) return FRCNN_E_ARG;
-  if (C % 4 || (act != FRCNN_ACT_NONE && act != FRCNN_ACT_RELU)) return FRCNN_E_UNSUPPORTED;
-  const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+  if (C % 4 || (m != 2 && m != 4) || (act != FRCNN_ACT_NONE && act != FRCNN_ACT_RELU)) return FRCNN_E_UNSUPPORTED;
+  const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
   const long long tot = (long long)N * TH * TW * (C / 4);
+  if (m == 4) {
+    hipLaunchKernelGGL(k_wino4_output, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)m_d, N, H, W,
+                       C / 4, TH, TW, (const float4*)bias_d, act, (float4*)y_d);
+    LAUNCH_CHECK();
+    return FRCNN_OK;
+  }
   hipLaunchKernelGGL(k_wino_output, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)m_d, N, H, W,
                      C / 4, TH, TW, (const float4*)bias_d, act, (float4*)y_d);
   LAUNCH_CHECK();

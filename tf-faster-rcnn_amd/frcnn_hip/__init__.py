@@ -40,9 +40,9 @@ SIGNATURES = {
     "frcnn_conv2d_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "frcnn_gemm_batched_nt": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
-    "frcnn_winograd_filter_transform": (c_int, [_P, c_int, c_int, _P, _P]),
-    "frcnn_winograd_input_transform": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
-    "frcnn_winograd_output_transform": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P]),
+    "frcnn_winograd_filter_transform": (c_int, [_P, c_int, c_int, _P, c_int, _P]),
+    "frcnn_winograd_input_transform": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "frcnn_winograd_output_transform": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P]),
     "frcnn_set_tuning": (c_int, [c_int, c_int]),
     "frcnn_pack_filter_hwio": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "frcnn_maxpool_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),

@@ -230,23 +230,27 @@ def conv2d(x, w_packed, bias, KH, KW, stride=1, pad=(0, 0, 0, 0), act=ACT_NONE, 
     return out
 
 
-def winograd_filter_transform(w_hwio, scale=None):
-    """HOST: 3x3 HWIO filter -> U [16, Cout, Cin] (F(2x2,3x3), optional folded per-output scale)."""
+def winograd_filter_transform(w_hwio, scale=None, m=2):
+    """HOST: 3x3 HWIO filter -> U [(m+2)^2, Cout, Cin] (F(m x m,3x3), optional folded per-output scale)."""
     w = np.ascontiguousarray(w_hwio, dtype=np.float32)
     assert w.shape[0] == 3 and w.shape[1] == 3
     Cin, Cout = w.shape[2], w.shape[3]
-    out = np.empty((16, Cout, Cin), dtype=np.float32)
+    out = np.empty(((m + 2) ** 2, Cout, Cin), dtype=np.float32)
     sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float32)
     call("frcnn_winograd_filter_transform", w.ctypes.data_as(ctypes.c_void_p), Cin, Cout,
-         None if sc is None else sc.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+         None if sc is None else sc.ctypes.data_as(ctypes.c_void_p), int(m), out.ctypes.data_as(ctypes.c_void_p))
     return out
 
 
-def winograd_input_transform(x, v):
+def winograd_tiles(N, H, W, m):
+    return N * ((H + m - 1) // m) * ((W + m - 1) // m)
+
+
+def winograd_input_transform(x, v, m=2):
     _chk(x), _chk(v)
     N, H, W, C = x.shape
-    assert v.numel() == 16 * N * ((H + 1) // 2) * ((W + 1) // 2) * C
-    call("frcnn_winograd_input_transform", _ptr(x), N, H, W, C, _ptr(v), _stream())
+    assert v.numel() == (m + 2) ** 2 * winograd_tiles(N, H, W, m) * C
+    call("frcnn_winograd_input_transform", _ptr(x), N, H, W, C, int(m), _ptr(v), _stream())
     return v
 
 
@@ -260,26 +264,27 @@ def gemm_batched_nt(x, w, y):
     return y
 
 
-def winograd_output_transform(m, bias, act, out):
-    _chk(m), _chk(out)
+def winograd_output_transform(mm, bias, act, out, m=2):
+    _chk(mm), _chk(out)
     N, H, W, C = out.shape
-    assert m.numel() == 16 * N * ((H + 1) // 2) * ((W + 1) // 2) * C
-    call("frcnn_winograd_output_transform", _ptr(m), N, H, W, C, _ptr(bias), int(act), _ptr(out), _stream())
+    assert mm.numel() == (m + 2) ** 2 * winograd_tiles(N, H, W, m) * C
+    call("frcnn_winograd_output_transform", _ptr(mm), N, H, W, C, int(m), _ptr(bias), int(act), _ptr(out), _stream())
     return out
 
 
 def conv3x3_winograd(x, u, bias, act=ACT_NONE, out=None, v_buf=None, m_buf=None):
-    """3x3 / stride 1 / pad 1 convolution as Winograd F(2x2,3x3): x [N,H,W,Cin], u [16,Cout,Cin] -> [N,H,W,Cout]."""
+    """3x3 / stride 1 / pad 1 convolution as Winograd F(m x m,3x3): x [N,H,W,Cin], u [(m+2)^2,Cout,Cin] -> [N,H,W,Cout]."""
     N, H, W, Cin = x.shape
-    Cout = u.shape[1]
-    T = N * ((H + 1) // 2) * ((W + 1) // 2)
+    G, Cout = u.shape[0], u.shape[1]
+    m = {16: 2, 36: 4}[G]
+    T = winograd_tiles(N, H, W, m)
     dev = x.device
-    v = torch.empty((16, T, Cin), dtype=torch.float32, device=dev) if v_buf is None else v_buf
-    m = torch.empty((16, T, Cout), dtype=torch.float32, device=dev) if m_buf is None else m_buf
+    v = torch.empty((G, T, Cin), dtype=torch.float32, device=dev) if v_buf is None else v_buf
+    mm = torch.empty((G, T, Cout), dtype=torch.float32, device=dev) if m_buf is None else m_buf
     out = torch.empty((N, H, W, Cout), dtype=torch.float32, device=dev) if out is None else out
-    winograd_input_transform(x, v)
-    gemm_batched_nt(v, u, m)
-    return winograd_output_transform(m, bias, act, out)
+    winograd_input_transform(x, v, m)
+    gemm_batched_nt(v, u, mm)
+    return winograd_output_transform(mm, bias, act, out, m)
 
 
 def maxpool(x, k, stride, pad=(0, 0, 0, 0), out=None):

@@ -110,9 +110,9 @@ class Session(object):
         self.conv_info[scope] = {"w": res[0], "b": res[1], "scale": scale if bn_eps is not None else None, "bn": bn_eps is not None}
         return res
 
-    def winograd_params(self, scope, bn_eps=None):
-        """(U_d [16,Cout,Cin], bias_d) for a 3x3 stride-1 scope run as Winograd F(2x2,3x3) (TEST mode only)."""
-        key = ("wino", scope, bn_eps)
+    def winograd_params(self, scope, bn_eps=None, m=2):
+        """(U_d [(m+2)^2,Cout,Cin], bias_d) for a 3x3 stride-1 scope run as Winograd F(m x m,3x3) (TEST mode only)."""
+        key = ("wino", scope, bn_eps, m)
         if key in self.packed:
             return self.packed[key]
         w = self.variables[scope + "/weights"]
@@ -121,7 +121,7 @@ class Session(object):
             scale, bias = self.fold_bn(scope, bn_eps)
         elif (scope + "/biases") in self.variables:
             bias = self.variables[scope + "/biases"]
-        res = (self.to_device(ops.winograd_filter_transform(w, scale)), None if bias is None else self.to_device(bias))
+        res = (self.to_device(ops.winograd_filter_transform(w, scale, m)), None if bias is None else self.to_device(bias))
         self.packed[key] = res
         return res
 

@@ -62,8 +62,9 @@ __C = AttrDict(
     ROOT_DIR=osp.abspath(osp.join(osp.dirname(__file__), '..', '..')),
     MATLAB='matlab', EXP_DIR='default', USE_GPU_NMS=True, USE_E2E_TF=False, POOLING_MODE='crop', POOLING_SIZE=7,
     ANCHOR_SCALES=[8, 16, 32], ANCHOR_RATIOS=[0.5, 1, 2], RPN_CHANNELS=512,
-    # device-path switches (no reference counterpart): Winograd F(2x2,3x3) for the 3x3 stride-1 convolutions at test time
-    HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=128))
+    # device-path switches (no reference counterpart): Winograd F(m x m,3x3) for the 3x3 stride-1 convolutions at test
+    # time; m = WINOGRAD_M (4 or 2) except scopes containing a WINOGRAD_F2_SCOPES token, which use m = 2
+    HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=64, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=()))
 __C.DATA_DIR = osp.abspath(osp.join(__C.ROOT_DIR, 'data'))
 cfg = __C
 

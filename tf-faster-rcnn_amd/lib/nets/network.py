@@ -105,19 +105,22 @@ class Network(object):
         return out
 
     def _conv_winograd(self, x, scope, act, bn_eps):
-        """3x3 / stride 1 / SAME convolution as Winograd F(2x2,3x3): input transform -> 16 GEMMs in ONE launch of the
-        f32-MFMA kernel -> output transform with bias + ReLU.  Exact algebra (f32), 2.25x fewer multiplications."""
+        """3x3 / stride 1 / SAME convolution as Winograd F(m x m,3x3): input transform -> (m+2)^2 GEMMs in ONE launch of
+        the f32-MFMA kernel -> output transform with bias + ReLU.  Exact algebra in f32; m = 2 (2.25x fewer
+        multiplications, rounding like the direct kernel) or m = 4 (4x fewer; a single layer rounds ~10x worse than
+        direct, but through the full ResNet-101 the outputs move by ~1e-6 relative, profiles/r01_e_winograd_error.txt)."""
         sess = self._sess
-        u, b = sess.winograd_params(scope, bn_eps=bn_eps)
+        m = 2 if any(tok in scope for tok in cfg.HIP.WINOGRAD_F2_SCOPES) else int(cfg.HIP.WINOGRAD_M)
+        u, b = sess.winograd_params(scope, bn_eps=bn_eps, m=m)
         N, H, W, Cin = x.shape
-        Cout = u.shape[1]
-        T = N * ((H + 1) // 2) * ((W + 1) // 2)
-        v = sess.buf(self._tag + "/wino_v", (16, T, Cin))
-        m = sess.buf(self._tag + "/wino_m", (16, T, Cout))
+        G, Cout = u.shape[0], u.shape[1]
+        T = ops.winograd_tiles(N, H, W, m)
+        v = sess.buf(self._tag + "/wino_v", (G, T, Cin))
+        mm = sess.buf(self._tag + "/wino_m", (G, T, Cout))
         out = sess.buf(self._tag + "/" + scope, (N, H, W, Cout))
-        sess.mark("op:wino_in", 0, lambda: ops.winograd_input_transform(x, v))
-        sess.mark("conv:" + scope, 2 * 16 * T * Cout * Cin, lambda: ops.gemm_batched_nt(v, u, m))
-        sess.mark("op:wino_out", 0, lambda: ops.winograd_output_transform(m, b, act, out))
+        sess.mark("op:wino_in", 0, lambda: ops.winograd_input_transform(x, v, m))
+        sess.mark("conv:" + scope, 2 * G * T * Cout * Cin, lambda: ops.gemm_batched_nt(v, u, mm))
+        sess.mark("op:wino_out", 0, lambda: ops.winograd_output_transform(mm, b, act, out, m))
         return out
 
     def trainable_scope(self, scope):
@@ -353,7 +356,7 @@ class Network(object):
         c = cfg[self._mode]
         key = (self._tag, tuple(image_d.shape), self._im_info[:2], self._mode, cfg.TEST.MODE, self._fuse_tail_entry,
                c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH, cfg.TEST.RPN_TOP_N, cfg.POOLING_SIZE,
-               bool(cfg.HIP.WINOGRAD), int(cfg.HIP.WINOGRAD_MIN_CIN))
+               bool(cfg.HIP.WINOGRAD), int(cfg.HIP.WINOGRAD_MIN_CIN), int(cfg.HIP.WINOGRAD_M), tuple(cfg.HIP.WINOGRAD_F2_SCOPES))
         cur = torch.cuda.current_stream(sess.device)
         if not use_graph or sess.profile is not None:
             sess.flops_last_forward = 0
