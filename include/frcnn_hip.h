@@ -83,6 +83,20 @@ int frcnn_proposal_top_layer(const float* rpn_cls_prob_d, const float* rpn_bbox_
                              int rpn_top_n, float* rois_d, float* scores_d, void* ws, size_t ws_bytes,
                              void* stream);
 
+/* USE_E2E_TF graph (the reference's default, lib/model/config.py:275).
+ * frcnn_non_max_suppression: tf.image.non_max_suppression(boxes [k,4], scores [k], max_output_size, iou_threshold) as called
+ * at lib/layer_utils/proposal_layer.py:72 -- order (score desc, index asc), overlap WITHOUT the +1 pixel convention, corner
+ * order normalised, degenerate boxes never overlap, suppress iff iou > iou_threshold (f32); k <= 65536.
+ * Workspace: frcnn_nms_workspace_bytes(k).
+ * frcnn_proposal_layer_tf: proposal_layer_tf (proposal_layer.py:56-84): decode + clip ALL H*W*A anchors, that NMS over all of
+ * them (no pre-NMS top-N), first post_nms_topn survivors -> rois [post,5] (zero padded), scores [post], *num_d.
+ * Workspace: frcnn_proposal_workspace_bytes(H, W, A, 0). */
+int frcnn_non_max_suppression(const float* boxes_d, const float* scores_d, int k, int max_output_size, float iou_threshold,
+                              int* selected_d, int* num_d, void* ws, size_t ws_bytes, void* stream);
+int frcnn_proposal_layer_tf(const float* rpn_cls_prob_d, const float* rpn_bbox_pred_d, float im_h, float im_w, int H, int W,
+                            int A, int feat_stride, const double* base_d, int post_nms_topn, float nms_thresh, float* rois_d,
+                            float* scores_d, int* num_d, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- RoI pooling: replaces tf.image.crop_and_resize as called from lib/nets/resnet_v1.py:55-76
  * and lib/nets/network.py:141-157 ----------------------------------------------------------- */
 /* feat_d [H,W,C] (batch 1), rois_d [R,5] image coords, out_d [R,pool,pool,C].  fuse_max2x2 != 0:

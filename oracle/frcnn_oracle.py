@@ -205,6 +205,83 @@ def proposal_top_layer(rpn_cls_prob, rpn_bbox_pred, im_info, _feat_stride, ancho
     return blob, scores[top].reshape(-1, 1)
 
 
+# ----------------------------------------------------------------------------- USE_E2E_TF graph (config.py:275)
+# The reference's default graph replaces the numpy layers by TensorFlow ops.  The graph wiring below is PINNED by running
+# the reference's own *_tf function bodies on oracle/tf_numpy_shim.py (gen_golden.py).  The two TensorFlow kernels are
+# third-party code absent from /root/reference -- restated from TensorFlow r1.2 (the version README.md:56 names),
+# tensorflow/core/kernels/non_max_suppression_op.cc and topk_op.cc: PARITY UNPINNED for these two functions.
+def tf_non_max_suppression(boxes, scores, max_output_size, iou_threshold):
+    """non_max_suppression_op.cc (r1.2): candidates in decreasing score order (std::sort on score; ties are
+    implementation-defined there, (score desc, index asc) here); a candidate is selected unless its IoU with an already
+    selected box is > iou_threshold; stops at max_output_size.  ComputeIOU: corners normalised with min/max, area WITHOUT
+    +1, 0 when either area <= 0, all in float32.  Returns int32 indices."""
+    b = np.ascontiguousarray(boxes, dtype=f32)
+    sc = np.asarray(scores, dtype=f32).reshape(-1)
+    thr = f32(iou_threshold)
+    y0, y1 = np.minimum(b[:, 0], b[:, 2]), np.maximum(b[:, 0], b[:, 2])
+    x0, x1 = np.minimum(b[:, 1], b[:, 3]), np.maximum(b[:, 1], b[:, 3])
+    area = (y1 - y0) * (x1 - x0)
+    order = order_desc(sc)
+    sel = np.empty((max(int(max_output_size), 0),), dtype=np.int64)
+    n = 0
+    for i in order:
+        if n >= max_output_size:
+            break
+        if n and area[i] > 0:
+            s_ = sel[:n]
+            ih = np.maximum(np.minimum(y1[i], y1[s_]) - np.maximum(y0[i], y0[s_]), f32(0))
+            iw = np.maximum(np.minimum(x1[i], x1[s_]) - np.maximum(x0[i], x0[s_]), f32(0))
+            inter = ih * iw
+            with np.errstate(divide="ignore", invalid="ignore"):
+                iou = inter / ((area[i] + area[s_]) - inter)
+            if np.any((iou > thr) & (area[s_] > 0)):
+                continue
+        sel[n] = i
+        n += 1
+    return sel[:n].astype(np.int32)
+
+
+def tf_top_k(values, k):
+    """topk_op.cc: the k largest, descending; equal values -> lower index first.  Returns (values, int32 indices)."""
+    v = np.asarray(values)
+    idx = order_desc(v.reshape(-1))[:k]
+    return v.reshape(-1)[idx], idx.astype(np.int32)
+
+
+def generate_anchors_pre_tf(height, width, feat_stride=16, anchor_scales=(8, 16, 32), anchor_ratios=(0.5, 1, 2)):
+    """snippets.py:32-49: base anchors TRUNCATED to int32 (tf.constant(..., dtype=tf.int32)), integer shifts, then f32."""
+    base = generate_anchors(ratios=np.array(anchor_ratios), scales=np.array(anchor_scales)).astype(np.int32)
+    A = base.shape[0]
+    xs = np.arange(int(width), dtype=np.int32) * np.int32(feat_stride)
+    ys = np.arange(int(height), dtype=np.int32) * np.int32(feat_stride)
+    out = np.empty((int(height), int(width), A, 4), dtype=np.int32)
+    out[..., 0] = base[None, None, :, 0] + xs[None, :, None]
+    out[..., 1] = base[None, None, :, 1] + ys[:, None, None]
+    out[..., 2] = base[None, None, :, 2] + xs[None, :, None]
+    out[..., 3] = base[None, None, :, 3] + ys[:, None, None]
+    n = int(height) * int(width) * A
+    return out.reshape(n, 4).astype(f32), n
+
+
+def proposal_layer_tf(rpn_cls_prob, rpn_bbox_pred, im_info, anchors, num_anchors, post_nms_topN=300, nms_thresh=0.7):
+    """proposal_layer.py:56-84: decode + clip ALL anchors, TF NMS over all of them, at most post_nms_topN rows."""
+    scores = np.ascontiguousarray(rpn_cls_prob[:, :, :, num_anchors:]).reshape(-1)
+    deltas = rpn_bbox_pred.reshape(-1, 4)
+    props = clip_boxes(bbox_transform_inv(anchors.astype(f32), deltas), im_info[:2])
+    keep = tf_non_max_suppression(props, scores, post_nms_topN, nms_thresh)
+    blob = np.concatenate([np.zeros((keep.shape[0], 1), dtype=f32), props[keep].astype(f32)], axis=1)
+    return blob, scores[keep].reshape(-1, 1)
+
+
+def proposal_top_layer_tf(rpn_cls_prob, rpn_bbox_pred, im_info, anchors, num_anchors, rpn_top_n=5000):
+    """proposal_top_layer.py:58-85: tf.nn.top_k, decode + clip only those, no NMS."""
+    scores = np.ascontiguousarray(rpn_cls_prob[:, :, :, num_anchors:]).reshape(-1)
+    top_scores, top = tf_top_k(scores, rpn_top_n)
+    props = clip_boxes(bbox_transform_inv(anchors[top].astype(f32), rpn_bbox_pred.reshape(-1, 4)[top]), im_info[:2])
+    blob = np.concatenate([np.zeros((rpn_top_n, 1), dtype=f32), props.astype(f32)], axis=1)
+    return blob, top_scores.reshape(-1, 1)
+
+
 # ----------------------------------------------------------------------------- test-time post-processing
 def im_detect_post(scores, bbox_pred, rois, im_scale, im_shape):
     """model/test.py:95-102: rois/scale, per-class decode, final clip.  -> scores [R,C], boxes [R,4C]."""

@@ -101,6 +101,35 @@ def main(write=True):
     g["top_38x63_a9_rois"], g["top_38x63_a9_scores"] = blob, sc
     out["proposal"] = g
 
+    # ---- USE_E2E_TF graph (config.py:275): the reference's *_tf bodies on the numpy-backed tf shim
+    ref_shim.install_tf_numpy(ora)
+    g = {}
+    for tag, (H, W, scales) in {"a9_38x63": (38, 63, (8, 16, 32)), "a15_50x84": (50, 84, (2, 4, 8, 16, 32)),
+                                "odd_7x9": (7, 9, (3, 5, 7))}.items():      # odd scales: .5 base coordinates get truncated
+        anc, n = ref.generate_anchors_pre_tf(H, W, 16, scales, (0.5, 1, 2))
+        pin("generate_anchors_pre_tf " + tag, (anc, np.int64(n)), tuple(np.asarray(v) if i == 0 else np.int64(v) for i, v in
+                                                                  enumerate(ora.generate_anchors_pre_tf(H, W, 16, scales, (0.5, 1, 2)))))
+        g["anchors_" + tag + "_first"], g["anchors_" + tag + "_last"] = anc[:64], anc[-64:]
+    for tag, (H, W, scales, post, info) in {
+            "38x63_a9": (38, 63, (8, 16, 32), 300, im_info),
+            "10x14_a9": (10, 14, (8, 16, 32), 300, np.array([160, 224, 1.0], dtype=f32)),
+            "50x84_a15": (50, 84, (2, 4, 8, 16, 32), 1000, np.array([800, 1333, 1.6], dtype=f32))}.items():
+        A = 3 * len(scales)
+        prob, dl = synth.rpn_outputs(H, W, A, seed=5)
+        anc, _ = ref.generate_anchors_pre_tf(H, W, 16, scales, (0.5, 1, 2))
+        cfg.TEST.RPN_POST_NMS_TOP_N = post
+        blob, sc = ref.proposal_layer_tf(prob, dl, info, "TEST", [16], anc, A)
+        pin("proposal_layer_tf " + tag, (blob, sc), ora.proposal_layer_tf(prob, dl, info, anc, A, post_nms_topN=post, nms_thresh=0.7))
+        g["tf_" + tag + "_rois"], g["tf_" + tag + "_scores"] = blob, sc
+        g["tf_" + tag + "_in_sha"] = np.frombuffer(bytes.fromhex(sha(prob) + sha(dl)), dtype=np.uint8)
+    cfg.TEST.RPN_POST_NMS_TOP_N = 300
+    prob, dl = synth.rpn_outputs(38, 63, 9, seed=5)
+    anc, _ = ref.generate_anchors_pre_tf(38, 63, 16, (8, 16, 32), (0.5, 1, 2))
+    blob, sc = ref.proposal_top_layer_tf(prob, dl, im_info, [16], anc, 9)
+    pin("proposal_top_layer_tf", (blob, sc), ora.proposal_top_layer_tf(prob, dl, im_info, anc, 9))
+    g["tf_top_38x63_a9_rois"], g["tf_top_38x63_a9_scores"] = blob, sc
+    out["proposal_tf"] = g
+
     # ---- cpu_nms (cpu_nms.pyx:17-68) + py_cpu_nms cross statement
     g = {}
     for tag, (k, thr, cl) in {"u3000_t07": (3000, 0.7, 0), "c3000_t03": (3000, 0.3, 12), "c6000_t07": (6000, 0.7, 40),

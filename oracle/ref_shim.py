@@ -66,9 +66,9 @@ def load_reference():
     from model.config import cfg
     cfg.USE_GPU_NMS = False
     from layer_utils.generate_anchors import generate_anchors
-    from layer_utils.snippets import generate_anchors_pre
-    from layer_utils.proposal_layer import proposal_layer
-    from layer_utils.proposal_top_layer import proposal_top_layer
+    from layer_utils.snippets import generate_anchors_pre, generate_anchors_pre_tf
+    from layer_utils.proposal_layer import proposal_layer, proposal_layer_tf
+    from layer_utils.proposal_top_layer import proposal_top_layer, proposal_top_layer_tf
     from layer_utils.anchor_target_layer import anchor_target_layer
     from layer_utils.proposal_target_layer import proposal_target_layer
     from model.bbox_transform import bbox_transform, bbox_transform_inv, clip_boxes
@@ -79,3 +79,10 @@ def load_reference():
 
     ns = types.SimpleNamespace(**{k: v for k, v in locals().items() if callable(v) or k == "cfg"})
     return ns
+
+
+def install_tf_numpy(ora):
+    """Give the stub `tensorflow` module the numpy-backed ops of oracle/tf_numpy_shim.py so the reference's *_tf function
+    bodies (USE_E2E_TF graph) can run; `ora` supplies the two restated TensorFlow kernels."""
+    import tf_numpy_shim
+    sys.modules["tensorflow"].__dict__.update({k: v for k, v in tf_numpy_shim.build(ora).__dict__.items() if not k.startswith("__")})

@@ -223,3 +223,65 @@ def test_host_mirror_seams_numpy_in_numpy_out(dev, golden):
     blob, sc = proposal_layer(prob, dl, np.array([600, 1000, 1.6], dtype=f32), b"TEST", [16, ], anc, 9)
     assert np.array_equal(sc, golden["proposal"]["test_38x63_a9_scores"])
     assert np.allclose(blob, golden["proposal"]["test_38x63_a9_rois"], rtol=0, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ USE_E2E_TF graph
+@pytest.mark.parametrize("k,thr,cl,seed,cap", [(3000, 0.7, 12, 21, 300), (400, 0.3, 8, 22, 400), (21546, 0.7, 300, 23, 300),
+                                               (65536, 0.5, 2000, 24, 1000), (65, 0.5, 2, 25, 65), (1, 0.5, 0, 26, 5)])
+def test_tf_non_max_suppression_bit_exact_vs_oracle(dev, k, thr, cl, seed, cap):
+    """frcnn_non_max_suppression == the oracle's restatement of tf.image.non_max_suppression (r1.2): selected indices
+    bit-exact, incl. k beyond the 16384 of the Cython-rule kernels, flipped corners and zero-area boxes."""
+    from frcnn_hip import ops
+    d = synth.random_dets(k, seed=seed, cluster=cl)
+    boxes, scores = d[:, :4].copy(), d[:, 4].copy()
+    if k > 8:
+        boxes[5] = boxes[5][[2, 3, 0, 1]]
+        boxes[7, 2] = boxes[7, 0]
+    sel, num = ops.non_max_suppression(T(boxes, dev), T(scores, dev), cap, thr)
+    n = int(num.item())
+    want = ora.tf_non_max_suppression(boxes, scores, cap, thr)
+    assert n == want.shape[0] and np.array_equal(sel[:n].cpu().numpy(), want)
+
+
+def test_tf_non_max_suppression_rule_differs_from_cython_rule(dev):
+    from frcnn_hip import ops
+    b = np.array([[0, 0, 2, 2], [0, 0, 2, 1], [10, 10, 10, 30]], dtype=f32)       # IoU(0,1) = 0.5 exactly without the +1 rule
+    s = np.array([0.9, 0.8, 0.7], dtype=f32)
+    sel, num = ops.non_max_suppression(T(b, dev), T(s, dev), 10, 0.5)
+    assert sel[:int(num.item())].cpu().tolist() == [0, 1, 2]                      # `>`: equality survives; zero-area box kept
+    sel, num = ops.non_max_suppression(T(b, dev), T(s, dev), 10, 0.49)
+    assert sel[:int(num.item())].cpu().tolist() == [0, 2]
+    sel, num = ops.non_max_suppression(T(b, dev), T(s, dev), 1, 0.49)
+    assert int(num.item()) == 1
+    e, num = ops.non_max_suppression(torch.zeros((0, 4), device=dev), torch.zeros((0,), device=dev), 10, 0.5)
+    assert int(num.item()) == 0
+
+
+@pytest.mark.parametrize("tag,H,W,scales,post,info", [
+    ("38x63_a9", 38, 63, (8, 16, 32), 300, (600, 1000, 1.6)),
+    ("10x14_a9", 10, 14, (8, 16, 32), 300, (160, 224, 1.0)),
+    ("50x84_a15", 50, 84, (2, 4, 8, 16, 32), 1000, (800, 1333, 1.6))])
+def test_proposal_layer_tf_vs_reference_golden(dev, golden, tag, H, W, scales, post, info):
+    """Goldens: the reference's proposal_layer_tf body (proposal_layer.py:56-84) on the numpy-backed tf shim."""
+    from frcnn_hip import ops
+    g = golden["proposal_tf"]
+    A = 3 * len(scales)
+    prob, dl = synth.rpn_outputs(H, W, A, seed=5)
+    base = np.trunc(ops.generate_anchors(16, (0.5, 1, 2), scales))
+    rois, scores, num = ops.proposal_layer_tf(T(prob, dev), T(dl, dev), info[0], info[1], 16, T(base, dev), post, 0.7)
+    n = int(num.item())
+    rois, scores = rois.cpu().numpy(), scores.cpu().numpy()
+    want_r, want_s = g["tf_" + tag + "_rois"], g["tf_" + tag + "_scores"]
+    assert n == want_r.shape[0]
+    assert np.array_equal(scores[:n], want_s)                                     # same anchors selected, same order
+    assert np.allclose(rois[:n], want_r, rtol=0, atol=1e-3)
+    assert np.all(rois[n:] == 0) and np.all(scores[n:] == 0)
+
+
+def test_truncated_anchor_table_matches_generate_anchors_pre_tf(dev, golden):
+    from frcnn_hip import ops
+    base = np.trunc(ops.generate_anchors(16, (0.5, 1, 2), (3, 5, 7)))
+    got = ops.generate_anchors_pre(7, 9, 16, T(base, dev)).cpu().numpy()
+    want, _ = ora.generate_anchors_pre_tf(7, 9, 16, (3, 5, 7), (0.5, 1, 2))
+    assert np.array_equal(got, want)
+    assert np.array_equal(got[:64], golden["proposal_tf"]["anchors_odd_7x9_first"])

@@ -255,3 +255,24 @@ def test_direct_conv_path_equals_winograd_path(small_net):
     if np.array_equal(direct[3], wino[3]):
         for a, b in zip(direct[:3], wino[:3]):
             assert rel_err(b, a) <= 2e-5
+
+
+def test_use_e2e_tf_graph_semantics(small_net):
+    """cfg.USE_E2E_TF (the reference's default graph): truncated anchors + proposal_layer_tf.  The proposals of the device
+    chain equal the oracle's proposal_layer_tf on the device's own RPN outputs; the rest of the chain is unchanged."""
+    from model.config import cfg
+    sess, net, image, im_info = small_net
+    cfg.USE_E2E_TF = True
+    try:
+        cls_score, cls_prob, bbox_pred, rois = net.test_image(sess, image, im_info)
+        prob = net._predictions["rpn_cls_prob"].cpu().numpy()
+        dl = net._predictions["rpn_bbox_pred"].cpu().numpy()
+        n = int(net._num_rois[0].item())
+    finally:
+        cfg.USE_E2E_TF = False
+    H, W = prob.shape[1:3]
+    anc, _ = ora.generate_anchors_pre_tf(H, W, 16, SCALES, RATIOS)
+    want, _ = ora.proposal_layer_tf(prob, dl, im_info, anc, len(SCALES) * len(RATIOS), post_nms_topN=48, nms_thresh=0.7)
+    assert n == want.shape[0] and np.allclose(rois[:n], want, rtol=0, atol=2e-2)
+    ref = DenseRef(sess.variables, 50, 21, SCALES, RATIOS).test_image(image, im_info, rois=rois, post=48)
+    assert rel_err(cls_score, ref["cls_score"]) <= 1e-4 and rel_err(bbox_pred, ref["bbox_pred"]) <= 1e-4

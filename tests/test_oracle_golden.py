@@ -73,6 +73,72 @@ def test_proposal_top_layer(golden):
     assert np.array_equal(blob, g["top_38x63_a9_rois"]) and np.array_equal(sc, g["top_38x63_a9_scores"])
 
 
+# ---- USE_E2E_TF graph (the reference's default): goldens = the reference's *_tf bodies run on oracle/tf_numpy_shim.py
+@pytest.mark.parametrize("tag,H,W,scales,post,info", [
+    ("38x63_a9", 38, 63, (8, 16, 32), 300, (600, 1000, 1.6)),
+    ("10x14_a9", 10, 14, (8, 16, 32), 300, (160, 224, 1.0)),
+    ("50x84_a15", 50, 84, (2, 4, 8, 16, 32), 1000, (800, 1333, 1.6))])
+def test_proposal_layer_tf(golden, tag, H, W, scales, post, info):
+    g = golden["proposal_tf"]
+    A = 3 * len(scales)
+    prob, dl = synth.rpn_outputs(H, W, A, seed=5)
+    assert np.array_equal(np.concatenate([sha(prob), sha(dl)]), g["tf_" + tag + "_in_sha"])
+    anc, _ = ora.generate_anchors_pre_tf(H, W, 16, scales, (0.5, 1, 2))
+    blob, sc = ora.proposal_layer_tf(prob, dl, np.array(info, dtype=f32), anc, A, post_nms_topN=post, nms_thresh=0.7)
+    assert np.array_equal(blob, g["tf_" + tag + "_rois"]) and np.array_equal(sc, g["tf_" + tag + "_scores"])
+
+
+def test_proposal_top_layer_tf_and_truncated_anchors(golden):
+    g = golden["proposal_tf"]
+    prob, dl = synth.rpn_outputs(38, 63, 9, seed=5)
+    anc, _ = ora.generate_anchors_pre_tf(38, 63, 16)
+    blob, sc = ora.proposal_top_layer_tf(prob, dl, np.array([600, 1000, 1.6], dtype=f32), anc, 9)
+    assert np.array_equal(blob, g["tf_top_38x63_a9_rois"]) and np.array_equal(sc, g["tf_top_38x63_a9_scores"])
+    odd, n = ora.generate_anchors_pre_tf(7, 9, 16, (3, 5, 7), (0.5, 1, 2))
+    assert n == 7 * 9 * 9 and np.array_equal(odd[:64], g["anchors_odd_7x9_first"]) and np.array_equal(odd[-64:], g["anchors_odd_7x9_last"])
+    full = ora.generate_anchors(ratios=(0.5, 1, 2), scales=(3, 5, 7))
+    assert np.any(full != np.trunc(full))                       # the case really exercises the int32 truncation
+    assert np.array_equal(odd[:9], np.trunc(full).astype(f32))
+
+
+def _tf_iou_scalar(a, b):
+    """Second, scalar statement of ComputeIOU (TensorFlow r1.2 non_max_suppression_op.cc) in f32."""
+    ymin_i, xmin_i, ymax_i, xmax_i = min(a[0], a[2]), min(a[1], a[3]), max(a[0], a[2]), max(a[1], a[3])
+    ymin_j, xmin_j, ymax_j, xmax_j = min(b[0], b[2]), min(b[1], b[3]), max(b[0], b[2]), max(b[1], b[3])
+    area_i = f32(f32(ymax_i - ymin_i) * f32(xmax_i - xmin_i))
+    area_j = f32(f32(ymax_j - ymin_j) * f32(xmax_j - xmin_j))
+    if area_i <= 0 or area_j <= 0:
+        return f32(0)
+    ih = max(f32(min(ymax_i, ymax_j) - max(ymin_i, ymin_j)), f32(0))
+    iw = max(f32(min(xmax_i, xmax_j) - max(xmin_i, xmin_j)), f32(0))
+    inter = f32(ih * iw)
+    return f32(inter / f32(f32(area_i + area_j) - inter))
+
+
+def test_tf_nms_two_statements_agree():
+    """tf.image.non_max_suppression is third-party (parity unpinned): the vectorised oracle against a literal scalar
+    transcription of the r1.2 loop, incl. degenerate boxes, flipped corners and the strict `>` at equality."""
+    for seed, k, thr in ((1, 400, 0.7), (2, 400, 0.3), (3, 64, 0.5)):
+        d = synth.random_dets(k, seed=seed, cluster=8)
+        boxes, scores = d[:, :4].copy(), d[:, 4].copy()
+        boxes[5] = boxes[5][[2, 3, 0, 1]]                     # flipped corners
+        boxes[7, 2] = boxes[7, 0]                             # zero area
+        order = ora.order_desc(scores)
+        sel = []
+        for i in order:
+            if len(sel) >= 50:
+                break
+            if all(not (_tf_iou_scalar(boxes[i], boxes[j]) > f32(thr)) for j in reversed(sel)):
+                sel.append(int(i))
+        got = ora.tf_non_max_suppression(boxes, scores, 50, thr)
+        assert got.dtype == np.int32 and got.tolist() == sel
+    # equality is NOT suppressed (iou > thr): two boxes with IoU exactly 0.5
+    b = np.array([[0, 0, 2, 2], [0, 0, 2, 1]], dtype=f32)
+    assert ora.tf_non_max_suppression(b, np.array([0.9, 0.8], dtype=f32), 10, 0.5).tolist() == [0, 1]
+    assert ora.tf_non_max_suppression(b, np.array([0.9, 0.8], dtype=f32), 10, 0.49).tolist() == [0]
+    assert ora.tf_non_max_suppression(np.zeros((0, 4), f32), np.zeros((0,), f32), 10, 0.5).shape == (0,)
+
+
 @pytest.mark.parametrize("tag,k,thr,cl", [("u3000_t07", 3000, 0.7, 0), ("c3000_t03", 3000, 0.3, 12),
                                           ("c6000_t07", 6000, 0.7, 40), ("c700_t05", 700, 0.5, 5), ("one", 1, 0.3, 0)])
 def test_cpu_nms(golden, tag, k, thr, cl):

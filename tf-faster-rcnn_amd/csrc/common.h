@@ -62,6 +62,20 @@ __device__ __forceinline__ bool iou_suppresses(const float4 a, float aa, const f
   return ovr >= thr;
 }
 
+// tf.image.non_max_suppression's overlap test (TensorFlow r1.2 core/kernels/non_max_suppression_op.cc, ComputeIOU + the
+// `> iou_threshold` test): corner order normalised with min/max, NO +1 on widths, degenerate boxes never overlap, f32.
+__device__ __forceinline__ float box_area_tf(const float4 b) {
+  return (rmax(b.y, b.w) - rmin(b.y, b.w)) * (rmax(b.x, b.z) - rmin(b.x, b.z));
+}
+__device__ __forceinline__ bool iou_suppresses_tf(const float4 a, float aa, const float4 b, float ab, float thr) {
+  if (aa <= 0.0f || ab <= 0.0f) return false;
+  const float ymin = rmax(rmin(a.y, a.w), rmin(b.y, b.w)), xmin = rmax(rmin(a.x, a.z), rmin(b.x, b.z));
+  const float ymax = rmin(rmax(a.y, a.w), rmax(b.y, b.w)), xmax = rmin(rmax(a.x, a.z), rmax(b.x, b.z));
+  const float inter = rmax(ymax - ymin, 0.0f) * rmax(xmax - xmin, 0.0f);
+  const float iou = inter / ((aa + ab) - inter);
+  return iou > thr;
+}
+
 // bbox_transform_inv for one box / one delta quadruple (lib/model/bbox_transform.py:35-65), f32.
 __device__ __forceinline__ float4 decode_box(const float4 b, const float4 d) {
   const float w = (b.z - b.x) + 1.0f;

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void k_rank(const u64* __restrict__ keys, int 
 __global__ void k_scatter_topk(const float4* __restrict__ boxes, const u64* __restrict__ keys,
                                const u32* __restrict__ rank, int N, int K, float4* __restrict__ sboxes,
                                float* __restrict__ sscores, int* __restrict__ sidx, const float* __restrict__ prob,
-                               int A, const float* __restrict__ dets) {
+                               int A, const float* __restrict__ dets, const float* __restrict__ flat) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   const u32 r = rank[n];
@@ -128,8 +128,10 @@ __global__ void k_scatter_topk(const float4* __restrict__ boxes, const u64* __re
   if (prob) {
     const int a = n % A, pix = n / A;
     s = prob[(size_t)pix * 2 * A + A + a];
-  } else {
+  } else if (dets) {
     s = dets[5 * (size_t)n + 4];
+  } else {
+    s = flat[n];
   }
   sscores[r] = s;
 }
@@ -139,6 +141,7 @@ __global__ void k_scatter_topk(const float4* __restrict__ boxes, const u64* __re
 // = one 64-box row tile x one 64-box column tile; lane i builds its own 64-bit word, no ballot
 // needed.  Only the upper triangle (column tile >= row tile) is computed and ever read.
 // ------------------------------------------------------------------------------------------------
+template <bool TF>
 __global__ __launch_bounds__(256) void k_nms_mask(const float4* __restrict__ boxes, int K, int cb, float thr,
                                                   u64* __restrict__ mask) {
   __shared__ float4 cbox[64];
@@ -150,19 +153,20 @@ __global__ __launch_bounds__(256) void k_nms_mask(const float4* __restrict__ box
     const int j = ct * 64 + threadIdx.x;
     const float4 b = (j < K) ? boxes[j] : make_float4(0, 0, 0, 0);
     cbox[threadIdx.x] = b;
-    carea[threadIdx.x] = box_area(b);
+    carea[threadIdx.x] = TF ? box_area_tf(b) : box_area(b);
   }
   __syncthreads();
   if (rt >= cb || ct < rt) return;
   const int i = rt * 64 + lane;
   if (i >= K) return;
   const float4 bi = boxes[i];
-  const float ai = box_area(bi);
+  const float ai = TF ? box_area_tf(bi) : box_area(bi);
   const int nj = min(64, K - ct * 64);
   u64 bits = 0;
   for (int j = 0; j < nj; ++j) {
     const int gj = ct * 64 + j;
-    if (gj > i && iou_suppresses(bi, ai, cbox[j], carea[j], thr)) bits |= (1ull << j);
+    const bool sup = TF ? iou_suppresses_tf(bi, ai, cbox[j], carea[j], thr) : iou_suppresses(bi, ai, cbox[j], carea[j], thr);
+    if (gj > i && sup) bits |= (1ull << j);
   }
   mask[(size_t)i * cb + ct] = bits;
 }
@@ -267,6 +271,91 @@ __global__ __launch_bounds__(64) void k_nms_reduce_rois(const u64* __restrict__ 
   if (threadIdx.x == 0) *num = n;
 }
 
+// Same scan for K up to 65536 boxes (tf.image.non_max_suppression sees ALL H*W*A anchors, proposal_layer.py:56-72): the
+// removed-bit words live in LDS (word w is owned by lane w & 63, so there is no cross-lane hazard beyond the chunk read).
+#define NMS_WIDE_WORDS 1024
+template <typename Emit>
+__device__ __forceinline__ int greedy_reduce_wave_wide(const u64* __restrict__ mask, int K, int cb, int max_keep, Emit emit) {
+  __shared__ u64 remv[NMS_WIDE_WORDS];
+  const int lane = threadIdx.x & 63;
+  for (int w = lane; w < cb; w += 64) remv[w] = 0ull;
+  __syncthreads();
+  int total = 0;
+  for (int c = 0; c < cb && total < max_keep; ++c) {
+    const int i = c * 64 + lane;
+    const u64 d = (i < K) ? mask[(size_t)i * cb + c] : 0ull;
+    const u64 sel = remv[c];
+    const u32 cur_lo = (u32)__builtin_amdgcn_readfirstlane((u32)sel);
+    const u32 cur_hi = (u32)__builtin_amdgcn_readfirstlane((u32)(sel >> 32));
+    u64 cur = ((u64)cur_hi << 32) | (u64)cur_lo;
+    const int nvalid = min(64, K - c * 64);
+    if (nvalid < 64) cur |= (~0ull) << nvalid;
+    u64 kept = 0;
+#pragma unroll
+    for (int b = 0; b < 64; ++b) {
+      const u64 db = readlane_u64(d, b);
+      if (!((cur >> b) & 1ull)) {
+        kept |= (1ull << b);
+        cur |= db;
+      }
+    }
+    if ((kept >> lane) & 1ull) {
+      const int pos = total + __popcll(kept & ((1ull << lane) - 1ull));
+      if (pos < max_keep) emit(pos, i);
+    }
+    total += __popcll(kept);
+    if (total >= max_keep) break;
+    for (int w = (c + 1) - ((c + 1) & 63) + lane; w < cb; w += 64) {     // words > c, lane-owned
+      if (w <= c) continue;
+      u64 acc = remv[w];
+      u64 kk = kept;
+      while (kk) {
+        const int b = __ffsll((long long)kk) - 1;
+        kk &= kk - 1;
+        acc |= mask[(size_t)(c * 64 + b) * cb + w];
+      }
+      remv[w] = acc;
+    }
+    __syncthreads();          // single wave: orders the LDS writes before the next chunk's broadcast read
+  }
+  return min(total, max_keep);
+}
+
+__global__ __launch_bounds__(64) void k_nms_reduce_keep_wide(const u64* __restrict__ mask, int K, int cb, int max_keep,
+                                                             const int* __restrict__ sidx, int* __restrict__ keep,
+                                                             int* __restrict__ num) {
+  const int n = greedy_reduce_wave_wide(mask, K, cb, max_keep, [&](int pos, int i) { keep[pos] = sidx ? sidx[i] : i; });
+  if (threadIdx.x == 0) *num = n;
+}
+
+__global__ __launch_bounds__(64) void k_nms_reduce_rois_wide(const u64* __restrict__ mask, int K, int cb, int max_keep,
+                                                             const float4* __restrict__ sboxes,
+                                                             const float* __restrict__ sscores, float* __restrict__ rois,
+                                                             float* __restrict__ scores, int* __restrict__ num) {
+  const int n = greedy_reduce_wave_wide(mask, K, cb, max_keep, [&](int pos, int i) {
+    const float4 b = sboxes[i];
+    float* r = rois + 5 * (size_t)pos;
+    r[0] = 0.0f; r[1] = b.x; r[2] = b.y; r[3] = b.z; r[4] = b.w;
+    scores[pos] = sscores[i];
+  });
+  for (int p = n + (int)threadIdx.x; p < max_keep; p += 64) {
+    float* r = rois + 5 * (size_t)p;
+    r[0] = r[1] = r[2] = r[3] = r[4] = 0.0f;
+    scores[p] = 0.0f;
+  }
+  if (threadIdx.x == 0) *num = n;
+}
+
+// keys for separate boxes [k,4] / scores [k] arrays (tf.image.non_max_suppression's inputs)
+__global__ void k_boxes_scores_key(const float4* __restrict__ in_boxes, const float* __restrict__ in_scores, int k,
+                                   float4* __restrict__ boxes, u64* __restrict__ keys, u32* __restrict__ rank) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= k) return;
+  boxes[n] = in_boxes[n];
+  keys[n] = make_key(in_scores[n], (u32)n);
+  rank[n] = 0u;
+}
+
 // proposal_top_layer gather (proposal_top_layer.py:46-55)
 __global__ void k_top_rois(const float4* __restrict__ sboxes, const float* __restrict__ sscores, int K,
                            float* __restrict__ rois, float* __restrict__ scores) {
@@ -300,7 +389,8 @@ static SortWs carve(void* ws, int N, int K) {
   return s;
 }
 
-static int launch_rank_scatter(const SortWs& s, int N, int K, const float* prob, int A, const float* dets, hipStream_t st) {
+static int launch_rank_scatter(const SortWs& s, int N, int K, const float* prob, int A, const float* dets, hipStream_t st,
+                               const float* flat = nullptr) {
   // enough (i-block, j-slice) pairs to fill 256 CUs x 8 waves/SIMD, at least 2048 keys per slice
   const int iblocks = cdiv(N, 256);
   int js = max(1, min(cdiv(N, 2048), cdiv(4096, iblocks)));
@@ -309,14 +399,15 @@ static int launch_rank_scatter(const SortWs& s, int N, int K, const float* prob,
   hipLaunchKernelGGL(k_rank, dim3(iblocks, js), dim3(256), 0, st, s.keys, N, jchunk, s.rank);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(k_scatter_topk, dim3(cdiv(N, 256)), dim3(256), 0, st, s.boxes, s.keys, s.rank, N, K, s.sboxes,
-                     s.sscores, s.sidx, prob, A, dets);
+                     s.sscores, s.sidx, prob, A, dets, flat);
   LAUNCH_CHECK();
   return FRCNN_OK;
 }
 
-static int launch_mask(const float4* boxes, int K, float thr, u64* mask, hipStream_t st) {
+static int launch_mask(const float4* boxes, int K, float thr, u64* mask, hipStream_t st, bool tf = false) {
   const int cb = cdiv(K, 64);
-  hipLaunchKernelGGL(k_nms_mask, dim3(cb, cdiv(cb, 4)), dim3(256), 0, st, boxes, K, cb, thr, mask);
+  if (tf) hipLaunchKernelGGL(k_nms_mask<true>, dim3(cb, cdiv(cb, 4)), dim3(256), 0, st, boxes, K, cb, thr, mask);
+  else hipLaunchKernelGGL(k_nms_mask<false>, dim3(cb, cdiv(cb, 4)), dim3(256), 0, st, boxes, K, cb, thr, mask);
   LAUNCH_CHECK();
   return FRCNN_OK;
 }
@@ -461,6 +552,61 @@ extern "C" int frcnn_proposal_top_layer(const float* rpn_cls_prob_d, const float
   if (rc) return rc;
   hipLaunchKernelGGL(k_top_rois, dim3(cdiv(rpn_top_n, 256)), dim3(256), 0, st, s.sboxes, s.sscores, rpn_top_n, rois_d,
                      scores_d);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// USE_E2E_TF graph (the reference's default, lib/model/config.py:275): tf.image.non_max_suppression semantics
+// ------------------------------------------------------------------------------------------------
+extern "C" int frcnn_non_max_suppression(const float* boxes_d, const float* scores_d, int k, int max_output_size,
+                                         float iou_threshold, int* selected_d, int* num_d, void* ws, size_t ws_bytes,
+                                         void* stream) {
+  if (!num_d || k < 0 || max_output_size < 0) return FRCNN_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (k == 0 || max_output_size == 0) {
+    HIP_TRY(hipMemsetAsync(num_d, 0, sizeof(int), st));
+    return FRCNN_OK;
+  }
+  if (!boxes_d || !scores_d || !selected_d || !ws) return FRCNN_E_ARG;
+  if (k > 64 * NMS_WIDE_WORDS) return FRCNN_E_UNSUPPORTED;
+  SortWs s = carve(ws, k, k);
+  if (s.bytes > ws_bytes) return FRCNN_E_WS;
+  hipLaunchKernelGGL(k_boxes_scores_key, dim3(cdiv(k, 256)), dim3(256), 0, st, (const float4*)boxes_d, scores_d, k, s.boxes,
+                     s.keys, s.rank);
+  LAUNCH_CHECK();
+  int rc = launch_rank_scatter(s, k, k, nullptr, 0, nullptr, st, scores_d);
+  if (rc) return rc;
+  rc = launch_mask(s.sboxes, k, iou_threshold, s.mask, st, true);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_nms_reduce_keep_wide, dim3(1), dim3(64), 0, st, s.mask, k, cdiv(k, 64), min(max_output_size, k), s.sidx,
+                     selected_d, num_d);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+extern "C" int frcnn_proposal_layer_tf(const float* rpn_cls_prob_d, const float* rpn_bbox_pred_d, float im_h, float im_w,
+                                       int H, int W, int A, int feat_stride, const double* base_d, int post_nms_topn,
+                                       float nms_thresh, float* rois_d, float* scores_d, int* num_d, void* ws,
+                                       size_t ws_bytes, void* stream) {
+  if (!rpn_cls_prob_d || !rpn_bbox_pred_d || !base_d || !rois_d || !scores_d || !num_d || !ws) return FRCNN_E_ARG;
+  if (H <= 0 || W <= 0 || A <= 0 || post_nms_topn <= 0) return FRCNN_E_ARG;
+  const long long NN = (long long)H * W * A;
+  if (NN > 64 * NMS_WIDE_WORDS) return FRCNN_E_UNSUPPORTED;
+  const int N = (int)NN;
+  hipStream_t st = (hipStream_t)stream;
+  SortWs s = carve(ws, N, N);
+  if (s.bytes > ws_bytes) return FRCNN_E_WS;
+  hipLaunchKernelGGL(k_decode_clip_key, dim3(cdiv(N, 256)), dim3(256), 0, st, rpn_cls_prob_d,
+                     (const float4*)rpn_bbox_pred_d, base_d, A, W, feat_stride, N, im_w - 1.0f, im_h - 1.0f, s.boxes,
+                     s.keys, s.rank);
+  LAUNCH_CHECK();
+  int rc = launch_rank_scatter(s, N, N, rpn_cls_prob_d, A, nullptr, st);
+  if (rc) return rc;
+  rc = launch_mask(s.sboxes, N, nms_thresh, s.mask, st, true);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_nms_reduce_rois_wide, dim3(1), dim3(64), 0, st, s.mask, N, cdiv(N, 64), post_nms_topn, s.sboxes,
+                     s.sscores, rois_d, scores_d, num_d);
   LAUNCH_CHECK();
   return FRCNN_OK;
 }

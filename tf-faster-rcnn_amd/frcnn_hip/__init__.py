@@ -30,6 +30,9 @@ SIGNATURES = {
                                      _P, _P, _P, _P, c_size_t, _P]),
     "frcnn_proposal_top_layer": (c_int, [_P, _P, c_float, c_float, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P,
                                          c_size_t, _P]),
+    "frcnn_non_max_suppression": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P, c_size_t, _P]),
+    "frcnn_proposal_layer_tf": (c_int, [_P, _P, c_float, c_float, c_int, c_int, c_int, c_int, _P, c_int, c_float, _P, _P, _P,
+                                        _P, c_size_t, _P]),
     "frcnn_crop_and_resize": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_float, c_int, c_int, _P, _P]),
     "frcnn_crop_and_resize_bias_act": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_float, c_int, _P, c_int, _P, _P]),
     "frcnn_detect_post_workspace_bytes": (c_size_t, [c_int, c_int]),

@@ -92,6 +92,23 @@ def nms_sorted(boxes, thresh, max_keep=None):
     return keep, num
 
 
+def non_max_suppression(boxes, scores, max_output_size, iou_threshold, selected=None, num=None):
+    """tf.image.non_max_suppression(boxes [k,4], scores [k], max_output_size, iou_threshold) on device (the NMS of the
+    reference's USE_E2E_TF graph, proposal_layer.py:72).  -> (selected int32 [max_output_size], num int32 [1])."""
+    _chk(boxes), _chk(scores)
+    k = boxes.shape[0]
+    assert boxes.shape == (k, 4) and scores.numel() == k
+    m = min(int(max_output_size), k)
+    dev = boxes.device
+    selected = torch.empty((max(m, 1),), dtype=torch.int32, device=dev) if selected is None else selected
+    num = torch.zeros((1,), dtype=torch.int32, device=dev) if num is None else num
+    nb = lib().frcnn_nms_workspace_bytes(max(k, 1))
+    ws = workspace(nb, dev, "nms")
+    call("frcnn_non_max_suppression", _ptr(boxes), _ptr(scores), k, m, float(iou_threshold), _ptr(selected), _ptr(num),
+         _ptr(ws), ws.numel(), _stream())
+    return selected, num
+
+
 def bbox_overlaps(boxes, query):
     _chk(boxes, torch.float64), _chk(query, torch.float64)
     out = torch.empty((boxes.shape[0], query.shape[0]), dtype=torch.float64, device=boxes.device)
@@ -115,6 +132,25 @@ def proposal_layer(rpn_cls_prob, rpn_bbox_pred, im_h, im_w, feat_stride, base_d,
     call("frcnn_proposal_layer", _ptr(rpn_cls_prob), _ptr(rpn_bbox_pred), float(im_h), float(im_w), H, W, A,
          int(feat_stride), _ptr(base_d), int(pre_nms_topn), int(post_nms_topn), float(nms_thresh), _ptr(rois),
          _ptr(scores), _ptr(num), _ptr(ws), ws.numel(), _stream())
+    return rois, scores, num
+
+
+def proposal_layer_tf(rpn_cls_prob, rpn_bbox_pred, im_h, im_w, feat_stride, base_d, post_nms_topn, nms_thresh, rois=None,
+                      scores=None, num=None):
+    """lib/layer_utils/proposal_layer.py:56-84 (USE_E2E_TF): NMS with tf.image.non_max_suppression semantics over ALL
+    anchors, no pre-NMS top-N.  Returns (rois [post,5] zero padded, scores [post,1], num [1])."""
+    _chk(rpn_cls_prob), _chk(rpn_bbox_pred), _chk(base_d, torch.float64)
+    _, H, W, A2 = rpn_cls_prob.shape
+    A = A2 // 2
+    dev = rpn_cls_prob.device
+    rois = torch.empty((post_nms_topn, 5), dtype=torch.float32, device=dev) if rois is None else rois
+    scores = torch.empty((post_nms_topn, 1), dtype=torch.float32, device=dev) if scores is None else scores
+    num = torch.zeros((1,), dtype=torch.int32, device=dev) if num is None else num
+    nb = lib().frcnn_proposal_workspace_bytes(H, W, A, 0)
+    ws = workspace(nb, dev, "proposal")
+    call("frcnn_proposal_layer_tf", _ptr(rpn_cls_prob), _ptr(rpn_bbox_pred), float(im_h), float(im_w), H, W, A,
+         int(feat_stride), _ptr(base_d), int(post_nms_topn), float(nms_thresh), _ptr(rois), _ptr(scores), _ptr(num),
+         _ptr(ws), ws.numel(), _stream())
     return rois, scores, num
 
 

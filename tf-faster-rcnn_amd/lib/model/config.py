@@ -6,7 +6,9 @@ points and `--set KEY VALUE` overrides behave identically.  Differences, on purp
   * yaml.safe_load instead of the Loader-less yaml.load (config.py:362 raises under PyYAML >= 6);
   * USE_GPU_NMS keeps its meaning "use the accelerator NMS" -- which is now the HIP kernel with
     the CPU/Cython suppression rule (`>=`), the path BASELINE.json names;
-  * USE_E2E_TF defaults to False: there is no TF graph; the py_func seam functions ARE the path.
+  * USE_E2E_TF defaults to False (the reference: True): the numpy/Cython layer semantics are the path BASELINE.json
+    names.  True selects the reference's TF-op semantics on the same kernels: int32-truncated anchors, proposal_layer_tf
+    (tf.image.non_max_suppression over ALL anchors: no +1 areas, `>`), proposal_top_layer_tf.
 """
 import ast
 import os

@@ -145,7 +145,10 @@ class Network(object):
         h = int(np.ceil(self._im_info[0] / np.float32(self._feat_stride[0])))
         w = int(np.ceil(self._im_info[1] / np.float32(self._feat_stride[0])))
         base = ops.generate_anchors(16, self._anchor_ratios, self._anchor_scales)
-        key = ("base_anchors", tuple(self._anchor_ratios), tuple(self._anchor_scales))
+        if cfg.USE_E2E_TF:
+            # generate_anchors_pre_tf (snippets.py:44): tf.constant(anchors, dtype=tf.int32) truncates the base anchors
+            base = np.trunc(base)
+        key = ("base_anchors", tuple(self._anchor_ratios), tuple(self._anchor_scales), bool(cfg.USE_E2E_TF))
         if key not in self._sess.packed:
             self._sess.packed[key] = self._sess.to_device(base, torch.float64)
         self._base_anchors = self._sess.packed[key]
@@ -163,6 +166,13 @@ class Network(object):
         scores = s.buf(self._tag + "/roi_scores", (B * post, 1))
         num = s.buf(self._tag + "/num_rois", (B,), torch.int32)
         for b in range(B):
+            if cfg.USE_E2E_TF:
+                # network.py:112-121 -> proposal_layer_tf: tf.image.non_max_suppression over ALL anchors, no pre-NMS top-N
+                s.mark("op:proposal_layer_tf", 0, lambda: ops.proposal_layer_tf(
+                    rpn_cls_prob[b:b + 1], rpn_bbox_pred[b:b + 1], self._im_info[0], self._im_info[1], self._feat_stride[0],
+                    self._base_anchors, post, float(c.RPN_NMS_THRESH),
+                    rois=rois[b * post:(b + 1) * post], scores=scores[b * post:(b + 1) * post], num=num[b:b + 1]))
+                continue
             s.mark("op:proposal_layer", 0, lambda: ops.proposal_layer(
                 rpn_cls_prob[b:b + 1], rpn_bbox_pred[b:b + 1], self._im_info[0], self._im_info[1], self._feat_stride[0],
                 self._base_anchors, int(c.RPN_PRE_NMS_TOP_N), post, float(c.RPN_NMS_THRESH),
@@ -172,6 +182,8 @@ class Network(object):
         return rois, scores
 
     def _proposal_top_layer(self, rpn_cls_prob, rpn_bbox_pred, name):
+        # network.py:88-108.  USE_E2E_TF's proposal_top_layer_tf (tf.nn.top_k: descending, equal scores -> lower index first)
+        # selects and orders exactly like the kernel's (score desc, index asc) keys, so both settings share it.
         n, s = int(cfg.TEST.RPN_TOP_N), self._sess
         assert rpn_cls_prob.shape[0] == 1, "TEST.MODE 'top' is provided for single images"
         self._rois_per_image = n
@@ -356,7 +368,7 @@ class Network(object):
         c = cfg[self._mode]
         key = (self._tag, tuple(image_d.shape), self._im_info[:2], self._mode, cfg.TEST.MODE, self._fuse_tail_entry,
                c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH, cfg.TEST.RPN_TOP_N, cfg.POOLING_SIZE,
-               bool(cfg.HIP.WINOGRAD), int(cfg.HIP.WINOGRAD_MIN_CIN), int(cfg.HIP.WINOGRAD_M), tuple(cfg.HIP.WINOGRAD_F2_SCOPES))
+               bool(cfg.HIP.WINOGRAD), int(cfg.HIP.WINOGRAD_MIN_CIN), int(cfg.HIP.WINOGRAD_M), tuple(cfg.HIP.WINOGRAD_F2_SCOPES), bool(cfg.USE_E2E_TF))
         cur = torch.cuda.current_stream(sess.device)
         if not use_graph or sess.profile is not None:
             sess.flops_last_forward = 0
