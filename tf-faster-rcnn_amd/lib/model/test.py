@@ -38,9 +38,10 @@ def detect(sess, net, blob, im_scale, im_shape, max_per_image=100, thresh=0.):
     return out
 
 
-def test_net(sess, net, images, num_classes=None, max_per_image=100, thresh=0.):
+def test_net(sess, net, images, num_classes=None, max_per_image=100, thresh=0., imdb=None, output_dir=None):
     """images: iterable of (blob, im_scale, im_shape).  Returns all_boxes[cls][image] like the
-    reference; prints the same per-image timing line (test.py:183-185)."""
+    reference; prints the same per-image timing line (test.py:183-185).  With an imdb (datasets.pascal_voc) the
+    detections are written and evaluated as at test.py:187-192: `detections.pkl` + imdb.evaluate_detections."""
     images = list(images)
     num_classes = net._num_classes if num_classes is None else num_classes
     all_boxes = [[[] for _ in range(len(images))] for _ in range(num_classes)]
@@ -56,4 +57,12 @@ def test_net(sess, net, images, num_classes=None, max_per_image=100, thresh=0.):
         _t['misc'].toc()
         print('im_detect: {:d}/{:d} {:.3f}s {:.3f}s'.format(i + 1, len(images), _t['im_detect'].average_time,
                                                             _t['misc'].average_time))
+    if imdb is not None and output_dir is not None:
+        import os
+        import pickle
+        os.makedirs(output_dir, exist_ok=True)
+        with open(os.path.join(output_dir, 'detections.pkl'), 'wb') as f:
+            pickle.dump(all_boxes, f, pickle.HIGHEST_PROTOCOL)
+        print('Evaluating detections')
+        imdb.evaluate_detections(all_boxes, output_dir)
     return all_boxes
