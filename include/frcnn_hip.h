@@ -154,6 +154,16 @@ int frcnn_conv2d_nhwc(const float* x_d, int N, int H, int W, int Cin, const floa
  * key 2 = 1 enables the EXPERIMENTAL bf16x3 split-operand MFMA path for every non-stem conv (f32 in/out, f32-class
  * accuracy, see csrc/conv_igemm_b3.hip); key 3 = force its tile configuration. */
 int frcnn_set_tuning(int key, int value);
+/* Image preprocessing on device (lib/model/test.py:26-58 _get_image_blob, lib/utils/blob.py:33-47 prep_im_for_blob).
+ * frcnn_prep_image_shape (HOST): the scale rule -- target_size / min side, capped so that round(scale * max side) <=
+ * max_size -- and cv2.resize's output size cvRound(src * scale).
+ * frcnn_prep_image: BGR [h][w][3] uint8 (src_is_float 0) or float32 (1) on device -> (pixel - pixel_means[c]) resized
+ * with cv2.INTER_LINEAR semantics into float32 [OH][OW][out_c]; out_c = 4 adds the zero 4th channel of the staged stem
+ * input.  pixel_means: HOST double[3]. */
+int frcnn_prep_image_shape(int h, int w, int target_size, int max_size, double* im_scale, int* out_h, int* out_w);
+int frcnn_prep_image(const void* src_d, int src_is_float, int h, int w, const double* pixel_means, double im_scale, float* out_d,
+                     int OH, int OW, int out_c, void* stream);
+
 /* G independent NT GEMMs in one launch (f32 MFMA): y[g][m][n] = sum_k x[g][m][k] * w[g][n][k];  K % 32 == 0. */
 int frcnn_gemm_batched_nt(const float* x_d, const float* w_d, float* y_d, int G, int M, int N, int K, void* stream);
 /* Winograd F(m x m, 3x3), m = 2 or 4, for stride-1 pad-1 3x3 convolutions (exact algebra, f32): filter transform on the

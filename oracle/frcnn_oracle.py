@@ -282,6 +282,52 @@ def proposal_top_layer_tf(rpn_cls_prob, rpn_bbox_pred, im_info, anchors, num_anc
     return blob, top_scores.reshape(-1, 1)
 
 
+# ----------------------------------------------------------------------------- image preprocessing (model/test.py:26-58)
+# cv2.resize is third-party (OpenCV, not vendored, cv2 not installable offline): restated from OpenCV 3.x
+# modules/imgproc/src/resize.cpp (32f INTER_LINEAR path).  PARITY UNPINNED for cv2_resize_linear; the scale rule and
+# the mean subtraction around it are the reference's own lines and are restated literally.
+def cv2_resize_linear(im, fx, fy):
+    """cv2.resize(im, None, None, fx=fx, fy=fy, interpolation=cv2.INTER_LINEAR) for a float32 [h,w,c] image."""
+    im = np.ascontiguousarray(im, dtype=f32)
+    h, w = im.shape[:2]
+    OW, OH = int(np.round(w * fx)), int(np.round(h * fy))           # saturate_cast<int> == round half to even
+    sx_inv, sy_inv = 1.0 / fx, 1.0 / fy
+
+    def taps(n_out, inv, n_in, clamp_weight):
+        f = ((np.arange(n_out, dtype=np.float64) + 0.5) * inv - 0.5).astype(f32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(f32)).astype(f32)
+        if clamp_weight:                                              # columns: weight zeroed at the borders
+            lo = s < 0
+            f[lo], s[lo] = 0, 0
+            last = s + 1 >= n_in
+            hi = s >= n_in - 1
+            f[hi], s[hi] = 0, n_in - 1
+            return s, np.where(last, s, s + 1), f, last
+        return np.clip(s, 0, n_in - 1), np.clip(s + 1, 0, n_in - 1), f, None     # rows: indices clamped, weight kept
+
+    x0, x1, ax, last = taps(OW, sx_inv, w, True)
+    y0, y1, ay, _ = taps(OH, sy_inv, h, False)
+    a0, a1 = (f32(1) - ax)[None, :, None], ax[None, :, None]
+    rows0, rows1 = im[y0], im[y1]
+    one = last[None, :, None]
+    r0 = np.where(one, rows0[:, x0] * f32(1), rows0[:, x0] * a0 + rows0[:, x1] * a1).astype(f32)
+    r1 = np.where(one, rows1[:, x0] * f32(1), rows1[:, x0] * a0 + rows1[:, x1] * a1).astype(f32)
+    b0, b1 = (f32(1) - ay)[:, None, None], ay[:, None, None]
+    return (r0 * b0 + r1 * b1).astype(f32)
+
+
+def get_image_blob(im, pixel_means, target_size=600, max_size=1000):
+    """model/test.py:26-58 for one scale: (blob [1,H,W,3] f32, im_scale)."""
+    im_orig = im.astype(f32, copy=True)
+    im_orig -= np.asarray(pixel_means)                                # float64 means: f64 subtraction, stored as f32 (:35-36)
+    smin, smax = np.min(im_orig.shape[0:2]), np.max(im_orig.shape[0:2])
+    im_scale = float(target_size) / float(smin)
+    if np.round(im_scale * smax) > max_size:
+        im_scale = float(max_size) / float(smax)
+    return cv2_resize_linear(im_orig, im_scale, im_scale)[None], im_scale
+
+
 # ----------------------------------------------------------------------------- test-time post-processing
 def im_detect_post(scores, bbox_pred, rois, im_scale, im_shape):
     """model/test.py:95-102: rois/scale, per-class decode, final clip.  -> scores [R,C], boxes [R,4C]."""

@@ -235,3 +235,38 @@ def test_conv3x3_winograd_f4(dev, N, H, W, Cin, Cout, act, bias):
     ref = ref_conv(x, w * scale[None, None, None, :], b, 1, (1, 1, 1, 1), act)
     assert y.shape == ref.shape
     assert np.abs(y - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("h,w,target,max_size", [(375, 500, 600, 1000), (480, 640, 600, 1000), (300, 1000, 600, 1000), (600, 800, 600, 1000),
+                                                 (97, 131, 64, 80)])
+def test_prep_image_vs_oracle(dev, h, w, target, max_size):
+    """frcnn_prep_image == the oracle's restatement of _get_image_blob (mean subtraction in f64, cv2.INTER_LINEAR resize).
+    Same f32 operations in the same order: compared bit for bit; staged 4th channel is zero."""
+    import frcnn_oracle as ora
+    from frcnn_hip import ops
+    rng = np.random.RandomState(h + w)
+    im = (rng.rand(h, w, 3) * 255).astype(np.uint8)
+    means = np.array([[[102.9801, 115.9465, 122.7717]]])
+    want, want_scale = ora.get_image_blob(im, means, target, max_size)
+    scale, OH, OW = ops.prep_image_shape(h, w, target, max_size)
+    assert scale == want_scale and (1, OH, OW, 3) == want.shape
+    got = ops.prep_image(torch.from_numpy(im).to(dev), means, scale, (OH, OW)).cpu().numpy()
+    assert got.shape == (1, OH, OW, 4) and np.all(got[..., 3] == 0)
+    assert np.array_equal(got[..., :3], want)
+    got_f = ops.prep_image(torch.from_numpy(im.astype(np.float32)).to(dev), means, scale, (OH, OW), out_c=3).cpu().numpy()
+    assert np.array_equal(got_f, want)                                          # float32 source, 3-channel output
+
+
+def test_prep_image_properties(dev):
+    from frcnn_hip import ops
+    rng = np.random.RandomState(1)
+    im = (rng.rand(60, 90, 3) * 255).astype(np.uint8)
+    means = np.array([10.5, 20.25, 30.125])
+    same = ops.prep_image(torch.from_numpy(im).to(dev), means, 1.0, (60, 90), out_c=3).cpu().numpy()[0]
+    assert np.array_equal(same, (im.astype(np.float64) - means).astype(np.float32))          # scale 1: exactly im - means
+    const = np.full((40, 50, 3), 77, dtype=np.uint8)
+    up = ops.prep_image(torch.from_numpy(const).to(dev), np.zeros(3), 1.6, (64, 80), out_c=3).cpu().numpy()
+    assert np.abs(up - 77).max() <= 1e-5                                                    # constants stay constant
+    ramp = np.tile(np.arange(50, dtype=np.float32)[None, :, None], (40, 1, 3))
+    r = ops.prep_image(torch.from_numpy(ramp).to(dev), np.zeros(3), 1.6, (64, 80), out_c=3).cpu().numpy()[0]
+    assert np.allclose(r[10, :4, 0], [0, 0.4375, 1.0625, 1.6875]) and r[10, -1, 0] == 49    # pixel-centre alignment, clamped edges

@@ -276,3 +276,27 @@ def test_use_e2e_tf_graph_semantics(small_net):
     assert n == want.shape[0] and np.allclose(rois[:n], want, rtol=0, atol=2e-2)
     ref = DenseRef(sess.variables, 50, 21, SCALES, RATIOS).test_image(image, im_info, rois=rois, post=48)
     assert rel_err(cls_score, ref["cls_score"]) <= 1e-4 and rel_err(bbox_pred, ref["bbox_pred"]) <= 1e-4
+
+
+def test_raw_bgr_image_entry_points(small_net):
+    """model.test.im_detect_bgr / detect_bgr (the reference's `im_detect(sess, net, im)` signature): uint8 BGR in, the
+    device _get_image_blob (frcnn_prep_image) in front of the same chain == oracle blob fed through the blob entry points."""
+    from model.config import cfg
+    from model.test import detect, detect_bgr, im_detect, im_detect_bgr
+    sess, net, _, _ = small_net
+    rng = np.random.RandomState(11)
+    im = (rng.rand(120, 160, 3) * 255).astype(np.uint8)
+    old = (cfg.TEST.SCALES, cfg.TEST.MAX_SIZE)
+    cfg.TEST.SCALES, cfg.TEST.MAX_SIZE = (150,), 220
+    try:
+        blob, im_scale = ora.get_image_blob(im, cfg.PIXEL_MEANS, 150, 220)
+        assert blob.shape == (1, 150, 200, 3) and im_scale == 1.25
+        s1, b1 = im_detect_bgr(sess, net, im)
+        s2, b2 = im_detect(sess, net, blob, im_scale, im.shape)
+        assert np.array_equal(s1, s2) and np.array_equal(b1, b2)
+        d1 = detect_bgr(sess, net, torch.from_numpy(im).to(sess.device))          # device-resident source image
+        d2 = detect(sess, net, blob, im_scale, im.shape[:2])
+        for j in range(1, 21):
+            assert np.array_equal(d1[j], d2[j])
+    finally:
+        cfg.TEST.SCALES, cfg.TEST.MAX_SIZE = old

@@ -197,3 +197,23 @@ def test_pin_against_live_reference():
     r = subprocess.run([sys.executable, os.path.join(root, "oracle", "gen_golden.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "MISMATCH" not in r.stdout
+
+
+def test_get_image_blob_known_answers():
+    """oracle.get_image_blob / cv2_resize_linear (cv2 is third party: parity unpinned) -- the published INTER_LINEAR facts:
+    scale 1 is the identity, pixel-centre alignment ((dx+0.5)/fx-0.5), clamped borders, dst = round-half-even(src*fx), and
+    the reference's scale rule incl. the MAX_SIZE cap (test.py:45-48)."""
+    rng = np.random.RandomState(0)
+    im = (rng.rand(375, 500, 3) * 255).astype(np.uint8)
+    means = np.array([[[102.9801, 115.9465, 122.7717]]])
+    blob, s = ora.get_image_blob(im, means)
+    assert blob.shape == (1, 600, 800, 3) and s == 1.6 and blob.dtype == f32
+    blob, s = ora.get_image_blob(im[:150], means)                          # 150 x 500: capped by MAX_SIZE
+    assert s == 2.0 and blob.shape == (1, 300, 1000, 3)
+    assert np.array_equal(ora.cv2_resize_linear(im.astype(f32), 1.0, 1.0), im.astype(f32))
+    ramp = np.tile(np.arange(50, dtype=f32)[None, :, None], (40, 1, 3))
+    r = ora.cv2_resize_linear(ramp, 1.6, 1.6)
+    assert r.shape == (64, 80, 3) and np.allclose(r[10, :4, 0], [0, 0.4375, 1.0625, 1.6875]) and r[10, -1, 0] == 49
+    down = ora.cv2_resize_linear(ramp, 0.5, 0.5)
+    assert down.shape == (20, 25, 3) and np.allclose(down[0, :3, 0], [0.5, 2.5, 4.5])     # 2:1 -> mean of the two centre taps
+    assert ora.cv2_resize_linear(np.zeros((5, 5, 3), f32), 0.5, 0.5).shape == (2, 2, 3)    # 2.5 rounds to even

@@ -42,6 +42,8 @@ SIGNATURES = {
     "frcnn_bbox_overlaps": (c_int, [_P, c_int, _P, c_int, _P, _P]),
     "frcnn_conv2d_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "frcnn_prep_image_shape": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "frcnn_prep_image": (c_int, [_P, c_int, c_int, c_int, _P, c_double, _P, c_int, c_int, c_int, _P]),
     "frcnn_gemm_batched_nt": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "frcnn_winograd_filter_transform": (c_int, [_P, c_int, c_int, _P, c_int, _P]),
     "frcnn_winograd_input_transform": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),

@@ -266,6 +266,28 @@ def conv2d(x, w_packed, bias, KH, KW, stride=1, pad=(0, 0, 0, 0), act=ACT_NONE, 
     return out
 
 
+def prep_image_shape(h, w, target_size, max_size):
+    """HOST: (im_scale, OH, OW) of _get_image_blob / prep_im_for_blob for an h x w image."""
+    sc, oh, ow = ctypes.c_double(), ctypes.c_int(), ctypes.c_int()
+    call("frcnn_prep_image_shape", int(h), int(w), int(target_size), int(max_size), ctypes.byref(sc), ctypes.byref(oh),
+         ctypes.byref(ow))
+    return sc.value, oh.value, ow.value
+
+
+def prep_image(im_d, pixel_means, im_scale, out_hw, out=None, out_c=4):
+    """im_d: BGR uint8 or float32 [h,w,3] on device -> float32 [1,OH,OW,out_c] = resize(im - PIXEL_MEANS) (cv2 INTER_LINEAR)."""
+    assert im_d.is_cuda and im_d.is_contiguous() and im_d.dim() == 3 and im_d.shape[2] == 3
+    assert im_d.dtype in (torch.uint8, torch.float32)
+    h, w = im_d.shape[:2]
+    OH, OW = out_hw
+    out = torch.empty((1, OH, OW, out_c), dtype=torch.float32, device=im_d.device) if out is None else out
+    assert out.shape == (1, OH, OW, out_c)
+    means = (ctypes.c_double * 3)(*[float(v) for v in np.asarray(pixel_means, dtype=np.float64).reshape(-1)[:3]])
+    call("frcnn_prep_image", _ptr(im_d), 1 if im_d.dtype == torch.float32 else 0, h, w, means, float(im_scale), _ptr(out), OH, OW,
+         int(out_c), _stream())
+    return out
+
+
 def winograd_filter_transform(w_hwio, scale=None, m=2):
     """HOST: 3x3 HWIO filter -> U [(m+2)^2, Cout, Cin] (F(m x m,3x3), optional folded per-output scale)."""
     w = np.ascontiguousarray(w_hwio, dtype=np.float32)

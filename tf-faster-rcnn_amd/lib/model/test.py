@@ -1,8 +1,9 @@
 """model.test -- the test loop of the reference (lib/model/test.py) on the device chain.
 
-`im_detect` / `test_net` keep the reference's names and return conventions; image decoding and the
-cv2 resize of `_get_image_blob` (test.py:26-58) are host preprocessing outside the hot path (SURVEY.md
-8f row 2), so `im_detect` takes the ALREADY SCALED, mean-subtracted blob plus its scale."""
+`im_detect` / `test_net` keep the reference's names and return conventions.  `im_detect` / `detect` take the ALREADY
+SCALED, mean-subtracted blob plus its scale; `_get_image_blob` (test.py:26-58) is provided ON DEVICE
+(`frcnn_prep_image`: uint8 BGR in HBM -> mean-subtracted, cv2.INTER_LINEAR-resized, staged stem input), and
+`im_detect_bgr` / `detect_bgr` are the raw-image forms (the reference's `im_detect(sess, net, im)` signature)."""
 import numpy as np
 import torch
 
@@ -22,6 +23,37 @@ def im_detect(sess, net, blob, im_scale, im_shape):
     rois, bbox_pred = p["rois"][:n].contiguous(), p["bbox_pred"][:n].contiguous()
     pred_boxes = ops.im_detect_boxes(rois, bbox_pred, im_scale, im_shape[0], im_shape[1])      # test.py:95-102
     return p["cls_prob"][:n].cpu().numpy(), pred_boxes.cpu().numpy()
+
+
+def _get_image_blob(sess, net, im):
+    """test.py:26-58 on device for cfg.TEST.SCALES[0]: im = BGR uint8 (or float32) [h,w,3], numpy or device tensor.
+    Returns (staged image [1,H,W,4] on device -- zero 4th channel, what forward_device takes --, im_scale)."""
+    if isinstance(im, np.ndarray):
+        im = torch.from_numpy(np.ascontiguousarray(im)).to(sess.device, non_blocking=True)     # 3 B/pixel over PCIe
+    im_scale, OH, OW = ops.prep_image_shape(im.shape[0], im.shape[1], cfg.TEST.SCALES[0], cfg.TEST.MAX_SIZE)
+    out = sess.buf(net._tag + "/image", (1, OH, OW, 4))
+    ops.prep_image(im, cfg.PIXEL_MEANS, im_scale, (OH, OW), out=out, out_c=4)
+    return out, im_scale
+
+
+def im_detect_bgr(sess, net, im):
+    """The reference's `im_detect(sess, net, im)` (test.py:86-107): raw BGR image in, (scores, pred_boxes) out."""
+    img, im_scale = _get_image_blob(sess, net, im)
+    im_info = np.array([img.shape[1], img.shape[2], im_scale], dtype=np.float32)
+    p = net.forward_device(sess, img, im_info)
+    n = p["rois"].shape[0] if net._num_rois is None else int(net._num_rois.item())
+    pred_boxes = ops.im_detect_boxes(p["rois"][:n].contiguous(), p["bbox_pred"][:n].contiguous(), im_scale, im.shape[0], im.shape[1])
+    return p["cls_prob"][:n].cpu().numpy(), pred_boxes.cpu().numpy()
+
+
+def detect_bgr(sess, net, im, max_per_image=100, thresh=0.):
+    """Raw BGR image -> per-class detections, everything after the (optional) H2D copy on the GPU."""
+    img, im_scale = _get_image_blob(sess, net, im)
+    im_info = np.array([img.shape[1], img.shape[2], im_scale], dtype=np.float32)
+    dets, cnt = net.detect_device(sess, img, im_info, im.shape[:2], max_per_image=max_per_image, thresh=thresh)
+    n = min(int(cnt.item()), dets.shape[0])
+    rec = dets[:n].cpu().numpy()
+    return [np.zeros((0, 5), dtype=np.float32)] + [rec[rec[:, 5] == j, :5] for j in range(1, net._num_classes)]
 
 
 def detect(sess, net, blob, im_scale, im_shape, max_per_image=100, thresh=0.):
