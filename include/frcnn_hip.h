@@ -154,6 +154,11 @@ int frcnn_conv2d_nhwc(const float* x_d, int N, int H, int W, int Cin, const floa
  * key 2 = 1 enables the EXPERIMENTAL bf16x3 split-operand MFMA path for every non-stem conv (f32 in/out, f32-class
  * accuracy, see csrc/conv_igemm_b3.hip); key 3 = force its tile configuration. */
 int frcnn_set_tuning(int key, int value);
+/* HOST: CRC-32C (Castagnoli) of n bytes, crc = 0 to start or a previous result to extend: the checksum of TensorFlow
+ * checkpoint shards / index blocks (frcnn_hip/tensor_bundle.py replaces pywrap_tensorflow.NewCheckpointReader,
+ * lib/model/train_val.py:105-114). */
+unsigned int frcnn_crc32c(const void* data, size_t n, unsigned int crc);
+
 /* Image preprocessing on device (lib/model/test.py:26-58 _get_image_blob, lib/utils/blob.py:33-47 prep_im_for_blob).
  * frcnn_prep_image_shape (HOST): the scale rule -- target_size / min side, capped so that round(scale * max side) <=
  * max_size -- and cv2.resize's output size cvRound(src * scale).

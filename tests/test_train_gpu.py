@@ -235,3 +235,55 @@ def test_sgd_steps_on_a_fixed_batch_reduce_the_loss(dev):
         assert np.mean(hist[-4:]) < 0.8 * np.mean(hist[:4]), hist
     finally:
         cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO = old
+
+
+def test_snapshot_and_resume_continue_the_same_run(dev, tmp_path):
+    """train_val.py:58-100,204-233 on TF V2 bundles written without TensorFlow: run 4 steps; run 2 steps, snapshot, restore
+    into a fresh session + solver (weights, Momentum slots, iteration, sampling stream), run 2 more -> the same losses as
+    the uninterrupted run and the same final weights.  The step right after the restore must agree to f32 rounding (same
+    weights, same sampling stream); later steps only to ~1e-2: float atomics in the crop backward perturb the weights at
+    1e-7, and a flipped NMS / sampling decision downstream of that changes the sampled RoIs (true of two uninterrupted runs too)."""
+    from frcnn_hip.runtime import Session
+    from frcnn_hip.tensor_bundle import BundleReader
+    from model.config import cfg
+    from model.train_val import SolverWrapper
+    from nets.resnet_v1 import resnetv1
+    old = (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.SNAPSHOT_ITERS, cfg.TRAIN.STEPSIZE, cfg.TRAIN.DISPLAY)
+    cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.SNAPSHOT_ITERS, cfg.TRAIN.STEPSIZE = 64, 0.0, 2e-4, 2, [3]
+    cfg.TRAIN.DISPLAY = 1000
+    rng = np.random.RandomState(2)
+    image = ((rng.rand(1, 128, 160, 3) * 255.0).astype(np.float32) - cfg.PIXEL_MEANS.astype(np.float32)) * np.float32(1 / 256.0)
+    gt = np.array([[16, 16, 79, 79, 3], [60, 30, 150, 110, 7], [5, 70, 60, 120, 12]], dtype=np.float32)
+
+    def layer():
+        while True:
+            yield dict(data=image, im_info=np.array([128, 160, 1.0], dtype=np.float32), gt_boxes=gt)
+
+    def solver(tag):
+        sess = Session(device=dev, seed=5)
+        net = resnetv1(num_layers=50)
+        net.create_architecture("TRAIN", 21, tag=tag, anchor_scales=(4, 8, 16), anchor_ratios=(0.5, 1, 2))
+        sess.init_variables(net.variable_specs())
+        return sess, net, SolverWrapper(sess, net, layer())
+
+    try:
+        _, _, sw = solver("snapA")
+        full = sw.train_model(4, verbose=False)
+        want = sw.state.export_variables(slots=True)
+        _, _, sw = solver("snapB")
+        first = sw.train_model(2, verbose=False, snapshot_dir=str(tmp_path))
+        ck, pk = str(tmp_path / "res101_faster_rcnn_iter_2.ckpt"), str(tmp_path / "res101_faster_rcnn_iter_2.pkl")
+        shapes = BundleReader(ck).get_variable_to_shape_map()
+        assert shapes["global_step"] == [] and "resnet_v1_50/block3/unit_1/bottleneck_v1/conv2/weights/Momentum" in shapes
+        assert "resnet_v1_50/conv1/weights/Momentum" not in shapes                     # frozen stem: no optimizer slot
+        sess, net, sw = solver("snapC")
+        assert sw.restore(ck, pk) == 2
+        rest = sw.train_model(4, verbose=False, start_iter=2)
+        assert first == full[:2]
+        assert np.allclose(rest[0], full[2], rtol=1e-5, atol=0) and np.allclose(rest[1], full[3], rtol=2e-2, atol=0), (first + rest, full)
+        got = sw.state.export_variables(slots=False)
+        for k in got:
+            scale = max(float(np.abs(want[k]).max()), 1e-12)
+            assert np.abs(got[k] - want[k]).max() <= 2e-3 * scale, k
+    finally:
+        (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.SNAPSHOT_ITERS, cfg.TRAIN.STEPSIZE, cfg.TRAIN.DISPLAY) = old

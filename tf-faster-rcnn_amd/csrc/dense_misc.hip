@@ -203,3 +203,36 @@ extern "C" int frcnn_graph_destroy(void* graph_exec) {
   HIP_TRY(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
   return FRCNN_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// HOST: CRC-32C (Castagnoli, reflected 0x82F63B78), slicing by 8 -- the checksum of TensorFlow checkpoint data and index
+// blocks (frcnn_hip/tensor_bundle.py; tensorflow/core/lib/hash/crc32c.cc).  crc = 0 to start, or a previous result to extend.
+// ------------------------------------------------------------------------------------------------
+extern "C" unsigned int frcnn_crc32c(const void* data, size_t n, unsigned int crc) {
+  static unsigned int T[8][256];
+  static bool ready = false;
+  if (!ready) {
+    for (unsigned int i = 0; i < 256; ++i) {
+      unsigned int c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+      T[0][i] = c;
+    }
+    for (unsigned int i = 0; i < 256; ++i)
+      for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xFFu];
+    ready = true;
+  }
+  const unsigned char* p = (const unsigned char*)data;
+  unsigned int c = crc ^ 0xFFFFFFFFu;
+  while (n && ((size_t)p & 7)) { c = T[0][(c ^ *p++) & 0xFFu] ^ (c >> 8); --n; }
+  while (n >= 8) {
+    unsigned long long v;
+    __builtin_memcpy(&v, p, 8);
+    v ^= (unsigned long long)c;
+    c = T[7][v & 0xFF] ^ T[6][(v >> 8) & 0xFF] ^ T[5][(v >> 16) & 0xFF] ^ T[4][(v >> 24) & 0xFF] ^ T[3][(v >> 32) & 0xFF] ^
+        T[2][(v >> 40) & 0xFF] ^ T[1][(v >> 48) & 0xFF] ^ T[0][(v >> 56) & 0xFF];
+    p += 8;
+    n -= 8;
+  }
+  while (n--) c = T[0][(c ^ *p++) & 0xFFu] ^ (c >> 8);
+  return c ^ 0xFFFFFFFFu;
+}

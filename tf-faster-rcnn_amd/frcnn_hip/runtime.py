@@ -20,20 +20,16 @@ class VarSpec(object):
         self.shape, self.init, self.arg = tuple(int(s) for s in shape), init, arg
 
 
-class Session(object):
-    def __init__(self, device=None, seed=3):
-        if not torch.cuda.is_available():
-            raise RuntimeError("frcnn_hip.Session needs a GPU: the product path has no CPU fallback")
-        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.stream = torch.cuda.Stream(device=self.device)
+class VariableStore(object):
+    """Host side of a session: the variables under their TF/slim names (numpy, HWIO filters, [in,out] matrices), their
+    initialisation and checkpoint I/O.  No device state -- Session adds that."""
+
+    def __init__(self, seed=3):
         self.variables = collections.OrderedDict()     # TF name -> numpy (HWIO conv, [in,out] fc)
         self.packed = {}                                # layer key -> device tensors
         self.conv_info = {}                             # scope -> {w (folded, device), b, scale (np or None), bn}
-        self.buffers = {}
         self.graphs = {}
         self.seed = seed
-        self.profile = None                             # list of (tag, flops, ev0, ev1) when profiling
-        self.flops_last_forward = 0
 
     # ---- variables ---------------------------------------------------------------------------
     def init_variables(self, specs, seed=None):
@@ -72,6 +68,46 @@ class Session(object):
             self.variables[k] = np.asarray(v, dtype=np.float32)
         self.packed.clear()
         self.graphs.clear()
+
+    def restore(self, ckpt_prefix, names=None, verify=True):
+        """tf.train.Saver(...).restore(sess, ckpt) without TensorFlow (tools/test_net.py:110-114, train_val.py:185-190):
+        loads `names` (default: every declared variable) from a V2 checkpoint by their TF/slim names.  A missing name or a
+        shape mismatch raises, like Saver does.  Returns the names restored."""
+        from .tensor_bundle import BundleReader
+        reader = BundleReader(ckpt_prefix, verify=verify)
+        names = list(self.variables) if names is None else list(names)
+        values = {}
+        for name in names:
+            if not reader.has_tensor(name):
+                raise KeyError("Key %s not found in checkpoint %s" % (name, ckpt_prefix))
+            v = reader.get_tensor(name)
+            if name in self.variables and tuple(v.shape) != tuple(self.variables[name].shape):
+                if v.size != self.variables[name].size or name.rsplit("/", 2)[-2] not in ("fc6", "fc7"):
+                    raise ValueError("%s: checkpoint shape %s, variable shape %s" % (name, list(v.shape), list(self.variables[name].shape)))
+                v = v.reshape(self.variables[name].shape)     # the fc6 / fc7 matrix stored as a filter or vice versa (vgg16.py:81-100)
+            values[name] = v
+        self.load_variables(values)
+        self.conv_info.clear()
+        return names
+
+    def save(self, ckpt_prefix, extra=None):
+        """tf.train.Saver.save: every variable (+ `extra`, e.g. momentum slots / global_step) as a V2 checkpoint."""
+        from .tensor_bundle import write_bundle
+        tensors = {k: np.asarray(v) for k, v in self.variables.items()}
+        tensors.update(extra or {})
+        return write_bundle(ckpt_prefix, tensors)
+
+
+class Session(VariableStore):
+    def __init__(self, device=None, seed=3):
+        if not torch.cuda.is_available():
+            raise RuntimeError("frcnn_hip.Session needs a GPU: the product path has no CPU fallback")
+        VariableStore.__init__(self, seed)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.buffers = {}
+        self.profile = None                             # list of (tag, flops, ev0, ev1) when profiling
+        self.flops_last_forward = 0
 
     # ---- device-side images of the variables ----------------------------------------------------
     def to_device(self, a, dtype=torch.float32):

@@ -17,7 +17,7 @@ from . import ACT_NONE, ACT_RELU, ops
 class Param(object):
     """One trainable filter (+ optional bias) on the device."""
 
-    def __init__(self, scope, wf, bias, scale_np, bias_trainable, flat_w, flat_b):
+    def __init__(self, scope, wf, bias, scale_np, bias_trainable, flat_w, flat_b, master_hwio=None):
         dev = wf.device
         self.scope = scope
         self.wf = wf                                            # folded filter used by the forward kernels
@@ -25,6 +25,12 @@ class Param(object):
         self.scale = None if scale_np is None else torch.from_numpy(np.ascontiguousarray(scale_np, dtype=np.float32)).to(dev)
         if self.scale is None:
             self.w = wf                                         # no fold: master == forward filter
+        elif master_hwio is not None and master_hwio.size == wf.numel():
+            # the un-folded variable itself (exactly what a snapshot stores), and the folded copy recomputed from it with the
+            # SGD kernel's own f32 product, so a resumed run starts from the very state the interrupted one had
+            m = np.ascontiguousarray(master_hwio.reshape((wf.shape[1], wf.shape[2], wf.shape[3], wf.shape[0])).transpose(3, 0, 1, 2))
+            self.w = torch.from_numpy(m.astype(np.float32)).to(dev)
+            wf.copy_(self.w * self.scale.view(-1, 1, 1, 1))
         else:
             self.w = (wf / self.scale.view(-1, 1, 1, 1)).contiguous()
         self.acc_w = torch.zeros_like(self.w)
@@ -68,7 +74,7 @@ class TrainState(object):
             off += nw
             fb = self.flat[off:off + nb] if nb else None
             off += nb
-            self.params[sc] = Param(sc, info["w"], info["b"], info["scale"], nb > 0, fw, fb)
+            self.params[sc] = Param(sc, info["w"], info["b"], info["scale"], nb > 0, fw, fb, sess.variables.get(sc + "/weights"))
         self.reg_scopes = [sc for sc in sess.conv_info]            # slim regularises every conv/fc weight, frozen or not
         return self
 
@@ -166,6 +172,42 @@ class TrainState(object):
             if p.bias is not None:
                 ops.sgd_momentum(p.bias, p.acc_b, None, p.grad_b, None, p.bias.numel(), lr * (2.0 if self.double_bias else 1.0),
                                  self.momentum, self.weight_decay if self.bias_decay else 0.0, gs)
+
+    # ---- checkpoint view (tf.train.Saver saves the variables AND the optimizer slots `<variable>/Momentum`) ----------
+    def _names(self, p):
+        return p.scope + "/weights", p.scope + "/biases"
+
+    def export_variables(self, slots=True):
+        """{TF/slim variable name: ndarray in the variable's own layout (HWIO filters, [in,out] matrices)} of every TRAINED
+        parameter, read back from the device master copies (packed [Cout][KH][KW][Cin]); with slots=True also the momentum
+        accumulators under `<name>/Momentum` (MomentumOptimizer's slot name)."""
+        out = {}
+        for p in self.params.values():
+            wname, bname = self._names(p)
+            ref = self.sess.variables[wname]
+            for suffix, t in (("", p.w),) + ((("/Momentum", p.acc_w),) if slots else ()):
+                hwio = t.detach().cpu().numpy().transpose(1, 2, 3, 0)          # [O,KH,KW,I] -> [KH,KW,I,O]
+                if hwio.size != ref.size:
+                    raise ValueError("%s: device filter has %d values, variable %d (channel-folded stem filters are not exportable)"
+                                     % (wname, hwio.size, ref.size))
+                out[wname + suffix] = np.ascontiguousarray(hwio).reshape(ref.shape)
+            if p.bias is not None:
+                out[bname] = p.bias.detach().cpu().numpy().copy()
+                if slots:
+                    out[bname + "/Momentum"] = p.acc_b.detach().cpu().numpy().copy()
+        return out
+
+    def import_slots(self, reader_or_dict):
+        """Restore the momentum accumulators written by export_variables(slots=True)."""
+        get = reader_or_dict.get_tensor if hasattr(reader_or_dict, "get_tensor") else reader_or_dict.__getitem__
+        for p in self.params.values():
+            wname, bname = self._names(p)
+            acc = np.asarray(get(wname + "/Momentum"), dtype=np.float32)
+            kh, kw = p.w.shape[1], p.w.shape[2]
+            acc = acc.reshape(kh, kw, p.w.shape[3], p.w.shape[0]).transpose(3, 0, 1, 2)
+            p.acc_w.copy_(torch.from_numpy(np.ascontiguousarray(acc)))
+            if p.bias is not None:
+                p.acc_b.copy_(torch.from_numpy(np.asarray(get(bname + "/Momentum"), dtype=np.float32)))
 
     def regularization_loss(self, out):
         """slim l2_regularizer(WEIGHT_DECAY): wd * sum(w^2)/2 over every conv / fc weight (network.py:315-317)."""

@@ -5,8 +5,12 @@ SolverWrapper keeps the reference's schedule semantics: momentum SGD (MomentumOp
 learning rate multiplied by cfg.TRAIN.GAMMA at every cfg.TRAIN.STEPSIZE entry (:269-274), a progress line every
 cfg.TRAIN.DISPLAY iterations in the reference's format (:298-302).  Data-parallel: one process per GPU, one image
 per rank per step, one bucketed RCCL all-reduce of the flat gradient buffer (new relative to the reference, which
-trains on a single GPU with IMS_PER_BATCH 1).  Checkpointing / roidb feeding / TensorBoard are out of scope
-(SURVEY.md 2); `data_layer` is any iterator of blobs {'data','im_info','gt_boxes'}."""
+trains on a single GPU with IMS_PER_BATCH 1).  Checkpoints are TensorFlow V2 bundles read / written without TensorFlow
+(frcnn_hip/tensor_bundle.py): `initialize` = ImageNet weights + fix_variables (:177-202), `snapshot` = Saver.save of the
+variables, the Momentum slots and a `.pkl` with the iteration (:58-100), `restore` (:204-233).  roidb feeding / TensorBoard
+are out of scope; `data_layer` is any iterator of blobs {'data','im_info','gt_boxes'}."""
+import os
+import pickle
 import time
 
 import numpy as np
@@ -22,13 +26,66 @@ class SolverWrapper(object):
                                 double_bias=cfg.TRAIN.DOUBLE_BIAS, bias_decay=cfg.TRAIN.BIAS_DECAY)
         self.state.all_reduce, self.state.world_size = all_reduce, world_size
 
-    def train_model(self, max_iters, verbose=True):
+    # ---- checkpoints -------------------------------------------------------------------------------------------------
+    def get_variables_in_checkpoint_file(self, file_name):
+        """train_val.py:105-114 (pywrap_tensorflow.NewCheckpointReader(...).get_variable_to_shape_map())."""
+        from frcnn_hip.tensor_bundle import BundleReader
+        try:
+            return BundleReader(file_name).get_variable_to_shape_map()
+        except Exception as e:                                                    # the reference prints and carries on
+            print(str(e))
+            if "corrupted compressed block contents" in str(e):
+                print("It's likely that your checkpoint file has been compressed with SNAPPY.")
+
+    def initialize(self, pretrained_model):
+        """train_val.py:177-202: restore what the ImageNet checkpoint holds, then the per-network fixes (RGB->BGR stem,
+        VGG fc6/fc7 reshape, MobileNet input scale).  Call after sess.init_variables(net.variable_specs())."""
+        print('Loading initial model weights from {:s}'.format(pretrained_model))
+        var_keep_dic = self.get_variables_in_checkpoint_file(pretrained_model)
+        names = self.net.get_variables_to_restore(list(self.sess.variables), var_keep_dic)
+        self.sess.restore(pretrained_model, names)
+        print('Loaded.')
+        self.net.fix_variables(self.sess, pretrained_model)
+        print('Fixed.')
+        return cfg.TRAIN.LEARNING_RATE, 0, list(cfg.TRAIN.STEPSIZE)
+
+    def snapshot(self, it, output_dir):
+        """train_val.py:58-100: `<prefix>_iter_<it>.ckpt` (variables + Momentum slots + global_step) and a .pkl with the
+        iteration (the reference also pickles numpy RNG / data-layer cursors; the sampling here is seeded per step)."""
+        os.makedirs(output_dir, exist_ok=True)
+        base = os.path.join(output_dir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_{:d}'.format(it))
+        extra = self.state.export_variables(slots=True) if self.state.params else {}
+        for k, v in extra.items():                                                # trained values replace the initial ones
+            if not k.endswith("/Momentum"):
+                self.sess.variables[k] = v
+        extra["global_step"] = np.array(it, dtype=np.int64)
+        self.sess.save(base + '.ckpt', {k: v for k, v in extra.items() if k.endswith("/Momentum") or k == "global_step"})
+        with open(base + '.pkl', 'wb') as f:
+            pickle.dump({'iter': it, 'sample_seed': int(self.net._sample_seed)}, f, pickle.HIGHEST_PROTOCOL)
+        print('Wrote snapshot to: {:s}'.format(base + '.ckpt'))
+        return base + '.ckpt', base + '.pkl'
+
+    def restore(self, sfile, nfile):
+        """train_val.py:204-233: weights + optimizer slots + iteration from a snapshot; returns the iteration."""
+        from frcnn_hip.tensor_bundle import BundleReader
+        print('Restoring model snapshots from {:s}'.format(sfile))
+        self.sess.restore(sfile)
+        self.state.pending_slots = BundleReader(sfile)           # imported right after TrainState.build(), before the first update
+        with open(nfile, 'rb') as f:
+            meta = pickle.load(f)
+        self.net._sample_seed = meta.get('sample_seed', 0)        # the fg/bg sampling stream continues where it stopped
+        return meta['iter']
+
+    def train_model(self, max_iters, verbose=True, start_iter=0, snapshot_dir=None):
         lr = cfg.TRAIN.LEARNING_RATE
         stepsizes = sorted(cfg.TRAIN.STEPSIZE, reverse=True)
         next_stepsize = stepsizes.pop() if stepsizes else None
         history = []
         t0 = time.time()
-        for it in range(1, max_iters + 1):
+        while next_stepsize is not None and start_iter > next_stepsize:          # resumed past a step: :225-231
+            lr *= cfg.TRAIN.GAMMA
+            next_stepsize = stepsizes.pop() if stepsizes else None
+        for it in range(start_iter + 1, max_iters + 1):
             if next_stepsize is not None and it == next_stepsize + 1:          # :269-274
                 lr *= cfg.TRAIN.GAMMA
                 next_stepsize = stepsizes.pop() if stepsizes else None
@@ -36,6 +93,8 @@ class SolverWrapper(object):
             blobs = next(self.data_layer)
             rpn_loss_cls, rpn_loss_box, loss_cls, loss_box, total_loss = self.net.train_step(self.sess, blobs, self.state)
             history.append(total_loss)
+            if snapshot_dir is not None and it % cfg.TRAIN.SNAPSHOT_ITERS == 0:
+                self.snapshot(it, snapshot_dir)
             if verbose and it % cfg.TRAIN.DISPLAY == 0:
                 print('iter: %d / %d, total loss: %.6f\n >>> rpn_loss_cls: %.6f\n >>> rpn_loss_box: %.6f\n >>> loss_cls: %.6f\n'
                       ' >>> loss_box: %.6f\n >>> lr: %f' % (it, max_iters, total_loss, rpn_loss_cls, rpn_loss_box, loss_cls, loss_box, lr))

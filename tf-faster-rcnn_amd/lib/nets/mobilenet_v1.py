@@ -5,6 +5,7 @@ Conv2d_0 = conv2d_same 3x3/2 (channel-folded MFMA GEMM), then 13 depthwise-separ
 depthwise 3x3 (VALU, bandwidth bound: frcnn_dwconv3x3_nhwc; stride 2 = explicit pad (1,1) + VALID,
 mobilenet_v1.py:41-49) and pointwise 1x1 (MFMA GEMM); frozen BN (eps 1e-3, :182) folded, ReLU6
 everywhere.  Layers 0-11 = stride-16 head (512 ch), layers 12-13 = per-RoI tail + spatial mean."""
+import numpy as np
 from frcnn_hip import ACT_RELU6, ops
 from model.config import cfg
 from nets.network import Network
@@ -16,6 +17,12 @@ _SEP = [(1, 64), (2, 128), (1, 128), (2, 256), (1, 256), (2, 512), (1, 512), (1,
 
 
 class mobilenetv1(Network):
+    _rgb_first_conv = "/Conv2d_0"
+
+    def _fix_one(self, name, value):
+        # mobilenet_v1.py:266-278: tf.reverse(Conv2d_0_rgb / (255.0 / 2.0), [2]) -- the released weights expect [-1,1] inputs
+        return np.ascontiguousarray((value / np.float32(255.0 / 2.0))[:, :, ::-1, :]).astype(np.float32)
+
     def __init__(self):
         Network.__init__(self)
         self._feat_stride = [16, ]

@@ -123,6 +123,40 @@ class Network(object):
         sess.mark("op:wino_out", 0, lambda: ops.winograd_output_transform(mm, b, act, out, m))
         return out
 
+    # ------------------------------------------------------------------ ImageNet-pretrained weights (train_val.py:177-202)
+    _rgb_first_conv = None                   # scope tail of the stem conv whose input channels are RGB in the released weights
+
+    def get_variables_to_restore(self, variables, var_keep_dic):
+        """Names to restore verbatim from a pretrained checkpoint: everything the checkpoint has, minus the variables
+        fix_variables() rewrites (resnet_v1.py:154-167, vgg16.py:62-79, mobilenet_v1.py:253-264)."""
+        skip = set(self._variables_to_fix_names())
+        self._variables_to_fix = {}
+        keep = []
+        for name in variables:
+            if name in skip:
+                self._variables_to_fix[name] = True
+                continue
+            if name in var_keep_dic:
+                keep.append(name)
+        return keep
+
+    def _variables_to_fix_names(self):
+        return [] if self._rgb_first_conv is None else [self._scope + self._rgb_first_conv + "/weights"]
+
+    def fix_variables(self, sess, pretrained_model):
+        """RGB -> BGR on the stem filter (`tf.reverse(conv1_rgb, [2])`, resnet_v1.py:168-178); subclasses add their own."""
+        from frcnn_hip.tensor_bundle import BundleReader
+        reader = BundleReader(pretrained_model)
+        fixed = {}
+        for name in self._variables_to_fix_names():
+            fixed[name] = self._fix_one(name, reader.get_tensor(name))
+        sess.load_variables(fixed)
+        sess.conv_info.clear()
+        return sorted(fixed)
+
+    def _fix_one(self, name, value):
+        return np.ascontiguousarray(value[:, :, ::-1, :])
+
     def trainable_scope(self, scope):
         """Which filters the solver updates (reference: `trainable=` flags of the slim layers)."""
         return True
@@ -341,12 +375,6 @@ class Network(object):
         names = ["rois", "rpn_cls_score", "rpn_cls_prob", "rpn_bbox_pred", "cls_score", "cls_prob", "bbox_pred"]
         return {k: k for k in names}
 
-    def get_variables_to_restore(self, variables, var_keep_dic):
-        raise NotImplementedError
-
-    def fix_variables(self, sess, pretrained_model):
-        raise NotImplementedError
-
     # ------------------------------------------------------------------ execution
     def _stage_image(self, sess, image):
         """[1,H,W,3] (BGR - PIXEL_MEANS, like blobs['data']) -> static device buffer [1,H,W,4]; the
@@ -428,6 +456,9 @@ class Network(object):
         losses = self.train_forward(sess, blobs)
         if not train_op.params:
             train_op.build()
+            if getattr(train_op, "pending_slots", None) is not None:          # resumed run: momentum before the first update
+                train_op.import_slots(train_op.pending_slots)
+                train_op.pending_slots = None
         train_op.backward(self._loss_seeds)
         total = sess.buf(self._tag + "/total_loss", (1,))
         train_op.regularization_loss(total)

@@ -3,6 +3,7 @@ libfrcnn_hip.so: 13 3x3 SAME conv+bias+ReLU layers (implicit GEMM on the f32 MFM
 SAME max pools -> stride-16 conv5_3; RoI pooling = 14x14 crop + 2x2 max (network.py:141-157, fused in
 one kernel); fc6/fc7 as a 7x7 VALID conv and a 1x1 conv over the [R,7,7,512] crops (slim.flatten is
 NHWC order, so fc6's [25088,4096] matrix IS the HWIO filter [7,7,512,4096])."""
+import numpy as np
 from frcnn_hip import ACT_RELU, ops
 from nets.network import Network
 
@@ -10,6 +11,17 @@ _CFG = [("conv1", 2, 64), ("conv2", 2, 128), ("conv3", 3, 256), ("conv4", 3, 512
 
 
 class vgg16(Network):
+    _rgb_first_conv = "/conv1/conv1_1"
+
+    def _variables_to_fix_names(self):
+        # vgg16.py:62-79: the ImageNet checkpoint stores fc6 / fc7 as conv filters [7,7,512,4096] / [1,1,4096,4096]
+        return [self._scope + t + "/weights" for t in ("/fc6", "/fc7", "/conv1/conv1_1")]
+
+    def _fix_one(self, name, value):
+        if name.endswith("/fc6/weights") or name.endswith("/fc7/weights"):        # tf.reshape(fc6_conv, fc6.get_shape()), :93-96
+            return np.ascontiguousarray(value).reshape(self._var_specs[name].shape)
+        return np.ascontiguousarray(value[:, :, ::-1, :])                         # tf.reverse(conv1_rgb, [2]), :97-98
+
     def __init__(self):
         Network.__init__(self)
         self._feat_stride = [16, ]
