@@ -12,6 +12,7 @@ shapes = {  # name: (N,H,W,Cin,Cout,k,pad)
  "b3c1x4": (4,38,63,1024,256,1,0), "b3c2x4": (4,38,63,256,256,3,1), "b3c3x4": (4,38,63,256,1024,1,0), "rpnx4": (4,38,63,1024,512,3,1),
  "b2c2x4": (4,75,125,128,128,3,1), "b2c3x4": (4,75,125,128,512,1,0), "b2c1x4": (4,75,125,512,128,1,0), "b1c2x4": (4,150,250,64,64,3,1),
  "b1c3x4": (4,150,250,64,256,1,0), "b1c1x4": (4,150,250,256,64,1,0),
+ "b4c1x4": (1200,7,7,2048,512,1,0), "b4c3x4": (1200,7,7,512,2048,1,0),
  "b4c1": (300,7,7,2048,512,1,0), "b4c2": (300,7,7,512,512,3,1), "b4c3": (300,7,7,512,2048,1,0),
 }
 cfgs = [int(c) for c in sys.argv[1].split(",")]
