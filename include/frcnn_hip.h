@@ -150,6 +150,16 @@ int frcnn_conv2d_nhwc(const float* x_d, int N, int H, int W, int Cin, const floa
                       const float* residual_d, int RH, int RW, int res_stride, float* y_d, int OH, int OW,
                       int Cout, int KH, int KW, int stride, int pad_top, int pad_left, int act, int fold_w,
                       void* stream);
+/* frcnn_conv2d_nhwc with a scratch buffer: launches that would leave most of the 256 CUs idle (a single 38x63 image,
+ * weight-gradient GEMMs) are cut along K into S workgroup sets writing separate partial sums (no atomics, deterministic),
+ * then reduced with bias / residual / activation.  frcnn_conv2d_workspace_bytes: bytes that make the split possible for
+ * this shape (0: the plain launch is used anyway).  Same arguments and results (to f32 summation order) otherwise. */
+size_t frcnn_conv2d_workspace_bytes(int N, int OH, int OW, int Cout, int KH, int KW, int Cin, int fold_w);
+int frcnn_conv2d_nhwc_ws(const float* x_d, int N, int H, int W, int Cin, const float* w_d, const float* bias_d,
+                         const float* residual_d, int RH, int RW, int res_stride, float* y_d, int OH, int OW, int Cout, int KH,
+                         int KW, int stride, int pad_top, int pad_left, int act, int fold_w, void* ws, size_t ws_bytes,
+                         void* stream);
+
 /* Tuning knobs for A/B experiments: key 0 = force conv tile configuration id (-1 = automatic); key 1 = ablation bits;
  * key 2 = 1 enables the EXPERIMENTAL bf16x3 split-operand MFMA path for every non-stem conv (f32 in/out, f32-class
  * accuracy, see csrc/conv_igemm_b3.hip); key 3 = force its tile configuration. */
@@ -261,6 +271,10 @@ int frcnn_sgd_momentum(float* w_d, float* acc_d, float* w_folded_d, const float*
                        long long n, int K, float lr, float momentum, float weight_decay, float grad_scale, void* stream);
 /* out (+)= scale * sum(w^2)   (slim l2_regularizer value); ws >= 2 KiB. */
 int frcnn_sumsq(const float* w_d, long long n, double scale, float* out_d, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* The same over `count` tensors in two launches: ptr_table_d = device array of `count` float pointers, sizes_d = their
+ * element counts; *out_d (+)= scale * sum over all tensors of sum(w^2); ws >= 8 * count doubles.  Deterministic. */
+int frcnn_sumsq_multi(const void* ptr_table_d, const long long* sizes_d, int count, double scale, float* out_d, int accumulate,
+                      void* ws, size_t ws_bytes, void* stream);
 
 /* ---- stream capture (one hipGraph per image-shape; replaces the per-image sess.run) ---------- */
 int frcnn_graph_begin(void* stream);

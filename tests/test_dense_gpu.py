@@ -270,3 +270,46 @@ def test_prep_image_properties(dev):
     ramp = np.tile(np.arange(50, dtype=np.float32)[None, :, None], (40, 1, 3))
     r = ops.prep_image(torch.from_numpy(ramp).to(dev), np.zeros(3), 1.6, (64, 80), out_c=3).cpu().numpy()[0]
     assert np.allclose(r[10, :4, 0], [0, 0.4375, 1.0625, 1.6875]) and r[10, -1, 0] == 49    # pixel-centre alignment, clamped edges
+
+
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin, Cout, k, stride, pad, act, residual(res_stride or 0), bias
+    (1, 38, 63, 1024, 256, 1, 1, (0, 0, 0, 0), 1, 0, True),        # block3 conv1, one image: 152 tiles -> split 4
+    (1, 38, 63, 256, 256, 3, 1, (1, 1, 1, 1), 1, 0, True),         # 3x3: splits start inside a tap (c0 != 0) and at tap boundaries
+    (1, 38, 63, 512, 512, 1, 1, (0, 0, 0, 0), 1, 1, True),         # + residual + ReLU in the finish kernel
+    (1, 19, 32, 512, 128, 3, 2, (1, 1, 1, 1), 0, 2, False),        # stride 2 + subsampled residual, no bias
+    (1, 1, 256, 2400, 2304, 1, 1, (0, 0, 0, 0), 0, 0, False),      # weight-gradient shape: dW[256][2304] over 2400 positions
+    (1, 38, 63, 512, 18, 1, 1, (0, 0, 0, 0), 0, 0, True),          # RPN score head (Cout <= 32 tile path)
+], ids=lambda c: "%dx%dx%d-%d-k%d" % (c[1], c[2], c[3], c[4], c[5]))
+def test_conv2d_split_k_equals_plain_launch(dev, case):
+    """Under-filled launches run split-K (frcnn_conv2d_nhwc_ws): same 2e-5 bound vs float64 as the plain kernel, equal to
+    it up to f32 summation order, and deterministic (partials are stored, not atomically added)."""
+    import frcnn_hip
+    from frcnn_hip import ops
+    N, H, W, Cin, Cout, k, stride, pad, act, res, has_bias = case
+    rng = np.random.RandomState(Cin + Cout)
+    x = rng.randn(N, H, W, Cin).astype(np.float32)
+    w = (rng.randn(k, k, Cin, Cout) * np.sqrt(2.0 / (k * k * Cin))).astype(np.float32)
+    b = rng.randn(Cout).astype(np.float32) if has_bias else None
+    OH, OW = ops.conv_out_size(H, k, stride, pad[0], pad[1]), ops.conv_out_size(W, k, stride, pad[2], pad[3])
+    assert frcnn_hip.lib().frcnn_conv2d_workspace_bytes(N, OH, OW, Cout, k, k, Cin, 0) > 0          # the split path really runs
+    r = rng.randn(N, (OH - 1) * res + 1, (OW - 1) * res + 1, Cout).astype(np.float32) if res else None
+    ref = ref_conv(x, w, b, stride, pad, act, r, res if res else 1)
+    xd, wd = torch.from_numpy(x).to(dev), torch.from_numpy(ops.pack_filter_hwio(w)).to(dev)
+    bd = None if b is None else torch.from_numpy(b).to(dev)
+    rd = None if r is None else torch.from_numpy(r).to(dev)
+    outs = []
+    for flag in (True, True, False):
+        ops.split_k = flag
+        try:
+            outs.append(ops.conv2d(xd, wd, bd, k, k, stride, pad, act, rd, res if res else 1).cpu().numpy())
+        finally:
+            ops.split_k = True
+    scale = np.abs(ref).max()
+    assert np.array_equal(outs[0], outs[1])                                  # deterministic
+    assert np.abs(outs[0] - ref).max() <= 2e-5 * scale and np.abs(outs[2] - ref).max() <= 2e-5 * scale
+    assert np.abs(outs[0] - outs[2]).max() <= 1e-5 * scale
+    if res == 1:                                                             # in-place accumulation (residual is the output buffer)
+        acc = rd.clone()
+        ops.conv2d(xd, wd, bd, k, k, stride, pad, act, acc, 1, out=acc)
+        assert np.array_equal(acc.cpu().numpy(), outs[0])

@@ -286,6 +286,44 @@ __global__ void k_sumsq_finish(const double* __restrict__ partial, int nb, doubl
   for (int i = 0; i < nb; ++i) s += partial[i];
   *out = (accumulate ? *out : 0.f) + (float)(s * scale);
 }
+// All regularised tensors in two launches (the per-tensor form costs two launches per filter: 320 per ResNet-152 step).
+// grid = (SSQ_BLOCKS, count): block (b, t) reduces a strided part of tensor t; one block then adds the partials in index order.
+#define SSQ_BLOCKS 8
+__global__ __launch_bounds__(256) void k_sumsq_multi(const float* const* __restrict__ ptrs, const long long* __restrict__ sizes,
+                                                     double* __restrict__ partial) {
+  __shared__ double sh[4];
+  const float* w = ptrs[blockIdx.y];
+  const long long n = sizes[blockIdx.y];
+  double s = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)SSQ_BLOCKS * 256) s += (double)w[i] * (double)w[i];
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.y * SSQ_BLOCKS + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ __launch_bounds__(256) void k_sumsq_multi_finish(const double* __restrict__ partial, int np, double scale,
+                                                            float* __restrict__ out, int accumulate) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < np; i += 256) s += partial[i];
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = (accumulate ? *out : 0.f) + (float)((sh[0] + sh[1] + sh[2] + sh[3]) * scale);
+}
+extern "C" int frcnn_sumsq_multi(const void* ptr_table_d, const long long* sizes_d, int count, double scale, float* out_d,
+                                 int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  if (!ptr_table_d || !sizes_d || !out_d || !ws || count <= 0 || count > 65535) return FRCNN_E_ARG;
+  if (ws_bytes < sizeof(double) * (size_t)count * SSQ_BLOCKS) return FRCNN_E_WS;
+  hipLaunchKernelGGL(k_sumsq_multi, dim3(SSQ_BLOCKS, count), dim3(256), 0, (hipStream_t)stream, (const float* const*)ptr_table_d, sizes_d,
+                     (double*)ws);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_sumsq_multi_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)ws, count * SSQ_BLOCKS, scale, out_d,
+                     accumulate);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
 extern "C" int frcnn_sumsq(const float* w_d, long long n, double scale, float* out_d, int accumulate, void* ws, size_t ws_bytes, void* stream) {
   if (!w_d || !out_d || !ws || n <= 0) return FRCNN_E_ARG;
   const int nb = (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);

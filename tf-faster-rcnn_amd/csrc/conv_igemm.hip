@@ -41,6 +41,8 @@ struct ConvParams {
   int batch;                       // grid.y (1 for convolutions)
   long long gx, gw, gy;            // batched GEMM use (grid.y = batch index): element strides of x / w / y per batch
   int dbg;                         // experiments only: bit0 skip MFMAs, bit1 skip slab loads after the prologue
+  int splits, kchunk;              // split-K: grid.z = splits, each covers kchunk slabs and writes raw partial sums to y + z*gz
+  long long gz;
 };
 
 #define GLOBAL_AS __attribute__((address_space(1)))
@@ -99,7 +101,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
   const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
   const float* const px = p.x + (size_t)blockIdx.y * p.gx;        // batched GEMM: independent problems along grid.y
   const float* const pw = p.w + (size_t)blockIdx.y * p.gw;
-  float* const py = p.y + (size_t)blockIdx.y * p.gy;
+  float* const py = p.y + (size_t)blockIdx.y * p.gy + (size_t)blockIdx.z * p.gz;
+  // split-K (under-filled launches: single images, weight gradients): this workgroup reduces slabs [s_begin, s_begin + nloc)
+  const int s_begin = (int)blockIdx.z * p.kchunk;
+  const int nloc = p.splits > 1 ? min(p.nsteps - s_begin, p.kchunk) : p.nsteps;
 
   // ---- per-lane source descriptors of the rows this lane stages -------------------------------
   const int lrow = lane >> 3, lpos = lane & 7;
@@ -131,10 +136,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
     const int n = bn0 + row - BM;
     const int q4 = (lpos ^ ((row >> 1) & 7)) * 4;
     const bool ok = n < p.Cout;
-    b_ptr[t] = ok ? pw + (size_t)n * p.Ktot + q4 : zero;
+    b_ptr[t] = ok ? pw + (size_t)n * p.Ktot + q4 + (size_t)s_begin * 32 : zero;
     b_inc[t] = ok ? 32 : 0;
   }
   int kh = 0, kw = 0, c0 = 0;                                   // k position of the NEXT slab to issue
+  if (!FOLDW && s_begin) {
+    const int k0 = s_begin * 32, tap = k0 / p.Cin;
+    c0 = k0 - tap * p.Cin;
+    kh = tap / p.KW;
+    kw = tap - kh * p.KW;
+  }
 
   auto set_tap = [&]() {
 #pragma unroll
@@ -143,7 +154,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
       bool ok = (unsigned)ih < (unsigned)p.H;
       if (FOLDW) ok = ok && ((unsigned)(iw + (a_q4[t] >> 2)) < (unsigned)p.W);
       else ok = ok && ((unsigned)iw < (unsigned)p.W);
-      a_ptr[t] = ok ? px + (size_t)(a_base[t] + (ih * p.W + iw) * p.Cin + a_q4[t]) : zero;
+      a_ptr[t] = ok ? px + (size_t)(a_base[t] + (ih * p.W + iw) * p.Cin + c0 + a_q4[t]) : zero;   // c0 != 0 only at a split's start
       a_inc[t] = ok ? 32 : 0;
     }
   };
@@ -191,16 +202,17 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
   const int a_row0 = (wm0 + frow) * 32, b_row0 = (BM + wn0 + frow) * 32;
 
   // ---- prologue: P slabs in flight ---------------------------------------------------------------
+  if (c0 != 0) set_tap();                                        // a split that starts inside a tap
 #pragma unroll
   for (int s = 0; s < P; ++s)
-    if (s < p.nsteps) issue_slab(s);
+    if (s < nloc) issue_slab(s);
 
-  for (int step = 0; step < p.nsteps; ++step) {
+  for (int step = 0; step < nloc; ++step) {
     // slab `step` must have landed: at most the P-1 younger slabs may still be in flight
-    if (step + P <= p.nsteps) wait_vmcnt<(P - 1) * G>();
+    if (step + P <= nloc) wait_vmcnt<(P - 1) * G>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();          // every wave finished slab step-1 and sees slab step
-    const bool more = (step + P < p.nsteps) && !(p.dbg & 2);
+    const bool more = (step + P < nloc) && !(p.dbg & 2);
     const int nbuf = (step + P) % NS;
     if (!ILV) { if (more) issue_slab(nbuf); }
     else if (more && c0 == 0) set_tap();
@@ -330,7 +342,7 @@ static int launch_conv(ConvParams p, hipStream_t st) {
   }
   p.mtiles = cdiv(p.M, BM);
   p.ntiles = cdiv(p.Cout, BN);
-  hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles, p.batch), dim3(NT), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles, p.batch, p.splits), dim3(NT), lds, st, p);
   LAUNCH_CHECK();
   return FRCNN_OK;
 }
@@ -375,10 +387,81 @@ static int launch_cfg(int id, const ConvParams& p, hipStream_t st) {
   }
 }
 
+// ---- split-K for under-filled launches ------------------------------------------------------------------------------
+// A 38x63 feature map of ONE image gives 38 x Cout/64 tiles (152 for Cout = 256) and a weight-gradient GEMM Cout/64 x K/64
+// tiles for 256 CUs x 2..5 resident workgroups.  Such launches are cut along K: grid.z = S workgroup sets, each reduces
+// kchunk slabs into its own [M][Cout] partial (plain stores, no atomics -> deterministic), then k_splitk_finish adds the S
+// partials in a fixed order and applies bias / residual / activation.
+static int plan_splits(int M, int Cout, int nsteps) {
+  if (g_force_cfg >= 0 || g_b3) return 1;
+  const long long big = (long long)cdiv(M, 128) * cdiv(Cout, 128);
+  if (Cout >= 96 && big >= 384 && nsteps >= 8) return 1;
+  const long long tiles = (long long)cdiv(M, 64) * cdiv(Cout, Cout > 32 ? 64 : 32);
+  if (tiles >= 384 || nsteps < 16) return 1;
+  int S = (int)min((long long)8, (640 + tiles - 1) / tiles);
+  S = min(S, nsteps / 8);
+  if (S < 2) return 1;
+  const int kchunk = cdiv(nsteps, S);
+  return cdiv(nsteps, kchunk);
+}
+
+extern "C" size_t frcnn_conv2d_workspace_bytes(int N, int OH, int OW, int Cout, int KH, int KW, int Cin, int fold_w) {
+  if (fold_w || N <= 0 || OH <= 0 || OW <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || Cin <= 0 || Cin % 32) return 0;
+  const long long M = (long long)N * OH * OW;
+  if (M >= (1ll << 29)) return 0;
+  const int S = plan_splits((int)M, Cout, KH * KW * (Cin / 32));
+  return S > 1 ? (size_t)S * (size_t)M * (size_t)Cout * sizeof(float) : 0;
+}
+
+__global__ void k_splitk_finish(const float* __restrict__ part, int S, int M, int Cout, const float* __restrict__ bias,
+                                const float* res, int res_stride, int OH, int OW, int RH, int RW, int act,
+                                float* y) {      // res may alias y (in-place gradient accumulation): no __restrict__ on the pair
+  const long long total = (long long)M * Cout;
+  const int ohow = OH * OW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    float v = part[i];
+    for (int s = 1; s < S; ++s) v += part[(size_t)s * total + i];
+    const int m = (int)(i / Cout), n = (int)(i - (long long)m * Cout);
+    if (bias) v += bias[n];
+    if (res) {
+      size_t ro;
+      if (res_stride == 1) ro = (size_t)i;
+      else {
+        const int img = m / ohow, rem = m % ohow, oh = rem / OW, ow = rem % OW;
+        ro = ((size_t)(img * RH + oh * res_stride) * RW + ow * res_stride) * Cout + n;
+      }
+      v += res[ro];
+    }
+    if (act == FRCNN_ACT_RELU) v = fmaxf(v, 0.f);
+    else if (act == FRCNN_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+    y[i] = v;
+  }
+}
+
+static int conv2d_impl(const float* x_d, int N, int H, int W, int Cin, const float* w_d, const float* bias_d,
+                       const float* residual_d, int RH, int RW, int res_stride, float* y_d, int OH, int OW, int Cout, int KH, int KW,
+                       int stride, int pad_top, int pad_left, int act, int fold_w, void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int frcnn_conv2d_nhwc(const float* x_d, int N, int H, int W, int Cin, const float* w_d, const float* bias_d,
                                  const float* residual_d, int RH, int RW, int res_stride, float* y_d, int OH, int OW,
                                  int Cout, int KH, int KW, int stride, int pad_top, int pad_left, int act, int fold_w,
                                  void* stream) {
+  return conv2d_impl(x_d, N, H, W, Cin, w_d, bias_d, residual_d, RH, RW, res_stride, y_d, OH, OW, Cout, KH, KW, stride, pad_top,
+                     pad_left, act, fold_w, nullptr, 0, stream);
+}
+
+// Same convolution with a scratch buffer of frcnn_conv2d_workspace_bytes(...) bytes: under-filled launches run split-K.
+extern "C" int frcnn_conv2d_nhwc_ws(const float* x_d, int N, int H, int W, int Cin, const float* w_d, const float* bias_d,
+                                    const float* residual_d, int RH, int RW, int res_stride, float* y_d, int OH, int OW,
+                                    int Cout, int KH, int KW, int stride, int pad_top, int pad_left, int act, int fold_w,
+                                    void* ws, size_t ws_bytes, void* stream) {
+  return conv2d_impl(x_d, N, H, W, Cin, w_d, bias_d, residual_d, RH, RW, res_stride, y_d, OH, OW, Cout, KH, KW, stride, pad_top,
+                     pad_left, act, fold_w, ws, ws_bytes, stream);
+}
+
+static int conv2d_impl(const float* x_d, int N, int H, int W, int Cin, const float* w_d, const float* bias_d,
+                       const float* residual_d, int RH, int RW, int res_stride, float* y_d, int OH, int OW, int Cout, int KH, int KW,
+                       int stride, int pad_top, int pad_left, int act, int fold_w, void* ws, size_t ws_bytes, void* stream) {
   if (!x_d || !w_d || !y_d) return FRCNN_E_ARG;
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0)
     return FRCNN_E_ARG;
@@ -399,14 +482,30 @@ extern "C" int frcnn_conv2d_nhwc(const float* x_d, int N, int H, int W, int Cin,
   p.Ktot = fold_w ? KH * 32 : KH * KW * Cin;
   p.nsteps = fold_w ? KH : KH * KW * (Cin / 32);
   p.mtiles = p.ntiles = 0;
-  p.gx = p.gw = p.gy = 0;
+  p.gx = p.gw = p.gy = p.gz = 0;
   p.batch = 1;
+  p.splits = 1; p.kchunk = p.nsteps;
   p.dbg = g_dbg;
   hipStream_t st = (hipStream_t)stream;
   if (fold_w) return launch_conv<128, 64, 32, 64, 3, true>(p, st);
   if (g_b3) return frcnn_conv2d_b3_dispatch(x_d, N, H, W, Cin, w_d, bias_d, residual_d, RH, RW, res_stride, y_d, OH, OW, Cout, KH,
                                             KW, stride, pad_top, pad_left, act, g_b3_cfg, st);
   if (g_force_cfg >= 0) return launch_cfg(g_force_cfg, p, st);
+  if (ws) {
+    const int S = plan_splits(p.M, Cout, p.nsteps);
+    if (S > 1 && (size_t)S * p.M * Cout * sizeof(float) <= ws_bytes) {
+      ConvParams q = p;
+      q.bias = nullptr; q.res = nullptr; q.act = FRCNN_ACT_NONE; q.y = (float*)ws;
+      q.kchunk = cdiv(p.nsteps, S); q.splits = S; q.gz = (long long)p.M * Cout;
+      const int rc = launch_cfg(Cout > 32 ? 7 : 4, q, st);
+      if (rc) return rc;
+      const long long total = (long long)p.M * Cout;
+      hipLaunchKernelGGL(k_splitk_finish, dim3((unsigned)min((long long)2048, (total + 255) / 256)), dim3(256), 0, st, (const float*)ws, S,
+                         p.M, Cout, bias_d, residual_d, p.res_stride, OH, OW, RH, RW, act, y_d);
+      LAUNCH_CHECK();
+      return FRCNN_OK;
+    }
+  }
   // Tile choice, from the measured sweep (profiles/r01_conv_tile_sweep.txt).  f32 MFMA needs few
   // bytes per FLOP, so the limiter is never LDS or HBM but (a) how many of the 1024 SIMDs get a wave
   // and (b) the per-slab barrier/ds_read overhead: 128x128 tiles with 8 waves (2 accumulators each)
@@ -429,9 +528,10 @@ extern "C" int frcnn_gemm_batched_nt(const float* x_d, const float* w_d, float* 
   p.stride = 1; p.pad_top = 0; p.pad_left = 0; p.act = FRCNN_ACT_NONE;
   p.RH = p.RW = 0; p.res_stride = 1;
   p.M = M; p.Ktot = K; p.nsteps = K / 32; p.mtiles = p.ntiles = 0;
-  p.gx = (long long)M * K; p.gw = (long long)N * K; p.gy = (long long)M * N;
+  p.gx = (long long)M * K; p.gw = (long long)N * K; p.gy = (long long)M * N; p.gz = 0;
   p.dbg = 0;
   p.batch = G;
+  p.splits = 1; p.kchunk = p.nsteps;
   const long long big = (long long)cdiv(M, 128) * cdiv(N, 128) * G;
   if (g_force_cfg >= 0) return launch_cfg(g_force_cfg, p, (hipStream_t)stream);
   return (N >= 96 && big >= 384 && p.nsteps >= 8) ? launch_cfg(N >= 1024 ? 10 : 0, p, (hipStream_t)stream)

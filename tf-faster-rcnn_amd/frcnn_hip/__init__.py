@@ -42,6 +42,9 @@ SIGNATURES = {
     "frcnn_bbox_overlaps": (c_int, [_P, c_int, _P, c_int, _P, _P]),
     "frcnn_conv2d_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "frcnn_conv2d_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "frcnn_conv2d_nhwc_ws": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int,
+                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "frcnn_crc32c": (ctypes.c_uint32, [_P, c_size_t, ctypes.c_uint32]),
     "frcnn_prep_image_shape": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P]),
     "frcnn_prep_image": (c_int, [_P, c_int, c_int, c_int, _P, c_double, _P, c_int, c_int, c_int, _P]),
@@ -77,6 +80,7 @@ SIGNATURES = {
     "frcnn_crop_and_resize_bwd": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_float, c_int, _P, _P]),
     "frcnn_sgd_momentum": (c_int, [_P, _P, _P, _P, _P, c_longlong, c_int, c_float, c_float, c_float, c_float, _P]),
     "frcnn_sumsq": (c_int, [_P, c_longlong, c_double, _P, c_int, _P, c_size_t, _P]),
+    "frcnn_sumsq_multi": (c_int, [_P, _P, c_int, c_double, _P, c_int, _P, c_size_t, _P]),
     "frcnn_graph_begin": (c_int, [_P]),
     "frcnn_graph_end": (c_int, [_P, ctypes.POINTER(c_void_p)]),
     "frcnn_graph_launch": (c_int, [_P, _P]),

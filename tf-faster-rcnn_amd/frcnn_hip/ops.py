@@ -12,6 +12,7 @@ import torch
 from . import ACT_NONE, call, lib
 
 _ws_cache = {}
+_ws_retired = []
 ws_scope = "default"     # set by callers that run several independent chains concurrently (one scope per stream)
 
 
@@ -36,6 +37,8 @@ def workspace(nbytes, device, tag="default"):
     key = (str(device), tag, ws_scope)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _ws_retired.append(buf)         # a captured hipGraph may still hold this address: never hand it back to the allocator
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
@@ -247,6 +250,9 @@ def conv_out_size(n, k, stride, pad_lo, pad_hi):
     return (n + pad_lo + pad_hi - k) // stride + 1
 
 
+split_k = True      # module switch: allow split-K launches (frcnn_conv2d_nhwc_ws) where the library's plan asks for them
+
+
 def conv2d(x, w_packed, bias, KH, KW, stride=1, pad=(0, 0, 0, 0), act=ACT_NONE, residual=None, res_stride=1,
            fold_w=False, out=None):
     """x [N,H,W,Cin]; w_packed [Cout,KH,KW,Cin] (fold_w: [Cout,KH,8,4]); pad = (top, bottom, left, right)."""
@@ -260,6 +266,13 @@ def conv2d(x, w_packed, bias, KH, KW, stride=1, pad=(0, 0, 0, 0), act=ACT_NONE, 
     if residual is not None:
         _chk(residual)
         RH, RW = residual.shape[1], residual.shape[2]
+    nb = lib().frcnn_conv2d_workspace_bytes(N, OH, OW, Cout, KH, KW, Cin, 1 if fold_w else 0) if split_k else 0
+    if nb:                                  # under-filled launch: split-K through a per-chain scratch buffer
+        ws = workspace(nb, x.device, "conv_splitk")
+        call("frcnn_conv2d_nhwc_ws", _ptr(x), N, H, W, Cin, _ptr(w_packed), _ptr(bias), _ptr(residual), RH, RW,
+             int(res_stride), _ptr(out), OH, OW, Cout, KH, KW, int(stride), int(pad[0]), int(pad[2]), int(act),
+             1 if fold_w else 0, _ptr(ws), ws.numel(), _stream())
+        return out
     call("frcnn_conv2d_nhwc", _ptr(x), N, H, W, Cin, _ptr(w_packed), _ptr(bias), _ptr(residual), RH, RW,
          int(res_stride), _ptr(out), OH, OW, Cout, KH, KW, int(stride), int(pad[0]), int(pad[2]), int(act),
          1 if fold_w else 0, _stream())
@@ -539,6 +552,15 @@ def sgd_momentum(w, acc, w_folded, grad, scale, K, lr, momentum, weight_decay, g
 def sumsq(w, scale, out, accumulate):
     ws = workspace(4096, w.device, "sumsq")
     call("frcnn_sumsq", _ptr(w), w.numel(), float(scale), _ptr(out), 1 if accumulate else 0, _ptr(ws), ws.numel(), _stream())
+
+
+def sumsq_multi(ptr_table, sizes, scale, out, accumulate=False):
+    """ptr_table int64 [count] (device pointers of float tensors), sizes int64 [count], both on device."""
+    count = ptr_table.numel()
+    ws = workspace(8 * 8 * count, out.device, "sumsq")
+    call("frcnn_sumsq_multi", _ptr(ptr_table), _ptr(sizes), count, float(scale), _ptr(out), 1 if accumulate else 0, _ptr(ws), ws.numel(),
+         _stream())
+    return out
 
 
 class Graph:

@@ -210,18 +210,23 @@ class TrainState(object):
                 p.acc_b.copy_(torch.from_numpy(np.asarray(get(bname + "/Momentum"), dtype=np.float32)))
 
     def regularization_loss(self, out):
-        """slim l2_regularizer(WEIGHT_DECAY): wd * sum(w^2)/2 over every conv / fc weight (network.py:315-317)."""
-        first = True
-        for sc in self.reg_scopes:
-            p = self.params.get(sc)
-            if p is not None:
-                w = p.w
-            else:
+        """slim l2_regularizer(WEIGHT_DECAY): wd * sum(w^2)/2 over every conv / fc weight (network.py:315-317), all tensors in
+        two launches (the master tensors are static, so the pointer table is built once)."""
+        if getattr(self, "_reg_table", None) is None:
+            tensors = []
+            for sc in self.reg_scopes:
+                p = self.params.get(sc)
+                if p is not None:
+                    tensors.append(p.w)
+                    continue
                 info = self.sess.conv_info[sc]
                 if "w_master" not in info:
                     info["w_master"] = info["w"] if info["scale"] is None else \
                         (info["w"] / torch.from_numpy(info["scale"]).to(info["w"].device).view(-1, 1, 1, 1)).contiguous()
-                w = info["w_master"]
-            ops.sumsq(w, 0.5 * self.weight_decay, out, not first)
-            first = False
+                tensors.append(info["w_master"])
+            dev = self.sess.device
+            self._reg_keep = tensors
+            self._reg_table = (torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64, device=dev),
+                               torch.tensor([t.numel() for t in tensors], dtype=torch.int64, device=dev))
+        ops.sumsq_multi(self._reg_table[0], self._reg_table[1], 0.5 * self.weight_decay, out, False)
         return out
