@@ -231,6 +231,13 @@ int frcnn_proposal_target_layer(const float* rpn_rois_d, const float* rpn_scores
                                 long long seed, float* rois_d, float* roi_scores_d, float* labels_d,
                                 float* bbox_targets_d, float* inside_w_d, float* outside_w_d, int* counts_d,
                                 void* stream);
+/* Same with the valid row count on the device (*num_rois_d = the proposal layer's num output; rows beyond it are ignored):
+ * no host round trip between the proposal layer and the target layer. */
+int frcnn_proposal_target_layer_dn(const float* rpn_rois_d, const float* rpn_scores_d, int max_rois, const int* num_rois_d,
+                                   const float* gt_boxes_d, int G, int num_classes, int batch_size, double fg_fraction,
+                                   double fg_thresh, double bg_thresh_hi, double bg_thresh_lo, const double* means4,
+                                   const double* stds4, long long seed, float* rois_d, float* roi_scores_d, float* labels_d,
+                                   float* bbox_targets_d, float* inside_w_d, float* outside_w_d, int* counts_d, void* stream);
 /* Losses of lib/nets/network.py:264-321, value + gradient w.r.t. the logits / predictions in one call.
  * softmax CE: logits [R,C] rows (rpn_A = 0) or the RPN pair layout (rpn_A = A: logits [H*W,2A], element
  * r = (a*H+h)*W+w pairs channels (a, A+a), labels_d in the [1,1,A*H,W] layout); label < 0 is ignored;
@@ -272,7 +279,7 @@ int frcnn_sgd_momentum(float* w_d, float* acc_d, float* w_folded_d, const float*
 /* out (+)= scale * sum(w^2)   (slim l2_regularizer value); ws >= 2 KiB. */
 int frcnn_sumsq(const float* w_d, long long n, double scale, float* out_d, int accumulate, void* ws, size_t ws_bytes, void* stream);
 /* The same over `count` tensors in two launches: ptr_table_d = device array of `count` float pointers, sizes_d = their
- * element counts; *out_d (+)= scale * sum over all tensors of sum(w^2); ws >= 8 * count doubles.  Deterministic. */
+ * element counts; *out_d (+)= scale * sum over all tensors of sum(w^2); ws >= 64 * count doubles.  Deterministic. */
 int frcnn_sumsq_multi(const void* ptr_table_d, const long long* sizes_d, int count, double scale, float* out_d, int accumulate,
                       void* ws, size_t ws_bytes, void* stream);
 

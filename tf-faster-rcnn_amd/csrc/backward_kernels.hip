@@ -288,7 +288,7 @@ __global__ void k_sumsq_finish(const double* __restrict__ partial, int nb, doubl
 }
 // All regularised tensors in two launches (the per-tensor form costs two launches per filter: 320 per ResNet-152 step).
 // grid = (SSQ_BLOCKS, count): block (b, t) reduces a strided part of tensor t; one block then adds the partials in index order.
-#define SSQ_BLOCKS 8
+#define SSQ_BLOCKS 64
 __global__ __launch_bounds__(256) void k_sumsq_multi(const float* const* __restrict__ ptrs, const long long* __restrict__ sizes,
                                                      double* __restrict__ partial) {
   __shared__ double sh[4];

@@ -209,7 +209,7 @@ extern "C" int frcnn_anchor_target_layer(const float* gt_boxes_d, int G, float i
 // ------------------------------------------------------------------------------------------------
 #define PT_MAXN 3072
 __global__ __launch_bounds__(1024) void k_proposal_target(const float* __restrict__ rois, const float* __restrict__ scores,
-                                                          int N, const float* __restrict__ gt, int G, int C, int batch,
+                                                          int Nmax, const int* __restrict__ num_d, const float* __restrict__ gt, int G, int C, int batch,
                                                           int fg_per_image, double fg_thresh, double bg_hi, double bg_lo,
                                                           u64 seed, float4 means, float4 stds, float* __restrict__ out_rois,
                                                           float* __restrict__ out_scores, float* __restrict__ out_labels,
@@ -221,6 +221,7 @@ __global__ __launch_bounds__(1024) void k_proposal_target(const float* __restric
   __shared__ short fg_list[PT_MAXN], bg_list[PT_MAXN];   // candidates in random (key) order
   __shared__ int nfg_s, nbg_s;
   const int tid = threadIdx.x;
+  const int N = num_d ? max(0, min(*num_d, Nmax)) : Nmax;      // device-resident proposal count: no host round trip
   if (tid == 0) { nfg_s = 0; nbg_s = 0; }
   __syncthreads();
   for (int i = tid; i < N; i += 1024) {
@@ -288,25 +289,50 @@ __global__ __launch_bounds__(1024) void k_proposal_target(const float* __restric
   }
 }
 
-extern "C" int frcnn_proposal_target_layer(const float* rpn_rois_d, const float* rpn_scores_d, int N, const float* gt_boxes_d,
-                                           int G, int num_classes, int batch_size, double fg_fraction, double fg_thresh,
-                                           double bg_thresh_hi, double bg_thresh_lo, const double* means4, const double* stds4,
-                                           long long seed, float* rois_d, float* roi_scores_d, float* labels_d,
-                                           float* bbox_targets_d, float* inside_w_d, float* outside_w_d, int* counts_d,
-                                           void* stream) {
+static int proposal_target_impl(const float* rpn_rois_d, const float* rpn_scores_d, int N, const int* num_d, const float* gt_boxes_d,
+                                int G, int num_classes, int batch_size, double fg_fraction, double fg_thresh,
+                                double bg_thresh_hi, double bg_thresh_lo, const double* means4, const double* stds4,
+                                long long seed, float* rois_d, float* roi_scores_d, float* labels_d,
+                                float* bbox_targets_d, float* inside_w_d, float* outside_w_d, int* counts_d,
+                                void* stream) {
   if (!rpn_rois_d || !rpn_scores_d || !gt_boxes_d || !means4 || !stds4 || !rois_d || !roi_scores_d || !labels_d ||
       !bbox_targets_d || !inside_w_d || !outside_w_d || !counts_d)
     return FRCNN_E_ARG;
   if (N <= 0 || G <= 0 || num_classes < 2 || batch_size <= 0) return FRCNN_E_ARG;
   if (N > PT_MAXN || G > 32767) return FRCNN_E_UNSUPPORTED;
   const int fg_per_image = (int)nearbyint(fg_fraction * batch_size);     // np.round (:40)
-  hipLaunchKernelGGL(k_proposal_target, dim3(1), dim3(1024), 0, (hipStream_t)stream, rpn_rois_d, rpn_scores_d, N, gt_boxes_d,
+  hipLaunchKernelGGL(k_proposal_target, dim3(1), dim3(1024), 0, (hipStream_t)stream, rpn_rois_d, rpn_scores_d, N, num_d, gt_boxes_d,
                      G, num_classes, batch_size, fg_per_image, fg_thresh, bg_thresh_hi, bg_thresh_lo, (u64)seed,
                      make_float4((float)means4[0], (float)means4[1], (float)means4[2], (float)means4[3]),
                      make_float4((float)stds4[0], (float)stds4[1], (float)stds4[2], (float)stds4[3]), rois_d, roi_scores_d,
                      labels_d, bbox_targets_d, inside_w_d, outside_w_d, counts_d);
   LAUNCH_CHECK();
   return FRCNN_OK;
+}
+
+extern "C" int frcnn_proposal_target_layer(const float* rpn_rois_d, const float* rpn_scores_d, int N, const float* gt_boxes_d,
+                                           int G, int num_classes, int batch_size, double fg_fraction, double fg_thresh,
+                                           double bg_thresh_hi, double bg_thresh_lo, const double* means4, const double* stds4,
+                                           long long seed, float* rois_d, float* roi_scores_d, float* labels_d,
+                                           float* bbox_targets_d, float* inside_w_d, float* outside_w_d, int* counts_d,
+                                           void* stream) {
+  return proposal_target_impl(rpn_rois_d, rpn_scores_d, N, nullptr, gt_boxes_d, G, num_classes, batch_size, fg_fraction, fg_thresh,
+                              bg_thresh_hi, bg_thresh_lo, means4, stds4, seed, rois_d, roi_scores_d, labels_d, bbox_targets_d,
+                              inside_w_d, outside_w_d, counts_d, stream);
+}
+
+// Same, with the number of valid proposal rows read on the device (*num_rois_d, the proposal layer's own output): the
+// padded [max_rois,5] buffer goes straight in and the training step needs no host synchronisation here.
+extern "C" int frcnn_proposal_target_layer_dn(const float* rpn_rois_d, const float* rpn_scores_d, int max_rois, const int* num_rois_d,
+                                              const float* gt_boxes_d, int G, int num_classes, int batch_size, double fg_fraction,
+                                              double fg_thresh, double bg_thresh_hi, double bg_thresh_lo, const double* means4,
+                                              const double* stds4, long long seed, float* rois_d, float* roi_scores_d,
+                                              float* labels_d, float* bbox_targets_d, float* inside_w_d, float* outside_w_d,
+                                              int* counts_d, void* stream) {
+  if (!num_rois_d) return FRCNN_E_ARG;
+  return proposal_target_impl(rpn_rois_d, rpn_scores_d, max_rois, num_rois_d, gt_boxes_d, G, num_classes, batch_size, fg_fraction,
+                              fg_thresh, bg_thresh_hi, bg_thresh_lo, means4, stds4, seed, rois_d, roi_scores_d, labels_d,
+                              bbox_targets_d, inside_w_d, outside_w_d, counts_d, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

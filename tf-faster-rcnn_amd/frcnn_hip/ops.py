@@ -432,8 +432,9 @@ def anchor_target_layer(gt_boxes, im_h, im_w, H, W, base_d, feat_stride=16, rpn_
 
 
 def proposal_target_layer(rpn_rois, rpn_scores, gt_boxes, num_classes, batch_size=256, fg_fraction=0.25, fg_thresh=0.5,
-                          bg_hi=0.5, bg_lo=0.0, means=(0.0, 0.0, 0.0, 0.0), stds=(0.1, 0.1, 0.2, 0.2), seed=0):
-    """lib/layer_utils/proposal_target_layer.py:18-152 on device."""
+                          bg_hi=0.5, bg_lo=0.0, means=(0.0, 0.0, 0.0, 0.0), stds=(0.1, 0.1, 0.2, 0.2), seed=0, num=None):
+    """lib/layer_utils/proposal_target_layer.py:18-152 on device.  num: int32 [1] device tensor = valid rows of rpn_rois
+    (the proposal layer's count); without it every row is a proposal."""
     _chk(rpn_rois), _chk(rpn_scores), _chk(gt_boxes)
     dev, N, G, B, C = rpn_rois.device, rpn_rois.shape[0], gt_boxes.shape[0], int(batch_size), int(num_classes)
     rois = torch.empty((B, 5), dtype=torch.float32, device=dev)
@@ -443,6 +444,12 @@ def proposal_target_layer(rpn_rois, rpn_scores, gt_boxes, num_classes, batch_siz
     counts = torch.zeros((4,), dtype=torch.int32, device=dev)
     m = np.ascontiguousarray(means, dtype=np.float64)
     s = np.ascontiguousarray(stds, dtype=np.float64)
+    if num is not None:
+        call("frcnn_proposal_target_layer_dn", _ptr(rpn_rois), _ptr(rpn_scores), N, _ptr(num), _ptr(gt_boxes), G, C, B,
+             float(fg_fraction), float(fg_thresh), float(bg_hi), float(bg_lo), m.ctypes.data_as(ctypes.c_void_p),
+             s.ctypes.data_as(ctypes.c_void_p), int(seed), _ptr(rois), _ptr(sc), _ptr(labels), _ptr(tg), _ptr(iw), _ptr(ow),
+             _ptr(counts), _stream())
+        return rois, sc, labels, tg, iw, ow, counts
     call("frcnn_proposal_target_layer", _ptr(rpn_rois), _ptr(rpn_scores), N, _ptr(gt_boxes), G, C, B, float(fg_fraction),
          float(fg_thresh), float(bg_hi), float(bg_lo), m.ctypes.data_as(ctypes.c_void_p), s.ctypes.data_as(ctypes.c_void_p),
          int(seed), _ptr(rois), _ptr(sc), _ptr(labels), _ptr(tg), _ptr(iw), _ptr(ow), _ptr(counts), _stream())
@@ -557,7 +564,7 @@ def sumsq(w, scale, out, accumulate):
 def sumsq_multi(ptr_table, sizes, scale, out, accumulate=False):
     """ptr_table int64 [count] (device pointers of float tensors), sizes int64 [count], both on device."""
     count = ptr_table.numel()
-    ws = workspace(8 * 8 * count, out.device, "sumsq")
+    ws = workspace(8 * 64 * count, out.device, "sumsq")
     call("frcnn_sumsq_multi", _ptr(ptr_table), _ptr(sizes), count, float(scale), _ptr(out), 1 if accumulate else 0, _ptr(ws), ws.numel(),
          _stream())
     return out

@@ -91,14 +91,18 @@ class SolverWrapper(object):
                 next_stepsize = stepsizes.pop() if stepsizes else None
             self.state.lr = lr
             blobs = next(self.data_layer)
-            rpn_loss_cls, rpn_loss_box, loss_cls, loss_box, total_loss = self.net.train_step(self.sess, blobs, self.state)
-            history.append(total_loss)
-            if snapshot_dir is not None and it % cfg.TRAIN.SNAPSHOT_ITERS == 0:
-                self.snapshot(it, snapshot_dir)
+            # no host synchronisation inside a step: the losses stay on the device until somebody looks at them
+            history.append(self.net.train_step_async(self.sess, blobs, self.state))
             if verbose and it % cfg.TRAIN.DISPLAY == 0:
+                rpn_loss_cls, rpn_loss_box, loss_cls, loss_box, total_loss = history[-1].cpu().tolist()
                 print('iter: %d / %d, total loss: %.6f\n >>> rpn_loss_cls: %.6f\n >>> rpn_loss_box: %.6f\n >>> loss_cls: %.6f\n'
                       ' >>> loss_box: %.6f\n >>> lr: %f' % (it, max_iters, total_loss, rpn_loss_cls, rpn_loss_box, loss_cls, loss_box, lr))
-                print('speed: {:.3f}s / iter'.format((time.time() - t0) / it))
+                print('speed: {:.3f}s / iter'.format((time.time() - t0) / (it - start_iter)))
+            if snapshot_dir is not None and it % cfg.TRAIN.SNAPSHOT_ITERS == 0:
+                self.snapshot(it, snapshot_dir)
+        if history:
+            import torch
+            history = [float(v) for v in torch.stack(history)[:, 4].cpu().tolist()]
         return history
 
 

@@ -241,10 +241,10 @@ class Network(object):
     def _proposal_target_layer(self, rois, roi_scores, name):
         # network.py:185-208 -> lib/layer_utils/proposal_target_layer.py, on device
         t = cfg.TRAIN
-        n = int(self._num_rois.item())                    # rows of the padded proposal buffer that are real
-        out = ops.proposal_target_layer(rois[:n].contiguous(), roi_scores[:n, 0].contiguous(), self._gt_boxes, self._num_classes,
+        # the padded proposal buffer goes in whole; the kernel reads the valid row count on the device (no host sync here)
+        out = ops.proposal_target_layer(rois, roi_scores.view(-1), self._gt_boxes, self._num_classes,
                                         t.BATCH_SIZE, t.FG_FRACTION, t.FG_THRESH, t.BG_THRESH_HI, t.BG_THRESH_LO,
-                                        t.BBOX_NORMALIZE_MEANS, t.BBOX_NORMALIZE_STDS, seed=self._sample_seed + 1)
+                                        t.BBOX_NORMALIZE_MEANS, t.BBOX_NORMALIZE_STDS, seed=self._sample_seed + 1, num=self._num_rois)
         rois, roi_scores, labels, tg, iw, ow, counts = out
         self._proposal_targets = dict(rois=rois, labels=labels, bbox_targets=tg, bbox_inside_weights=iw, bbox_outside_weights=ow,
                                       counts=counts)
@@ -452,7 +452,12 @@ class Network(object):
 
     def train_step(self, sess, blobs, train_op):
         """One SGD step.  `train_op` is the solver handle (frcnn_hip.train.TrainState with .lr set), the stand-in
-        for the reference's TF train op.  Returns the five losses like network.py:488-498."""
+        for the reference's TF train op.  Returns the five losses like network.py:488-498 (one host read-back)."""
+        return tuple(float(v) for v in self.train_step_async(sess, blobs, train_op).cpu().tolist())
+
+    def train_step_async(self, sess, blobs, train_op):
+        """train_step without the host read-back: returns a DEVICE tensor [5] = (rpn_loss_cls, rpn_loss_box, loss_cls, loss_box,
+        total_loss).  Nothing in the step synchronises with the host, so the launch queue stays ahead of the GPU across steps."""
         losses = self.train_forward(sess, blobs)
         if not train_op.params:
             train_op.build()
@@ -460,13 +465,14 @@ class Network(object):
                 train_op.import_slots(train_op.pending_slots)
                 train_op.pending_slots = None
         train_op.backward(self._loss_seeds)
-        total = sess.buf(self._tag + "/total_loss", (1,))
+        total = torch.empty((1,), dtype=torch.float32, device=sess.device)
         train_op.regularization_loss(total)
-        total += losses["rpn_cross_entropy"] + losses["rpn_loss_box"] + losses["cross_entropy"] + losses["loss_box"]
-        out = [float(losses[k].item()) for k in ("rpn_cross_entropy", "rpn_loss_box", "cross_entropy", "loss_box")] + [float(total.item())]
+        parts = [losses[k].view(1) for k in ("rpn_cross_entropy", "rpn_loss_box", "cross_entropy", "loss_box")]
+        total = total + parts[0] + parts[1] + parts[2] + parts[3]
+        out = torch.cat(parts + [total])
         train_op.apply(train_op.lr, getattr(train_op, "world_size", 1), getattr(train_op, "all_reduce", None))
         self._sample_seed += 2
-        return tuple(out)
+        return out
 
     def train_step_no_return(self, sess, blobs, train_op):
         self.train_step(sess, blobs, train_op)
