@@ -300,3 +300,50 @@ def test_raw_bgr_image_entry_points(small_net):
             assert np.array_equal(d1[j], d2[j])
     finally:
         cfg.TEST.SCALES, cfg.TEST.MAX_SIZE = old
+
+
+def test_tools_test_net_on_a_voc_devkit_and_checkpoint(dev, tmp_path, capsys):
+    """tools/test_net.py --imdb voc_2007_test --model <TF V2 checkpoint>: JPEGs -> raw-image device path -> results files
+    -> VOC07 AP, with the weights restored from a checkpoint written without TensorFlow."""
+    import importlib.util
+    import os
+    import pickle
+    import sys
+    from PIL import Image
+    import gen_golden_eval as gge
+    from frcnn_hip.runtime import VariableStore
+    from model.config import cfg
+    from nets.resnet_v1 import resnetv1
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gt, dets = gge.synth_arrays(3, 4)
+    data_dir = tmp_path / "data"
+    voc = data_dir / "VOCdevkit2007" / "VOC2007"
+    index, _, _, _ = gge.build_devkit(str(voc), gt, dets, 4)
+    os.makedirs(str(voc / "JPEGImages"))
+    rng = np.random.RandomState(0)
+    for name in index:
+        Image.fromarray((rng.rand(120, 160, 3) * 255).astype(np.uint8)).save(str(voc / "JPEGImages" / (name + ".jpg")))
+    net = resnetv1(num_layers=50)
+    net.create_architecture("TEST", 21, tag="default", anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
+    store = VariableStore(seed=11)
+    store.init_variables(net.variable_specs())
+    ckpt = store.save(str(tmp_path / "res50_faster_rcnn_iter_1.ckpt"), {"global_step": np.array(1, dtype=np.int64)})
+    tools = os.path.join(root, "tf-faster-rcnn_amd", "tools")
+    sys.path.insert(0, tools)
+    spec = importlib.util.spec_from_file_location("frcnn_tools_test_net", os.path.join(tools, "test_net.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    old = (cfg.DATA_DIR, cfg.ROOT_DIR)
+    try:
+        rc = mod.main(["--imdb", "voc_2007_test", "--net", "res50", "--model", ckpt, "--comp", "--set", "DATA_DIR", str(data_dir),
+                       "ROOT_DIR", str(tmp_path)])
+    finally:
+        cfg.DATA_DIR, cfg.ROOT_DIR = old
+    assert rc == 0
+    out = capsys.readouterr().out
+    assert "Loaded." in out and "im_detect: 4/4" in out and "Mean AP = " in out
+    out_dir = tmp_path / "output" / "res50" / "voc_2007_test" / "default"
+    boxes = pickle.load(open(str(out_dir / "detections.pkl"), "rb"))
+    assert len(boxes) == 21 and len(boxes[1]) == 4 and sum(len(boxes[j][0]) for j in range(1, 21)) > 0
+    assert os.path.isfile(str(data_dir / "VOCdevkit2007" / "results" / "VOC2007" / "Main" / "comp4_det_test_aeroplane.txt"))
+    assert os.path.isfile(str(out_dir / "aeroplane_pr.pkl"))

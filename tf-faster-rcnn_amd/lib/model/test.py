@@ -70,6 +70,36 @@ def detect(sess, net, blob, im_scale, im_shape, max_per_image=100, thresh=0.):
     return out
 
 
+def imdb_images(imdb):
+    """BGR uint8 images of an imdb (datasets.pascal_voc), decoded with PIL (cv2 is not available here; both wrap libjpeg, the
+    decoded pixels may differ in the last bit from cv2.imread's)."""
+    from PIL import Image
+    for i in range(imdb.num_images):
+        yield np.ascontiguousarray(np.asarray(Image.open(imdb.image_path_at(i)).convert("RGB"))[:, :, ::-1])
+
+
+def test_net_imdb(sess, net, imdb, output_dir, max_per_image=100, thresh=0.):
+    """The reference's test_net(sess, net, imdb, weights_filename) (test.py:139-192): every image of the imdb through the
+    raw-image device path, then detections.pkl + imdb.evaluate_detections."""
+    import os
+    import pickle
+    all_boxes = [[[] for _ in range(imdb.num_images)] for _ in range(imdb.num_classes)]
+    _t = {'im_detect': Timer(), 'misc': Timer()}
+    for i, im in enumerate(imdb_images(imdb)):
+        _t['im_detect'].tic()
+        per_class = detect_bgr(sess, net, im, max_per_image, thresh)
+        _t['im_detect'].toc()
+        for j in range(1, imdb.num_classes):
+            all_boxes[j][i] = per_class[j]
+        print('im_detect: {:d}/{:d} {:.3f}s {:.3f}s'.format(i + 1, imdb.num_images, _t['im_detect'].average_time, _t['misc'].average_time))
+    os.makedirs(output_dir, exist_ok=True)
+    with open(os.path.join(output_dir, 'detections.pkl'), 'wb') as f:
+        pickle.dump(all_boxes, f, pickle.HIGHEST_PROTOCOL)
+    print('Evaluating detections')
+    imdb.evaluate_detections(all_boxes, output_dir)
+    return all_boxes
+
+
 def test_net(sess, net, images, num_classes=None, max_per_image=100, thresh=0., imdb=None, output_dir=None):
     """images: iterable of (blob, im_scale, im_shape).  Returns all_boxes[cls][image] like the
     reference; prints the same per-image timing line (test.py:183-185).  With an imdb (datasets.pascal_voc) the

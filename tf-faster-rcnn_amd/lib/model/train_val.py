@@ -120,10 +120,19 @@ def synthetic_data_layer(num_classes, seed=3, height=600, width=1000, scale=1.6,
         yield {'data': image, 'im_info': np.array([height, width, scale], dtype=np.float32), 'gt_boxes': gt}
 
 
-def train_net(network, sess, data_layer, max_iters=40000, all_reduce=None, world_size=1):
-    """Train a Faster R-CNN network (reference signature minus imdb/roidb/output dirs)."""
+def train_net(network, sess, data_layer, max_iters=40000, all_reduce=None, world_size=1, pretrained_model=None, output_dir=None,
+              resume=None):
+    """Train a Faster R-CNN network (reference signature minus imdb/roidb): pretrained_model = ImageNet checkpoint prefix
+    (train_val.py:177-202), output_dir = where snapshots go every cfg.TRAIN.SNAPSHOT_ITERS, resume = (ckpt, pkl)."""
     sw = SolverWrapper(sess, network, data_layer, all_reduce=all_reduce, world_size=world_size)
+    start = 0
+    if resume is not None:
+        start = sw.restore(*resume)
+    elif pretrained_model is not None:
+        sw.initialize(pretrained_model)
     print('Solving...')
-    hist = sw.train_model(max_iters)
+    hist = sw.train_model(max_iters, start_iter=start, snapshot_dir=output_dir)
+    if output_dir is not None and max_iters % cfg.TRAIN.SNAPSHOT_ITERS:
+        sw.snapshot(max_iters, output_dir)                        # the reference snapshots the last iteration too (:338-340)
     print('done solving')
     return hist

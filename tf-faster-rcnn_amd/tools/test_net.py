@@ -3,9 +3,10 @@
 
 Mirrors the command line of the reference's tools/test_net.py (flags --cfg --model --imdb --comp --num_dets --tag --net
 --set, /root/reference/tools/test_net.py:27-49) so existing launch scripts keep working.  What differs: there is no
-TensorFlow session and no dataset reader (out of scope) -- `--imdb synthetic_N` pushes N seeded
-600x1000 images through the device chain, `--model weights.npz` loads variables stored under their TF/slim names
-(otherwise the reference initialisers are used)."""
+TensorFlow session -- `--model` takes a TensorFlow V2 checkpoint prefix (read without TensorFlow) or an .npz of variables
+under their TF/slim names (otherwise the reference initialisers are used); `--imdb synthetic_N` pushes N seeded 600x1000
+images through the device chain, `--imdb voc_2007_test` reads `<cfg.DATA_DIR>/VOCdevkit2007` (JPEGs via PIL), runs the
+raw-image device path and the VOC evaluation (datasets/pascal_voc.py); other dataset readers are out of scope."""
 import argparse
 import pprint
 import sys
@@ -23,8 +24,8 @@ from nets.vgg16 import vgg16
 
 FLAGS = [  # (flag, dest, kwargs) -- same names / dests as the reference parser
     ("--cfg", "cfg_file", dict(type=str, default=None, help="optional config file")),
-    ("--model", "model", dict(type=str, default=None, help="variables to load (.npz, TF/slim names)")),
-    ("--imdb", "imdb_name", dict(type=str, default="synthetic_8", help="synthetic_N")),
+    ("--model", "model", dict(type=str, default=None, help="TF V2 checkpoint prefix, or .npz of variables (TF/slim names)")),
+    ("--imdb", "imdb_name", dict(type=str, default="synthetic_8", help="synthetic_N | voc_<year>_<split>")),
     ("--comp", "comp_mode", dict(action="store_true", help="competition mode (accepted, unused)")),
     ("--num_dets", "max_per_image", dict(type=int, default=100, help="max number of detections per image")),
     ("--tag", "tag", dict(type=str, default="", help="tag of the model")),
@@ -62,22 +63,39 @@ def main(argv):
         cfg_from_list(args.set_cfgs)
     print("Called with args:\n%s\nUsing config:" % (args,))
     pprint.pprint(cfg)
-    if not args.imdb_name.startswith("synthetic"):
-        raise SystemExit("only --imdb synthetic_N is available: dataset readers are out of scope (SURVEY.md section 2)")
+    imdb = None
+    if args.imdb_name.startswith("voc_"):
+        import os
+        from datasets.pascal_voc import pascal_voc
+        _, year, split = args.imdb_name.split("_")
+        imdb = pascal_voc(split, year, os.path.join(cfg.DATA_DIR, "VOCdevkit" + year))
+        imdb.competition_mode(args.comp_mode)
+    elif not args.imdb_name.startswith("synthetic"):
+        raise SystemExit("--imdb synthetic_N or voc_<year>_<split>: other dataset readers are out of scope (SURVEY.md section 2)")
     if args.net not in NETS:
         raise NotImplementedError(args.net)
-    n_images = int(args.imdb_name.split("_")[1]) if "_" in args.imdb_name else 8
+    n_images = int(args.imdb_name.split("_")[1]) if (imdb is None and "_" in args.imdb_name) else 8
     num_classes = 21
     net = NETS[args.net]()
     net.create_architecture("TEST", num_classes, tag=args.tag or "default", anchor_scales=cfg.ANCHOR_SCALES,
                             anchor_ratios=cfg.ANCHOR_RATIOS)
     sess = Session(seed=cfg.RNG_SEED)
     sess.init_variables(net.variable_specs())
-    if args.model:
+    if args.model and args.model.endswith(".npz"):
         print("Loading variables from %s" % args.model)
         sess.load_variables(dict(np.load(args.model)))
+    elif args.model:
+        print("Loading model check point from {:s}".format(args.model))          # tools/test_net.py:110-114
+        sess.restore(args.model)
+        print("Loaded.")
     else:
         print("No --model: reference initialisers, seed %d" % cfg.RNG_SEED)
+    if imdb is not None:
+        import os
+        from model.test import test_net_imdb
+        out_dir = os.path.join(cfg.ROOT_DIR, "output", args.net, imdb.name, args.tag or "default")
+        test_net_imdb(sess, net, imdb, out_dir, max_per_image=args.max_per_image)
+        return 0
     t0 = time.time()
     all_boxes = test_net(sess, net, synthetic_images(n_images), max_per_image=args.max_per_image)
     per_image = [sum(len(all_boxes[j][i]) for j in range(1, num_classes)) for i in range(n_images)]

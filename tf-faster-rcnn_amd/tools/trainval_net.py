@@ -23,7 +23,8 @@ from nets.resnet_v1 import resnetv1
 def parse_args():
     parser = argparse.ArgumentParser(description='Train a Faster R-CNN network')
     parser.add_argument('--cfg', dest='cfg_file', help='optional config file', default=None, type=str)
-    parser.add_argument('--weight', dest='weight', help='initialize with pretrained model weights (.npz)', type=str)
+    parser.add_argument('--weight', dest='weight', help='initialize with pretrained model weights (TF V2 checkpoint prefix, or .npz)', type=str)
+    parser.add_argument('--output', dest='output_dir', help='directory for snapshots (default: none written)', default=None, type=str)
     parser.add_argument('--imdb', dest='imdb_name', help='dataset to train on', default='synthetic', type=str)
     parser.add_argument('--imdbval', dest='imdbval_name', help='dataset to validate on', default='synthetic', type=str)
     parser.add_argument('--iters', dest='max_iters', help='number of iterations to train', default=70000, type=int)
@@ -62,7 +63,12 @@ if __name__ == '__main__':
     net = resnetv1(num_layers=int(args.net[3:]))
     net.create_architecture("TRAIN", num_classes, tag='default', anchor_scales=cfg.ANCHOR_SCALES, anchor_ratios=cfg.ANCHOR_RATIOS)
     sess.init_variables(net.variable_specs())
-    if args.weight:
+    pretrained = None
+    if args.weight and args.weight.endswith('.npz'):
         sess.load_variables(dict(np.load(args.weight)))
+    elif args.weight:
+        pretrained = args.weight                                        # ImageNet checkpoint: restore + fix_variables
     data = synthetic_data_layer(num_classes, seed=cfg.RNG_SEED + 1000 * rank, image_gain=1.0 / 256.0)
-    train_net(net, sess, data, max_iters=args.max_iters, all_reduce=all_reduce, world_size=world)
+    out_dir = getattr(args, 'output_dir', None)
+    train_net(net, sess, data, max_iters=args.max_iters, all_reduce=all_reduce, world_size=world, pretrained_model=pretrained,
+              output_dir=out_dir if rank == 0 else None)
