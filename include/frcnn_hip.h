@@ -186,6 +186,11 @@ int frcnn_gemm_batched_nt(const float* x_d, const float* w_d, float* y_d, int G,
  * T = N*ceil(H/m)*ceil(W/m), the (m+2)^2 GEMMs via frcnn_gemm_batched_nt, output transform (+bias, ReLU) back to NHWC
  * [N,H,W,Cout].  m = 4 does 4x fewer multiplications than direct but rounds ~10x worse (still f32-class). */
 int frcnn_winograd_filter_transform(const float* w_hwio, int Cin, int Cout, const float* scale, int m, float* u_out);
+/* The filter transform on the DEVICE from the packed filter [Cout][3][3][Cin] (training: filters change every step).
+ * transpose_flip = 0 -> U [(m+2)^2][Cout][Cin] (forward); 1 -> the data-gradient filter (taps flipped, channel roles swapped)
+ * U' [(m+2)^2][Cin][Cout]. */
+int frcnn_winograd_filter_transform_device(const float* w_packed_d, int Cout, int Cin, int m, int transpose_flip, float* u_d,
+                                           void* stream);
 int frcnn_winograd_input_transform(const float* x_d, int N, int H, int W, int C, int m, float* v_d, void* stream);
 int frcnn_winograd_output_transform(const float* m_d, int N, int H, int W, int C, int m, const float* bias_d, int act, float* y_d,
                                     void* stream);

@@ -313,3 +313,25 @@ def test_conv2d_split_k_equals_plain_launch(dev, case):
         acc = rd.clone()
         ops.conv2d(xd, wd, bd, k, k, stride, pad, act, acc, 1, out=acc)
         assert np.array_equal(acc.cpu().numpy(), outs[0])
+
+
+@pytest.mark.parametrize("m", [2, 4])
+@pytest.mark.parametrize("O,C", [(64, 96), (256, 128)])
+def test_winograd_filter_transform_on_device(dev, m, O, C):
+    """frcnn_winograd_filter_transform_device (training: per-step transform of the live packed filter) == the host float64
+    transform; transpose_flip gives the data-gradient filter: conv(dY, flip/transposed w) via Winograd == the direct dgrad."""
+    from frcnn_hip import ops
+    rng = np.random.RandomState(O + C + m)
+    w = (rng.randn(3, 3, C, O) * np.sqrt(2.0 / (9 * C))).astype(np.float32)
+    wp = torch.from_numpy(ops.pack_filter_hwio(w)).to(dev)
+    want = ops.winograd_filter_transform(w, None, m)
+    got = ops.winograd_filter_transform_device(wp, m, False).cpu().numpy()
+    assert got.shape == want.shape and np.abs(got - want).max() <= 1e-6 * np.abs(want).max()
+    w_flip = np.ascontiguousarray(w[::-1, ::-1].transpose(0, 1, 3, 2))              # HWIO of the dgrad conv: [kh,kw,O,C]
+    want_t = ops.winograd_filter_transform(w_flip, None, m)                          # [G, C, O]
+    got_t = ops.winograd_filter_transform_device(wp, m, True).cpu().numpy()
+    assert got_t.shape == want_t.shape and np.abs(got_t - want_t).max() <= 1e-6 * np.abs(want_t).max()
+    gy = rng.randn(2, 9, 11, O).astype(np.float32)
+    dx = ops.conv3x3_winograd(torch.from_numpy(gy).to(dev), torch.from_numpy(got_t).to(dev), None, 0).cpu().numpy()
+    ref = ref_conv(gy, w_flip, None, 1, (1, 1, 1, 1), 0)
+    assert np.abs(dx - ref).max() <= (2e-5 if m == 2 else 1e-4) * np.abs(ref).max()

@@ -136,21 +136,24 @@ def test_losses_value_and_gradient_vs_torch_float64(dev, golden):
         assert np.allclose(grad.cpu().numpy(), p.grad.numpy(), rtol=1e-5, atol=1e-9)
 
 
-def test_full_train_step_matches_torch_autograd(dev):
+@pytest.mark.parametrize("wino", [False, True], ids=["direct", "winograd"])
+def test_full_train_step_matches_torch_autograd(dev, wino):
     """TRAIN forward + reverse sweep + momentum SGD on the device vs torch float64
-    autograd of the reference graph, with the device-sampled rois/targets fed to the reference as constants."""
+    autograd of the reference graph, with the device-sampled rois/targets fed to the reference as constants.
+    wino: the 3x3 stride-1 layers' forward and data gradient as Winograd F(4x4,3x3) with device-transformed filters
+    (cfg.HIP.WINOGRAD_TRAIN, the default) or on the direct kernels -- same bounds."""
     from dense_ref import TrainRef
     from frcnn_hip.runtime import Session
     from frcnn_hip.train import TrainState
     from model.config import cfg
     from nets.resnet_v1 import resnetv1
     SC, RT = (4, 8, 16), (0.5, 1, 2)
-    old = (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO)
-    cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO = 64, 0.0
+    old = (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.WINOGRAD_TRAIN)
+    cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.WINOGRAD_TRAIN = 64, 0.0, wino
     try:
         sess = Session(device=dev, seed=5)
         net = resnetv1(num_layers=50)
-        net.create_architecture("TRAIN", 21, tag="train", anchor_scales=SC, anchor_ratios=RT)
+        net.create_architecture("TRAIN", 21, tag="train_w%d" % int(wino), anchor_scales=SC, anchor_ratios=RT)
         sess.init_variables(net.variable_specs())
         rng = np.random.RandomState(2)
         H, W = 128, 160
@@ -162,6 +165,7 @@ def test_full_train_step_matches_torch_autograd(dev):
         counts = pt["counts"].cpu().numpy()
         assert counts[0] > 0 and counts[0] + counts[1] == 64
         ts = TrainState(sess, net, momentum=0.9, weight_decay=1e-4).build()
+        ts.winograd = (4, 64) if wino else None
         ts.backward(net._loss_seeds)
         torch.cuda.synchronize()
         ref = TrainRef(sess.variables, 50, 21, SC, RT, net.trainable_scope)
@@ -203,7 +207,7 @@ def test_full_train_step_matches_torch_autograd(dev):
         out = net.train_step(sess, blobs, ts)
         assert len(out) == 5 and all(np.isfinite(out)) and out[4] > sum(out[:4])   # total includes the L2 term
     finally:
-        cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO = old
+        cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.WINOGRAD_TRAIN = old
 
 
 def test_sgd_steps_on_a_fixed_batch_reduce_the_loss(dev):

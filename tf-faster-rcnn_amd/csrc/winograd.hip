@@ -254,3 +254,76 @@ extern "C" int frcnn_winograd_output_transform(const float* m_d, int N, int H, i
   LAUNCH_CHECK();
   return FRCNN_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------- filter transform on device
+// Training changes the filters every step, so U = G g G^T is recomputed on the device from the PACKED filter
+// [Cout][3][3][Cin] the convolution kernels use.  transpose_flip = 0: U[xi][o][c] for the forward convolution.
+// transpose_flip = 1: the data-gradient convolution's filter g'[kh][kw] = w[o][2-kh][2-kw][c] with the channel roles swapped,
+// U'[xi][c][o] (csrc/backward_kernels.hip k_flip_transpose composed with the transform).  f32 arithmetic.
+template <int M>
+__global__ void k_wino_filter(const float* __restrict__ w, int O, int C, int transpose_flip, float* __restrict__ U) {
+  // coalesce the 36 / 16 writes: consecutive threads run along the FAST axis of the output (c forward, o for transpose_flip)
+  const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long long)O * C) return;
+  int o, c;
+  if (transpose_flip) { o = (int)(id % O); c = (int)(id / O); }
+  else { c = (int)(id % C); o = (int)(id / C); }
+  float g[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int kh = transpose_flip ? 2 - i : i, kw = transpose_flip ? 2 - j : j;
+      g[i][j] = w[(((size_t)o * 3 + kh) * 3 + kw) * C + c];
+    }
+  constexpr int A = M + 2;
+  float t[A][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float g0 = g[0][j], g1 = g[1][j], g2 = g[2][j];
+    if (M == 2) {
+      t[0][j] = g0;
+      t[1][j] = 0.5f * (g0 + g1 + g2);
+      t[2][j] = 0.5f * (g0 - g1 + g2);
+      t[3][j] = g2;
+    } else {
+      t[0][j] = 0.25f * g0;
+      t[1][j] = (-1.0f / 6.0f) * (g0 + g1 + g2);
+      t[2][j] = (-1.0f / 6.0f) * (g0 - g1 + g2);
+      t[3][j] = (1.0f / 24.0f) * g0 + (1.0f / 12.0f) * g1 + (1.0f / 6.0f) * g2;
+      t[4][j] = (1.0f / 24.0f) * g0 - (1.0f / 12.0f) * g1 + (1.0f / 6.0f) * g2;
+      t[A - 1][j] = g2;
+    }
+  }
+  const size_t plane = (size_t)O * C;
+  float* out = U + (transpose_flip ? (size_t)c * O + o : (size_t)o * C + c);
+#pragma unroll
+  for (int i = 0; i < A; ++i) {
+    const float a0 = t[i][0], a1 = t[i][1], a2 = t[i][2];
+    float r[A];
+    if (M == 2) {
+      r[0] = a0; r[1] = 0.5f * (a0 + a1 + a2); r[2] = 0.5f * (a0 - a1 + a2); r[3] = a2;
+    } else {
+      r[0] = 0.25f * a0;
+      r[1] = (-1.0f / 6.0f) * (a0 + a1 + a2);
+      r[2] = (-1.0f / 6.0f) * (a0 - a1 + a2);
+      r[3] = (1.0f / 24.0f) * a0 + (1.0f / 12.0f) * a1 + (1.0f / 6.0f) * a2;
+      r[4] = (1.0f / 24.0f) * a0 - (1.0f / 12.0f) * a1 + (1.0f / 6.0f) * a2;
+      r[A - 1] = a2;
+    }
+#pragma unroll
+    for (int j = 0; j < A; ++j) out[(size_t)(i * A + j) * plane] = r[j];
+  }
+}
+
+extern "C" int frcnn_winograd_filter_transform_device(const float* w_packed_d, int Cout, int Cin, int m, int transpose_flip,
+                                                      float* u_d, void* stream) {
+  if (!w_packed_d || !u_d || Cout <= 0 || Cin <= 0) return FRCNN_E_ARG;
+  if (m != 2 && m != 4) return FRCNN_E_UNSUPPORTED;
+  const long long tot = (long long)Cout * Cin;
+  const dim3 grid((unsigned)((tot + 255) / 256)), block(256);
+  if (m == 2) hipLaunchKernelGGL(k_wino_filter<2>, grid, block, 0, (hipStream_t)stream, w_packed_d, Cout, Cin, transpose_flip ? 1 : 0, u_d);
+  else hipLaunchKernelGGL(k_wino_filter<4>, grid, block, 0, (hipStream_t)stream, w_packed_d, Cout, Cin, transpose_flip ? 1 : 0, u_d);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}

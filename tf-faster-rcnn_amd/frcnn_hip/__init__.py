@@ -50,6 +50,7 @@ SIGNATURES = {
     "frcnn_prep_image": (c_int, [_P, c_int, c_int, c_int, _P, c_double, _P, c_int, c_int, c_int, _P]),
     "frcnn_gemm_batched_nt": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "frcnn_winograd_filter_transform": (c_int, [_P, c_int, c_int, _P, c_int, _P]),
+    "frcnn_winograd_filter_transform_device": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "frcnn_winograd_input_transform": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "frcnn_winograd_output_transform": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P]),
     "frcnn_set_tuning": (c_int, [c_int, c_int]),

@@ -313,6 +313,18 @@ def winograd_filter_transform(w_hwio, scale=None, m=2):
     return out
 
 
+def winograd_filter_transform_device(w_packed, m=4, transpose_flip=False, out=None):
+    """Packed filter [Cout,3,3,Cin] on device -> U [(m+2)^2,Cout,Cin] (or, transpose_flip, the dgrad filter [(m+2)^2,Cin,Cout])."""
+    _chk(w_packed)
+    O, kh, kw, C = w_packed.shape
+    assert kh == 3 and kw == 3
+    shape = ((m + 2) ** 2, C, O) if transpose_flip else ((m + 2) ** 2, O, C)
+    out = torch.empty(shape, dtype=torch.float32, device=w_packed.device) if out is None else out
+    assert out.numel() == (m + 2) ** 2 * O * C
+    call("frcnn_winograd_filter_transform_device", _ptr(w_packed), O, C, int(m), 1 if transpose_flip else 0, _ptr(out), _stream())
+    return out.view(shape)
+
+
 def winograd_tiles(N, H, W, m):
     return N * ((H + m - 1) // m) * ((W + m - 1) // m)
 

@@ -151,7 +151,18 @@ class TrainState(object):
             if x.data_ptr() in needs:
                 gx, had = accumulate_into(x, x.shape, sc + "/in")
                 wf = sess.conv_info[sc]["w"]
-                if stride == 1 and Cout % 32 == 0:
+                wino = getattr(self, "winograd", None)          # (m, min channels) set by the Network from cfg.HIP, or None
+                if (wino is not None and not had and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1)
+                        and Cout % 32 == 0 and Cout >= wino[1] and wf.shape[3] % 4 == 0):
+                    # dX = conv(dY, flipped / transposed filter) is itself a 3x3 stride-1 SAME convolution: Winograd, with the
+                    # gradient filter transformed straight from the packed forward filter
+                    m = wino[0]
+                    G, Cin = (m + 2) ** 2, wf.shape[3]
+                    T = ops.winograd_tiles(N, OH, OW, m)
+                    u = ops.winograd_filter_transform_device(wf, m, True, out=sess.buf("bwd/wino_u", (G, Cin, Cout)))
+                    ops.conv3x3_winograd(gy, u, None, ACT_NONE, out=gx, v_buf=sess.buf("bwd/wino_v", (G, T, Cout)),
+                                         m_buf=sess.buf("bwd/wino_m", (G, T, Cin)))
+                elif stride == 1 and Cout % 32 == 0:
                     wd = ops.flip_transpose_filter(wf, out=sess.buf("bwd/wflip/" + sc, (wf.shape[3], k, k, Cout)))
                     dpad = (k - 1 - pad[0], k - 1 - pad[1], k - 1 - pad[2], k - 1 - pad[3])
                     ops.conv2d(gy, wd, None, k, k, 1, dpad, ACT_NONE, gx if had else None, 1, out=gx)

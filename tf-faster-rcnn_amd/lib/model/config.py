@@ -65,8 +65,9 @@ __C = AttrDict(
     MATLAB='matlab', EXP_DIR='default', USE_GPU_NMS=True, USE_E2E_TF=False, POOLING_MODE='crop', POOLING_SIZE=7,
     ANCHOR_SCALES=[8, 16, 32], ANCHOR_RATIOS=[0.5, 1, 2], RPN_CHANNELS=512,
     # device-path switches (no reference counterpart): Winograd F(m x m,3x3) for the 3x3 stride-1 convolutions at test
-    # time; m = WINOGRAD_M (4 or 2) except scopes containing a WINOGRAD_F2_SCOPES token, which use m = 2
-    HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=64, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=()))
+    # time; m = WINOGRAD_M (4 or 2) except scopes containing a WINOGRAD_F2_SCOPES token, which use m = 2.  WINOGRAD_TRAIN: also in
+    # the training step (forward and data gradient of those layers; filters transformed on the device every step)
+    HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=64, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=(), WINOGRAD_TRAIN=True))
 __C.DATA_DIR = osp.abspath(osp.join(__C.ROOT_DIR, 'data'))
 cfg = __C
 

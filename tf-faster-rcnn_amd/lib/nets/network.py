@@ -78,10 +78,12 @@ class Network(object):
               res_stride=1, fold_w=False, out_affine=None, real_cin=None, no_bias=False):
         sess = self._sess
         N, H, W, Cin = x.shape
-        if (self._mode == "TEST" and cfg.HIP.WINOGRAD and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1)
+        wino = (cfg.HIP.WINOGRAD and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1)
                 and residual is None and not fold_w and out_affine is None and not no_bias
-                and Cin % 32 == 0 and Cin >= cfg.HIP.WINOGRAD_MIN_CIN and act in (ACT_NONE, ACT_RELU)):
+                and Cin % 32 == 0 and Cin >= cfg.HIP.WINOGRAD_MIN_CIN and act in (ACT_NONE, ACT_RELU))
+        if wino and self._mode == "TEST":
             return self._conv_winograd(x, scope, act, bn_eps)
+        wino = wino and cfg.HIP.WINOGRAD_TRAIN
         w, b = sess.conv_params(scope, bn_eps=bn_eps, fold_w=fold_w,
                                 out_scale=None if out_affine is None else out_affine[0],
                                 out_shift=None if out_affine is None else out_affine[1])
@@ -93,8 +95,16 @@ class Network(object):
         Cout = w.shape[0]
         out = sess.buf(self._tag + "/" + scope, (N, OH, OW, Cout))
         flops = 2 * N * OH * OW * Cout * k * k * (Cin if real_cin is None else real_cin)
-        sess.mark("conv:" + scope, flops,
-                  lambda: ops.conv2d(x, w, b, k, k, stride, pad, act, residual, res_stride, fold_w, out=out))
+        if wino:
+            # TRAIN: the filter changes every step -> transform the live (folded) device filter, then the same Winograd chain
+            m = int(cfg.HIP.WINOGRAD_M)
+            G, T = (m + 2) ** 2, ops.winograd_tiles(N, H, W, m)
+            u = ops.winograd_filter_transform_device(w, m, False, out=sess.buf(self._tag + "/wino_u", (G, Cout, Cin)))
+            v, mm = sess.buf(self._tag + "/wino_v", (G, T, Cin)), sess.buf(self._tag + "/wino_m", (G, T, Cout))
+            sess.mark("conv:" + scope, 2 * G * T * Cout * Cin, lambda: ops.conv3x3_winograd(x, u, b, act, out=out, v_buf=v, m_buf=mm))
+        else:
+            sess.mark("conv:" + scope, flops,
+                      lambda: ops.conv2d(x, w, b, k, k, stride, pad, act, residual, res_stride, fold_w, out=out))
         if self._mode == "TRAIN":
             self._tape.append(dict(kind="conv", scope=scope, x=x, y=out, k=k, stride=stride, pad=tuple(pad), act=act,
                                    residual=residual, res_stride=res_stride))
@@ -464,6 +474,7 @@ class Network(object):
             if getattr(train_op, "pending_slots", None) is not None:          # resumed run: momentum before the first update
                 train_op.import_slots(train_op.pending_slots)
                 train_op.pending_slots = None
+        train_op.winograd = (int(cfg.HIP.WINOGRAD_M), int(cfg.HIP.WINOGRAD_MIN_CIN)) if (cfg.HIP.WINOGRAD and cfg.HIP.WINOGRAD_TRAIN) else None
         train_op.backward(self._loss_seeds)
         total = torch.empty((1,), dtype=torch.float32, device=sess.device)
         train_op.regularization_loss(total)
