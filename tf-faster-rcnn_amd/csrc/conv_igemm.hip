@@ -40,7 +40,7 @@ struct ConvParams {
   int mtiles, ntiles;
   int batch;                       // grid.y (1 for convolutions)
   long long gx, gw, gy;            // batched GEMM use (grid.y = batch index): element strides of x / w / y per batch
-  int dbg;                         // experiments only: bit0 skip MFMAs, bit1 skip slab loads after the prologue
+  int dbg;                         // unused by the kernels (kept for the tuning ABI); run-time switches in the hot loop cost MFMA issue slots
   int splits, kchunk;              // split-K: grid.z = splits, each covers kchunk slabs and writes raw partial sums to y + z*gz
   long long gz;
 };
@@ -71,7 +71,7 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_base) {
       : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool FOLDW, bool ILV = false>
+template <int BM, int BN, int WM, int WN, int NS, bool FOLDW, bool ILV = false, bool RF = false>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const ConvParams p) {
   constexpr int NW = (BM / WM) * (BN / WN);
   constexpr int NT = NW * 64;
@@ -212,23 +212,38 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
     if (step + P <= nloc) wait_vmcnt<(P - 1) * G>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();          // every wave finished slab step-1 and sees slab step
-    const bool more = (step + P < nloc) && !(p.dbg & 2);
+    const bool more = step + P < nloc;
     const int nbuf = (step + P) % NS;
+    const float* sb = smem + (step % NS) * SLAB;
+    float4 a[4][TM], b[4][TN];
+    // RF ("reads first"): the fragment reads the first MFMAs need are issued BEFORE the next slab's direct-to-LDS loads, so
+    // their LDS latency overlaps the ~100 instructions of load issue instead of following it (the asm loads carry a memory
+    // clobber: reads written after them cannot be hoisted above them by the compiler)
+    constexpr int RF_FIRST = !RF ? 0 : (TM * TN == 1 ? 4 : 1);
+#pragma unroll
+    for (int s = 0; s < RF_FIRST; ++s) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[s][i] = *(const float4*)(sb + a_row0 + i * 1024 + koff[s]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[s][j] = *(const float4*)(sb + b_row0 + j * 1024 + koff[s]);
+    }
     if (!ILV) { if (more) issue_slab(nbuf); }
     else if (more && c0 == 0) set_tap();
-    const float* sb = smem + (step % NS) * SLAB;
     // MFMA order: consecutive instructions always target DIFFERENT accumulators; single-tile waves split k
     // over two accumulators (KSPLIT).  ILV: the wave's G slab loads are spread between the four k-groups
     // so their issue slots hide behind MFMAs instead of delaying the first MFMA after the barrier.
-    float4 a[4][TM], b[4][TN];
     if (!ILV) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = RF_FIRST; s < 4; ++s) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) a[s][i] = *(const float4*)(sb + a_row0 + i * 1024 + koff[s]);
 #pragma unroll
         for (int j = 0; j < TN; ++j) b[s][j] = *(const float4*)(sb + b_row0 + j * 1024 + koff[s]);
       }
+      // single-tile waves have only 4 MFMAs (256 cycles) per k-group -- too few to cover the next group's fragment reads,
+      // so keep all eight reads ahead of the MFMAs (counted lgkmcnt waits still let the first MFMA start early); multi-tile
+      // waves are left to the scheduler, which pipelines group s+1's reads under group s's 16 MFMAs
+      if (TM * TN == 1) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -242,19 +257,19 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
           for (int t = (s * G) / 4; t < ((s + 1) * G) / 4; ++t) issue_one(nbuf, t);
         }
       }
-      if (!(p.dbg & 1)) {
+      // (no run-time switches in here: a branch per k-group splits the loop body into basic blocks, and the compiler then
+      //  waits for ALL sixteen fragment reads (s_waitcnt lgkmcnt(0)) before the first MFMA instead of counting them down)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              const float av = e == 0 ? a[s][i].x : e == 1 ? a[s][i].y : e == 2 ? a[s][i].z : a[s][i].w;
-              const float bv = e == 0 ? b[s][j].x : e == 1 ? b[s][j].y : e == 2 ? b[s][j].z : b[s][j].w;
-              if (KSPLIT && (e & 1)) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc2[i][j], 0, 0, 0);
-              else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
-            }
-      }
+          for (int j = 0; j < TN; ++j) {
+            const float av = e == 0 ? a[s][i].x : e == 1 ? a[s][i].y : e == 2 ? a[s][i].z : a[s][i].w;
+            const float bv = e == 0 ? b[s][j].x : e == 1 ? b[s][j].y : e == 2 ? b[s][j].z : b[s][j].w;
+            if (KSPLIT && (e & 1)) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc2[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+          }
     }
     if (ILV && more) advance_k();
   }
@@ -329,13 +344,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool FOLDW, bool ILV = false>
+template <int BM, int BN, int WM, int WN, int NS, bool FOLDW, bool ILV = false, bool RF = false>
 static int launch_conv(ConvParams p, hipStream_t st) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   constexpr size_t ring = sizeof(float) * NS * (BM + BN) * 32, epi = sizeof(float) * BM * BN;
   constexpr size_t lds = ring > epi ? ring : epi;     // the epilogue tile reuses the ring memory
   static bool attr_set = false;
-  auto kern = k_conv_igemm<BM, BN, WM, WN, NS, FOLDW, ILV>;
+  auto kern = k_conv_igemm<BM, BN, WM, WN, NS, FOLDW, ILV, RF>;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
@@ -383,6 +398,10 @@ static int launch_cfg(int id, const ConvParams& p, hipStream_t st) {
     case 17: return launch_conv<128, 64, 64, 32, 2, false>(p, st);          // 48 KB: 3 workgroups / CU
     case 18: return launch_conv<64, 128, 32, 64, 2, false>(p, st);
     case 19: return launch_conv<128, 64, 32, 32, 2, false>(p, st);          // 8 single-tile waves
+    case 20: return launch_conv<128, 128, 64, 64, 2, false, false, true>(p, st);   // reads-first variants of 0 / 10 / 7 / 4
+    case 21: return launch_conv<128, 128, 32, 64, 2, false, false, true>(p, st);
+    case 22: return launch_conv<64, 64, 32, 32, 2, false, false, true>(p, st);
+    case 23: return launch_conv<64, 32, 32, 32, 4, false, false, true>(p, st);
     default: return FRCNN_E_ARG;
   }
 }
@@ -512,7 +531,7 @@ static int conv2d_impl(const float* x_d, int N, int H, int W, int Cin, const flo
   // for the per-RoI tail (M = 14700), 64x64 tiles with a shallow ring (32 KB LDS -> up to 5
   // workgroups per CU) for the 38x63 / 75x125 / 150x250 feature maps.
   const long long big = (long long)cdiv(p.M, 128) * cdiv(Cout, 128);
-  if (Cout >= 96 && big >= 384 && p.nsteps >= 8) return launch_cfg(Cout >= 1024 ? 10 : 0, p, st);   // 8 waves help the residual epilogue
+  if (Cout >= 96 && big >= 384 && p.nsteps >= 8) return launch_cfg(Cout >= 1024 ? 21 : 20, p, st);   // reads-first; 8 waves help the residual epilogue
   if (Cout > 32) return launch_cfg(7, p, st);
   return launch_cfg(4, p, st);
 }
@@ -534,7 +553,7 @@ extern "C" int frcnn_gemm_batched_nt(const float* x_d, const float* w_d, float* 
   p.splits = 1; p.kchunk = p.nsteps;
   const long long big = (long long)cdiv(M, 128) * cdiv(N, 128) * G;
   if (g_force_cfg >= 0) return launch_cfg(g_force_cfg, p, (hipStream_t)stream);
-  return (N >= 96 && big >= 384 && p.nsteps >= 8) ? launch_cfg(N >= 1024 ? 10 : 0, p, (hipStream_t)stream)
+  return (N >= 96 && big >= 384 && p.nsteps >= 8) ? launch_cfg(N >= 1024 ? 21 : 20, p, (hipStream_t)stream)
                                                  : launch_cfg(N > 32 ? 7 : 4, p, (hipStream_t)stream);
 }
 
