@@ -27,6 +27,7 @@
 // lib/nets/resnet_v1.py:80-125 (7x7/2 stem via fold_w, bottleneck 1x1 / 3x3 / conv2d_same
 // stride 2, projection and subsample shortcuts), vgg16.py:26-60.
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -207,71 +208,76 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
   for (int s = 0; s < P; ++s)
     if (s < nloc) issue_slab(s);
 
-  for (int step = 0; step < nloc; ++step) {
+  // One slab of the main loop.  MORE (compile time): a further slab is issued into the ring slot that just became free.  The
+  // loop is peeled (MORE for steps [0, nloc-P), !MORE for the last P) so that the unrolled body has NO run-time branch: any
+  // branch in here splits it into basic blocks and the compiler then serialises fragment reads and MFMAs (s_waitcnt lgkmcnt(0)
+  // for all sixteen reads before the first MFMA) instead of pipelining them with counted waits.
+  auto slab = [&](auto more_c, int step) {
+    constexpr bool MORE = decltype(more_c)::value;
     // slab `step` must have landed: at most the P-1 younger slabs may still be in flight
-    if (step + P <= nloc) wait_vmcnt<(P - 1) * G>();
+    if (MORE || step + P <= nloc) wait_vmcnt<(P - 1) * G>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();          // every wave finished slab step-1 and sees slab step
-    const bool more = step + P < nloc;
     const int nbuf = (step + P) % NS;
     const float* sb = smem + (step % NS) * SLAB;
     float4 a[4][TM], b[4][TN];
-    // RF ("reads first"): the fragment reads the first MFMAs need are issued BEFORE the next slab's direct-to-LDS loads, so
-    // their LDS latency overlaps the ~100 instructions of load issue instead of following it (the asm loads carry a memory
-    // clobber: reads written after them cannot be hoisted above them by the compiler)
-    constexpr int RF_FIRST = !RF ? 0 : (TM * TN == 1 ? 4 : 1);
+    auto read_frag = [&](int q) {
 #pragma unroll
-    for (int s = 0; s < RF_FIRST; ++s) {
+      for (int i = 0; i < TM; ++i) a[q][i] = *(const float4*)(sb + a_row0 + i * 1024 + koff[q]);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[s][i] = *(const float4*)(sb + a_row0 + i * 1024 + koff[s]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[s][j] = *(const float4*)(sb + b_row0 + j * 1024 + koff[s]);
-    }
-    if (!ILV) { if (more) issue_slab(nbuf); }
-    else if (more && c0 == 0) set_tap();
-    // MFMA order: consecutive instructions always target DIFFERENT accumulators; single-tile waves split k
-    // over two accumulators (KSPLIT).  ILV: the wave's G slab loads are spread between the four k-groups
-    // so their issue slots hide behind MFMAs instead of delaying the first MFMA after the barrier.
-    if (!ILV) {
-#pragma unroll
-      for (int s = RF_FIRST; s < 4; ++s) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[s][i] = *(const float4*)(sb + a_row0 + i * 1024 + koff[s]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[s][j] = *(const float4*)(sb + b_row0 + j * 1024 + koff[s]);
-      }
-      // single-tile waves have only 4 MFMAs (256 cycles) per k-group -- too few to cover the next group's fragment reads,
-      // so keep all eight reads ahead of the MFMAs (counted lgkmcnt waits still let the first MFMA start early); multi-tile
-      // waves are left to the scheduler, which pipelines group s+1's reads under group s's 16 MFMAs
-      if (TM * TN == 1) __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (ILV) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[s][i] = *(const float4*)(sb + a_row0 + i * 1024 + koff[s]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[s][j] = *(const float4*)(sb + b_row0 + j * 1024 + koff[s]);
-        if (more) {
-#pragma unroll
-          for (int t = (s * G) / 4; t < ((s + 1) * G) / 4; ++t) issue_one(nbuf, t);
-        }
-      }
-      // (no run-time switches in here: a branch per k-group splits the loop body into basic blocks, and the compiler then
-      //  waits for ALL sixteen fragment reads (s_waitcnt lgkmcnt(0)) before the first MFMA instead of counting them down)
+      for (int j = 0; j < TN; ++j) b[q][j] = *(const float4*)(sb + b_row0 + j * 1024 + koff[q]);
+    };
+    // MFMA order: consecutive instructions always target DIFFERENT accumulators; single-tile waves split k over two
+    // accumulators (KSPLIT)
+    auto mfma_group = [&](int q) {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
-            const float av = e == 0 ? a[s][i].x : e == 1 ? a[s][i].y : e == 2 ? a[s][i].z : a[s][i].w;
-            const float bv = e == 0 ? b[s][j].x : e == 1 ? b[s][j].y : e == 2 ? b[s][j].z : b[s][j].w;
+            const float av = e == 0 ? a[q][i].x : e == 1 ? a[q][i].y : e == 2 ? a[q][i].z : a[q][i].w;
+            const float bv = e == 0 ? b[q][j].x : e == 1 ? b[q][j].y : e == 2 ? b[q][j].z : b[q][j].w;
             if (KSPLIT && (e & 1)) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc2[i][j], 0, 0, 0);
             else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
           }
+    };
+    if (ILV) {
+      // the wave's G slab loads are spread between the four k-groups so that their issue slots hide behind MFMAs; group q+1's
+      // fragment reads are written BEFORE group q's loads (the asm loads carry a memory clobber, reads cannot cross them)
+      if (MORE && c0 == 0) set_tap();
+      read_frag(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < 3) read_frag(q + 1);
+        if (MORE) {
+#pragma unroll
+          for (int t = (q * G) / 4; t < ((q + 1) * G) / 4; ++t) issue_one(nbuf, t);
+        }
+        mfma_group(q);
+      }
+      if (MORE) advance_k();
+    } else {
+      // RF ("reads first"): the fragment reads the first MFMAs need are issued BEFORE the next slab's direct-to-LDS loads,
+      // so their LDS latency overlaps the ~100 instructions of load issue instead of following it
+      constexpr int RF_FIRST = !RF ? 0 : (TM * TN == 1 ? 4 : 1);
+#pragma unroll
+      for (int q = 0; q < RF_FIRST; ++q) read_frag(q);
+      if (MORE) issue_slab(nbuf);
+#pragma unroll
+      for (int q = RF_FIRST; q < 4; ++q) read_frag(q);
+      // single-tile waves have only 4 MFMAs (256 cycles) per k-group -- too few to cover the next group's fragment reads, so
+      // keep all eight reads ahead of the MFMAs; multi-tile waves are left to the scheduler, which pipelines group q+1's reads
+      // under group q's 16 MFMAs
+      if (TM * TN == 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mfma_group(q);
     }
-    if (ILV && more) advance_k();
+  };
+  {
+    int step = 0;
+    for (; step + P < nloc; ++step) slab(std::true_type{}, step);
+    for (; step < nloc; ++step) slab(std::false_type{}, step);
   }
   if (KSPLIT) {
 #pragma unroll
@@ -516,7 +522,7 @@ static int conv2d_impl(const float* x_d, int N, int H, int W, int Cin, const flo
       ConvParams q = p;
       q.bias = nullptr; q.res = nullptr; q.act = FRCNN_ACT_NONE; q.y = (float*)ws;
       q.kchunk = cdiv(p.nsteps, S); q.splits = S; q.gz = (long long)p.M * Cout;
-      const int rc = launch_cfg(Cout > 32 ? 7 : 4, q, st);
+      const int rc = launch_cfg(Cout > 32 ? 15 : 4, q, st);
       if (rc) return rc;
       const long long total = (long long)p.M * Cout;
       hipLaunchKernelGGL(k_splitk_finish, dim3((unsigned)min((long long)2048, (total + 255) / 256)), dim3(256), 0, st, (const float*)ws, S,
@@ -532,7 +538,7 @@ static int conv2d_impl(const float* x_d, int N, int H, int W, int Cin, const flo
   // workgroups per CU) for the 38x63 / 75x125 / 150x250 feature maps.
   const long long big = (long long)cdiv(p.M, 128) * cdiv(Cout, 128);
   if (Cout >= 96 && big >= 384 && p.nsteps >= 8) return launch_cfg(Cout >= 1024 ? 21 : 20, p, st);   // reads-first; 8 waves help the residual epilogue
-  if (Cout > 32) return launch_cfg(7, p, st);
+  if (Cout > 32) return launch_cfg(15, p, st);
   return launch_cfg(4, p, st);
 }
 
@@ -554,7 +560,7 @@ extern "C" int frcnn_gemm_batched_nt(const float* x_d, const float* w_d, float* 
   const long long big = (long long)cdiv(M, 128) * cdiv(N, 128) * G;
   if (g_force_cfg >= 0) return launch_cfg(g_force_cfg, p, (hipStream_t)stream);
   return (N >= 96 && big >= 384 && p.nsteps >= 8) ? launch_cfg(N >= 1024 ? 21 : 20, p, (hipStream_t)stream)
-                                                 : launch_cfg(N > 32 ? 7 : 4, p, (hipStream_t)stream);
+                                                 : launch_cfg(N > 32 ? 15 : 4, p, (hipStream_t)stream);
 }
 
 // HOST: HWIO -> [Cout][KH][KW][Cin] with optional per-output-channel scale (folded frozen BN).
