@@ -169,6 +169,11 @@ int frcnn_set_tuning(int key, int value);
  * lib/model/train_val.py:105-114). */
 unsigned int frcnn_crc32c(const void* data, size_t n, unsigned int crc);
 
+/* HOST: Snappy raw-format decompression (compressed LevelDB-table blocks of V1 TensorFlow checkpoints, the case
+ * lib/model/train_val.py:108-113 warns about).  Returns bytes written (== the length header) or -1 on malformed input or
+ * cap too small. */
+long long frcnn_snappy_uncompress(const unsigned char* src, size_t n, unsigned char* dst, size_t cap);
+
 /* Image preprocessing on device (lib/model/test.py:26-58 _get_image_blob, lib/utils/blob.py:33-47 prep_im_for_blob).
  * frcnn_prep_image_shape (HOST): the scale rule -- target_size / min side, capped so that round(scale * max side) <=
  * max_size -- and cv2.resize's output size cvRound(src * scale).

@@ -188,3 +188,119 @@ def test_session_restore_and_per_network_fixes(tmp_path):
         assert all(np.array_equal(sess2.variables[k], sess.variables[k]) for k in sess.variables)
         with pytest.raises(KeyError):
             sess2.restore(prefix)                                                # the ImageNet checkpoint has no RPN / head variables
+
+
+# ---------------------------------------------------------------------------------------------------- V1 checkpoints + snappy
+def _pb(field, payload):
+    return _varint((field << 3) | 2) + _varint(len(payload)) + payload
+
+
+def _pbv(field, v):
+    return _varint(field << 3) + _varint(v)
+
+
+def _shape_pb(shape):
+    return b"".join(_pb(2, _pbv(1, d)) for d in shape)
+
+
+def _snappy_literals(data, chunk=60):
+    """A valid Snappy stream made of literals only (what a compressor emits for incompressible data)."""
+    out = _varint(len(data))
+    for i in range(0, len(data), chunk):
+        part = data[i:i + chunk]
+        out += bytes([(len(part) - 1) << 2]) + part
+    return out
+
+
+def _write_v1(path, tensors, slices=None, snappy=False):
+    """Test-side writer of the V1 layout (SavedTensorSlices protos in an SSTable), assembled from the format description."""
+    metas, entries = b"", []
+    for name, a in sorted(tensors.items()):
+        dt = {np.dtype(np.float32): 1, np.dtype(np.int64): 9, np.dtype(np.int32): 3}[a.dtype]
+        parts = (slices or {}).get(name, [tuple((0, None) for _ in a.shape)])
+        metas += _pb(1, _pb(1, name.encode()) + _pb(2, _shape_pb(a.shape)) + _pbv(3, dt))
+        for k, ext in enumerate(parts):
+            idx = tuple(slice(st, None if ln is None else st + ln) for st, ln in ext)
+            sub = np.ascontiguousarray(a[idx]) if ext else a
+            ext_pb = b"".join(_pb(1, (_pbv(1, st) if st else b"") + (_pbv(2, ln) if ln is not None else b"")) for st, ln in ext)
+            if a.dtype == np.float32:
+                vals = _pb(5, sub.astype("<f4").tobytes())                       # packed float_val, as SaveData/Fill writes it
+            elif a.dtype == np.int64:
+                vals = _pb(10, b"".join(_varint(int(v) & ((1 << 64) - 1)) for v in sub.ravel()))
+            else:
+                vals = _pb(4, sub.astype("<i4").tobytes())                       # tensor_content
+            tensor = _pbv(1, dt) + _pb(2, _shape_pb(sub.shape)) + vals
+            entries.append((b"\\x00" + name.encode() + b"\\x00" + bytes([k + 1]), _pb(2, _pb(1, name.encode()) + _pb(2, ext_pb) + _pb(3, tensor))))
+    items = [(b"", _pb(1, metas))] + sorted(entries)
+    if not snappy:
+        tb.write_table(path, items)
+        return
+    # one snappy-compressed data block (type byte 1), hand-assembled like test_reader_on_hand_assembled_bundle
+    block, restarts = b"", []
+    for k, v in items:
+        restarts.append(len(block))
+        block += _varint(0) + _varint(len(k)) + _varint(len(v)) + k + v
+    block += b"".join(struct.pack("<I", r) for r in restarts) + struct.pack("<I", len(restarts))
+    comp = _snappy_literals(block)
+
+    def trailer(b, t):
+        return b + bytes([t]) + struct.pack("<I", tb.mask_crc(tb.crc32c(b + bytes([t]))))
+
+    f = trailer(comp, 1)
+    meta = struct.pack("<I", 0) + struct.pack("<I", 1)
+    meta_off = len(f)
+    f += trailer(meta, 0)
+    handle = _varint(0) + _varint(len(comp))
+    last = items[-1][0]
+    index = _varint(0) + _varint(len(last)) + _varint(len(handle)) + last + handle + struct.pack("<I", 0) + struct.pack("<I", 1)
+    index_off = len(f)
+    f += trailer(index, 0)
+    footer = _varint(meta_off) + _varint(len(meta)) + _varint(index_off) + _varint(len(index))
+    f += footer + bytes(40 - len(footer)) + struct.pack("<Q", 0xdb4775248b80fb57)
+    with open(path, "wb") as fh:
+        fh.write(f)
+
+
+def test_snappy_uncompress_known_streams():
+    # google/snappy format_description.txt: literals, copies with 1/2/4-byte offsets, overlapping (run-length) copies
+    assert tb.snappy_uncompress(bytes([11]) + bytes([10 << 2]) + b"hello world") == b"hello world"
+    assert tb.snappy_uncompress(bytes([9, 2 << 2]) + b"abc" + bytes([((6 - 4) << 2) | 1, 3])) == b"abcabcabc"        # copy-1: len 6, offset 3
+    assert tb.snappy_uncompress(bytes([10, 0]) + b"x" + bytes([((9 - 1) << 2) | 2, 1, 0])) == b"x" * 10               # copy-2, overlapping run
+    assert tb.snappy_uncompress(bytes([8, 3 << 2]) + b"wxyz" + bytes([((4 - 1) << 2) | 3, 4, 0, 0, 0])) == b"wxyzwxyz"  # copy-4
+    long_lit = bytes(range(256)) * 2
+    assert tb.snappy_uncompress(_varint(512) + bytes([61 << 2]) + struct.pack("<H", 511) + long_lit) == long_lit      # 2-byte literal length
+    assert tb.snappy_uncompress(_snappy_literals(long_lit)) == long_lit
+    for bad in (bytes([5, 0]) + b"x", bytes([3, ((4 - 1) << 2) | 2, 9, 0]), bytes([200])):                             # short / offset before start / cut header
+        with pytest.raises(IOError, match="corrupted compressed block contents"):
+            tb.snappy_uncompress(bad)
+
+
+@pytest.mark.parametrize("snappy", [False, True], ids=["plain", "snappy"])
+def test_v1_checkpoint_reader(tmp_path, snappy):
+    rng = np.random.RandomState(4)
+    tensors = {"resnet_v1_101/conv1/weights": rng.randn(7, 7, 3, 8).astype(np.float32),
+               "resnet_v1_101/block1/unit_1/bottleneck_v1/conv1/BatchNorm/gamma": rng.rand(8).astype(np.float32),
+               "partitioned/embedding": rng.randn(10, 6).astype(np.float32),
+               "global_step": np.array(123456789012, dtype=np.int64), "ids": np.arange(-3, 4, dtype=np.int32)}
+    slices = {"partitioned/embedding": [((0, 4), (0, None)), ((4, 6), (0, None))]}          # two row partitions
+    path = str(tmp_path / "resnet_v1_101.ckpt")
+    _write_v1(path, tensors, slices, snappy=snappy)
+    r = tb.open_checkpoint(path)
+    assert isinstance(r, tb.CheckpointReaderV1)
+    assert r.get_variable_to_shape_map() == {k: list(v.shape) for k, v in tensors.items()}
+    for k, v in tensors.items():
+        got = r.get_tensor(k)
+        assert got.dtype == v.dtype and got.shape == v.shape and np.array_equal(got, v), k
+    assert not r.has_tensor("nope")
+    with pytest.raises(KeyError):
+        r.get_tensor("nope")
+    # the factory picks V2 when an index file exists, and Session.restore reads either
+    tb.write_bundle(str(tmp_path / "v2.ckpt"), tensors)
+    assert isinstance(tb.open_checkpoint(str(tmp_path / "v2.ckpt")), tb.BundleReader)
+    from frcnn_hip.runtime import VariableStore
+    st = VariableStore()
+    st.variables["resnet_v1_101/conv1/weights"] = np.zeros((7, 7, 3, 8), np.float32)
+    st.restore(path, ["resnet_v1_101/conv1/weights"])
+    assert np.array_equal(st.variables["resnet_v1_101/conv1/weights"], tensors["resnet_v1_101/conv1/weights"])
+    with pytest.raises(IOError, match="not found"):
+        tb.open_checkpoint(str(tmp_path / "missing.ckpt"))

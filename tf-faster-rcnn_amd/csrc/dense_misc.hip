@@ -236,3 +236,71 @@ extern "C" unsigned int frcnn_crc32c(const void* data, size_t n, unsigned int cr
   while (n--) c = T[0][(c ^ *p++) & 0xFFu] ^ (c >> 8);
   return c ^ 0xFFFFFFFFu;
 }
+
+// ------------------------------------------------------------------------------------------------
+// HOST: Snappy raw-format decompression (the block compression of LevelDB tables; V1 TensorFlow checkpoints written by
+// early TensorFlow releases -- the slim ImageNet .ckpt files -- use it, which is what lib/model/train_val.py:108-113 warns
+// about).  Format (google/snappy format_description.txt): varint32 uncompressed length, then elements tagged by the low two
+// bits of the first byte: 00 literal (length-1 in the upper six bits, 60..63 = 1..4 length bytes follow), 01 copy with
+// 11-bit offset (length 4..11), 10 copy with 16-bit offset, 11 copy with 32-bit offset (length-1 in the upper six bits).
+// Returns the number of bytes written, or -1 on malformed input / insufficient capacity.
+// ------------------------------------------------------------------------------------------------
+extern "C" long long frcnn_snappy_uncompress(const unsigned char* src, size_t n, unsigned char* dst, size_t cap) {
+  if (!src || (!dst && cap)) return -1;
+  size_t ip = 0;
+  unsigned long long ulen = 0;
+  int shift = 0;
+  for (;;) {
+    if (ip >= n || shift > 28) return -1;
+    const unsigned char c = src[ip++];
+    ulen |= (unsigned long long)(c & 0x7F) << shift;
+    if (!(c & 0x80)) break;
+    shift += 7;
+  }
+  if (ulen > cap) return -1;
+  size_t op = 0;
+  while (ip < n) {
+    const unsigned tag = src[ip++];
+    size_t len, off;
+    switch (tag & 3) {
+      case 0: {
+        len = (tag >> 2) + 1;
+        if (len > 60) {
+          const unsigned nb = (unsigned)len - 60;
+          if (ip + nb > n) return -1;
+          len = 0;
+          for (unsigned b = 0; b < nb; ++b) len |= (size_t)src[ip + b] << (8 * b);
+          len += 1;
+          ip += nb;
+        }
+        if (ip + len > n || op + len > ulen) return -1;
+        __builtin_memcpy(dst + op, src + ip, len);
+        ip += len;
+        op += len;
+        continue;
+      }
+      case 1:
+        if (ip + 1 > n) return -1;
+        len = ((tag >> 2) & 7) + 4;
+        off = ((size_t)(tag >> 5) << 8) | src[ip];
+        ip += 1;
+        break;
+      case 2:
+        if (ip + 2 > n) return -1;
+        len = (tag >> 2) + 1;
+        off = (size_t)src[ip] | ((size_t)src[ip + 1] << 8);
+        ip += 2;
+        break;
+      default:
+        if (ip + 4 > n) return -1;
+        len = (tag >> 2) + 1;
+        off = (size_t)src[ip] | ((size_t)src[ip + 1] << 8) | ((size_t)src[ip + 2] << 16) | ((size_t)src[ip + 3] << 24);
+        ip += 4;
+        break;
+    }
+    if (off == 0 || off > op || op + len > ulen) return -1;
+    for (size_t k = 0; k < len; ++k) dst[op + k] = dst[op + k - off];     // byte-wise on purpose: copies may overlap (runs)
+    op += len;
+  }
+  return op == ulen ? (long long)op : -1;
+}

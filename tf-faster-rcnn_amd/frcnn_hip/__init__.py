@@ -46,6 +46,7 @@ SIGNATURES = {
     "frcnn_conv2d_nhwc_ws": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "frcnn_crc32c": (ctypes.c_uint32, [_P, c_size_t, ctypes.c_uint32]),
+    "frcnn_snappy_uncompress": (c_longlong, [_P, c_size_t, _P, c_size_t]),
     "frcnn_prep_image_shape": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P]),
     "frcnn_prep_image": (c_int, [_P, c_int, c_int, c_int, _P, c_double, _P, c_int, c_int, c_int, _P]),
     "frcnn_gemm_batched_nt": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -73,8 +73,8 @@ class VariableStore(object):
         """tf.train.Saver(...).restore(sess, ckpt) without TensorFlow (tools/test_net.py:110-114, train_val.py:185-190):
         loads `names` (default: every declared variable) from a V2 checkpoint by their TF/slim names.  A missing name or a
         shape mismatch raises, like Saver does.  Returns the names restored."""
-        from .tensor_bundle import BundleReader
-        reader = BundleReader(ckpt_prefix, verify=verify)
+        from .tensor_bundle import open_checkpoint
+        reader = open_checkpoint(ckpt_prefix, verify=verify)          # V2 bundle or V1 single file
         names = list(self.variables) if names is None else list(names)
         values = {}
         for name in names:

@@ -1,4 +1,5 @@
-"""TensorFlow checkpoint (V2 "tensor bundle") reader / writer without TensorFlow.
+"""TensorFlow checkpoint reader / writer without TensorFlow: V2 "tensor bundle" read + write, V1
+single-file checkpoints read (CheckpointReaderV1, at the end of this file); open_checkpoint() picks the format.
 
 What the reference gets from `pywrap_tensorflow.NewCheckpointReader` / `tf.train.Saver` (lib/model/train_val.py:105-114,
 177-202, tools/test_net.py:110-114): `<prefix>.index` + `<prefix>.data-SSSSS-of-NNNNN`.
@@ -20,7 +21,8 @@ bytes only):
                                     crc32c = 6 (fixed32, masked); slices = 7 }
   .data-* = the raw little-endian tensor bytes, entry by entry in key order.
 
-The bundle writer TensorFlow uses does not compress blocks; a snappy block (type 1) is reported, not decoded.
+The bundle writer TensorFlow uses does not compress blocks; Snappy blocks (type 1: old V1 files) are decoded by the
+native helper frcnn_snappy_uncompress.
 """
 import ctypes
 import os
@@ -68,6 +70,27 @@ def crc32c(data, crc=0):
     for b in mv.tobytes():
         c = _TABLE[(c ^ b) & 0xFF] ^ (c >> 8)
     return c ^ 0xFFFFFFFF
+
+
+def snappy_uncompress(data):
+    """Snappy raw format (compressed table blocks of V1 checkpoints) through the native helper frcnn_snappy_uncompress."""
+    mv = bytes(data)
+    n = shift = pos = 0
+    while True:                                  # varint32 length header
+        if pos >= len(mv):
+            raise IOError("corrupted compressed block contents")
+        b = mv[pos]
+        pos += 1
+        n |= (b & 0x7F) << shift
+        if not b & 0x80:
+            break
+        shift += 7
+    from . import lib
+    out = ctypes.create_string_buffer(max(n, 1))
+    got = lib().frcnn_snappy_uncompress(mv, ctypes.c_size_t(len(mv)), out, ctypes.c_size_t(n))
+    if got != n:
+        raise IOError("corrupted compressed block contents")           # the message train_val.py:111 looks for
+    return out.raw[:n]
 
 
 def mask_crc(c):
@@ -187,7 +210,7 @@ def _read_block(data, offset, size, verify):
         if unmask_crc(stored) != crc32c(data[offset:offset + size + 1]):
             raise IOError("checkpoint index: block checksum mismatch at offset %d" % offset)
     if ctype == 1:
-        raise IOError("corrupted compressed block contents: the index is SNAPPY-compressed, which this reader does not decode")
+        return snappy_uncompress(raw)
     if ctype != 0:
         raise IOError("checkpoint index: unknown block compression type %d" % ctype)
     return raw
@@ -362,3 +385,139 @@ def write_bundle(prefix, tensors):
             offset += len(raw)
     write_table(prefix + ".index", items)
     return prefix
+
+
+
+# ------------------------------------------------------------------------------------------------ V1 checkpoints
+class CheckpointReaderV1(object):
+    """TensorFlow V1 checkpoint (one file, what `tf.train.Saver` wrote before 1.0 -- the slim ImageNet `resnet_v1_101.ckpt`,
+    `vgg_16.ckpt`, `mobilenet_v1_1.0_224.ckpt` the reference starts training from, train_val.py:177-190).
+
+    Format (tensorflow/core/util/{tensor_slice_writer,saved_tensor_slice_util}.cc, saved_tensor_slice.proto; restated,
+    PARITY UNPINNED like the V2 reader): the same SSTable container, blocks optionally Snappy-compressed; key "" ->
+    SavedTensorSlices{meta = 1: SavedTensorSliceMeta{tensor = 1: {name = 1, shape = 2, type = 3, slice = 4}}}; every other
+    key -> SavedTensorSlices{data = 2: SavedSlice{name = 1, slice = 2: TensorSliceProto{extent = 1: {start = 1, length = 2}},
+    data = 3: TensorProto{dtype = 1, tensor_shape = 2, tensor_content = 4, float_val = 5 (packed), double_val = 6,
+    int_val = 7, int64_val = 10, bool_val = 11, half_val = 13}}}.  Slices of a partitioned variable are assembled."""
+
+    _VAL_FIELDS = {5: ("<f4", False), 6: ("<f8", False), 7: (None, True), 10: (None, True), 11: (None, True), 13: (None, True)}
+
+    def __init__(self, path, verify=True):
+        self.prefix = path
+        self._shapes, self._dtypes, self._slices = {}, {}, {}
+        for key, value in read_table(path, verify):
+            for field, _, v in _pb_fields(value):
+                if field == 1 and key == b"":
+                    self._read_meta(v)
+                elif field == 2:
+                    self._index_slice(v)
+
+    def _read_meta(self, meta):
+        for field, _, t in _pb_fields(meta):
+            if field != 1:
+                continue
+            name, shape, dtype = None, [], 0
+            for f2, _, v in _pb_fields(t):
+                if f2 == 1:
+                    name = v.decode("utf-8")
+                elif f2 == 2:
+                    shape = _decode_shape(v)
+                elif f2 == 3:
+                    dtype = v
+            self._shapes[name], self._dtypes[name] = shape, dtype
+
+    def _index_slice(self, saved_slice):
+        name, extents, tensor = None, [], None
+        for field, _, v in _pb_fields(saved_slice):
+            if field == 1:
+                name = v.decode("utf-8")
+            elif field == 2:
+                for f2, _, ext in _pb_fields(v):
+                    if f2 == 1:
+                        start, length = 0, None
+                        for f3, _, x in _pb_fields(ext):
+                            if f3 == 1:
+                                start = _signed64(x)
+                            elif f3 == 2:
+                                length = _signed64(x)
+                        extents.append((start, length))
+            elif field == 3:
+                tensor = v
+        self._slices.setdefault(name, []).append((extents, tensor))
+
+    def has_tensor(self, name):
+        return name in self._shapes
+
+    def get_variable_to_shape_map(self):
+        return {k: list(v) for k, v in self._shapes.items()}
+
+    def get_variable_to_dtype_map(self):
+        return {k: DTYPES.get(v) for k, v in self._dtypes.items()}
+
+    @staticmethod
+    def _tensor_values(tensor, dt):
+        """Flat values of a TensorProto in dtype dt (tensor_content, or the packed / repeated *_val field)."""
+        shape, chunks, ints = [], [], []
+        for field, wt, v in _pb_fields(tensor):
+            if field == 2:
+                shape = _decode_shape(v)
+            elif field == 4:
+                chunks.append(np.frombuffer(v, dtype=dt.newbyteorder("<")))
+            elif field in (5, 6) and wt == 2:
+                chunks.append(np.frombuffer(v, dtype="<f4" if field == 5 else "<f8"))
+            elif field in (5, 6):                                              # unpacked scalar: fixed32 / fixed64 bits
+                chunks.append(np.array([v], dtype="<u4" if field == 5 else "<u8").view("<f4" if field == 5 else "<f8"))
+            elif field in (7, 10, 11, 13):
+                if wt == 2:
+                    pos = 0
+                    while pos < len(v):
+                        x, pos = _get_varint(v, pos)
+                        ints.append(_signed64(x))
+                else:
+                    ints.append(_signed64(v))
+        if ints:
+            arr = np.array(ints, dtype=np.int64)
+            chunks.append(arr.astype(np.uint16).view(np.float16) if dt == np.float16 else arr)
+        flat = np.concatenate(chunks) if chunks else np.zeros((0,), dtype=dt)
+        return shape, flat.astype(dt, copy=False)
+
+    def get_tensor(self, name):
+        if name not in self._shapes:
+            raise KeyError("Key %s not found in checkpoint" % name)
+        if self._dtypes[name] not in DTYPES:
+            raise NotImplementedError("tensor %s has dtype enum %d" % (name, self._dtypes[name]))
+        dt = np.dtype(DTYPES[self._dtypes[name]])
+        full = tuple(self._shapes[name])
+        out = np.zeros(full, dtype=dt)
+        for extents, tensor in self._slices.get(name, []):
+            shape, flat = self._tensor_values(tensor, dt)
+            index = tuple(slice(st, None if ln is None else st + ln) for st, ln in extents) if extents else ()
+            region = out[index] if index else out
+            n = int(np.prod(region.shape, dtype=np.int64))
+            if flat.size == 1 and n > 1:
+                flat = np.full((n,), flat[0], dtype=dt)                      # TensorProto's "repeat the last value" compression
+            if flat.size != n:
+                raise IOError("tensor %s: slice holds %d values for a region of %s" % (name, flat.size, list(region.shape)))
+            region[...] = flat.reshape(region.shape)
+        return out
+
+
+def _decode_shape(buf):
+    dims = []
+    for f, _, dim in _pb_fields(buf):
+        if f == 2:
+            size = 0
+            for f3, _, sv in _pb_fields(dim):
+                if f3 == 1:
+                    size = _signed64(sv)
+            dims.append(size)
+    return dims
+
+
+def open_checkpoint(path, verify=True):
+    """`pywrap_tensorflow.NewCheckpointReader(path)`: a V2 bundle (`<path>.index` + data shards) or a V1 single file."""
+    if path.endswith(".index") or os.path.isfile(path + ".index"):
+        return BundleReader(path, verify=verify)
+    if os.path.isfile(path):
+        return CheckpointReaderV1(path, verify=verify)
+    raise IOError("checkpoint %s not found (neither %s.index nor a V1 file)" % (path, path))

@@ -29,9 +29,9 @@ class SolverWrapper(object):
     # ---- checkpoints -------------------------------------------------------------------------------------------------
     def get_variables_in_checkpoint_file(self, file_name):
         """train_val.py:105-114 (pywrap_tensorflow.NewCheckpointReader(...).get_variable_to_shape_map())."""
-        from frcnn_hip.tensor_bundle import BundleReader
+        from frcnn_hip.tensor_bundle import open_checkpoint
         try:
-            return BundleReader(file_name).get_variable_to_shape_map()
+            return open_checkpoint(file_name).get_variable_to_shape_map()
         except Exception as e:                                                    # the reference prints and carries on
             print(str(e))
             if "corrupted compressed block contents" in str(e):

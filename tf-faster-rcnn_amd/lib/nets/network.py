@@ -155,8 +155,8 @@ class Network(object):
 
     def fix_variables(self, sess, pretrained_model):
         """RGB -> BGR on the stem filter (`tf.reverse(conv1_rgb, [2])`, resnet_v1.py:168-178); subclasses add their own."""
-        from frcnn_hip.tensor_bundle import BundleReader
-        reader = BundleReader(pretrained_model)
+        from frcnn_hip.tensor_bundle import open_checkpoint
+        reader = open_checkpoint(pretrained_model)
         fixed = {}
         for name in self._variables_to_fix_names():
             fixed[name] = self._fix_one(name, reader.get_tensor(name))
