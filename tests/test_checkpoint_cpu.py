@@ -304,3 +304,31 @@ def test_v1_checkpoint_reader(tmp_path, snappy):
     assert np.array_equal(st.variables["resnet_v1_101/conv1/weights"], tensors["resnet_v1_101/conv1/weights"])
     with pytest.raises(IOError, match="not found"):
         tb.open_checkpoint(str(tmp_path / "missing.ckpt"))
+
+
+def test_find_previous_and_remove_snapshot(tmp_path):
+    """train_val.py:155-175, 235-256: newest snapshot pair is found (STEPSIZE+1 extras skipped), old ones are pruned."""
+    import time
+    sys.path.insert(0, os.path.join(ROOT, "tf-faster-rcnn_amd", "lib"))
+    from model.config import cfg
+    from model.train_val import find_previous, remove_snapshot
+    old = (cfg.TRAIN.STEPSIZE, cfg.TRAIN.SNAPSHOT_KEPT)
+    cfg.TRAIN.STEPSIZE, cfg.TRAIN.SNAPSHOT_KEPT = [30], 2
+    try:
+        assert find_previous(str(tmp_path)) == (0, [], [])
+        now = time.time()
+        for k, it in enumerate((10, 20, 31, 40)):                                 # 31 = STEPSIZE + 1: not a resume point
+            base = str(tmp_path / ("res101_faster_rcnn_iter_%d" % it))
+            for suffix in (".ckpt.index", ".ckpt.data-00000-of-00001", ".pkl"):
+                with open(base + suffix, "wb") as f:
+                    f.write(b"x")
+                os.utime(base + suffix, (now + k, now + k))
+        n, nfiles, sfiles = find_previous(str(tmp_path))
+        assert n == 3 and [os.path.basename(s) for s in sfiles] == ["res101_faster_rcnn_iter_%d.ckpt" % i for i in (10, 20, 40)]
+        assert [os.path.basename(s) for s in nfiles] == ["res101_faster_rcnn_iter_%d.pkl" % i for i in (10, 20, 40)]
+        remove_snapshot(nfiles, sfiles)
+        assert len(nfiles) == 2 and len(sfiles) == 2
+        left = sorted(os.listdir(str(tmp_path)))
+        assert not any("iter_10" in f for f in left) and any("iter_20.ckpt.index" in f for f in left) and any("iter_31" in f for f in left)
+    finally:
+        cfg.TRAIN.STEPSIZE, cfg.TRAIN.SNAPSHOT_KEPT = old

@@ -19,12 +19,40 @@ from frcnn_hip.train import TrainState
 from model.config import cfg
 
 
+def find_previous(output_dir):
+    """train_val.py:155-175: snapshots in output_dir, oldest first -> (count, pkl files, checkpoint prefixes).  A V2 bundle
+    has no `.meta` graph file here, so `<prefix>.ckpt.index` marks a snapshot; the extra snapshots the reference takes right
+    before a learning-rate step (iteration STEPSIZE + 1) are skipped like at :160-164."""
+    import glob
+    pattern = os.path.join(output_dir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_*.ckpt.index')
+    sfiles = sorted(glob.glob(pattern), key=os.path.getmtime)
+    red = [os.path.join(output_dir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_{:d}.ckpt.index'.format(st + 1)) for st in cfg.TRAIN.STEPSIZE]
+    sfiles = [f[:-len('.index')] for f in sfiles if f not in red]
+    nfiles = sorted(glob.glob(os.path.join(output_dir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_*.pkl')), key=os.path.getmtime)
+    red = [r.replace('.ckpt.index', '.pkl') for r in red]
+    nfiles = [n for n in nfiles if n not in red]
+    assert len(nfiles) == len(sfiles), 'snapshot .ckpt / .pkl files do not pair up in %s' % output_dir
+    return len(sfiles), nfiles, sfiles
+
+
+def remove_snapshot(np_paths, ss_paths):
+    """train_val.py:235-256: keep the newest cfg.TRAIN.SNAPSHOT_KEPT snapshots, delete older ones (both files of the bundle)."""
+    for _ in range(max(0, len(np_paths) - cfg.TRAIN.SNAPSHOT_KEPT)):
+        os.remove(str(np_paths.pop(0)))
+    for _ in range(max(0, len(ss_paths) - cfg.TRAIN.SNAPSHOT_KEPT)):
+        sfile = ss_paths.pop(0)
+        for suffix in ('.data-00000-of-00001', '.index'):
+            if os.path.exists(sfile + suffix):
+                os.remove(sfile + suffix)
+
+
 class SolverWrapper(object):
     def __init__(self, sess, network, data_layer, all_reduce=None, world_size=1):
         self.sess, self.net, self.data_layer = sess, network, data_layer
         self.state = TrainState(sess, network, momentum=cfg.TRAIN.MOMENTUM, weight_decay=cfg.TRAIN.WEIGHT_DECAY,
                                 double_bias=cfg.TRAIN.DOUBLE_BIAS, bias_decay=cfg.TRAIN.BIAS_DECAY)
         self.state.all_reduce, self.state.world_size = all_reduce, world_size
+        self.np_paths, self.ss_paths = [], []                     # snapshots written / found so far, oldest first
 
     # ---- checkpoints -------------------------------------------------------------------------------------------------
     def get_variables_in_checkpoint_file(self, file_name):
@@ -63,6 +91,9 @@ class SolverWrapper(object):
         with open(base + '.pkl', 'wb') as f:
             pickle.dump({'iter': it, 'sample_seed': int(self.net._sample_seed)}, f, pickle.HIGHEST_PROTOCOL)
         print('Wrote snapshot to: {:s}'.format(base + '.ckpt'))
+        self.np_paths.append(base + '.pkl')
+        self.ss_paths.append(base + '.ckpt')
+        remove_snapshot(self.np_paths, self.ss_paths)             # keep cfg.TRAIN.SNAPSHOT_KEPT (train_val.py:309-311)
         return base + '.ckpt', base + '.pkl'
 
     def restore(self, sfile, nfile):
@@ -74,6 +105,9 @@ class SolverWrapper(object):
         with open(nfile, 'rb') as f:
             meta = pickle.load(f)
         self.net._sample_seed = meta.get('sample_seed', 0)        # the fg/bg sampling stream continues where it stopped
+        if sfile not in self.ss_paths:
+            self.np_paths.append(nfile)
+            self.ss_paths.append(sfile)
         return meta['iter']
 
     def train_model(self, max_iters, verbose=True, start_iter=0, snapshot_dir=None):
@@ -126,6 +160,11 @@ def train_net(network, sess, data_layer, max_iters=40000, all_reduce=None, world
     (train_val.py:177-202), output_dir = where snapshots go every cfg.TRAIN.SNAPSHOT_ITERS, resume = (ckpt, pkl)."""
     sw = SolverWrapper(sess, network, data_layer, all_reduce=all_reduce, world_size=world_size)
     start = 0
+    if resume is None and output_dir is not None and os.path.isdir(output_dir):
+        lsf, nfiles, sfiles = find_previous(output_dir)            # train_val.py:243-252: continue from the newest snapshot
+        if lsf:
+            sw.np_paths, sw.ss_paths = list(nfiles[:-1]), list(sfiles[:-1])
+            resume = (sfiles[-1], nfiles[-1])
     if resume is not None:
         start = sw.restore(*resume)
     elif pretrained_model is not None:
