@@ -347,3 +347,20 @@ def test_tools_test_net_on_a_voc_devkit_and_checkpoint(dev, tmp_path, capsys):
     assert len(boxes) == 21 and len(boxes[1]) == 4 and sum(len(boxes[j][0]) for j in range(1, 21)) > 0
     assert os.path.isfile(str(data_dir / "VOCdevkit2007" / "results" / "VOC2007" / "Main" / "comp4_det_test_aeroplane.txt"))
     assert os.path.isfile(str(out_dir / "aeroplane_pr.pkl"))
+    # tools/reval.py on that run: --nms re-applies the (device) NMS; the lists were NMS'd at the same threshold already
+    spec = importlib.util.spec_from_file_location("frcnn_tools_reval", os.path.join(tools, "reval.py"))
+    reval = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(reval)
+    from model.test import apply_nms
+    again = apply_nms(boxes, cfg.TEST.NMS)
+    for j in range(1, 21):
+        for i in range(4):
+            a, b = np.asarray(boxes[j][i], dtype=np.float32).reshape(-1, 5), again[j][i]
+            valid = a[(a[:, 2] > a[:, 0]) & (a[:, 3] > a[:, 1])]                 # clipped boxes can be degenerate (test.py:124)
+            assert (len(valid) == 0 and len(b) == 0) or np.array_equal(valid, b)
+    old = (cfg.DATA_DIR, cfg.ROOT_DIR)
+    try:
+        assert reval.main([str(out_dir), "--imdb", "voc_2007_test", "--nms", "--comp", "--set", "DATA_DIR", str(data_dir)]) == 0
+    finally:
+        cfg.DATA_DIR, cfg.ROOT_DIR = old
+    assert "Applying NMS to all detections" in capsys.readouterr().out

@@ -70,6 +70,28 @@ def detect(sess, net, blob, im_scale, im_shape, max_per_image=100, thresh=0.):
     return out
 
 
+def apply_nms(all_boxes, thresh):
+    """test.py:109-135: non-maximum suppression (the device NMS behind model.nms_wrapper.nms) on every all_boxes[cls][image]
+    of a finished test_net run; degenerate boxes (x2 <= x1 or y2 <= y1) are dropped first.  Returns a new nested list."""
+    from model.nms_wrapper import nms
+    num_classes, num_images = len(all_boxes), len(all_boxes[0])
+    nms_boxes = [[[] for _ in range(num_images)] for _ in range(num_classes)]
+    for c in range(num_classes):
+        for i in range(num_images):
+            dets = all_boxes[c][i]
+            if isinstance(dets, list) or len(dets) == 0:
+                continue
+            dets = np.asarray(dets, dtype=np.float32)
+            dets = dets[(dets[:, 2] > dets[:, 0]) & (dets[:, 3] > dets[:, 1])]
+            if dets.shape[0] == 0:
+                continue
+            keep = nms(dets, thresh)
+            if len(keep) == 0:
+                continue
+            nms_boxes[c][i] = dets[keep, :].copy()
+    return nms_boxes
+
+
 def imdb_images(imdb):
     """BGR uint8 images of an imdb (datasets.pascal_voc), decoded with PIL (cv2 is not available here; both wrap libjpeg, the
     decoded pixels may differ in the last bit from cv2.imread's)."""
