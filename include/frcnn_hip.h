@@ -199,6 +199,14 @@ int frcnn_winograd_filter_transform_device(const float* w_packed_d, int Cout, in
 int frcnn_winograd_input_transform(const float* x_d, int N, int H, int W, int C, int m, float* v_d, void* stream);
 int frcnn_winograd_output_transform(const float* m_d, int N, int H, int W, int C, int m, const float* bias_d, int act, float* y_d,
                                     void* stream);
+/* Winograd for 7x7 maps (the per-RoI crops of block4): each row of 7 outputs = F(4,3) + F(3,3), 11 transform points per
+ * dimension, 121 GEMMs of [R x Cin] x [Cin x Cout] (one row per RoI) instead of the 144 of 2x2 F(4x4,3x3) tiles.  Same roles as
+ * the frcnn_winograd_* functions: U [121][Cout][Cin] (host float64, or on the device from the packed filter, optionally the
+ * flipped / transposed data-gradient form), V [121][R][C], M [121][R][Cout] -> y [R][7][7][Cout] (+ bias, ReLU). */
+int frcnn_winograd7_filter_transform(const float* w_hwio, int Cin, int Cout, const float* scale, float* u_out);
+int frcnn_winograd7_filter_transform_device(const float* w_packed_d, int Cout, int Cin, int transpose_flip, float* u_d, void* stream);
+int frcnn_winograd7_input_transform(const float* x_d, int R, int C, float* v_d, void* stream);
+int frcnn_winograd7_output_transform(const float* m_d, int R, int C, const float* bias_d, int act, float* y_d, void* stream);
 /* HOST helper: HWIO (TF layout, [KH][KW][Cin][Cout]) -> packed [Cout][KH][KW][Cin], optionally
  * multiplying output channel o by scale[o] (folded frozen batch-norm gamma/sqrt(var+eps)). */
 int frcnn_pack_filter_hwio(const float* w_hwio, int KH, int KW, int Cin, int Cout, const float* scale, float* out);

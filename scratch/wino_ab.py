@@ -16,9 +16,10 @@ def timeit(fn, n=8, rounds=5):
         if r: ts.append(e0.elapsed_time(e1) * 1000 / n)
     return float(np.median(ts))
 MM = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-GG = (MM + 2) ** 2
+GG = ops.winograd_points(MM)
 print("F(%d,3) %-7s %9s %9s %9s %9s %9s | %9s %9s" % (MM, "shape", "direct", "wino", "in_tr", "gemm", "out_tr", "err_dir", "err_wino"))
 for name, (N,H,W,Cin,Cout) in shapes.items():
+    if MM == 7 and H != 7: continue
     torch.manual_seed(0)
     x = torch.randn(N,H,W,Cin, device=dev).relu(); w_hwio = (torch.randn(3,3,Cin,Cout) * (2.0/(9*Cin))**0.5).numpy(); b = torch.randn(Cout, device=dev)
     wp = torch.from_numpy(np.ascontiguousarray(w_hwio.transpose(3,0,1,2))).to(dev)
@@ -35,7 +36,7 @@ for name, (N,H,W,Cin,Cout) in shapes.items():
     ed = (out_d[:nref].double()-ref).abs().max().item()/sc; ew = (out_w[:nref].double()-ref).abs().max().item()/sc
     L = lib(); S = torch.cuda.current_stream().cuda_stream
     t_d = timeit(fd); t_w = timeit(fw)
-    t_i = timeit(lambda: ops.call("frcnn_winograd_input_transform", x.data_ptr(), N,H,W,Cin, MM, v.data_ptr(), S))
+    t_i = timeit(lambda: ops.winograd_input_transform(x, v, MM))
     t_g = timeit(lambda: ops.call("frcnn_gemm_batched_nt", v.data_ptr(), u.data_ptr(), m.data_ptr(), GG, T, Cout, Cin, S))
-    t_o = timeit(lambda: ops.call("frcnn_winograd_output_transform", m.data_ptr(), N,H,W,Cout, MM, b.data_ptr(), 1, out_w.data_ptr(), S))
+    t_o = timeit(lambda: ops.winograd_output_transform(m, b, 1, out_w, MM))
     print("%-7s %9.1f %9.1f %9.1f %9.1f %9.1f | %9.2e %9.2e" % (name, t_d, t_w, t_i, t_g, t_o, ed, ew))

@@ -335,3 +335,35 @@ def test_winograd_filter_transform_on_device(dev, m, O, C):
     dx = ops.conv3x3_winograd(torch.from_numpy(gy).to(dev), torch.from_numpy(got_t).to(dev), None, 0).cpu().numpy()
     ref = ref_conv(gy, w_flip, None, 1, (1, 1, 1, 1), 0)
     assert np.abs(dx - ref).max() <= (2e-5 if m == 2 else 1e-4) * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("R,Cin,Cout,act,bias", [(5, 64, 96, 1, True), (300, 512, 512, 1, True), (3, 32, 20, 0, False)])
+def test_conv3x3_winograd_7x7_mixed_scheme(dev, R, Cin, Cout, act, bias):
+    """7x7 maps (per-RoI crops): rows of 7 outputs = F(4,3) + F(3,3), 121 GEMMs (csrc/winograd7.hip).  Exact algebra; bounded
+    like F(4x4,3x3) (measured ~3e-6).  Host and device filter transforms agree; the flipped / transposed form gives the data
+    gradient."""
+    from frcnn_hip import ops
+    rng = np.random.RandomState(R + Cin)
+    x = np.maximum(rng.randn(R, 7, 7, Cin), 0).astype(np.float32)
+    w = (rng.randn(3, 3, Cin, Cout) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
+    b = rng.randn(Cout).astype(np.float32) if bias else None
+    scale = (0.5 + rng.rand(Cout)).astype(np.float32)
+    u_host = ops.winograd_filter_transform(w, scale, 7)
+    assert u_host.shape == (121, Cout, Cin)
+    u = torch.from_numpy(u_host).to(dev)
+    bd = None if b is None else torch.from_numpy(b).to(dev)
+    y = ops.conv3x3_winograd(torch.from_numpy(x).to(dev), u, bd, act).cpu().numpy()
+    ref = ref_conv(x, w * scale[None, None, None, :], b, 1, (1, 1, 1, 1), act)
+    assert y.shape == ref.shape and np.abs(y - ref).max() <= 1e-4 * np.abs(ref).max()
+    wp = torch.from_numpy(ops.pack_filter_hwio(w, scale)).to(dev)
+    u_dev = ops.winograd_filter_transform_device(wp, 7, False).cpu().numpy()
+    assert np.abs(u_dev - u_host).max() <= 1e-6 * np.abs(u_host).max()
+    if Cout % 32 == 0:                                   # the data-gradient GEMMs reduce over Cout
+        ws = w * scale[None, None, None, :]
+        w_flip = np.ascontiguousarray(ws[::-1, ::-1].transpose(0, 1, 3, 2))
+        u_t = ops.winograd_filter_transform_device(wp, 7, True)
+        assert tuple(u_t.shape) == (121, Cin, Cout)
+        gy = rng.randn(R, 7, 7, Cout).astype(np.float32)
+        dx = ops.conv3x3_winograd(torch.from_numpy(gy).to(dev), u_t, None, 0).cpu().numpy()
+        rd = ref_conv(gy, w_flip, None, 1, (1, 1, 1, 1), 0)
+        assert np.abs(dx - rd).max() <= 1e-4 * np.abs(rd).max()

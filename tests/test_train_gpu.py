@@ -165,7 +165,7 @@ def test_full_train_step_matches_torch_autograd(dev, wino):
         counts = pt["counts"].cpu().numpy()
         assert counts[0] > 0 and counts[0] + counts[1] == 64
         ts = TrainState(sess, net, momentum=0.9, weight_decay=1e-4).build()
-        ts.winograd = (4, 64) if wino else None
+        ts.winograd = (4, 64, True) if wino else None
         ts.backward(net._loss_seeds)
         torch.cuda.synchronize()
         ref = TrainRef(sess.variables, 50, 21, SC, RT, net.trainable_scope)
@@ -244,9 +244,8 @@ def test_sgd_steps_on_a_fixed_batch_reduce_the_loss(dev):
 def test_snapshot_and_resume_continue_the_same_run(dev, tmp_path):
     """train_val.py:58-100,204-233 on TF V2 bundles written without TensorFlow: run 4 steps; run 2 steps, snapshot, restore
     into a fresh session + solver (weights, Momentum slots, iteration, sampling stream), run 2 more -> the same losses as
-    the uninterrupted run and the same final weights.  The step right after the restore must agree to f32 rounding (same
-    weights, same sampling stream); later steps only to ~1e-2: float atomics in the crop backward perturb the weights at
-    1e-7, and a flipped NMS / sampling decision downstream of that changes the sampled RoIs (true of two uninterrupted runs too)."""
+    the uninterrupted run.  The restored solver state (weights, Momentum, iteration, sampling seed) is compared BIT FOR BIT with
+    the state the interrupted run had; loss trajectories of separate runs are only compared loosely (float atomics)."""
     from frcnn_hip.runtime import Session
     from frcnn_hip.tensor_bundle import BundleReader
     from model.config import cfg
@@ -273,21 +272,27 @@ def test_snapshot_and_resume_continue_the_same_run(dev, tmp_path):
     try:
         _, _, sw = solver("snapA")
         full = sw.train_model(4, verbose=False)
-        want = sw.state.export_variables(slots=True)
         _, _, sw = solver("snapB")
         first = sw.train_model(2, verbose=False, snapshot_dir=str(tmp_path))
+        at_snapshot = sw.state.export_variables(slots=True)                         # weights + Momentum after iteration 2
         ck, pk = str(tmp_path / "res101_faster_rcnn_iter_2.ckpt"), str(tmp_path / "res101_faster_rcnn_iter_2.pkl")
         shapes = BundleReader(ck).get_variable_to_shape_map()
         assert shapes["global_step"] == [] and "resnet_v1_50/block3/unit_1/bottleneck_v1/conv2/weights/Momentum" in shapes
         assert "resnet_v1_50/conv1/weights/Momentum" not in shapes                     # frozen stem: no optimizer slot
         sess, net, sw = solver("snapC")
-        assert sw.restore(ck, pk) == 2
-        rest = sw.train_model(4, verbose=False, start_iter=2)
-        assert first == full[:2]
-        assert np.allclose(rest[0], full[2], rtol=1e-5, atol=0) and np.allclose(rest[1], full[3], rtol=2e-2, atol=0), (first + rest, full)
-        got = sw.state.export_variables(slots=False)
-        for k in got:
-            scale = max(float(np.abs(want[k]).max()), 1e-12)
-            assert np.abs(got[k] - want[k]).max() <= 2e-3 * scale, k
+        assert sw.restore(ck, pk) == 2 and net._sample_seed == 4                       # iteration + sampling stream
+        # the restored solver state, before any update: build the parameter set exactly as the first resumed step does
+        net.train_forward(sess, next(layer()))
+        sw.state.build()
+        sw.state.import_slots(sw.state.pending_slots)
+        sw.state.pending_slots = None
+        restored = sw.state.export_variables(slots=True)
+        assert sorted(restored) == sorted(at_snapshot)
+        for k in at_snapshot:                                                          # bit-identical weights and momentum
+            assert np.array_equal(restored[k], at_snapshot[k]), k
+        rest = sw.train_model(4, verbose=False, start_iter=2)                          # continues at iteration 3 with the decayed lr at 4
+        # trajectories of two separate runs agree only loosely: the crop backward adds with float atomics, and a 1e-7 change
+        # of the weights can flip an NMS / sampling decision downstream
+        assert np.allclose(first, full[:2], rtol=1e-3, atol=0) and np.allclose(rest, full[2:], rtol=5e-2, atol=0), (first + rest, full)
     finally:
         (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.SNAPSHOT_ITERS, cfg.TRAIN.STEPSIZE, cfg.TRAIN.DISPLAY) = old

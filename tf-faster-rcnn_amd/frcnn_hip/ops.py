@@ -306,8 +306,13 @@ def winograd_filter_transform(w_hwio, scale=None, m=2):
     w = np.ascontiguousarray(w_hwio, dtype=np.float32)
     assert w.shape[0] == 3 and w.shape[1] == 3
     Cin, Cout = w.shape[2], w.shape[3]
-    out = np.empty(((m + 2) ** 2, Cout, Cin), dtype=np.float32)
     sc = None if scale is None else np.ascontiguousarray(scale, dtype=np.float32)
+    if m == 7:                               # the mixed F(4,3)+F(3,3) scheme for 7x7 maps: 121 points
+        out = np.empty((121, Cout, Cin), dtype=np.float32)
+        call("frcnn_winograd7_filter_transform", w.ctypes.data_as(ctypes.c_void_p), Cin, Cout,
+             None if sc is None else sc.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+        return out
+    out = np.empty(((m + 2) ** 2, Cout, Cin), dtype=np.float32)
     call("frcnn_winograd_filter_transform", w.ctypes.data_as(ctypes.c_void_p), Cin, Cout,
          None if sc is None else sc.ctypes.data_as(ctypes.c_void_p), int(m), out.ctypes.data_as(ctypes.c_void_p))
     return out
@@ -318,22 +323,37 @@ def winograd_filter_transform_device(w_packed, m=4, transpose_flip=False, out=No
     _chk(w_packed)
     O, kh, kw, C = w_packed.shape
     assert kh == 3 and kw == 3
-    shape = ((m + 2) ** 2, C, O) if transpose_flip else ((m + 2) ** 2, O, C)
+    G = winograd_points(m)
+    shape = (G, C, O) if transpose_flip else (G, O, C)
     out = torch.empty(shape, dtype=torch.float32, device=w_packed.device) if out is None else out
-    assert out.numel() == (m + 2) ** 2 * O * C
-    call("frcnn_winograd_filter_transform_device", _ptr(w_packed), O, C, int(m), 1 if transpose_flip else 0, _ptr(out), _stream())
+    assert out.numel() == G * O * C
+    if m == 7:
+        call("frcnn_winograd7_filter_transform_device", _ptr(w_packed), O, C, 1 if transpose_flip else 0, _ptr(out), _stream())
+    else:
+        call("frcnn_winograd_filter_transform_device", _ptr(w_packed), O, C, int(m), 1 if transpose_flip else 0, _ptr(out), _stream())
     return out.view(shape)
 
 
+def winograd_points(m):
+    """GEMMs per layer: (m+2)^2 for F(m x m,3x3); 121 for the mixed 7x7 scheme (m == 7)."""
+    return 121 if m == 7 else (m + 2) ** 2
+
+
 def winograd_tiles(N, H, W, m):
+    if m == 7:
+        assert H == 7 and W == 7
+        return N
     return N * ((H + m - 1) // m) * ((W + m - 1) // m)
 
 
 def winograd_input_transform(x, v, m=2):
     _chk(x), _chk(v)
     N, H, W, C = x.shape
-    assert v.numel() == (m + 2) ** 2 * winograd_tiles(N, H, W, m) * C
-    call("frcnn_winograd_input_transform", _ptr(x), N, H, W, C, int(m), _ptr(v), _stream())
+    assert v.numel() == winograd_points(m) * winograd_tiles(N, H, W, m) * C
+    if m == 7:
+        call("frcnn_winograd7_input_transform", _ptr(x), N, C, _ptr(v), _stream())
+    else:
+        call("frcnn_winograd_input_transform", _ptr(x), N, H, W, C, int(m), _ptr(v), _stream())
     return v
 
 
@@ -350,8 +370,11 @@ def gemm_batched_nt(x, w, y):
 def winograd_output_transform(mm, bias, act, out, m=2):
     _chk(mm), _chk(out)
     N, H, W, C = out.shape
-    assert mm.numel() == (m + 2) ** 2 * winograd_tiles(N, H, W, m) * C
-    call("frcnn_winograd_output_transform", _ptr(mm), N, H, W, C, int(m), _ptr(bias), int(act), _ptr(out), _stream())
+    assert mm.numel() == winograd_points(m) * winograd_tiles(N, H, W, m) * C
+    if m == 7:
+        call("frcnn_winograd7_output_transform", _ptr(mm), N, C, _ptr(bias), int(act), _ptr(out), _stream())
+    else:
+        call("frcnn_winograd_output_transform", _ptr(mm), N, H, W, C, int(m), _ptr(bias), int(act), _ptr(out), _stream())
     return out
 
 
@@ -359,7 +382,7 @@ def conv3x3_winograd(x, u, bias, act=ACT_NONE, out=None, v_buf=None, m_buf=None)
     """3x3 / stride 1 / pad 1 convolution as Winograd F(m x m,3x3): x [N,H,W,Cin], u [(m+2)^2,Cout,Cin] -> [N,H,W,Cout]."""
     N, H, W, Cin = x.shape
     G, Cout = u.shape[0], u.shape[1]
-    m = {16: 2, 36: 4}[G]
+    m = {16: 2, 36: 4, 121: 7}[G]
     T = winograd_tiles(N, H, W, m)
     dev = x.device
     v = torch.empty((G, T, Cin), dtype=torch.float32, device=dev) if v_buf is None else v_buf

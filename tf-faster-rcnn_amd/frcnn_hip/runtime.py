@@ -147,7 +147,8 @@ class Session(VariableStore):
         return res
 
     def winograd_params(self, scope, bn_eps=None, m=2):
-        """(U_d [(m+2)^2,Cout,Cin], bias_d) for a 3x3 stride-1 scope run as Winograd F(m x m,3x3) (TEST mode only)."""
+        """(U_d [(m+2)^2,Cout,Cin], bias_d) for a 3x3 stride-1 scope run as Winograd F(m x m,3x3); m = 7: the mixed 7x7 scheme,
+        U_d [121,Cout,Cin] (TEST mode; training transforms the live filter on the device)."""
         key = ("wino", scope, bn_eps, m)
         if key in self.packed:
             return self.packed[key]

@@ -156,8 +156,8 @@ class TrainState(object):
                         and Cout % 32 == 0 and Cout >= wino[1] and wf.shape[3] % 4 == 0):
                     # dX = conv(dY, flipped / transposed filter) is itself a 3x3 stride-1 SAME convolution: Winograd, with the
                     # gradient filter transformed straight from the packed forward filter
-                    m = wino[0]
-                    G, Cin = (m + 2) ** 2, wf.shape[3]
+                    m = 7 if (wino[0] == 4 and len(wino) > 2 and wino[2] and OH == 7 and OW == 7) else wino[0]
+                    G, Cin = ops.winograd_points(m), wf.shape[3]
                     T = ops.winograd_tiles(N, OH, OW, m)
                     u = ops.winograd_filter_transform_device(wf, m, True, out=sess.buf("bwd/wino_u", (G, Cin, Cout)))
                     ops.conv3x3_winograd(gy, u, None, ACT_NONE, out=gx, v_buf=sess.buf("bwd/wino_v", (G, T, Cout)),

@@ -66,8 +66,9 @@ __C = AttrDict(
     ANCHOR_SCALES=[8, 16, 32], ANCHOR_RATIOS=[0.5, 1, 2], RPN_CHANNELS=512,
     # device-path switches (no reference counterpart): Winograd F(m x m,3x3) for the 3x3 stride-1 convolutions at test
     # time; m = WINOGRAD_M (4 or 2) except scopes containing a WINOGRAD_F2_SCOPES token, which use m = 2.  WINOGRAD_TRAIN: also in
-    # the training step (forward and data gradient of those layers; filters transformed on the device every step)
-    HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=64, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=(), WINOGRAD_TRAIN=True))
+    # the training step (forward and data gradient of those layers; filters transformed on the device every step).
+    # WINOGRAD_7X7: 7x7 maps (per-RoI crops) use the mixed F(4,3)+F(3,3) scheme (121 instead of 144 products per RoI)
+    HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=64, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=(), WINOGRAD_TRAIN=True, WINOGRAD_7X7=True))
 __C.DATA_DIR = osp.abspath(osp.join(__C.ROOT_DIR, 'data'))
 cfg = __C
 

@@ -97,8 +97,8 @@ class Network(object):
         flops = 2 * N * OH * OW * Cout * k * k * (Cin if real_cin is None else real_cin)
         if wino:
             # TRAIN: the filter changes every step -> transform the live (folded) device filter, then the same Winograd chain
-            m = int(cfg.HIP.WINOGRAD_M)
-            G, T = (m + 2) ** 2, ops.winograd_tiles(N, H, W, m)
+            m = self._winograd_scheme(scope, H, W)
+            G, T = ops.winograd_points(m), ops.winograd_tiles(N, H, W, m)
             u = ops.winograd_filter_transform_device(w, m, False, out=sess.buf(self._tag + "/wino_u", (G, Cout, Cin)))
             v, mm = sess.buf(self._tag + "/wino_v", (G, T, Cin)), sess.buf(self._tag + "/wino_m", (G, T, Cout))
             sess.mark("conv:" + scope, 2 * G * T * Cout * Cin, lambda: ops.conv3x3_winograd(x, u, b, act, out=out, v_buf=v, m_buf=mm))
@@ -114,15 +114,23 @@ class Network(object):
                 self._requires_grad.add(out.data_ptr())
         return out
 
+    @staticmethod
+    def _winograd_scheme(scope, H, W):
+        """2 / 4 = F(m x m,3x3) tiles; 7 = the mixed F(4,3)+F(3,3) scheme for 7x7 maps (121 instead of 144 GEMM rows per RoI)."""
+        if any(tok in scope for tok in cfg.HIP.WINOGRAD_F2_SCOPES):
+            return 2
+        m = int(cfg.HIP.WINOGRAD_M)
+        return 7 if (m == 4 and H == 7 and W == 7 and cfg.HIP.WINOGRAD_7X7) else m
+
     def _conv_winograd(self, x, scope, act, bn_eps):
         """3x3 / stride 1 / SAME convolution as Winograd F(m x m,3x3): input transform -> (m+2)^2 GEMMs in ONE launch of
         the f32-MFMA kernel -> output transform with bias + ReLU.  Exact algebra in f32; m = 2 (2.25x fewer
         multiplications, rounding like the direct kernel) or m = 4 (4x fewer; a single layer rounds ~10x worse than
         direct, but through the full ResNet-101 the outputs move by ~1e-6 relative, profiles/r01_e_winograd_error.txt)."""
         sess = self._sess
-        m = 2 if any(tok in scope for tok in cfg.HIP.WINOGRAD_F2_SCOPES) else int(cfg.HIP.WINOGRAD_M)
-        u, b = sess.winograd_params(scope, bn_eps=bn_eps, m=m)
         N, H, W, Cin = x.shape
+        m = self._winograd_scheme(scope, H, W)
+        u, b = sess.winograd_params(scope, bn_eps=bn_eps, m=m)
         G, Cout = u.shape[0], u.shape[1]
         T = ops.winograd_tiles(N, H, W, m)
         v = sess.buf(self._tag + "/wino_v", (G, T, Cin))
@@ -406,7 +414,7 @@ class Network(object):
         c = cfg[self._mode]
         key = (self._tag, tuple(image_d.shape), self._im_info[:2], self._mode, cfg.TEST.MODE, self._fuse_tail_entry,
                c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH, cfg.TEST.RPN_TOP_N, cfg.POOLING_SIZE,
-               bool(cfg.HIP.WINOGRAD), int(cfg.HIP.WINOGRAD_MIN_CIN), int(cfg.HIP.WINOGRAD_M), tuple(cfg.HIP.WINOGRAD_F2_SCOPES), bool(cfg.USE_E2E_TF))
+               bool(cfg.HIP.WINOGRAD), int(cfg.HIP.WINOGRAD_MIN_CIN), int(cfg.HIP.WINOGRAD_M), tuple(cfg.HIP.WINOGRAD_F2_SCOPES), bool(cfg.HIP.WINOGRAD_7X7), bool(cfg.USE_E2E_TF))
         cur = torch.cuda.current_stream(sess.device)
         if not use_graph or sess.profile is not None:
             sess.flops_last_forward = 0
@@ -474,7 +482,8 @@ class Network(object):
             if getattr(train_op, "pending_slots", None) is not None:          # resumed run: momentum before the first update
                 train_op.import_slots(train_op.pending_slots)
                 train_op.pending_slots = None
-        train_op.winograd = (int(cfg.HIP.WINOGRAD_M), int(cfg.HIP.WINOGRAD_MIN_CIN)) if (cfg.HIP.WINOGRAD and cfg.HIP.WINOGRAD_TRAIN) else None
+        train_op.winograd = ((int(cfg.HIP.WINOGRAD_M), int(cfg.HIP.WINOGRAD_MIN_CIN), bool(cfg.HIP.WINOGRAD_7X7))
+                             if (cfg.HIP.WINOGRAD and cfg.HIP.WINOGRAD_TRAIN) else None)
         train_op.backward(self._loss_seeds)
         total = torch.empty((1,), dtype=torch.float32, device=sess.device)
         train_op.regularization_loss(total)
