@@ -239,7 +239,7 @@ def main():
                        "gflop_per_image_launched": round(flops_per_image / B / 1e9, 2), "gflop_per_image_reference_graph": 622.29},
         }
         traffic = None      # HBM bytes per conv launch from the committed rocprofv3 PMC passes of this command (scratch/gpu_pmc2.sh)
-        tpath = os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json")
         if os.path.exists(tpath) and B == 4 and not args.reference_order:
             try:
                 traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
