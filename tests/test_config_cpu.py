@@ -1,0 +1,81 @@
+"""CPU: the cfg system keeps the reference's behaviour (lib/model/config.py:325-387): YAML files as shipped under
+experiments/cfgs merge into the defaults with type checks, `--set` overrides come after the file and parse literals."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tf-faster-rcnn_amd", "lib"))
+from model import config as C  # noqa: E402
+
+# the text of the reference's experiments/cfgs/res101-lg.yml (the C3 configuration of BASELINE.json)
+RES101_LG = """EXP_DIR: res101-lg
+TRAIN:
+  HAS_RPN: True
+  IMS_PER_BATCH: 1
+  BBOX_NORMALIZE_TARGETS_PRECOMPUTED: True
+  RPN_POSITIVE_OVERLAP: 0.7
+  RPN_BATCHSIZE: 256
+  PROPOSAL_METHOD: gt
+  BG_THRESH_LO: 0.0
+  DISPLAY: 20
+  BATCH_SIZE: 256
+  DOUBLE_BIAS: False
+  SNAPSHOT_PREFIX: res101_faster_rcnn
+  SCALES: [800]
+  MAX_SIZE: 1333
+TEST:
+  HAS_RPN: True
+  SCALES: [800]
+  MAX_SIZE: 1333
+  RPN_POST_NMS_TOP_N: 1000
+POOLING_MODE: crop
+ANCHOR_SCALES: [2,4,8,16,32]
+"""
+
+
+@pytest.fixture
+def restore_cfg():
+    import copy
+    saved = copy.deepcopy(dict(C.cfg))
+    yield
+    for k in list(C.cfg):
+        C.cfg[k] = saved[k]
+
+
+def test_yaml_file_then_set_overrides(tmp_path, restore_cfg):
+    f = tmp_path / "res101-lg.yml"
+    f.write_text(RES101_LG)
+    C.cfg_from_file(str(f))
+    cfg = C.cfg
+    assert cfg.EXP_DIR == "res101-lg" and cfg.TEST.RPN_POST_NMS_TOP_N == 1000 and cfg.TEST.MAX_SIZE == 1333
+    assert tuple(cfg.TEST.SCALES) == (800,) and isinstance(cfg.TEST.SCALES, tuple)          # list in the file, tuple in the defaults
+    assert cfg.ANCHOR_SCALES == [2, 4, 8, 16, 32] and cfg.TRAIN.DOUBLE_BIAS is False and cfg.TRAIN.BG_THRESH_LO == 0.0
+    # tools apply --set AFTER the file (tools/test_net.py:64-67): the stock script's 4 scales override the yml's 5
+    C.cfg_from_list(["ANCHOR_SCALES", "[4,8,16,32]", "ANCHOR_RATIOS", "[0.5,1,2]", "TEST.NMS", "0.25", "TRAIN.SNAPSHOT_PREFIX", "abc"])
+    assert cfg.ANCHOR_SCALES == [4, 8, 16, 32] and cfg.TEST.NMS == 0.25 and cfg.TRAIN.SNAPSHOT_PREFIX == "abc"
+    assert cfg.PIXEL_MEANS.shape == (1, 1, 3) and cfg.PIXEL_MEANS.dtype == np.float64
+
+
+def test_type_mismatch_and_unknown_keys_are_rejected(tmp_path, restore_cfg):
+    f = tmp_path / "bad.yml"
+    f.write_text("TEST:\n  NO_SUCH_KEY: 1\n")
+    with pytest.raises(KeyError):
+        C.cfg_from_file(str(f))
+    f.write_text("TEST:\n  NMS: [1, 2]\n")
+    with pytest.raises(ValueError):
+        C.cfg_from_file(str(f))
+    with pytest.raises(AssertionError):
+        C.cfg_from_list(["TEST.NO_SUCH_KEY", "1"])
+    with pytest.raises(AssertionError):
+        C.cfg_from_list(["TEST.NMS", "abc"])                              # str does not match float
+    C.cfg_from_list(["TRAIN.SCALES", "[600, 800]"])                        # list literal -> the default's tuple type
+    assert C.cfg.TRAIN.SCALES == (600, 800)
+
+
+def test_device_path_switches_exist_with_documented_defaults():
+    h = C.cfg.HIP
+    assert h.WINOGRAD is True and h.WINOGRAD_M == 4 and h.WINOGRAD_TRAIN is True and h.WINOGRAD_7X7 is True and h.WINOGRAD_MIN_CIN == 64
+    assert C.cfg.USE_E2E_TF is False and C.cfg.USE_GPU_NMS is True and C.cfg.POOLING_SIZE == 7
