@@ -192,7 +192,7 @@ def main():
 
         # ---- roofline of the dominant kernel (k_conv_igemm): HIP events around every conv launch, on
         #      the stream the kernels run on, over `profile_steps` further steps of the same workload
-        conv_ms, conv_flops, conv_launches = 0.0, 0, 0
+        conv_ms, conv_flops, conv_launches, conv_bytes = 0.0, 0, 0, 0
         if rank == 0 and args.profile_steps > 0:
           with torch.cuda.stream(run_stream):
             sess.profile = []
@@ -201,7 +201,7 @@ def main():
             run_stream.synchronize()
             per_layer = {}
             per_image_scale = 1.0 / B
-            for tag, fl, e0, e1 in sess.profile:
+            for tag, fl, e0, e1, nb in sess.profile:
                 ms = e0.elapsed_time(e1)
                 a = per_layer.setdefault(tag, [0.0, 0, 0])
                 a[0] += ms; a[1] += fl; a[2] += 1
@@ -209,6 +209,7 @@ def main():
                     conv_ms += ms
                     conv_flops += fl
                     conv_launches += 1
+                    conv_bytes += nb
             sess.profile = None
             if args.layer_report:
                 with open(args.layer_report, "w") as f:
@@ -250,6 +251,7 @@ def main():
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                                "kernel": "k_conv_igemm (f32 MFMA 32x32x2 implicit GEMM, all tile shapes)",
+                               "algorithmic_bytes_per_launch": conv_bytes // max(conv_launches, 1),
                                "launches_per_step": conv_launches // args.profile_steps,
                                "avg_launch_us": round(1000.0 * conv_ms / conv_launches, 2),
                                "conv_ms_per_image": round(conv_ms / args.profile_steps / B, 3),

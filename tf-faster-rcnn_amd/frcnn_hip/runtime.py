@@ -172,7 +172,8 @@ class Session(VariableStore):
         return t
 
     # ---- profiling hook: HIP events around selected launches, on the stream they run on ----------
-    def mark(self, tag, flops, fn):
+    def mark(self, tag, flops, fn, nbytes=0):
+        """nbytes: algorithmic HBM bytes of the launch (operands read once + result written once), for the roofline report."""
         self.flops_last_forward += flops
         if self.profile is None:
             return fn()
@@ -180,7 +181,7 @@ class Session(VariableStore):
         e0.record()
         r = fn()
         e1.record()
-        self.profile.append((tag, flops, e0, e1))
+        self.profile.append((tag, flops, e0, e1, nbytes))
         return r
 
     def synchronize(self):

@@ -101,10 +101,12 @@ class Network(object):
             G, T = ops.winograd_points(m), ops.winograd_tiles(N, H, W, m)
             u = ops.winograd_filter_transform_device(w, m, False, out=sess.buf(self._tag + "/wino_u", (G, Cout, Cin)))
             v, mm = sess.buf(self._tag + "/wino_v", (G, T, Cin)), sess.buf(self._tag + "/wino_m", (G, T, Cout))
-            sess.mark("conv:" + scope, 2 * G * T * Cout * Cin, lambda: ops.conv3x3_winograd(x, u, b, act, out=out, v_buf=v, m_buf=mm))
+            sess.mark("conv:" + scope, 2 * G * T * Cout * Cin, lambda: ops.conv3x3_winograd(x, u, b, act, out=out, v_buf=v, m_buf=mm),
+                      nbytes=4 * (v.numel() + u.numel() + mm.numel()))
         else:
             sess.mark("conv:" + scope, flops,
-                      lambda: ops.conv2d(x, w, b, k, k, stride, pad, act, residual, res_stride, fold_w, out=out))
+                      lambda: ops.conv2d(x, w, b, k, k, stride, pad, act, residual, res_stride, fold_w, out=out),
+                      nbytes=4 * (x.numel() + w.numel() + out.numel() + (out.numel() if residual is not None else 0)))
         if self._mode == "TRAIN":
             self._tape.append(dict(kind="conv", scope=scope, x=x, y=out, k=k, stride=stride, pad=tuple(pad), act=act,
                                    residual=residual, res_stride=res_stride))
@@ -137,7 +139,8 @@ class Network(object):
         mm = sess.buf(self._tag + "/wino_m", (G, T, Cout))
         out = sess.buf(self._tag + "/" + scope, (N, H, W, Cout))
         sess.mark("op:wino_in", 0, lambda: ops.winograd_input_transform(x, v, m))
-        sess.mark("conv:" + scope, 2 * G * T * Cout * Cin, lambda: ops.gemm_batched_nt(v, u, mm))
+        sess.mark("conv:" + scope, 2 * G * T * Cout * Cin, lambda: ops.gemm_batched_nt(v, u, mm),
+                  nbytes=4 * (v.numel() + u.numel() + mm.numel()))
         sess.mark("op:wino_out", 0, lambda: ops.winograd_output_transform(mm, b, act, out, m))
         return out
 
