@@ -126,6 +126,7 @@ def main():
     from model.config import cfg
     from nets.resnet_v1 import resnetv1
 
+    cfg.USE_GPU_NMS = False           # the reference's CPU/Cython suppression rule (cpu_nms.pyx:65): the path BASELINE.json pins
     sess = Session(device=dev, seed=cfg.RNG_SEED)
     S = max(1, args.streams)
     nets = []

@@ -26,20 +26,26 @@ extern "C" {
 #define FRCNN_E_UNSUPPORTED (-3)
 #define FRCNN_E_HIP(e) (-(1000 + (int)(e)))
 
+/* NMS suppression rule.  CPU: suppress iff (double)ovr >= thresh (lib/nms/cpu_nms.pyx:65, lib/nms/cpu_nms.c:2239-2241).
+ * GPU: suppress iff ovr > (float)thresh (lib/nms/nms_kernel.cu:71; same test as lib/nms/py_cpu_nms.py:35).  Both use the
+ * +1 pixel convention and f32 IoU arithmetic with one rounding per operation. */
+#define FRCNN_NMS_RULE_CPU 0
+#define FRCNN_NMS_RULE_GPU 1
+
 #define FRCNN_ACT_NONE 0
 #define FRCNN_ACT_RELU 1
 #define FRCNN_ACT_RELU6 2
 
 /* ---- library ------------------------------------------------------------------------------- */
-int frcnn_abi_version(void);                 /* bumps when a signature changes */
+int frcnn_abi_version(void);                 /* bumps when a signature changes (2: batched detection stages, NMS rule) */
 const char* frcnn_build_info(void);          /* "gfx950 ..." */
 
 /* ---- NMS: replaces lib/nms/gpu_nms.hpp:1-2 (`_nms`), lib/nms/cpu_nms.pyx:17-68 -------------- */
 /* Source-compatible with the reference's extern "C++" `_nms` (lib/nms/gpu_nms.hpp:1-2, driver
  * lib/nms/nms_kernel.cu:91-144): HOST pointers, blocking, boxes [n, boxes_dim>=4] already sorted
- * by descending score, keep_out capacity n.  Difference on purpose: suppression uses the CPU/Cython
- * rule `ovr >= thresh` (cpu_nms.pyx:65) -- the path BASELINE.json names -- not the CUDA kernel's
- * `>` (nms_kernel.cu:71).  Allocates/frees its own device scratch like the original did. */
+ * by descending score, keep_out capacity n.  Applies the CUDA kernel's rule FRCNN_NMS_RULE_GPU (`devIoU > thresh`,
+ * nms_kernel.cu:71), so it returns what the reference `_nms` returns, also at IoU == thresh.  Allocates/frees its own
+ * device scratch like the original did.  n <= 65536. */
 void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
           float nms_overlap_thresh, int device_id);
 
@@ -48,13 +54,18 @@ size_t frcnn_nms_workspace_bytes(int max_boxes);
  * keep_d [max_keep] int32 receives kept ORIGINAL indices in descending-score order
  * (ties: lower index first), num_keep_d the count (<= max_keep; the greedy scan stops there, which
  * equals truncating the full keep list, lib/layer_utils/proposal_layer.py:44-45).
- * Suppress iff (double)ovr >= thresh, exactly as lib/nms/cpu_nms.c:2239-2241.  k <= 16384. */
+ * frcnn_nms: rule FRCNN_NMS_RULE_CPU -- suppress iff (double)ovr >= thresh, exactly as lib/nms/cpu_nms.c:2239-2241.
+ * frcnn_nms_rule: the rule is an argument (FRCNN_NMS_RULE_GPU = what gpu_nms / the CUDA kernel compute).  k <= 65536. */
 int frcnn_nms(const float* dets_d, int k, double thresh, int max_keep, int* keep_d, int* num_keep_d,
               void* ws, size_t ws_bytes, void* stream);
+int frcnn_nms_rule(const float* dets_d, int k, double thresh, int rule, int max_keep, int* keep_d, int* num_keep_d,
+                   void* ws, size_t ws_bytes, void* stream);
 /* Same, for input already sorted by descending score (boxes_d rows of `stride` floats, the first
  * four are x1,y1,x2,y2): the device-pointer form of `_nms`. */
 int frcnn_nms_sorted(const float* boxes_d, int k, int stride, double thresh, int max_keep, int* keep_d,
                      int* num_keep_d, void* ws, size_t ws_bytes, void* stream);
+int frcnn_nms_sorted_rule(const float* boxes_d, int k, int stride, double thresh, int rule, int max_keep, int* keep_d,
+                          int* num_keep_d, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- anchors: replaces lib/layer_utils/generate_anchors.py:41-105, snippets.py:14-30 --------- */
 /* HOST: base anchors, float64 [n_ratios*n_scales, 4], ratio-major; np.round half-to-even. */
@@ -72,16 +83,33 @@ size_t frcnn_proposal_workspace_bytes(int H, int W, int A, int pre_nms_topn);
  * im_info[0], im_info[1] (scaled image), base_d = float64 base anchors [A,4] (anchors are
  * re-generated in-kernel from the anchor index; they are never read from HBM).
  * rois_d [post_nms_topn,5] = (0,x1,y1,x2,y2), scores_d [post_nms_topn]; rows >= *num_d are zero.
- * pre_nms_topn <= 0 means "all" (proposal_layer.py:35); min(pre,N) <= 16384. */
+ * pre_nms_topn <= 0 means "all" (proposal_layer.py:35); min(pre, H*W*A) <= 65536.  Rule FRCNN_NMS_RULE_CPU. */
 int frcnn_proposal_layer(const float* rpn_cls_prob_d, const float* rpn_bbox_pred_d, float im_h,
                          float im_w, int H, int W, int A, int feat_stride, const double* base_d,
                          int pre_nms_topn, int post_nms_topn, double nms_thresh, float* rois_d,
                          float* scores_d, int* num_d, void* ws, size_t ws_bytes, void* stream);
+/* The same layer for B same-size images in the same launches (the reference graph is batch-1, lib/nets/network.py:388; a
+ * batch is B independent images): rpn_cls_prob_d [B,H,W,2A], rpn_bbox_pred_d [B,H,W,4A] -> rois_d [B*post_nms_topn,5] with
+ * rois[:,0] = image index (the batch_inds column of proposal_layer.py:49-51), scores_d [B*post_nms_topn], num_d [B];
+ * `rule` = FRCNN_NMS_RULE_CPU / _GPU (what lib/model/nms_wrapper.py:15-23 picks by cfg.USE_GPU_NMS).
+ * Stages per launch: decode+clip+key, exact radix select of the pre_nms_topn best keys, counting sort of those, 64x64-tile
+ * suppression bitmask, greedy reduce with prefetched mask rows. */
+size_t frcnn_proposal_batched_workspace_bytes(int B, int H, int W, int A, int pre_nms_topn);
+int frcnn_proposal_layer_batched(const float* rpn_cls_prob_d, const float* rpn_bbox_pred_d, int B, float im_h, float im_w,
+                                 int H, int W, int A, int feat_stride, const double* base_d, int pre_nms_topn,
+                                 int post_nms_topn, double nms_thresh, int rule, float* rois_d, float* scores_d, int* num_d,
+                                 void* ws, size_t ws_bytes, void* stream);
 /* TEST.MODE 'top': top rpn_top_n by score, decode+clip, no NMS; requires H*W*A >= rpn_top_n. */
 int frcnn_proposal_top_layer(const float* rpn_cls_prob_d, const float* rpn_bbox_pred_d, float im_h,
                              float im_w, int H, int W, int A, int feat_stride, const double* base_d,
                              int rpn_top_n, float* rois_d, float* scores_d, void* ws, size_t ws_bytes,
                              void* stream);
+/* proposal_top_layer for H*W*A < rpn_top_n (lib/layer_utils/proposal_top_layer.py:30-33): the reference then draws
+ * `npr.choice(length, size=rpn_top_n, replace=True)` from numpy's global stream; the caller draws the same indices on the
+ * host and this entry decodes + clips exactly those anchors in the given order.  top_inds_d [n_inds] int32 (device). */
+int frcnn_proposal_top_layer_inds(const float* rpn_cls_prob_d, const float* rpn_bbox_pred_d, float im_h, float im_w, int H,
+                                  int W, int A, int feat_stride, const double* base_d, const int* top_inds_d, int n_inds,
+                                  float* rois_d, float* scores_d, void* stream);
 
 /* USE_E2E_TF graph (the reference's default, lib/model/config.py:275).
  * frcnn_non_max_suppression: tf.image.non_max_suppression(boxes [k,4], scores [k], max_output_size, iou_threshold) as called
@@ -96,21 +124,34 @@ int frcnn_non_max_suppression(const float* boxes_d, const float* scores_d, int k
 int frcnn_proposal_layer_tf(const float* rpn_cls_prob_d, const float* rpn_bbox_pred_d, float im_h, float im_w, int H, int W,
                             int A, int feat_stride, const double* base_d, int post_nms_topn, float nms_thresh, float* rois_d,
                             float* scores_d, int* num_d, void* ws, size_t ws_bytes, void* stream);
+/* B images per launch (layouts as frcnn_proposal_layer_batched); workspace frcnn_proposal_batched_workspace_bytes(B,H,W,A,0). */
+int frcnn_proposal_layer_tf_batched(const float* rpn_cls_prob_d, const float* rpn_bbox_pred_d, int B, float im_h, float im_w,
+                                    int H, int W, int A, int feat_stride, const double* base_d, int post_nms_topn,
+                                    float nms_thresh, float* rois_d, float* scores_d, int* num_d, void* ws, size_t ws_bytes,
+                                    void* stream);
 
 /* ---- RoI pooling: replaces tf.image.crop_and_resize as called from lib/nets/resnet_v1.py:55-76
  * and lib/nets/network.py:141-157 ----------------------------------------------------------- */
 /* feat_d [H,W,C] (batch 1), rois_d [R,5] image coords, out_d [R,pool,pool,C].  fuse_max2x2 != 0:
- * sample a (2*pool)^2 grid and take the 2x2/2 max (network.py:152-157).  C % 4 == 0. */
+ * sample a (2*pool)^2 grid and take the 2x2/2 max (network.py:152-157).  C % 4 == 0.  rois[:,0] must be 0 (rows with
+ * another value produce zeros). */
 int frcnn_crop_and_resize(const float* feat_d, int H, int W, int C, const float* rois_d, int R,
                           float feat_stride, int pool, int fuse_max2x2, float* out_d, void* stream);
+/* feat_d [N,H,W,C]: the box_ind argument of tf.image.crop_and_resize is rois[:,0], as at network.py:143 / resnet_v1.py:57
+ * (`batch_ids = rois[:, 0]`); rows whose index is outside [0,N) produce zeros.  Launch shape: one workgroup per
+ * (roi, output row, 1/8 channel slab) with the slab as the fastest block index, so each XCD's L2 holds one slab of the map. */
+int frcnn_crop_and_resize_batched(const float* feat_d, int N, int H, int W, int C, const float* rois_d, int R,
+                                  float feat_stride, int pool, int fuse_max2x2, float* out_d, void* stream);
 
-/* out = act(crop_and_resize(feat) + bias[c]).  A 1x1 convolution commutes with the (linear) bilinear crop,
- * so the two 1x1 convs that consume the RoI crops (block4/unit_1 shortcut and conv1, lib/nets/resnet_v1.py:
- * 115-125) can run once on the H x W map (2 394 pixels) instead of on R x 7 x 7 crops (14 700 pixels);
- * bias and ReLU are applied here, after the crop, because out-of-range samples are zeros. */
-int frcnn_crop_and_resize_bias_act(const float* feat_d, int H, int W, int C, const float* rois_d, int R,
+/* out = act(crop_and_resize(feat) + bias[c]), feat_d [N,H,W,C], image index = rois[:,0].  A 1x1 convolution commutes
+ * with the (linear) bilinear crop, so the two 1x1 convs that consume the RoI crops (block4/unit_1 shortcut and conv1,
+ * lib/nets/resnet_v1.py:115-125) can run once on the H x W map (2 394 pixels) instead of on R x 7 x 7 crops (14 700
+ * pixels); bias and ReLU are applied here, after the crop, because out-of-range samples are zeros. */
+int frcnn_crop_and_resize_bias_act(const float* feat_d, int N, int H, int W, int C, const float* rois_d, int R,
                                    float feat_stride, int pool, const float* bias_d, int act, float* out_d,
                                    void* stream);
+/* tuning knob for A/B runs: key 4 = channel-slab count of the crop kernels (-1 automatic). */
+int frcnn_detect_set_tuning(int key, int value);
 
 /* ---- test-time post-processing: replaces lib/model/test.py:95-102 (im_detect) and :162-180
  * (test_net per-class NMS + max_per_image cut) ----------------------------------------------- */
@@ -120,16 +161,32 @@ size_t frcnn_detect_post_workspace_bytes(int R, int C);
  * im_h, im_w: ORIGINAL image size.  out_dets_d [max_out,6] = x1,y1,x2,y2,score,class (class-major,
  * score-descending inside a class == all_boxes[j][i] order), *out_count_d = number of detections
  * (may exceed max_out only when ties straddle the max_per_image cut; excess rows are dropped).
- * R <= 1024. */
+ * R <= 1024.  Rule FRCNN_NMS_RULE_CPU. */
 int frcnn_detect_post(const float* cls_prob_d, const float* bbox_pred_d, const float* rois_d,
                       const int* num_rois_d, int R, int C, double im_scale, int im_h, int im_w,
                       double nms_thresh, float score_thresh, int max_per_image, float* out_dets_d,
                       int* out_count_d, int max_out, void* ws, size_t ws_bytes, void* stream);
+/* B images per launch: cls_prob_d [B*R,C], bbox_pred_d [B*R,4C], rois_d [B*R,5] (R rows per image), num_rois_d [B] or
+ * NULL -> out_dets_d [B,max_out,6] with `out_stride` floats between images (0 = dense, max_out*6), out_count_d [B].  One workgroup per (class, image); sort, bitmask and greedy reduce of a
+ * class live entirely in LDS.  `rule` as in frcnn_nms_rule. */
+size_t frcnn_detect_post_batched_workspace_bytes(int B, int R, int C);
+int frcnn_detect_post_batched(const float* cls_prob_d, const float* bbox_pred_d, const float* rois_d, const int* num_rois_d,
+                              int B, int R, int C, double im_scale, int im_h, int im_w, double nms_thresh, int rule,
+                              float score_thresh, int max_per_image, float* out_dets_d, int* out_count_d, int max_out,
+                              long long out_stride, void* ws, size_t ws_bytes, void* stream);
 
 /* The box stage of im_detect alone (lib/model/test.py:95-102): pred_boxes [R,4C] = clip(decode(rois/scale,
  * bbox_pred)) for every class, for callers that want the reference's (scores, pred_boxes) pair. */
 int frcnn_im_detect_boxes(const float* rois_d, const float* bbox_pred_d, int R, int C, double im_scale,
                           int im_h, int im_w, float* boxes_d, void* stream);
+
+/* ---- box codec: replaces lib/model/bbox_transform.py:14-81 (numpy in / numpy out helpers) -------------------- */
+/* bbox_transform_inv(boxes [N,4], deltas [N,4k]) -> out [N,4k] (class quadruple j of row i decoded against boxes[i]);
+ * clip_boxes(boxes [N,4k], im_shape) in place: every coordinate clamped to [0, dim-1];
+ * bbox_transform(ex_rois [N,4], gt_rois [N,4]) -> targets [N,4] (dx, dy, dw, dh) in float32. */
+int frcnn_bbox_transform_inv(const float* boxes_d, const float* deltas_d, int N, int k, float* out_d, void* stream);
+int frcnn_clip_boxes(float* boxes_d, int N, int k, float im_h, float im_w, void* stream);
+int frcnn_bbox_transform(const float* ex_rois_d, const float* gt_rois_d, int N, float* targets_d, void* stream);
 
 /* ---- IoU matrix: replaces lib/utils/bbox.pyx:15-55 ------------------------------------------ */
 /* boxes_d [n,4] f64, query_d [k,4] f64 -> out_d [n,k] f64. */
@@ -239,6 +296,16 @@ int frcnn_anchor_target_layer(const float* gt_boxes_d, int G, float im_h, float 
                               double pos_overlap, double neg_overlap, long long seed, float* labels_d,
                               float* bbox_targets_d, float* inside_w_d, float* outside_w_d, void* ws,
                               size_t ws_bytes, void* stream);
+/* Host-oracle sampling mode: the reference draws its fg/bg subsamples from numpy's GLOBAL
+ * MT19937 stream (anchor_target_layer.py:72-86); the py_func-compatible mirror lib/layer_utils/anchor_target_layer.py makes
+ * the same npr.choice calls on the host and hands the chosen `disable_inds` (as indices into ALL H*W*A anchors, int32 device
+ * array, fg and bg lists concatenated, no duplicates) to this entry, which then reproduces the reference's outputs bit for bit.
+ * n_disable = 0: nothing is disabled and nothing is sampled. */
+int frcnn_anchor_target_layer_inject(const float* gt_boxes_d, int G, float im_h, float im_w, int H, int W, int A, int feat_stride,
+                                     const double* base_d, int rpn_batchsize, double fg_fraction, double pos_overlap,
+                                     double neg_overlap, const int* disable_d, int n_disable, float* labels_d,
+                                     float* bbox_targets_d, float* inside_w_d, float* outside_w_d, void* ws, size_t ws_bytes,
+                                     void* stream);
 /* proposal_target_layer (lib/layer_utils/proposal_target_layer.py:18-152, USE_GT False).  rpn_rois_d [N,5],
  * rpn_scores_d [N], N <= 3072.  Outputs: rois_d [B,5], roi_scores_d [B], labels_d [B], bbox_targets_d /
  * inside_w_d / outside_w_d [B,4*num_classes], counts_d[4] = {fg sampled, bg sampled, fg candidates, bg candidates}.
@@ -256,6 +323,12 @@ int frcnn_proposal_target_layer_dn(const float* rpn_rois_d, const float* rpn_sco
                                    double fg_thresh, double bg_thresh_hi, double bg_thresh_lo, const double* means4,
                                    const double* stds4, long long seed, float* rois_d, float* roi_scores_d, float* labels_d,
                                    float* bbox_targets_d, float* inside_w_d, float* outside_w_d, int* counts_d, void* stream);
+/* Host-oracle sampling mode: keep_inds_d [batch_size] int32 = np.append(fg_inds, bg_inds) as the caller drew them with
+ * npr.choice (proposal_target_layer.py:119-138), the first n_fg rows are foreground; outputs as above, in that row order. */
+int frcnn_proposal_target_layer_inject(const float* rpn_rois_d, const float* rpn_scores_d, int N, const float* gt_boxes_d, int G,
+                                       int num_classes, int batch_size, const int* keep_inds_d, int n_fg, const double* means4,
+                                       const double* stds4, float* rois_d, float* roi_scores_d, float* labels_d,
+                                       float* bbox_targets_d, float* inside_w_d, float* outside_w_d, void* stream);
 /* Losses of lib/nets/network.py:264-321, value + gradient w.r.t. the logits / predictions in one call.
  * softmax CE: logits [R,C] rows (rpn_A = 0) or the RPN pair layout (rpn_A = A: logits [H*W,2A], element
  * r = (a*H+h)*W+w pairs channels (a, A+a), labels_d in the [1,1,A*H,W] layout); label < 0 is ignored;

@@ -151,6 +151,33 @@ def cpu_nms(dets, thresh):
     return keep[:n].tolist()
 
 
+def gpu_nms(dets, thresh):
+    """The reference's OTHER suppression rule: nms/nms_kernel.cu:24-33,71 (`devIoU(...) > nms_overlap_thresh`, all float32,
+    threshold a C float) == nms/py_cpu_nms.py:10-38 (`ovr <= thresh` kept; float32 arrays against a weak Python scalar).
+    Same +1 areas and operation order as cpu_nms; only the comparison differs.  PINNED against the reference's own
+    py_cpu_nms (oracle/gen_golden.py); the CUDA kernel itself cannot run here (nvcc may also contract `Sa + Sb` into an FMA,
+    which no CPU statement of the reference does)."""
+    d = np.ascontiguousarray(dets, dtype=f32)
+    k = d.shape[0]
+    if k == 0:
+        return []
+    x1, y1, x2, y2 = d[:, 0], d[:, 1], d[:, 2], d[:, 3]
+    areas = ((x2 - x1) + f32(1)) * ((y2 - y1) + f32(1))
+    order = order_desc(d[:, 4])
+    thr = f32(thresh)
+    keep = []
+    while order.size > 0:
+        i = order[0]
+        keep.append(int(i))
+        rest = order[1:]
+        w = np.maximum(f32(0), (np.minimum(x2[i], x2[rest]) - np.maximum(x1[i], x1[rest])) + f32(1))
+        h = np.maximum(f32(0), (np.minimum(y2[i], y2[rest]) - np.maximum(y1[i], y1[rest])) + f32(1))
+        inter = w * h
+        ovr = inter / ((areas[i] + areas[rest]) - inter)
+        order = rest[ovr <= thr]
+    return keep
+
+
 def nms(dets, thresh, force_cpu=False):
     """model/nms_wrapper.py:15-23 with cfg.USE_GPU_NMS = False."""
     if dets.shape[0] == 0:

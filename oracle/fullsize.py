@@ -1,0 +1,283 @@
+"""TEST INFRASTRUCTURE ONLY -- full-size (BASELINE.json configs[1] / configs[2]) end-to-end reference.
+
+The float64 torch-CPU restatement of the dense graph (oracle/dense_ref.py) plus the pinned numpy/C detection
+oracle (oracle/frcnn_oracle.py) run on the SAME seeded weights and image the GPU tests build, at the
+benchmark's real sizes:
+
+  c2  ResNet-101, 600x1000,  A = 9  (scales 8,16,32),      21 classes,  300 proposals   (configs[1])
+  c3  ResNet-101, 800x1333,  A = 15 (scales 2,4,8,16,32),  81 classes, 1000 proposals   (configs[2])
+
+A float64 pass of 622 / 1788 GFLOP takes minutes on host cores, and GPU-box minutes are scarce, so the
+reference is computed ONCE (oracle/gen_fullsize.py, here, on the CPU) and its small outputs are committed
+under tests/golden/full_<config>_<weights>.npz.  Everything is derived from np.random.RandomState seeds, so
+the GPU test rebuilds bit-identical weights and image from the same recipe (`build`), overrides the frozen
+batch-norm statistics from the fixture in "calibrated" mode, and compares.
+
+Weights modes
+  damped      runtime.VariableStore.init_variables as bench.py uses it: He filters, synthetic BN statistics,
+              last BN of each residual branch gamma ~ U(0.1, 0.3).
+  calibrated  gamma ~ U(0.5, 1.5) on EVERY BN (residual branch ends included) and moving_mean / moving_variance
+              set to the actual per-channel statistics of each convolution's output on this image (what a
+              trained network's frozen statistics are): every branch output is O(1) like a trained ResNet's,
+              instead of the damped gains.  The statistics (about 55 k channels) are part of the fixture.
+Both modes rescale the two 1x1 RPN heads by constants stored in the fixture so that the proposal stage sees
+the statistics SURVEY.md 8d prescribes (logit spread ~1, deltas ~N(0, 0.2^2)) and NMS has real work.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (os.path.join(ROOT, "tf-faster-rcnn_amd"), os.path.join(ROOT, "tf-faster-rcnn_amd", "lib")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+CONFIGS = {
+    "c2": dict(layers=101, H=600, W=1000, scale=1.6, scales=(8, 16, 32), ratios=(0.5, 1, 2), classes=21, post=300,
+               pre=6000, max_per_image=100),
+    "c3": dict(layers=101, H=800, W=1333, scale=1.6, scales=(2, 4, 8, 16, 32), ratios=(0.5, 1, 2), classes=81, post=1000,
+               pre=6000, max_per_image=100),
+}
+PIXEL_MEANS = np.array([[[102.9801, 115.9465, 122.7717]]])
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def fixture_path(config, weights):
+    return os.path.join(GOLD, "full_%s_%s.npz" % (config, weights))
+
+
+def synth_image(c, seed=3):
+    rng = np.random.RandomState(seed)
+    return (rng.rand(1, c["H"], c["W"], 3) * 255.0).astype(np.float32) - PIXEL_MEANS.astype(np.float32)
+
+
+def declare(config):
+    """(net, specs): the product's own variable declaration (host only, no GPU needed)."""
+    from nets.resnet_v1 import resnetv1
+    c = CONFIGS[config]
+    net = resnetv1(num_layers=c["layers"])
+    net.create_architecture("TEST", c["classes"], tag="full_" + config, anchor_scales=c["scales"], anchor_ratios=c["ratios"])
+    return net, net.variable_specs()
+
+
+def base_variables(config, weights, seed=3):
+    """Seeded weights before the fixture-borne parts (RPN head scales, calibrated BN statistics) are applied."""
+    from frcnn_hip.runtime import VariableStore
+    net, specs = declare(config)
+    store = VariableStore(seed=seed)
+    store.init_variables(specs)
+    v = store.variables
+    if weights == "calibrated":
+        rng = np.random.RandomState(seed + 1000)
+        for name in v:
+            if name.endswith("/BatchNorm/gamma"):
+                v[name] = rng.uniform(0.5, 1.5, size=v[name].shape).astype(np.float32)
+    elif weights != "damped":
+        raise ValueError(weights)
+    return net, v
+
+
+def apply_fixture(v, scope, fx):
+    """Weights exactly as the reference pass saw them: RPN head scales + (calibrated) BN statistics from the fixture."""
+    v[scope + "/rpn_cls_score/weights"] = (v[scope + "/rpn_cls_score/weights"] * np.float32(fx["rpn_cls_scale"])).astype(np.float32)
+    v[scope + "/rpn_bbox_pred/weights"] = (v[scope + "/rpn_bbox_pred/weights"] * np.float32(fx["rpn_box_scale"])).astype(np.float32)
+    if "bn_names" in fx:
+        names = [str(s) for s in fx["bn_names"]]
+        off = 0
+        mean, var = fx["bn_mean"], fx["bn_var"]
+        for s in names:
+            n = v[s + "/BatchNorm/moving_mean"].shape[0]
+            v[s + "/BatchNorm/moving_mean"] = mean[off:off + n].astype(np.float32)
+            v[s + "/BatchNorm/moving_variance"] = var[off:off + n].astype(np.float32)
+            off += n
+        assert off == mean.shape[0]
+    return v
+
+
+def build(config, weights, seed=3):
+    """For the GPU tests: (net, variables, image, im_info, fixture) with the fixture's weights applied."""
+    c = CONFIGS[config]
+    fx = np.load(fixture_path(config, weights))
+    net, v = base_variables(config, weights, seed)
+    apply_fixture(v, net._scope, fx)
+    image = synth_image(c, seed)
+    im_info = np.array([c["H"], c["W"], c["scale"]], dtype=np.float32)
+    return net, v, image, im_info, fx
+
+
+def proposal_candidates(prob, deltas, im_info, scales, ratios):
+    """Every anchor's (clipped box, fg score) exactly as proposal_layer.py:27-31 forms them, from RPN outputs cast to f32."""
+    import frcnn_oracle as ora
+    A = len(scales) * len(ratios)
+    prob = np.asarray(prob, dtype=np.float32)
+    deltas = np.asarray(deltas, dtype=np.float32)
+    anchors, _ = ora.generate_anchors_pre(prob.shape[1], prob.shape[2], 16, scales, ratios)
+    scores = prob[..., A:].reshape(-1)
+    boxes = ora.clip_boxes(ora.bbox_transform_inv(anchors, deltas.reshape(-1, 4)), np.asarray(im_info)[:2])
+    return boxes, scores
+
+
+def perclass_candidates(cls_prob, bbox_pred, rois, im_scale, orig_shape):
+    """(scores [R,C], boxes [R,4C]) of lib/model/test.py:95-102 from reference tensors cast to f32."""
+    import frcnn_oracle as ora
+    return ora.im_detect_post(np.asarray(cls_prob, dtype=np.float32), np.asarray(bbox_pred, dtype=np.float32),
+                              np.asarray(rois, dtype=np.float32), float(im_scale), orig_shape)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the GPU side of the harness (used by tests/test_fullsize_gpu.py and scratch/fullsize_policies.py)
+# ------------------------------------------------------------------------------------------------------------------
+POLICIES = {
+    # name -> cfg.HIP overrides
+    "direct": dict(WINOGRAD=False),
+    "f2": dict(WINOGRAD=True, WINOGRAD_M=2, WINOGRAD_F2_SCOPES=(), WINOGRAD_7X7=False),
+    "f4": dict(WINOGRAD=True, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=(), WINOGRAD_7X7=True),
+    "f4_rpn_f2": dict(WINOGRAD=True, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=("rpn_conv",), WINOGRAD_7X7=True),
+    "f4_rpn_block3_f2": dict(WINOGRAD=True, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=("rpn_conv", "block3"), WINOGRAD_7X7=True),
+    "f4_head_f2": dict(WINOGRAD=True, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=("rpn_conv", "block1", "block2", "block3"), WINOGRAD_7X7=True),
+}
+EPS_SCORE, EPS_IOU, TOL = 1e-4, 1e-3, 1e-4        # BASELINE.json north_star: 1e-4 on scores / box coordinates
+
+
+def rel_err(got, want):
+    return float(np.abs(np.asarray(got, dtype=np.float64) - np.asarray(want, dtype=np.float64)).max()) / max(1.0, float(np.abs(want).max()))
+
+
+def run_harness(config, weights, policy, dev, fuse_tail=True):
+    """One full-size image through the HIP chain under `policy`, compared stage by stage with the committed float64
+    reference.  Returns a flat report dict (errors, decision-margin summaries, `ok`)."""
+    import torch
+    import frcnn_oracle as ora
+    import margins as mg
+    from frcnn_hip.runtime import Session
+    from model.config import cfg
+    c = CONFIGS[config]
+    net, v, image, im_info, fx = build(config, weights)
+    saved = {k: cfg.HIP[k] for k in cfg.HIP}
+    saved_post, saved_nms = cfg.TEST.RPN_POST_NMS_TOP_N, cfg.USE_GPU_NMS
+    rep = dict(config=config, weights=weights, policy=policy, ok=True, notes=[])
+
+    def check(name, cond):
+        if not cond:
+            rep["ok"] = False
+            rep["notes"].append(name)
+    try:
+        for k, val in POLICIES[policy].items():
+            cfg.HIP[k] = val
+        cfg.TEST.RPN_POST_NMS_TOP_N = c["post"]
+        cfg.USE_GPU_NMS = False                                 # the CPU/Cython rule: the path BASELINE.json pins
+        sess = Session(device=dev, seed=3)
+        sess.load_variables(v)
+        net._fuse_tail_entry = bool(fuse_tail)
+        A = len(c["scales"]) * len(c["ratios"])
+        orig = (int(c["H"] / c["scale"]), int(c["W"] / c["scale"]))
+        img_d = net._stage_image(sess, image)
+        dets_d, cnt_d = net.detect_device(sess, img_d, im_info, orig, max_per_image=c["max_per_image"])
+        torch.cuda.synchronize()
+        p = {k: t.cpu().numpy() for k, t in net._predictions.items()}
+        n_rois = int(net._num_rois[0].item())
+        rois = p["rois"][:n_rois]
+        # ---- 1. dense tensors that do not depend on any decision
+        head = net._layers["head"].cpu().numpy()
+        rep["head_sub"] = rel_err(head[0, ::4, ::4, :], fx["head_sub"])
+        for k in ("rpn_cls_score", "rpn_cls_prob", "rpn_bbox_pred"):
+            rep[k] = rel_err(p[k], fx[k])
+            check(k, rep[k] <= TOL)
+        check("head", rep["head_sub"] <= TOL)
+        # ---- 2. proposal stage: bit-exact against the pinned oracle on the device's OWN RPN tensors ...
+        anchors, _ = ora.generate_anchors_pre(head.shape[1], head.shape[2], 16, c["scales"], c["ratios"])
+        wr, ws = ora.proposal_layer(p["rpn_cls_prob"], p["rpn_bbox_pred"], im_info, "TEST", [16], anchors, A, pre_nms_topN=c["pre"],
+                                    post_nms_topN=c["post"], nms_thresh=0.7)
+        same_shape = wr.shape == rois.shape
+        rep["prop_own_scores_exact"] = bool(same_shape and np.array_equal(net._sess.buffers[(net._tag + "/roi_scores", (c["post"], 1), torch.float32)][:n_rois].cpu().numpy(), ws))
+        rep["prop_own_box_abs_px"] = float(np.abs(rois - wr).max()) if same_shape else float("inf")
+        check("proposals vs oracle on identical inputs", rep["prop_own_scores_exact"] and rep["prop_own_box_abs_px"] <= TOL * max(c["H"], c["W"]))
+        # ---- ... and a valid outcome of the reference algorithm on the REFERENCE's RPN tensors (decision margins)
+        cb, cs = proposal_candidates(fx["rpn_cls_prob"], fx["rpn_bbox_pred"], im_info, c["scales"], c["ratios"])
+        sc_dev = net._sess.buffers[(net._tag + "/roi_scores", (c["post"], 1), torch.float32)][:n_rois].cpu().numpy().ravel()
+        m = mg.match_to_candidates(rois[:, 1:5], sc_dev, cb, cs, TOL * max(c["H"], c["W"]) * 4, EPS_SCORE)
+        pr = mg.check_greedy_nms(cb, cs, m, 0.7, EPS_SCORE, EPS_IOU, topn=c["pre"], max_keep=c["post"])
+        ref_m = mg.match_to_candidates(fx["rois"][:, 1:5], fx["roi_scores"].ravel(), cb, cs, 1e-6, 0.0)
+        rep["prop_same_as_ref"] = bool(np.array_equal(m, ref_m))
+        rep["prop_n"], rep["prop_ref_n"] = int(n_rois), int(fx["rois"].shape[0])
+        rep["prop_differing_rows"] = int((m != ref_m[:m.size]).sum()) if m.size == ref_m.size else -1
+        rep["prop_margin"] = mg.summarize(pr)
+        rep["prop_slack_score"], rep["prop_slack_iou"], rep["prop_fragile"] = pr["slack_score"], pr["slack_iou"], pr["fragile"]
+        check("proposal decisions within eps of the reference's", pr["ok"])
+        ok_m = m >= 0
+        rep["prop_score_abs"] = float(np.abs(sc_dev[ok_m] - cs[m[ok_m]]).max()) if ok_m.any() else float("inf")
+        rep["prop_box_abs_px"] = float(np.abs(rois[ok_m, 1:5] - cb[m[ok_m]]).max()) if ok_m.any() else float("inf")
+        check("proposal scores / boxes vs reference", rep["prop_score_abs"] <= EPS_SCORE and rep["prop_box_abs_px"] <= TOL * max(c["H"], c["W"]))
+        # ---- 3. RoI tail on the REFERENCE's rois (identical inputs for the per-RoI comparison)
+        R = c["post"]
+        pad = np.zeros((R, 5), dtype=np.float32)
+        pad[:fx["rois"].shape[0]] = fx["rois"]
+        with torch.cuda.stream(sess.stream):
+            net._sess = sess
+            rois_d = sess.to_device(pad)
+            head_d = net._layers["head"]
+            if net._fuse_tail_entry:
+                fc7 = net._fused_tail_entry(head_d, rois_d)
+            else:
+                fc7 = net._head_to_tail(net._crop_pool_layer(head_d, rois_d, "pool5"), False)
+            cls_prob_d, bbox_pred_d = net._region_classification(fc7, False)
+            cls_score_d = net._predictions["cls_score"]
+            sess.stream.synchronize()
+        nref = fx["rois"].shape[0]
+        rep["fc7_sub"] = rel_err(fc7[:nref].cpu().numpy()[::8], fx["fc7_sub"])
+        rep["cls_score"] = rel_err(cls_score_d[:nref].cpu().numpy(), fx["cls_score"])
+        rep["cls_prob_abs"] = float(np.abs(cls_prob_d[:nref].cpu().numpy() - fx["cls_prob"]).max())
+        rep["bbox_pred"] = rel_err(bbox_pred_d[:nref].cpu().numpy(), fx["bbox_pred"])
+        rep["logit_scale"] = float(np.abs(fx["cls_score"]).max())
+        check("cls_score", rep["cls_score"] <= TOL)
+        check("bbox_pred", rep["bbox_pred"] <= TOL)
+        # softmax of O(1e3) logits (the damped synthetic weights) amplifies a 1e-6 relative logit error past 1e-4 absolute:
+        # the probability bound is asserted where the logits have a trained network's scale
+        if rep["logit_scale"] <= 50.0:
+            check("cls_prob", rep["cls_prob_abs"] <= TOL)
+        # ---- 4. final detections: bit-exact vs the oracle on the device's own tensors, margins vs the reference's
+        n = int(cnt_d.reshape(-1)[0].item())
+        got = dets_d.reshape(-1, 6)[:n].cpu().numpy()
+        s_own, b_own = ora.im_detect_post(p["cls_prob"][:n_rois], p["bbox_pred"][:n_rois], rois, float(c["scale"]), orig + (3,))
+        want = ora.detections_to_records(ora.test_net_post(s_own, b_own, c["classes"], max_per_image=c["max_per_image"]))
+        rep["dets_own_exact"] = bool(n == want.shape[0] and np.array_equal(got[:, 4:], want[:, 4:]))
+        rep["dets_own_box_abs_px"] = float(np.abs(got[:, :4] - want[:, :4]).max()) if n == want.shape[0] and n else float("inf")
+        check("detections vs oracle on identical inputs", rep["dets_own_exact"] and rep["dets_own_box_abs_px"] <= TOL * max(orig))
+        rep["dets_n"], rep["dets_ref_n"] = n, int(fx["dets"].shape[0])
+        if rep["prop_same_as_ref"]:
+            # same proposals -> the per-class stage sees the reference's candidates up to f32 noise: margin check per class
+            s_ref, b_ref = perclass_candidates(fx["cls_prob"], fx["bbox_pred"], fx["rois"], c["scale"], orig + (3,))
+            floor = float(got[:, 4].min()) if n >= c["max_per_image"] else None
+            worst_s = worst_i = 0.0
+            frag = 0
+            ok = True
+            for j in range(1, c["classes"]):
+                rows = got[got[:, 5] == j]
+                mm = mg.match_to_candidates(rows[:, :4], rows[:, 4], b_ref[:, 4 * j:4 * j + 4], s_ref[:, j], TOL * max(orig) * 4, EPS_SCORE)
+                r = mg.check_greedy_nms(b_ref[:, 4 * j:4 * j + 4], s_ref[:, j], mm, 0.3, EPS_SCORE, EPS_IOU, score_floor=floor)
+                if rows.shape[0] == 0 and floor is not None:
+                    r = dict(ok=bool(not (s_ref[:, j] > floor + EPS_SCORE).any()), slack_score=0.0, slack_iou=0.0, fragile=0)
+                ok = ok and r["ok"]
+                worst_s, worst_i, frag = max(worst_s, r["slack_score"]), max(worst_i, r["slack_iou"]), frag + r["fragile"]
+            rep["dets_slack_score"], rep["dets_slack_iou"], rep["dets_fragile"] = worst_s, worst_i, frag
+            rep["dets_same_as_ref"] = bool(n == fx["dets"].shape[0] and np.array_equal(got[:, 5], fx["dets"][:, 5]) and
+                                           np.abs(got[:, :5] - fx["dets"][:, :5]).max() <= 1e-2)
+            check("final detections within eps of the reference's", ok)
+        sess.close()
+    finally:
+        for k, val in saved.items():
+            cfg.HIP[k] = val
+        cfg.TEST.RPN_POST_NMS_TOP_N, cfg.USE_GPU_NMS = saved_post, saved_nms
+    return rep
+
+
+def format_report(rep):
+    f = lambda k: ("%.2e" % rep[k]) if isinstance(rep.get(k), float) else str(rep.get(k))
+    return ("%-3s %-10s %-16s %s | head %s rpn_prob %s rpn_bbox %s | rois %s/%s same=%s diff_rows=%s slack(s %s, iou %s) fragile %s "
+            "own: exact=%s box %s px | tail cls_score %s cls_prob_abs %s bbox %s (|logit| %s) | dets %s/%s own_exact=%s same=%s slack(s %s, iou %s)%s"
+            % (rep["config"], rep["weights"], rep["policy"], "OK  " if rep["ok"] else "FAIL", f("head_sub"), f("rpn_cls_prob"), f("rpn_bbox_pred"),
+               rep.get("prop_n"), rep.get("prop_ref_n"), rep.get("prop_same_as_ref"), rep.get("prop_differing_rows"), f("prop_slack_score"),
+               f("prop_slack_iou"), rep.get("prop_fragile"), rep.get("prop_own_scores_exact"), f("prop_own_box_abs_px"), f("cls_score"),
+               f("cls_prob_abs"), f("bbox_pred"), f("logit_scale"), rep.get("dets_n"), rep.get("dets_ref_n"), rep.get("dets_own_exact"),
+               rep.get("dets_same_as_ref"), f("dets_slack_score"), f("dets_slack_iou"), ("  <- " + "; ".join(rep["notes"])) if rep["notes"] else ""))

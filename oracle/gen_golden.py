@@ -99,6 +99,12 @@ def main(write=True):
     blob, sc = ref.proposal_top_layer(prob, dl, im_info, [16], anc, 9)
     pin("proposal_top_layer", (blob, sc), ora.proposal_top_layer(prob, dl, im_info, [16], anc, 9))
     g["top_38x63_a9_rois"], g["top_38x63_a9_scores"] = blob, sc
+    # fewer anchors than RPN_TOP_N: the random fill of proposal_top_layer.py:30-33 (numpy global stream, seeded)
+    prob, dl = synth.rpn_outputs(5, 6, 9, seed=3)
+    anc, _ = ref.generate_anchors_pre(5, 6, 16, (8, 16, 32), (0.5, 1, 2))
+    np.random.seed(3)
+    blob, sc = ref.proposal_top_layer(prob, dl, np.array([80, 96, 1.0], dtype=f32), [16], anc, 9)
+    g["topfill_5x6_a9_rois"], g["topfill_5x6_a9_scores"] = blob, sc
     out["proposal"] = g
 
     # ---- USE_E2E_TF graph (config.py:275): the reference's *_tf bodies on the numpy-backed tf shim
@@ -139,6 +145,18 @@ def main(write=True):
         pin("cpu_nms " + tag, keep, np.array(ora.cpu_nms(d, thr), dtype=np.int64))
         g[tag + "_keep"] = keep.astype(np.int32)
         g[tag + "_in_sha"] = np.frombuffer(bytes.fromhex(sha(d)), dtype=np.uint8)
+        # the reference's second rule (nms_kernel.cu:71 `>`; its importable statement is py_cpu_nms.py:35)
+        keep_g = np.array(ref.py_cpu_nms(d, thr), dtype=np.int64)
+        pin("py_cpu_nms " + tag, keep_g, np.array(ora.gpu_nms(d, thr), dtype=np.int64))
+        g[tag + "_keep_gpu"] = keep_g.astype(np.int32)
+    d = synth.threshold_pairs()                              # IoU == thresh exactly: the two rules MUST differ here
+    keep_c = np.array(ref.cpu_nms(d, 0.5), dtype=np.int64)
+    keep_g = np.array(ref.py_cpu_nms(d, 0.5), dtype=np.int64)
+    assert keep_g.size == keep_c.size + 24, (keep_g.size, keep_c.size)
+    pin("cpu_nms eq_t05", keep_c, np.array(ora.cpu_nms(d, 0.5), dtype=np.int64))
+    pin("py_cpu_nms eq_t05", keep_g, np.array(ora.gpu_nms(d, 0.5), dtype=np.int64))
+    g["eq_t05_keep"], g["eq_t05_keep_gpu"] = keep_c.astype(np.int32), keep_g.astype(np.int32)
+    g["eq_t05_in_sha"] = np.frombuffer(bytes.fromhex(sha(d)), dtype=np.uint8)
     out["nms"] = g
 
     # ---- per-class post-processing (test.py:95-102,162-180), built from the reference's pieces
@@ -182,15 +200,31 @@ def main(write=True):
     anc, _ = ref.generate_anchors_pre(H, W, 16, (8, 16, 32), (0.5, 1, 2))
     gt = synth.gt_boxes(7, 21, seed=15)
     score = np.zeros((1, H, W, 2 * A), dtype=f32)
+    # the index draws of the reference run (numpy's global stream), recorded for the host-oracle sampling mode
+    draws = []
+    real_choice = np.random.choice
+
+    def recording_choice(a, size=None, replace=True, p=None):
+        r = real_choice(a, size=size, replace=replace, p=p)
+        draws.append(np.array(r))
+        return r
+    np.random.choice = recording_choice
     np.random.seed(3)
     at = ref.anchor_target_layer(score, gt, im_info, [16], anc, A)
+    inside = np.where((anc[:, 0] >= 0) & (anc[:, 1] >= 0) & (anc[:, 2] < im_info[1]) & (anc[:, 3] < im_info[0]))[0]
+    g["at_disable"] = inside[np.concatenate(draws)].astype(np.int32) if draws else np.zeros((0,), dtype=np.int32)
+    del draws[:]
     pin("anchor_target_layer", at, ora.anchor_target_layer(score, gt, im_info, [16], anc, A, rng=np.random.RandomState(3)))
     g["at_labels"], g["at_targets"], g["at_inside"], g["at_outside"] = at
     prob, dl = synth.rpn_outputs(H, W, A, seed=3)
     cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO = 256, 0.0            # experiments/cfgs/res101.yml:9,11
     rois, rsc = ref.proposal_layer(prob, dl, im_info, "TRAIN", [16], anc, A)
+    g["pt_in_rois"], g["pt_in_scores"] = rois, rsc
     np.random.seed(3)
     pt = ref.proposal_target_layer(rois, rsc, gt, 21)
+    g["pt_keep_inds"] = np.concatenate(draws).astype(np.int32)
+    g["pt_n_fg"] = np.int32(draws[0].size if len(draws) == 2 else (draws[0].size if (pt[2] > 0).all() else 0))
+    np.random.choice = real_choice
     pin("proposal_target_layer", pt, ora.proposal_target_layer(rois, rsc, gt, 21, rng=np.random.RandomState(3)))
     for n_, v in zip(("rois", "scores", "labels", "targets", "inside", "outside"), pt):
         g["pt_" + n_] = v

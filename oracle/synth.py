@@ -77,3 +77,22 @@ def gt_boxes(n, C, seed=3, im_w=1000.0, im_h=600.0):
     y1 = rng.rand(n) * np.maximum(im_h - h, 1)
     cls = rng.randint(1, C, size=n)
     return np.stack([x1, y1, np.minimum(x1 + w, im_w - 1), np.minimum(y1 + h, im_h - 1), cls], axis=1).astype(f32)
+
+
+def threshold_pairs(n_pairs=24, seed=3, thr=0.5, filler=200):
+    """dets whose decisive overlaps sit EXACTLY on the threshold: pair p is A = 10x10 and B = 10x20 sharing A's area
+    (+1 convention: inter 100, union 200 -> IoU = 0.5 exactly, also in float32), B scored below A; pairs are far apart, the
+    rest is random filler.  cpu_nms (`>= thresh`) suppresses every B, the CUDA kernel / py_cpu_nms (`> thresh`) keeps it."""
+    assert thr == 0.5
+    rng = np.random.RandomState(seed)
+    rows = []
+    for p in range(n_pairs):
+        ox, oy = 40.0 * (p % 12), 100.0 + 60.0 * (p // 12)
+        rows.append([ox, oy, ox + 9, oy + 9, 0.9 - 0.01 * p])
+        rows.append([ox, oy, ox + 9, oy + 19, 0.5 - 0.01 * p])
+    d = np.array(rows, dtype=f32)
+    fill = random_dets(filler, seed=seed + 1, im_w=1000.0, im_h=90.0)           # y < 90: never touches the pairs
+    fill[:, 4] = tie_free(0.05 + 0.3 * rng.rand(filler), rng)
+    out = np.vstack([d, fill]).astype(f32)
+    out[:, 4] = tie_free(out[:, 4], rng)
+    return out[rng.permutation(out.shape[0])]

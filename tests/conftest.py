@@ -32,3 +32,15 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _pin_cpu_cython_path():
+    """BASELINE.json's parity clause names the reference's CPU/Cython path: the goldens come from cpu_nms (`ovr >= thresh`).
+    cfg.USE_GPU_NMS defaults to True like the reference and then selects the CUDA kernel's `>` rule (tests/test_boundary_gpu.py
+    covers that mode explicitly), so the suite pins the CPU rule here."""
+    from model.config import cfg
+    old = cfg.USE_GPU_NMS
+    cfg.USE_GPU_NMS = False
+    yield
+    cfg.USE_GPU_NMS = old

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), "missing export: " + s
     assert sorted(frcnn_hip.SIGNATURES) == syms            # binding table == header
-    assert frcnn_hip.lib().frcnn_abi_version() == 1
+    assert frcnn_hip.lib().frcnn_abi_version() == 2
     assert b"gfx950" in frcnn_hip.lib().frcnn_build_info()
 
 

@@ -88,7 +88,7 @@ def test_nms_sorted_and_host_compat__nms(dev):
     n_h = ctypes.c_int(0)
     frcnn_hip.lib()._nms(keep_h.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n_h), ds.ctypes.data_as(ctypes.c_void_p),
                          3000, 5, ctypes.c_float(0.3), 0)
-    assert keep_h[:n_h.value].tolist() == ora.cpu_nms(ds, float(np.float32(0.3)))
+    assert keep_h[:n_h.value].tolist() == ora.gpu_nms(ds, 0.3)             # the CUDA kernel's rule (nms_kernel.cu:71), float threshold
 
 
 def _proposal_case(dev, H, W, scales, key, post, info, seed=3):

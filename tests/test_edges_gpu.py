@@ -20,10 +20,13 @@ def test_nms_limits_and_error_codes(dev):
     import frcnn_hip
     from frcnn_hip import ops
     L = frcnn_hip.lib()
-    d = synth.random_dets(16384, seed=1, cluster=300)                      # documented maximum
+    d = synth.random_dets(16384, seed=1, cluster=300)                      # largest size of the prefetching reduce
     keep, num = ops.nms(T(d, dev), 0.7, max_keep=2000)
     assert keep[:int(num.item())].cpu().numpy().tolist() == ora.cpu_nms(d, 0.7)[:2000]
-    big = torch.zeros((16385, 5), device=dev)
+    d2 = synth.random_dets(16385, seed=2, cluster=300)                     # first size of the wide (LDS removed-words) reduce
+    keep, num = ops.nms(T(d2, dev), 0.7, max_keep=500)
+    assert keep[:int(num.item())].cpu().numpy().tolist() == ora.cpu_nms(d2, 0.7)[:500]
+    big = torch.zeros((65537, 5), device=dev)                               # documented maximum 65536
     with pytest.raises(frcnn_hip.FrcnnHipError, match="not supported"):
         ops.nms(big, 0.7)
     ws = torch.empty(16, dtype=torch.uint8, device=dev)                     # workspace too small -> FRCNN_E_WS

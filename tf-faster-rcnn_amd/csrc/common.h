@@ -62,6 +62,19 @@ __device__ __forceinline__ bool iou_suppresses(const float4 a, float aa, const f
   return ovr >= thr;
 }
 
+// The reference's CUDA kernel rule (lib/nms/nms_kernel.cu:24-33,71 devIoU(...) > nms_overlap_thresh; the same test as
+// lib/nms/py_cpu_nms.py:35 `ovr <= thresh` kept): identical f32 IoU arithmetic with the +1 pixel convention, but strict
+// `>` against the threshold rounded to f32.
+__device__ __forceinline__ bool iou_suppresses_gt(const float4 a, float aa, const float4 b, float ab, float thr) {
+  const float xx1 = rmax(a.x, b.x), yy1 = rmax(a.y, b.y);
+  const float xx2 = rmin(a.z, b.z), yy2 = rmin(a.w, b.w);
+  const float w = rmax(0.0f, (xx2 - xx1) + 1.0f);
+  const float h = rmax(0.0f, (yy2 - yy1) + 1.0f);
+  const float inter = w * h;
+  const float ovr = inter / ((aa + ab) - inter);
+  return ovr > thr;
+}
+
 // tf.image.non_max_suppression's overlap test (TensorFlow r1.2 core/kernels/non_max_suppression_op.cc, ComputeIOU + the
 // `> iou_threshold` test): corner order normalised with min/max, NO +1 on widths, degenerate boxes never overlap, f32.
 __device__ __forceinline__ float box_area_tf(const float4 b) {
@@ -87,6 +100,16 @@ __device__ __forceinline__ float4 decode_box(const float4 b, const float4 d) {
   const float pw = expf(d.z) * w;
   const float ph = expf(d.w) * h;
   return make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph);
+}
+
+// inverse of sortable_u32 (exact: the score comes back bit for bit out of a sort key)
+__device__ __forceinline__ float unsortable_f32(u32 k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+// per-image slice of a batched scratch / tensor: base + b * stride_bytes
+template <typename T>
+__device__ __forceinline__ T* img_ptr(T* p, size_t stride_bytes, int b) {
+  return (T*)((char*)p + stride_bytes * (size_t)b);
 }
 
 __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {

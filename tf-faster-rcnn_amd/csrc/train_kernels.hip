@@ -154,6 +154,19 @@ __global__ void k_at_finish(const double* __restrict__ base, int A, int H, int W
   targets[n] = t; inside_w[n] = iw; outside_w[n] = ow;                   // (1,H,W,4A): index n*4 (:123-135)
 }
 
+// host-oracle sampling mode: the caller (the py_func-compatible mirror lib/layer_utils/anchor_target_layer.py) drew the
+// `disable_inds` of anchor_target_layer.py:72-86 from numpy's global stream exactly like the reference; those anchors lose
+// their label here and the candidate counts follow, so k_at_finish (no sampling) sees the reference's label set.
+__global__ void k_at_disable(const int* __restrict__ disable, int n_disable, int N, u64* __restrict__ fgkey,
+                             u64* __restrict__ bgkey, int* __restrict__ counts) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_disable) return;
+  const int n = disable[t];
+  if (n < 0 || n >= N) return;
+  if (fgkey[n] != ~0ull) { fgkey[n] = ~0ull; atomicSub(&counts[0], 1); }
+  else if (bgkey[n] != ~0ull) { bgkey[n] = ~0ull; atomicSub(&counts[1], 1); }
+}
+
 extern "C" size_t frcnn_anchor_target_workspace_bytes(int H, int W, int A, int max_gt) {
   const long long N = (long long)H * W * A;
   if (N <= 0) return 256;
@@ -170,13 +183,13 @@ static int launch_key_rank(const u64* keys, int N, u32* rank, hipStream_t st) {
   return FRCNN_OK;
 }
 
-extern "C" int frcnn_anchor_target_layer(const float* gt_boxes_d, int G, float im_h, float im_w, int H, int W, int A,
-                                         int feat_stride, const double* base_d, int rpn_batchsize, double fg_fraction,
-                                         double pos_overlap, double neg_overlap, long long seed, float* labels_d,
-                                         float* bbox_targets_d, float* inside_w_d, float* outside_w_d, void* ws,
-                                         size_t ws_bytes, void* stream) {
+static int anchor_target_impl(const float* gt_boxes_d, int G, float im_h, float im_w, int H, int W, int A, int feat_stride,
+                              const double* base_d, int rpn_batchsize, double fg_fraction, double pos_overlap,
+                              double neg_overlap, long long seed, const int* disable_d, int n_disable, float* labels_d,
+                              float* bbox_targets_d, float* inside_w_d, float* outside_w_d, void* ws, size_t ws_bytes,
+                              void* stream) {
   if (!gt_boxes_d || !base_d || !labels_d || !bbox_targets_d || !inside_w_d || !outside_w_d || !ws) return FRCNN_E_ARG;
-  if (G <= 0 || H <= 0 || W <= 0 || A <= 0 || rpn_batchsize <= 0) return FRCNN_E_ARG;
+  if (G <= 0 || H <= 0 || W <= 0 || A <= 0 || rpn_batchsize <= 0 || n_disable < 0 || (n_disable > 0 && !disable_d)) return FRCNN_E_ARG;
   const int N = H * W * A;
   AtWs s = at_carve(ws, N, G);
   if (s.bytes > ws_bytes) return FRCNN_E_WS;
@@ -190,12 +203,16 @@ extern "C" int frcnn_anchor_target_layer(const float* gt_boxes_d, int G, float i
   hipLaunchKernelGGL(k_at_labels, dim3(nb), dim3(256), 0, st, base_d, A, W, feat_stride, N, gt_boxes_d, G, s.maxov, s.gtmax,
                      neg_overlap, pos_overlap, (u64)seed, s.fgkey, s.bgkey, s.fgrank, s.bgrank, s.counts);
   LAUNCH_CHECK();
-  const int do_sample = seed >= 0 ? 1 : 0;
+  const int do_sample = (seed >= 0 && !disable_d) ? 1 : 0;
   if (do_sample) {
     int rc = launch_key_rank(s.fgkey, N, s.fgrank, st);
     if (rc) return rc;
     rc = launch_key_rank(s.bgkey, N, s.bgrank, st);
     if (rc) return rc;
+  }
+  if (n_disable > 0) {
+    hipLaunchKernelGGL(k_at_disable, dim3(cdiv(n_disable, 256)), dim3(256), 0, st, disable_d, n_disable, N, s.fgkey, s.bgkey, s.counts);
+    LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(k_at_finish, dim3(nb), dim3(256), 0, st, base_d, A, H, W, feat_stride, N, gt_boxes_d, s.argmax, s.fgkey,
                      s.bgkey, s.fgrank, s.bgrank, s.counts, rpn_batchsize, (int)(fg_fraction * rpn_batchsize), do_sample,
@@ -204,10 +221,59 @@ extern "C" int frcnn_anchor_target_layer(const float* gt_boxes_d, int G, float i
   return FRCNN_OK;
 }
 
+extern "C" int frcnn_anchor_target_layer(const float* gt_boxes_d, int G, float im_h, float im_w, int H, int W, int A,
+                                         int feat_stride, const double* base_d, int rpn_batchsize, double fg_fraction,
+                                         double pos_overlap, double neg_overlap, long long seed, float* labels_d,
+                                         float* bbox_targets_d, float* inside_w_d, float* outside_w_d, void* ws,
+                                         size_t ws_bytes, void* stream) {
+  return anchor_target_impl(gt_boxes_d, G, im_h, im_w, H, W, A, feat_stride, base_d, rpn_batchsize, fg_fraction, pos_overlap,
+                            neg_overlap, seed, nullptr, 0, labels_d, bbox_targets_d, inside_w_d, outside_w_d, ws, ws_bytes, stream);
+}
+
+extern "C" int frcnn_anchor_target_layer_inject(const float* gt_boxes_d, int G, float im_h, float im_w, int H, int W, int A,
+                                                int feat_stride, const double* base_d, int rpn_batchsize, double fg_fraction,
+                                                double pos_overlap, double neg_overlap, const int* disable_d, int n_disable,
+                                                float* labels_d, float* bbox_targets_d, float* inside_w_d, float* outside_w_d,
+                                                void* ws, size_t ws_bytes, void* stream) {
+  static const int none = 0;      // n_disable == 0 still means "no device sampling": pass a non-null list
+  return anchor_target_impl(gt_boxes_d, G, im_h, im_w, H, W, A, feat_stride, base_d, rpn_batchsize, fg_fraction, pos_overlap,
+                            neg_overlap, -1, n_disable > 0 ? disable_d : &none, n_disable, labels_d, bbox_targets_d, inside_w_d,
+                            outside_w_d, ws, ws_bytes, stream);
+}
+
 // ------------------------------------------------------------------------------------------------
 // proposal_target_layer (layer_utils/proposal_target_layer.py:18-152), one workgroup (N <= 4096 rois)
 // ------------------------------------------------------------------------------------------------
 #define PT_MAXN 3072
+// one output row of _sample_rois (:137-152): the sampled roi, its score, label (bg rows clamped to 0, :142), class-expanded
+// normalised regression targets and weights (:58-96)
+__device__ __forceinline__ void pt_emit_row(int s, int src, bool is_fg, int assigned, const float* __restrict__ rois,
+                                            const float* __restrict__ scores, const float* __restrict__ gt, int C, float4 means,
+                                            float4 stds, float* __restrict__ out_rois, float* __restrict__ out_scores,
+                                            float* __restrict__ out_labels, float* __restrict__ out_targets,
+                                            float* __restrict__ out_inside, float* __restrict__ out_outside) {
+  float* orow = out_rois + 5 * (size_t)s;
+  float* trow = out_targets + (size_t)s * 4 * C;
+  float* irow = out_inside + (size_t)s * 4 * C;
+  float* urow = out_outside + (size_t)s * 4 * C;
+  for (int c = 0; c < 4 * C; ++c) { trow[c] = 0.f; irow[c] = 0.f; urow[c] = 0.f; }
+  if (src < 0) { orow[0] = orow[1] = orow[2] = orow[3] = orow[4] = 0.f; out_scores[s] = 0.f; out_labels[s] = 0.f; return; }
+  const float* r = rois + 5 * (size_t)src;
+  orow[0] = r[0]; orow[1] = r[1]; orow[2] = r[2]; orow[3] = r[3]; orow[4] = r[4];
+  out_scores[s] = scores[src];
+  const float* g = gt + 5 * (size_t)assigned;
+  const float label = is_fg ? g[4] : 0.0f;                         // bg labels clamped to 0 (:142)
+  out_labels[s] = label;
+  if (label > 0.f) {                                               // :58-80, targets :83-96
+    const float4 t = encode_box(make_float4(r[1], r[2], r[3], r[4]), g);
+    const int c4 = 4 * (int)label;
+    trow[c4 + 0] = (float)(((double)t.x - (double)means.x) / (double)stds.x);
+    trow[c4 + 1] = (float)(((double)t.y - (double)means.y) / (double)stds.y);
+    trow[c4 + 2] = (float)(((double)t.z - (double)means.z) / (double)stds.z);
+    trow[c4 + 3] = (float)(((double)t.w - (double)means.w) / (double)stds.w);
+    for (int q = 0; q < 4; ++q) { irow[c4 + q] = 1.f; urow[c4 + q] = 1.f; }
+  }
+}
 __global__ __launch_bounds__(1024) void k_proposal_target(const float* __restrict__ rois, const float* __restrict__ scores,
                                                           int Nmax, const int* __restrict__ num_d, const float* __restrict__ gt, int G, int C, int batch,
                                                           int fg_per_image, double fg_thresh, double bg_hi, double bg_lo,
@@ -256,7 +322,6 @@ __global__ __launch_bounds__(1024) void k_proposal_target(const float* __restric
   else if (nbg > 0) { n_fg_out = 0; n_bg_out = batch; bg_repl = nbg < batch; }
   else { n_fg_out = 0; n_bg_out = 0; }                               // the reference drops into pdb here (:133-135)
   if (tid == 0) { out_counts[0] = n_fg_out; out_counts[1] = n_bg_out; out_counts[2] = nfg; out_counts[3] = nbg; }
-  const float4 z4 = make_float4(0, 0, 0, 0);
   for (int s = tid; s < batch; s += 1024) {
     int src = -1; bool is_fg = s < n_fg_out;
     if (is_fg) src = fg_list[fg_repl ? (int)((u32)(hash_key(seed ^ 0x1234567ull, (u32)s) >> 32) % (u32)nfg) : s];
@@ -264,29 +329,36 @@ __global__ __launch_bounds__(1024) void k_proposal_target(const float* __restric
       const int t = s - n_fg_out;
       src = bg_list[bg_repl ? (int)((u32)(hash_key(seed ^ 0x7654321ull, (u32)s) >> 32) % (u32)nbg) : t];
     }
-    float* orow = out_rois + 5 * (size_t)s;
-    float* trow = out_targets + (size_t)s * 4 * C;
-    float* irow = out_inside + (size_t)s * 4 * C;
-    float* urow = out_outside + (size_t)s * 4 * C;
-    for (int c = 0; c < 4 * C; ++c) { trow[c] = 0.f; irow[c] = 0.f; urow[c] = 0.f; }
-    if (src < 0) { orow[0] = orow[1] = orow[2] = orow[3] = orow[4] = 0.f; out_scores[s] = 0.f; out_labels[s] = 0.f; continue; }
-    const float* r = rois + 5 * (size_t)src;
-    orow[0] = r[0]; orow[1] = r[1]; orow[2] = r[2]; orow[3] = r[3]; orow[4] = r[4];
-    out_scores[s] = scores[src];
-    const float* g = gt + 5 * (size_t)assign[src];
-    const float label = is_fg ? g[4] : 0.0f;                         // bg labels clamped to 0 (:142)
-    out_labels[s] = label;
-    if (label > 0.f) {                                               // :58-80, targets :83-96
-      const float4 t = encode_box(make_float4(r[1], r[2], r[3], r[4]), g);
-      const int c4 = 4 * (int)label;
-      trow[c4 + 0] = (float)(((double)t.x - (double)means.x) / (double)stds.x);
-      trow[c4 + 1] = (float)(((double)t.y - (double)means.y) / (double)stds.y);
-      trow[c4 + 2] = (float)(((double)t.z - (double)means.z) / (double)stds.z);
-      trow[c4 + 3] = (float)(((double)t.w - (double)means.w) / (double)stds.w);
-      for (int q = 0; q < 4; ++q) { irow[c4 + q] = 1.f; urow[c4 + q] = 1.f; }
-    }
-    (void)z4;
+    pt_emit_row(s, src, is_fg, src >= 0 ? (int)assign[src] : 0, rois, scores, gt, C, means, stds, out_rois, out_scores, out_labels,
+                out_targets, out_inside, out_outside);
   }
+}
+
+// host-oracle sampling mode: keep_inds [batch] = np.append(fg_inds, bg_inds) as drawn by the caller from numpy's global
+// stream (proposal_target_layer.py:119-138); the first n_fg rows are foreground.  gt assignment (argmax IoU, f64) is
+// recomputed here for the selected rows.
+__global__ __launch_bounds__(256) void k_proposal_target_inject(const float* __restrict__ rois, const float* __restrict__ scores, int N,
+                                                                const float* __restrict__ gt, int G, int C, int batch,
+                                                                const int* __restrict__ keep_inds, int n_fg, float4 means, float4 stds,
+                                                                float* __restrict__ out_rois, float* __restrict__ out_scores,
+                                                                float* __restrict__ out_labels, float* __restrict__ out_targets,
+                                                                float* __restrict__ out_inside, float* __restrict__ out_outside) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= batch) return;
+  int src = keep_inds[s];
+  if (src < 0 || src >= N) src = -1;
+  int bi = 0;
+  if (src >= 0) {
+    const float* r = rois + 5 * (size_t)src;
+    const float4 b = make_float4(r[1], r[2], r[3], r[4]);
+    double best = -1.0;
+    for (int g = 0; g < G; ++g) {
+      const double o = iou_f64(b, gt + 5 * (size_t)g);
+      if (o > best) { best = o; bi = g; }
+    }
+  }
+  pt_emit_row(s, src, s < n_fg, bi, rois, scores, gt, C, means, stds, out_rois, out_scores, out_labels, out_targets, out_inside,
+              out_outside);
 }
 
 static int proposal_target_impl(const float* rpn_rois_d, const float* rpn_scores_d, int N, const int* num_d, const float* gt_boxes_d,
@@ -333,6 +405,24 @@ extern "C" int frcnn_proposal_target_layer_dn(const float* rpn_rois_d, const flo
   return proposal_target_impl(rpn_rois_d, rpn_scores_d, max_rois, num_rois_d, gt_boxes_d, G, num_classes, batch_size, fg_fraction,
                               fg_thresh, bg_thresh_hi, bg_thresh_lo, means4, stds4, seed, rois_d, roi_scores_d, labels_d,
                               bbox_targets_d, inside_w_d, outside_w_d, counts_d, stream);
+}
+
+extern "C" int frcnn_proposal_target_layer_inject(const float* rpn_rois_d, const float* rpn_scores_d, int N, const float* gt_boxes_d,
+                                                  int G, int num_classes, int batch_size, const int* keep_inds_d, int n_fg,
+                                                  const double* means4, const double* stds4, float* rois_d, float* roi_scores_d,
+                                                  float* labels_d, float* bbox_targets_d, float* inside_w_d, float* outside_w_d,
+                                                  void* stream) {
+  if (!rpn_rois_d || !rpn_scores_d || !gt_boxes_d || !means4 || !stds4 || !rois_d || !roi_scores_d || !labels_d ||
+      !bbox_targets_d || !inside_w_d || !outside_w_d || !keep_inds_d)
+    return FRCNN_E_ARG;
+  if (N <= 0 || G <= 0 || num_classes < 2 || batch_size <= 0 || n_fg < 0 || n_fg > batch_size) return FRCNN_E_ARG;
+  hipLaunchKernelGGL(k_proposal_target_inject, dim3(cdiv(batch_size, 256)), dim3(256), 0, (hipStream_t)stream, rpn_rois_d,
+                     rpn_scores_d, N, gt_boxes_d, G, num_classes, batch_size, keep_inds_d, n_fg,
+                     make_float4((float)means4[0], (float)means4[1], (float)means4[2], (float)means4[3]),
+                     make_float4((float)stds4[0], (float)stds4[1], (float)stds4[2], (float)stds4[3]), rois_d, roi_scores_d,
+                     labels_d, bbox_targets_d, inside_w_d, outside_w_d);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

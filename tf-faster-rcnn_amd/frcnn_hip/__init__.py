@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_PKG, "libfrcnn_hip.so")
 _lib = None
 
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+NMS_RULE_CPU, NMS_RULE_GPU = 0, 1        # FRCNN_NMS_RULE_*: `(double)ovr >= thresh` (cpu_nms.pyx:65) / `ovr > (float)thresh` (nms_kernel.cu:71)
 
 # name -> (restype, argtypes); must list every symbol include/frcnn_hip.h declares
 _P = c_void_p
@@ -23,23 +24,39 @@ SIGNATURES = {
     "frcnn_nms_workspace_bytes": (c_size_t, [c_int]),
     "frcnn_nms": (c_int, [_P, c_int, c_double, c_int, _P, _P, _P, c_size_t, _P]),
     "frcnn_nms_sorted": (c_int, [_P, c_int, c_int, c_double, c_int, _P, _P, _P, c_size_t, _P]),
+    "frcnn_nms_rule": (c_int, [_P, c_int, c_double, c_int, c_int, _P, _P, _P, c_size_t, _P]),
+    "frcnn_nms_sorted_rule": (c_int, [_P, c_int, c_int, c_double, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "frcnn_generate_anchors": (c_int, [c_int, _P, c_int, _P, c_int, _P]),
     "frcnn_generate_anchors_pre": (c_int, [c_int, c_int, c_int, _P, c_int, _P, _P]),
     "frcnn_proposal_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "frcnn_proposal_layer": (c_int, [_P, _P, c_float, c_float, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_double,
                                      _P, _P, _P, _P, c_size_t, _P]),
+    "frcnn_proposal_batched_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "frcnn_proposal_layer_batched": (c_int, [_P, _P, c_int, c_float, c_float, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_double,
+                                             c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "frcnn_proposal_top_layer_inds": (c_int, [_P, _P, c_float, c_float, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P]),
+    "frcnn_proposal_layer_tf_batched": (c_int, [_P, _P, c_int, c_float, c_float, c_int, c_int, c_int, c_int, _P, c_int, c_float, _P, _P,
+                                                _P, _P, c_size_t, _P]),
     "frcnn_proposal_top_layer": (c_int, [_P, _P, c_float, c_float, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P,
                                          c_size_t, _P]),
     "frcnn_non_max_suppression": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P, c_size_t, _P]),
     "frcnn_proposal_layer_tf": (c_int, [_P, _P, c_float, c_float, c_int, c_int, c_int, c_int, _P, c_int, c_float, _P, _P, _P,
                                         _P, c_size_t, _P]),
     "frcnn_crop_and_resize": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_float, c_int, c_int, _P, _P]),
-    "frcnn_crop_and_resize_bias_act": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_float, c_int, _P, c_int, _P, _P]),
+    "frcnn_crop_and_resize_batched": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_float, c_int, c_int, _P, _P]),
+    "frcnn_crop_and_resize_bias_act": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_float, c_int, _P, c_int, _P, _P]),
+    "frcnn_detect_set_tuning": (c_int, [c_int, c_int]),
+    "frcnn_detect_post_batched_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "frcnn_detect_post_batched": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_double, c_int, c_int, c_double, c_int, c_float, c_int,
+                                          _P, _P, c_int, c_longlong, _P, c_size_t, _P]),
     "frcnn_detect_post_workspace_bytes": (c_size_t, [c_int, c_int]),
     "frcnn_detect_post": (c_int, [_P, _P, _P, _P, c_int, c_int, c_double, c_int, c_int, c_double, c_float, c_int, _P, _P,
                                   c_int, _P, c_size_t, _P]),
     "frcnn_im_detect_boxes": (c_int, [_P, _P, c_int, c_int, c_double, c_int, c_int, _P, _P]),
     "frcnn_bbox_overlaps": (c_int, [_P, c_int, _P, c_int, _P, _P]),
+    "frcnn_bbox_transform_inv": (c_int, [_P, _P, c_int, c_int, _P, _P]),
+    "frcnn_clip_boxes": (c_int, [_P, c_int, c_int, c_float, c_float, _P]),
+    "frcnn_bbox_transform": (c_int, [_P, _P, c_int, _P, _P]),
     "frcnn_conv2d_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "frcnn_conv2d_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
@@ -69,6 +86,9 @@ SIGNATURES = {
     "frcnn_anchor_target_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "frcnn_anchor_target_layer": (c_int, [_P, c_int, c_float, c_float, c_int, c_int, c_int, c_int, _P, c_int, c_double, c_double,
                                           c_double, c_longlong, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "frcnn_anchor_target_layer_inject": (c_int, [_P, c_int, c_float, c_float, c_int, c_int, c_int, c_int, _P, c_int, c_double, c_double,
+                                                 c_double, _P, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "frcnn_proposal_target_layer_inject": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "frcnn_proposal_target_layer": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_double, c_double, c_double, c_double, _P, _P,
                                             c_longlong, _P, _P, _P, _P, _P, _P, _P, _P]),
     "frcnn_proposal_target_layer_dn": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, c_int, c_double, c_double, c_double, c_double, _P, _P,

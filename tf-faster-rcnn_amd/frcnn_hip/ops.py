@@ -9,7 +9,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import ACT_NONE, call, lib
+from . import ACT_NONE, NMS_RULE_CPU, call, lib
 
 _ws_cache = {}
 _ws_retired = []
@@ -66,8 +66,9 @@ def generate_anchors_pre(height, width, feat_stride, base_d, out=None):
 
 
 # ------------------------------------------------------------------------------------------ NMS
-def nms(dets, thresh, max_keep=None, keep=None, num=None):
-    """cpu_nms semantics on device.  dets f32 [k,5] any order -> (keep int32 [max_keep], num int32 [1])."""
+def nms(dets, thresh, max_keep=None, keep=None, num=None, rule=NMS_RULE_CPU):
+    """cpu_nms (rule NMS_RULE_CPU) / gpu_nms (NMS_RULE_GPU) semantics on device.  dets f32 [k,5] any order ->
+    (keep int32 [max_keep], num int32 [1])."""
     _chk(dets)
     k = dets.shape[0]
     max_keep = k if max_keep is None else min(max_keep, k)
@@ -76,11 +77,11 @@ def nms(dets, thresh, max_keep=None, keep=None, num=None):
     num = torch.zeros((1,), dtype=torch.int32, device=dev) if num is None else num
     nb = lib().frcnn_nms_workspace_bytes(max(k, 1))
     ws = workspace(nb, dev, "nms")
-    call("frcnn_nms", _ptr(dets), k, float(thresh), max_keep, _ptr(keep), _ptr(num), _ptr(ws), ws.numel(), _stream())
+    call("frcnn_nms_rule", _ptr(dets), k, float(thresh), int(rule), max_keep, _ptr(keep), _ptr(num), _ptr(ws), ws.numel(), _stream())
     return keep, num
 
 
-def nms_sorted(boxes, thresh, max_keep=None):
+def nms_sorted(boxes, thresh, max_keep=None, rule=NMS_RULE_CPU):
     """Device-pointer form of `_nms`: boxes f32 [k, >=4] sorted by descending score."""
     _chk(boxes)
     k, stride = boxes.shape
@@ -90,7 +91,7 @@ def nms_sorted(boxes, thresh, max_keep=None):
     num = torch.zeros((1,), dtype=torch.int32, device=dev)
     nb = lib().frcnn_nms_workspace_bytes(max(k, 1))
     ws = workspace(nb, dev, "nms")
-    call("frcnn_nms_sorted", _ptr(boxes), k, stride, float(thresh), max_keep, _ptr(keep), _ptr(num), _ptr(ws),
+    call("frcnn_nms_sorted_rule", _ptr(boxes), k, stride, float(thresh), int(rule), max_keep, _ptr(keep), _ptr(num), _ptr(ws),
          ws.numel(), _stream())
     return keep, num
 
@@ -119,21 +120,46 @@ def bbox_overlaps(boxes, query):
     return out
 
 
+def bbox_transform_inv(boxes, deltas, out=None):
+    """lib/model/bbox_transform.py:35-65 on device: boxes [N,4], deltas [N,4k] -> [N,4k]."""
+    _chk(boxes), _chk(deltas)
+    N, k = boxes.shape[0], deltas.shape[1] // 4
+    out = torch.empty((N, 4 * k), dtype=torch.float32, device=boxes.device) if out is None else out
+    call("frcnn_bbox_transform_inv", _ptr(boxes), _ptr(deltas), N, k, _ptr(out), _stream())
+    return out
+
+
+def clip_boxes(boxes, im_h, im_w):
+    """lib/model/bbox_transform.py:68-81 in place: boxes [N,4k]."""
+    _chk(boxes)
+    call("frcnn_clip_boxes", _ptr(boxes), boxes.shape[0], boxes.shape[1] // 4, float(im_h), float(im_w), _stream())
+    return boxes
+
+
+def bbox_transform(ex_rois, gt_rois):
+    """lib/model/bbox_transform.py:14-32 on device: [N,4] x [N,4] -> targets [N,4]."""
+    _chk(ex_rois), _chk(gt_rois)
+    out = torch.empty((ex_rois.shape[0], 4), dtype=torch.float32, device=ex_rois.device)
+    call("frcnn_bbox_transform", _ptr(ex_rois), _ptr(gt_rois), ex_rois.shape[0], _ptr(out), _stream())
+    return out
+
+
 # ------------------------------------------------------------------------------------------ proposals
 def proposal_layer(rpn_cls_prob, rpn_bbox_pred, im_h, im_w, feat_stride, base_d, pre_nms_topn, post_nms_topn,
-                   nms_thresh, rois=None, scores=None, num=None):
-    """lib/layer_utils/proposal_layer.py:16-53 on device.  Returns (rois [post,5], scores [post,1], num [1])."""
+                   nms_thresh, rois=None, scores=None, num=None, rule=NMS_RULE_CPU):
+    """lib/layer_utils/proposal_layer.py:16-53 on device, for the B images of rpn_cls_prob [B,H,W,2A] in one set of launches.
+    Returns (rois [B*post,5] with rois[:,0] = image index, scores [B*post,1], num [B])."""
     _chk(rpn_cls_prob), _chk(rpn_bbox_pred), _chk(base_d, torch.float64)
-    _, H, W, A2 = rpn_cls_prob.shape
+    B, H, W, A2 = rpn_cls_prob.shape
     A = A2 // 2
     dev = rpn_cls_prob.device
-    rois = torch.empty((post_nms_topn, 5), dtype=torch.float32, device=dev) if rois is None else rois
-    scores = torch.empty((post_nms_topn, 1), dtype=torch.float32, device=dev) if scores is None else scores
-    num = torch.zeros((1,), dtype=torch.int32, device=dev) if num is None else num
-    nb = lib().frcnn_proposal_workspace_bytes(H, W, A, int(pre_nms_topn))
+    rois = torch.empty((B * post_nms_topn, 5), dtype=torch.float32, device=dev) if rois is None else rois
+    scores = torch.empty((B * post_nms_topn, 1), dtype=torch.float32, device=dev) if scores is None else scores
+    num = torch.zeros((B,), dtype=torch.int32, device=dev) if num is None else num
+    nb = lib().frcnn_proposal_batched_workspace_bytes(B, H, W, A, int(pre_nms_topn))
     ws = workspace(nb, dev, "proposal")
-    call("frcnn_proposal_layer", _ptr(rpn_cls_prob), _ptr(rpn_bbox_pred), float(im_h), float(im_w), H, W, A,
-         int(feat_stride), _ptr(base_d), int(pre_nms_topn), int(post_nms_topn), float(nms_thresh), _ptr(rois),
+    call("frcnn_proposal_layer_batched", _ptr(rpn_cls_prob), _ptr(rpn_bbox_pred), B, float(im_h), float(im_w), H, W, A,
+         int(feat_stride), _ptr(base_d), int(pre_nms_topn), int(post_nms_topn), float(nms_thresh), int(rule), _ptr(rois),
          _ptr(scores), _ptr(num), _ptr(ws), ws.numel(), _stream())
     return rois, scores, num
 
@@ -141,20 +167,33 @@ def proposal_layer(rpn_cls_prob, rpn_bbox_pred, im_h, im_w, feat_stride, base_d,
 def proposal_layer_tf(rpn_cls_prob, rpn_bbox_pred, im_h, im_w, feat_stride, base_d, post_nms_topn, nms_thresh, rois=None,
                       scores=None, num=None):
     """lib/layer_utils/proposal_layer.py:56-84 (USE_E2E_TF): NMS with tf.image.non_max_suppression semantics over ALL
-    anchors, no pre-NMS top-N.  Returns (rois [post,5] zero padded, scores [post,1], num [1])."""
+    anchors, no pre-NMS top-N, B images per launch.  Returns (rois [B*post,5] zero padded, scores [B*post,1], num [B])."""
     _chk(rpn_cls_prob), _chk(rpn_bbox_pred), _chk(base_d, torch.float64)
-    _, H, W, A2 = rpn_cls_prob.shape
+    B, H, W, A2 = rpn_cls_prob.shape
     A = A2 // 2
     dev = rpn_cls_prob.device
-    rois = torch.empty((post_nms_topn, 5), dtype=torch.float32, device=dev) if rois is None else rois
-    scores = torch.empty((post_nms_topn, 1), dtype=torch.float32, device=dev) if scores is None else scores
-    num = torch.zeros((1,), dtype=torch.int32, device=dev) if num is None else num
-    nb = lib().frcnn_proposal_workspace_bytes(H, W, A, 0)
+    rois = torch.empty((B * post_nms_topn, 5), dtype=torch.float32, device=dev) if rois is None else rois
+    scores = torch.empty((B * post_nms_topn, 1), dtype=torch.float32, device=dev) if scores is None else scores
+    num = torch.zeros((B,), dtype=torch.int32, device=dev) if num is None else num
+    nb = lib().frcnn_proposal_batched_workspace_bytes(B, H, W, A, 0)
     ws = workspace(nb, dev, "proposal")
-    call("frcnn_proposal_layer_tf", _ptr(rpn_cls_prob), _ptr(rpn_bbox_pred), float(im_h), float(im_w), H, W, A,
+    call("frcnn_proposal_layer_tf_batched", _ptr(rpn_cls_prob), _ptr(rpn_bbox_pred), B, float(im_h), float(im_w), H, W, A,
          int(feat_stride), _ptr(base_d), int(post_nms_topn), float(nms_thresh), _ptr(rois), _ptr(scores), _ptr(num),
          _ptr(ws), ws.numel(), _stream())
     return rois, scores, num
+
+
+def proposal_top_layer_inds(rpn_cls_prob, rpn_bbox_pred, im_h, im_w, feat_stride, base_d, top_inds, rois=None, scores=None):
+    """proposal_top_layer.py:30-33,46-55 for caller-chosen anchor indices (int32 device tensor): decode + clip those."""
+    _chk(rpn_cls_prob), _chk(rpn_bbox_pred), _chk(base_d, torch.float64), _chk(top_inds, torch.int32)
+    _, H, W, A2 = rpn_cls_prob.shape
+    n = top_inds.numel()
+    dev = rpn_cls_prob.device
+    rois = torch.empty((n, 5), dtype=torch.float32, device=dev) if rois is None else rois
+    scores = torch.empty((n, 1), dtype=torch.float32, device=dev) if scores is None else scores
+    call("frcnn_proposal_top_layer_inds", _ptr(rpn_cls_prob), _ptr(rpn_bbox_pred), float(im_h), float(im_w), H, W, A2 // 2,
+         int(feat_stride), _ptr(base_d), _ptr(top_inds), n, _ptr(rois), _ptr(scores), _stream())
+    return rois, scores
 
 
 def proposal_top_layer(rpn_cls_prob, rpn_bbox_pred, im_h, im_w, feat_stride, base_d, rpn_top_n, rois=None, scores=None):
@@ -172,12 +211,14 @@ def proposal_top_layer(rpn_cls_prob, rpn_bbox_pred, im_h, im_w, feat_stride, bas
 
 
 def crop_and_resize(feat, rois, feat_stride, pool, max_pool=False, out=None):
-    """feat [1,H,W,C] or [H,W,C]; rois [R,5] -> [R,pool,pool,C] (TF crop_and_resize semantics)."""
+    """feat [N,H,W,C] or [H,W,C]; rois [R,5] with rois[:,0] = image index (the box_ind of tf.image.crop_and_resize,
+    network.py:143) -> [R,pool,pool,C] (TF crop_and_resize semantics)."""
     _chk(feat), _chk(rois)
     H, W, C = feat.shape[-3:]
+    N = feat.shape[0] if feat.dim() == 4 else 1
     R = rois.shape[0]
     out = torch.empty((R, pool, pool, C), dtype=torch.float32, device=feat.device) if out is None else out
-    call("frcnn_crop_and_resize", _ptr(feat), H, W, C, _ptr(rois), R, float(feat_stride), int(pool),
+    call("frcnn_crop_and_resize_batched", _ptr(feat), N, H, W, C, _ptr(rois), R, float(feat_stride), int(pool),
          1 if max_pool else 0, _ptr(out), _stream())
     return out
 
@@ -186,27 +227,37 @@ def crop_and_resize_bias_act(feat, rois, feat_stride, pool, bias, act, out=None)
     """act(crop_and_resize(feat) + bias): see frcnn_crop_and_resize_bias_act."""
     _chk(feat), _chk(rois)
     H, W, C = feat.shape[-3:]
+    N = feat.shape[0] if feat.dim() == 4 else 1
     R = rois.shape[0]
     out = torch.empty((R, pool, pool, C), dtype=torch.float32, device=feat.device) if out is None else out
-    call("frcnn_crop_and_resize_bias_act", _ptr(feat), H, W, C, _ptr(rois), R, float(feat_stride), int(pool), _ptr(bias),
+    call("frcnn_crop_and_resize_bias_act", _ptr(feat), N, H, W, C, _ptr(rois), R, float(feat_stride), int(pool), _ptr(bias),
          int(act), _ptr(out), _stream())
     return out
 
 
 def detect_post(cls_prob, bbox_pred, rois, num_rois, im_scale, im_h, im_w, nms_thresh=0.3, score_thresh=0.0,
-                max_per_image=100, max_out=None, out=None, count=None):
-    """lib/model/test.py:95-102 + :162-180 on device -> (dets [max_out,6], count [1])."""
+                max_per_image=100, max_out=None, out=None, count=None, batch=1, rule=NMS_RULE_CPU):
+    """lib/model/test.py:95-102 + :162-180 on device.  batch = 1: (dets [max_out,6], count [1]).  batch = B: cls_prob
+    [B*R,C] (R rows per image), num_rois [B] -> (dets [B,max_out,6], count [B]), one launch pair for all images."""
     _chk(cls_prob), _chk(bbox_pred), _chk(rois)
-    R, C = cls_prob.shape
+    B = int(batch)
+    R, C = cls_prob.shape[0] // B, cls_prob.shape[1]
+    if cls_prob.shape[0] != B * R or rois.shape[0] != B * R:
+        raise ValueError("detect_post: %d rows do not split into %d images" % (cls_prob.shape[0], B))
     dev = cls_prob.device
     max_out = (max_per_image + 28 if max_per_image > 0 else R * (C - 1)) if max_out is None else max_out
-    out = torch.empty((max_out, 6), dtype=torch.float32, device=dev) if out is None else out
-    count = torch.zeros((1,), dtype=torch.int32, device=dev) if count is None else count
-    nb = lib().frcnn_detect_post_workspace_bytes(R, C)
+    shape = (max_out, 6) if B == 1 else (B, max_out, 6)
+    out = torch.empty(shape, dtype=torch.float32, device=dev) if out is None else out
+    count = torch.zeros((B,), dtype=torch.int32, device=dev) if count is None else count
+    # a batched record may be a strided view (per-image slices contiguous, frcnn_hip.parallel.new_record)
+    if out.dtype != torch.float32 or out.shape[-1] != 6 or out.stride(-1) != 1 or out.stride(-2) != 6 or out.shape[-2] < max_out:
+        raise ValueError("detect_post: `out` must be float32 [.., >=max_out, 6] with contiguous images")
+    out_stride = out.stride(0) if out.dim() == 3 else 0
+    nb = lib().frcnn_detect_post_batched_workspace_bytes(B, R, C)
     ws = workspace(nb, dev, "detect_post")
-    call("frcnn_detect_post", _ptr(cls_prob), _ptr(bbox_pred), _ptr(rois), _ptr(num_rois), R, C, float(im_scale),
-         int(im_h), int(im_w), float(nms_thresh), float(score_thresh), int(max_per_image), _ptr(out), _ptr(count),
-         int(max_out), _ptr(ws), ws.numel(), _stream())
+    call("frcnn_detect_post_batched", _ptr(cls_prob), _ptr(bbox_pred), _ptr(rois), _ptr(num_rois), B, R, C, float(im_scale),
+         int(im_h), int(im_w), float(nms_thresh), int(rule), float(score_thresh), int(max_per_image), _ptr(out), _ptr(count),
+         int(max_out), int(out_stride), _ptr(ws), ws.numel(), _stream())
     return out, count
 
 
@@ -464,6 +515,38 @@ def anchor_target_layer(gt_boxes, im_h, im_w, H, W, base_d, feat_stride=16, rpn_
          int(rpn_batchsize), float(fg_fraction), float(pos_overlap), float(neg_overlap), int(seed), _ptr(labels), _ptr(tg),
          _ptr(iw), _ptr(ow), _ptr(ws), ws.numel(), _stream())
     return labels, tg, iw, ow
+
+
+def anchor_target_layer_inject(gt_boxes, im_h, im_w, H, W, base_d, disable, feat_stride=16, rpn_batchsize=256, fg_fraction=0.5,
+                               pos_overlap=0.7, neg_overlap=0.3):
+    """anchor_target_layer with the reference's host-drawn `disable_inds` (int32 device tensor of ALL-anchor indices, may be
+    empty): see frcnn_anchor_target_layer_inject."""
+    _chk(gt_boxes), _chk(base_d, torch.float64), _chk(disable, torch.int32)
+    A, G, dev = base_d.shape[0], gt_boxes.shape[0], gt_boxes.device
+    labels = torch.empty((1, 1, A * H, W), dtype=torch.float32, device=dev)
+    tg, iw, ow = (torch.empty((1, H, W, 4 * A), dtype=torch.float32, device=dev) for _ in range(3))
+    ws = workspace(lib().frcnn_anchor_target_workspace_bytes(H, W, A, G), dev, "anchor_target")
+    call("frcnn_anchor_target_layer_inject", _ptr(gt_boxes), G, float(im_h), float(im_w), H, W, A, int(feat_stride), _ptr(base_d),
+         int(rpn_batchsize), float(fg_fraction), float(pos_overlap), float(neg_overlap), _ptr(disable) if disable.numel() else None,
+         int(disable.numel()), _ptr(labels), _ptr(tg), _ptr(iw), _ptr(ow), _ptr(ws), ws.numel(), _stream())
+    return labels, tg, iw, ow
+
+
+def proposal_target_layer_inject(rpn_rois, rpn_scores, gt_boxes, num_classes, keep_inds, n_fg, means=(0.0, 0.0, 0.0, 0.0),
+                                 stds=(0.1, 0.1, 0.2, 0.2)):
+    """proposal_target_layer for host-drawn keep_inds (int32 device [batch], fg rows first): frcnn_proposal_target_layer_inject."""
+    _chk(rpn_rois), _chk(rpn_scores), _chk(gt_boxes), _chk(keep_inds, torch.int32)
+    dev, N, G, B, C = rpn_rois.device, rpn_rois.shape[0], gt_boxes.shape[0], keep_inds.numel(), int(num_classes)
+    rois = torch.empty((B, 5), dtype=torch.float32, device=dev)
+    sc = torch.empty((B,), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, 1), dtype=torch.float32, device=dev)
+    tg, iw, ow = (torch.empty((B, 4 * C), dtype=torch.float32, device=dev) for _ in range(3))
+    m = np.ascontiguousarray(means, dtype=np.float64)
+    s = np.ascontiguousarray(stds, dtype=np.float64)
+    call("frcnn_proposal_target_layer_inject", _ptr(rpn_rois), _ptr(rpn_scores), N, _ptr(gt_boxes), G, C, B, _ptr(keep_inds), int(n_fg),
+         m.ctypes.data_as(ctypes.c_void_p), s.ctypes.data_as(ctypes.c_void_p), _ptr(rois), _ptr(sc), _ptr(labels), _ptr(tg), _ptr(iw),
+         _ptr(ow), _stream())
+    return rois, sc, labels, tg, iw, ow
 
 
 def proposal_target_layer(rpn_rois, rpn_scores, gt_boxes, num_classes, batch_size=256, fg_fraction=0.25, fg_thresh=0.5,

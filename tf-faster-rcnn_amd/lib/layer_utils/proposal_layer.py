@@ -6,7 +6,7 @@ zero-padded device buffers + the count, no host hop)."""
 import numpy as np
 import torch
 
-from frcnn_hip import ops
+from frcnn_hip import NMS_RULE_CPU, NMS_RULE_GPU, ops
 from model.config import cfg
 
 
@@ -26,7 +26,8 @@ def proposal_layer(rpn_cls_prob, rpn_bbox_pred, im_info, cfg_key, _feat_stride, 
     base_d = (base if torch.is_tensor(base) else torch.from_numpy(np.ascontiguousarray(base))).to(dev, torch.float64).contiguous()
     info = im_info.cpu().numpy() if torch.is_tensor(im_info) else np.asarray(im_info)
     rois, scores, num = ops.proposal_layer(to_dev(rpn_cls_prob), to_dev(rpn_bbox_pred), float(info[0]), float(info[1]), stride,
-                                           base_d, int(pre_nms_topN), int(post_nms_topN), float(nms_thresh))
+                                           base_d, int(pre_nms_topN), int(post_nms_topN), float(nms_thresh),
+                                           rule=NMS_RULE_GPU if cfg.USE_GPU_NMS else NMS_RULE_CPU)      # nms_wrapper.py:15-23
     if on_device:
         return rois, scores, num
     n = int(num.item())

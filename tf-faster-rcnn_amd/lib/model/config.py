@@ -4,8 +4,10 @@ Same keys, defaults and helper functions as /root/reference/lib/model/config.py:
 (cfg, cfg_from_file, cfg_from_list, get_output_dir, get_output_tb_dir) so that the tools/ entry
 points and `--set KEY VALUE` overrides behave identically.  Differences, on purpose:
   * yaml.safe_load instead of the Loader-less yaml.load (config.py:362 raises under PyYAML >= 6);
-  * USE_GPU_NMS keeps its meaning "use the accelerator NMS" -- which is now the HIP kernel with
-    the CPU/Cython suppression rule (`>=`), the path BASELINE.json names;
+  * USE_GPU_NMS (default True, as in the reference) keeps its meaning "the CUDA kernel's NMS": the HIP kernels then apply
+    that kernel's rule, suppress iff IoU > thresh in float32 (lib/nms/nms_kernel.cu:71); False selects the Cython rule,
+    suppress iff (double)IoU >= thresh (lib/nms/cpu_nms.pyx:65) -- the path BASELINE.json pins (bench.py and the parity
+    tests set it).  Both run on the GPU; the two rules differ only when an IoU hits the threshold exactly;
   * USE_E2E_TF defaults to False (the reference: True): the numpy/Cython layer semantics are the path BASELINE.json
     names.  True selects the reference's TF-op semantics on the same kernels: int32-truncated anchors, proposal_layer_tf
     (tf.image.non_max_suppression over ALL anchors: no +1 areas, `>`), proposal_top_layer_tf.

@@ -3,8 +3,9 @@
 
 Contract kept: `dets` float32 [N,5] = (x1, y1, x2, y2, score); returns the list of kept ORIGINAL row indices in
 descending-score order; an empty input returns [] without touching the device.  `cfg.USE_GPU_NMS` and `force_cpu`
-still choose between the two module names the reference imports, but both are backed by the same HIP bitmask
-kernel with the CPU/Cython suppression rule (`ovr >= thresh`): there is no host implementation in the product."""
+choose between the two module names exactly like the reference does; both run the same HIP kernels and differ in the
+suppression rule the reference's two implementations have: gpu_nms `ovr > thresh` in float32 (nms_kernel.cu:71),
+cpu_nms `(double)ovr >= thresh` (cpu_nms.pyx:65).  There is no host implementation in the product."""
 from model.config import cfg
 import nms.cpu_nms as _cpu_mod
 import nms.gpu_nms as _gpu_mod

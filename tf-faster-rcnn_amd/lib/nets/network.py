@@ -15,7 +15,7 @@ import collections
 import numpy as np
 import torch
 
-from frcnn_hip import ACT_NONE, ACT_RELU, ops
+from frcnn_hip import ACT_NONE, ACT_RELU, NMS_RULE_CPU, NMS_RULE_GPU, ops
 from frcnn_hip.runtime import VarSpec
 from model.config import cfg
 
@@ -210,9 +210,15 @@ class Network(object):
         self._anchor_length = h * w * self._num_anchors
         self._anchors = None      # materialise on demand with ops.generate_anchors_pre
 
+    @staticmethod
+    def _nms_rule():
+        """lib/model/nms_wrapper.py:15-23: cfg.USE_GPU_NMS picks the reference's CUDA kernel (`ovr > thresh`,
+        nms_kernel.cu:71), otherwise the Cython cpu_nms rule (`ovr >= thresh`, cpu_nms.pyx:65) -- same HIP kernels."""
+        return NMS_RULE_GPU if cfg.USE_GPU_NMS else NMS_RULE_CPU
+
     def _proposal_layer(self, rpn_cls_prob, rpn_bbox_pred, name):
-        """network.py:110-131 -> frcnn_proposal_layer, once per image of the batch (the reference graph is
-        batch-1; a batch here is B independent images whose dense layers share launches)."""
+        """network.py:110-131 -> frcnn_proposal_layer_batched: ONE set of launches for the B images of the batch (the
+        reference graph is batch-1; a batch here is B independent images whose launches are shared).  rois[:,0] = image index."""
         c = cfg[self._mode]
         post = int(c.RPN_POST_NMS_TOP_N)
         s = self._sess
@@ -220,18 +226,17 @@ class Network(object):
         rois = s.buf(self._tag + "/rois", (B * post, 5))
         scores = s.buf(self._tag + "/roi_scores", (B * post, 1))
         num = s.buf(self._tag + "/num_rois", (B,), torch.int32)
-        for b in range(B):
-            if cfg.USE_E2E_TF:
-                # network.py:112-121 -> proposal_layer_tf: tf.image.non_max_suppression over ALL anchors, no pre-NMS top-N
-                s.mark("op:proposal_layer_tf", 0, lambda: ops.proposal_layer_tf(
-                    rpn_cls_prob[b:b + 1], rpn_bbox_pred[b:b + 1], self._im_info[0], self._im_info[1], self._feat_stride[0],
-                    self._base_anchors, post, float(c.RPN_NMS_THRESH),
-                    rois=rois[b * post:(b + 1) * post], scores=scores[b * post:(b + 1) * post], num=num[b:b + 1]))
-                continue
+        if cfg.USE_E2E_TF:
+            # network.py:112-121 -> proposal_layer_tf: tf.image.non_max_suppression over ALL anchors, no pre-NMS top-N
+            s.mark("op:proposal_layer_tf", 0, lambda: ops.proposal_layer_tf(
+                rpn_cls_prob, rpn_bbox_pred, self._im_info[0], self._im_info[1], self._feat_stride[0],
+                self._base_anchors, post, float(c.RPN_NMS_THRESH), rois=rois, scores=scores, num=num))
+        else:
+            N = rpn_cls_prob.shape[1] * rpn_cls_prob.shape[2] * self._num_anchors
             s.mark("op:proposal_layer", 0, lambda: ops.proposal_layer(
-                rpn_cls_prob[b:b + 1], rpn_bbox_pred[b:b + 1], self._im_info[0], self._im_info[1], self._feat_stride[0],
-                self._base_anchors, int(c.RPN_PRE_NMS_TOP_N), post, float(c.RPN_NMS_THRESH),
-                rois=rois[b * post:(b + 1) * post], scores=scores[b * post:(b + 1) * post], num=num[b:b + 1]))
+                rpn_cls_prob, rpn_bbox_pred, self._im_info[0], self._im_info[1], self._feat_stride[0],
+                self._base_anchors, int(c.RPN_PRE_NMS_TOP_N), post, float(c.RPN_NMS_THRESH), rois=rois, scores=scores, num=num,
+                rule=self._nms_rule()), nbytes=B * 36 * N)
         self._num_rois = num
         self._rois_per_image = post
         return rois, scores
@@ -293,15 +298,13 @@ class Network(object):
         return self._losses
 
     def _crop_images(self, bottom, rois, out, max_pool=False, bias=None, act=ACT_NONE):
-        """crop_and_resize of image b's RoI rows out of image b's feature map, for every image of the batch."""
-        B, per = bottom.shape[0], rois.shape[0] // bottom.shape[0]
+        """tf.image.crop_and_resize(bottom, boxes, box_ind = rois[:,0]) (network.py:141-157) for the whole batch in one launch."""
         fs, P = float(self._feat_stride[0]), cfg.POOLING_SIZE
-        for b in range(B):
-            r, o = rois[b * per:(b + 1) * per], out[b * per:(b + 1) * per]
-            if bias is None and act == ACT_NONE:
-                self._sess.mark("op:crop_and_resize", 0, lambda: ops.crop_and_resize(bottom[b], r, fs, P, max_pool=max_pool, out=o))
-            else:
-                self._sess.mark("op:crop_and_resize", 0, lambda: ops.crop_and_resize_bias_act(bottom[b], r, fs, P, bias, act, out=o))
+        nbytes = 4 * (bottom.numel() + out.numel())
+        if bias is None and act == ACT_NONE:
+            self._sess.mark("op:crop_and_resize", 0, lambda: ops.crop_and_resize(bottom, rois, fs, P, max_pool=max_pool, out=out), nbytes=nbytes)
+        else:
+            self._sess.mark("op:crop_and_resize", 0, lambda: ops.crop_and_resize_bias_act(bottom, rois, fs, P, bias, act, out=out), nbytes=nbytes)
         return out
 
     def _crop_pool_layer(self, bottom, rois, name):
@@ -415,7 +418,8 @@ class Network(object):
         self._im_info = (float(im_info[0]), float(im_info[1]), float(im_info[2]))
         ops.ws_scope = self._tag                       # scratch buffers are per network tag (= per stream)
         c = cfg[self._mode]
-        key = (self._tag, tuple(image_d.shape), self._im_info[:2], self._mode, cfg.TEST.MODE, self._fuse_tail_entry,
+        key = (self._tag, self._scope, self._num_classes, self._anchor_scales, self._anchor_ratios, bool(cfg.RESNET.MAX_POOL),
+               bool(cfg.USE_GPU_NMS), tuple(image_d.shape), self._im_info[:2], self._mode, cfg.TEST.MODE, self._fuse_tail_entry,
                c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH, cfg.TEST.RPN_TOP_N, cfg.POOLING_SIZE,
                bool(cfg.HIP.WINOGRAD), int(cfg.HIP.WINOGRAD_MIN_CIN), int(cfg.HIP.WINOGRAD_M), tuple(cfg.HIP.WINOGRAD_F2_SCOPES), bool(cfg.HIP.WINOGRAD_7X7), bool(cfg.USE_E2E_TF))
         cur = torch.cuda.current_stream(sess.device)
@@ -507,18 +511,13 @@ class Network(object):
         p = self.forward_device(sess, image_d, im_info)
         ops.ws_scope = self._tag
         B = image_d.shape[0]
-        per = self._rois_per_image
-        if B == 1:
-            return sess.mark("op:detect_post", 0, lambda: ops.detect_post(
-                p["cls_prob"], p["bbox_pred"], p["rois"], self._num_rois, float(im_info[2]), int(im_shape[0]),
-                int(im_shape[1]), float(cfg.TEST.NMS), float(thresh), int(max_per_image), out=out, count=count))
-        max_out = (max_per_image + 28) if out is None else out.shape[1]
-        out = sess.buf(self._tag + "/dets", (B, max_out, 6)) if out is None else out
-        count = sess.buf(self._tag + "/det_count", (B,), torch.int32) if count is None else count
-        for b in range(B):
-            sl = slice(b * per, (b + 1) * per)
-            nr = None if self._num_rois is None else self._num_rois[b:b + 1]
-            sess.mark("op:detect_post", 0, lambda: ops.detect_post(
-                p["cls_prob"][sl], p["bbox_pred"][sl], p["rois"][sl], nr, float(im_info[2]), int(im_shape[0]), int(im_shape[1]),
-                float(cfg.TEST.NMS), float(thresh), int(max_per_image), out=out[b], count=count[b:b + 1], max_out=max_out))
-        return out, count
+        R, C = self._rois_per_image, self._num_classes
+        max_out = None if out is None else out.shape[-2]
+        if B > 1:
+            max_out = (max_per_image + 28) if out is None else max_out
+            out = sess.buf(self._tag + "/dets", (B, max_out, 6)) if out is None else out
+            count = sess.buf(self._tag + "/det_count", (B,), torch.int32) if count is None else count
+        return sess.mark("op:detect_post", 0, lambda: ops.detect_post(
+            p["cls_prob"], p["bbox_pred"], p["rois"], self._num_rois, float(im_info[2]), int(im_shape[0]), int(im_shape[1]),
+            float(cfg.TEST.NMS), float(thresh), int(max_per_image), max_out=max_out, out=out, count=count, batch=B,
+            rule=self._nms_rule()), nbytes=B * R * 20 * C)

@@ -2,10 +2,11 @@
 
 lib/model/nms_wrapper.py:12-13 imports both native modules unconditionally, so the name must exist.
 There is no CPU implementation in the product (the CPU restatement lives in oracle/ and is test
-infrastructure only): `cpu_nms` executes the same HIP kernel as `gpu_nms`, whose suppression rule
-already IS the cpu_nms rule."""
-from nms.gpu_nms import gpu_nms
+infrastructure only): `cpu_nms` executes the HIP kernels with the Cython rule -- suppress iff
+`(double)ovr >= thresh` (cpu_nms.pyx:65, cpu_nms.c:2239-2241) -- the path BASELINE.json pins."""
+from frcnn_hip import NMS_RULE_CPU
+from nms.gpu_nms import _run
 
 
 def cpu_nms(dets, thresh):
-    return gpu_nms(dets, thresh, device_id=0)
+    return _run(dets, float(thresh), 0, NMS_RULE_CPU)
