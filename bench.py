@@ -1,18 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- images/sec of the MI355X Faster R-CNN hot path (BASELINE.json metric).
 
-One "step" = one 600x1000 image per GPU through the whole device chain: image (already in HBM) ->
-ResNet-101 head (f32 MFMA implicit-GEMM convs) -> RPN -> proposal layer (decode/clip/sort/NMS) ->
-crop_and_resize -> block4 per RoI -> cls/bbox -> per-class NMS + top-100 -> detection record in HBM.
-N > 1: one process per GPU (torchrun), one image per rank per step, fixed-size detection records
-all-gathered over RCCL/xGMI every step (north_star); weak scaling.
+One "step" = one batch of same-size images per GPU through the whole device chain: image (already in HBM) -> backbone head
+(f32 MFMA implicit-GEMM / Winograd convs) -> RPN -> proposal layer (decode / clip / top-N select / sort / NMS) -> crop_and_resize
+-> per-RoI tail -> cls/bbox -> per-class NMS + top-100 -> detection records in HBM.  `value` counts IMAGES.
+N > 1: one process per GPU (torchrun), every rank its own images, fixed-size detection records all-gathered over RCCL/xGMI
+every step (north_star); weak scaling.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 20 --warmup 3                      # the headline: configs[1]
+    python bench.py --config c3|c4|c5 ...                                # the other BASELINE.json configs (committed lines in profiles/)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement; extra objects `roofline`,
-`cpu_baseline`).  /root/reference is never read here.
+Prints ONE JSON line on rank 0 (contract in the task statement; extra objects `roofline`, `stages`, `cpu_baseline`).
+/root/reference is never read here.
 """
 import argparse
 import json
@@ -31,22 +32,51 @@ import torch  # noqa: E402
 
 METRIC = "images/sec (600×1000) ResNet-101 Faster R-CNN at 1/2/4/8 MI355X"
 F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-IM_H, IM_W, IM_SCALE = 600, 1000, 1.6
-NUM_CLASSES = 21
-ANCHOR_SCALES, ANCHOR_RATIOS = (8, 16, 32), (0.5, 1, 2)
+HBM_PEAK_GBS = 8000.0                 # same guide: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+# BASELINE.json configs; gflop_ref = the reference graph's direct-convolution FLOPs per image
+CONFIGS = {
+    "c2": dict(label="configs[1]: ResNet-101 VOC 600x1000, 300 proposals, 21 classes, A=9, TEST.MODE nms", net="res101", H=600, W=1000,
+               scales=(8, 16, 32), classes=21, post=300, gflop_ref=622.29, batch=4, streams=3),
+    "c3": dict(label="configs[2]: ResNet-101 COCO 800x1333, 1000 proposals, 81 classes, A=15, TEST.MODE nms", net="res101", H=800, W=1333,
+               scales=(2, 4, 8, 16, 32), classes=81, post=1000, gflop_ref=1787.9, batch=2, streams=3),
+    "c4": dict(label="configs[3]: MobileNet-V1 1.0 COCO 600x1000, 300 proposals, 81 classes, A=12", net="mobile", H=600, W=1000,
+               scales=(4, 8, 16, 32), classes=81, post=300, gflop_ref=70.2, batch=4, streams=3),
+    "c1": dict(label="configs[0] shape on the device chain: VGG16 VOC 600x1000, 300 proposals, 21 classes, A=9", net="vgg16", H=600, W=1000,
+               scales=(8, 16, 32), classes=21, post=300, gflop_ref=451.1, batch=2, streams=3),
+    "c5": dict(label="configs[4]: ResNet-152 COCO trainval step 600x1000 (anchor_target + proposal_target + losses + backward + "
+                     "Momentum SGD), 81 classes, A=12, 256 RoIs", net="res152", H=600, W=1000, scales=(4, 8, 16, 32), classes=81, post=2000,
+               gflop_ref=1910.0, batch=1, streams=1),
+}
+IM_SCALE = 1.6
+ANCHOR_RATIOS = (0.5, 1, 2)
 
 
-def synth_image(seed):
+def synth_image(c, seed):
     from model.config import cfg
     rng = np.random.RandomState(seed)
-    return (rng.rand(1, IM_H, IM_W, 3) * 255.0).astype(np.float32) - cfg.PIXEL_MEANS.astype(np.float32)
+    return (rng.rand(1, c["H"], c["W"], 3) * 255.0).astype(np.float32) - cfg.PIXEL_MEANS.astype(np.float32)
+
+
+def make_net(c):
+    if c["net"] == "res101":
+        from nets.resnet_v1 import resnetv1
+        return resnetv1(num_layers=101)
+    if c["net"] == "res152":
+        from nets.resnet_v1 import resnetv1
+        return resnetv1(num_layers=152)
+    if c["net"] == "vgg16":
+        from nets.vgg16 import vgg16
+        return vgg16()
+    from nets.mobilenet_v1 import mobilenetv1
+    return mobilenetv1()
 
 
 def calibrate_rpn(sess, net, img_d, im_info):
-    """Random-init RPN heads give near-constant scores and ~0 deltas, so NMS collapses the 6000 candidates
-    to ~140 boxes.  Rescale the two 1x1 RPN heads so the proposal stage sees the statistics SURVEY.md 8d
-    prescribes (logit spread ~1, deltas ~N(0,0.2^2)) and the full 300 proposals survive, as they do with a
-    trained model.  Weights only; the architecture and every shape stay those of the reference."""
+    """Random-init RPN heads give near-constant scores and ~0 deltas, so NMS collapses the 6000 candidates to ~140 boxes.
+    Rescale the two 1x1 RPN heads so the proposal stage sees the statistics SURVEY.md 8d prescribes (logit spread ~1,
+    deltas ~N(0,0.2^2)) and the full post_nms_topN proposals survive, as they do with a trained model.  Weights only; the
+    architecture and every shape stay those of the reference."""
     with torch.cuda.stream(sess.stream):
         p = net.forward_device(sess, img_d, im_info, use_graph=False)
         sess.stream.synchronize()
@@ -59,28 +89,103 @@ def calibrate_rpn(sess, net, img_d, im_info):
     sess.graphs.clear()
 
 
-def cpu_baseline(variables, image, rois_hint):
-    """Host-CPU number beside the GPU one: the oracle's restatement of the SAME workload (one image),
-    dense part = torch-CPU float32 on all host cores (TensorFlow-CPU is not installable offline),
-    detection part = the pinned numpy/C oracle (single thread, like the reference under the GIL)."""
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def cpu_baseline(variables, image, c):
+    """Host-CPU number beside the GPU one (rank 0, N = 1): the oracle's restatement of the SAME workload, one image per run,
+    best of 3 after one warm-up run.  Dense part: torch-CPU float32 on the PHYSICAL cores (TensorFlow-CPU is not installable
+    offline; over-subscribing the SMT threads halves this leg).  Detection part: the pinned numpy/C oracle, single thread like
+    the reference under the GIL; the NMS inside it is the reference's own compiled Cython cpu_nms when oracle/_ref travelled
+    with the snapshot (it is built from /root/reference/lib/nms/cpu_nms.pyx by oracle/build_ref.py)."""
+    import importlib.util
     import frcnn_oracle as ora
     from dense_ref import DenseRef
-    cores = torch.get_num_threads()
-    ref = DenseRef(variables, 101, NUM_CLASSES, ANCHOR_SCALES, ANCHOR_RATIOS, dtype=torch.float32)
-    im_info = np.array([IM_H, IM_W, IM_SCALE], dtype=np.float32)
-    t0 = time.time()
-    with torch.no_grad():
-        out = ref.test_image(image, im_info)
-    t_fwd = time.time() - t0
-    t1 = time.time()
-    sc, boxes = ora.im_detect_post(out["cls_prob"].astype(np.float32), out["bbox_pred"].astype(np.float32),
-                                   out["rois"].astype(np.float32), IM_SCALE, (int(IM_H / IM_SCALE), int(IM_W / IM_SCALE), 3))
-    ora.test_net_post(sc, boxes, NUM_CLASSES)
-    t_post = time.time() - t1
-    total = t_fwd + t_post
-    return {"value": round(1.0 / total, 4), "unit": "images/sec", "cores": int(cores), "kind": "port",
-            "sample": "1 image 600x1000 ResNet-101 (300 RoIs): torch-CPU f32 dense restatement on %d threads %.2fs "
-                      "(incl. numpy/C proposal_layer) + per-class NMS %.3fs" % (cores, t_fwd, t_post)}
+    cores = physical_cores()
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    ref_nms = None
+    try:                                                  # the reference's Cython kernel, loaded by FILE (the package name `nms` is this repo's mirror)
+        import glob
+        so = glob.glob(os.path.join(ROOT, "oracle", "_ref", "nms", "cpu_nms*.so"))
+        if so:
+            spec = importlib.util.spec_from_file_location("nms.cpu_nms", so[0])
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            ref_nms = mod.cpu_nms
+    except Exception:
+        ref_nms = None
+    saved_nms = ora.cpu_nms
+    if ref_nms is not None:
+        ora.cpu_nms = lambda d, t: list(ref_nms(np.ascontiguousarray(d, dtype=np.float32), float(t)))
+    ref = DenseRef(variables, 101, c["classes"], c["scales"], ANCHOR_RATIOS, dtype=torch.float32)
+    im_info = np.array([c["H"], c["W"], IM_SCALE], dtype=np.float32)
+    orig = (int(c["H"] / IM_SCALE), int(c["W"] / IM_SCALE), 3)
+    best, parts, best_threads = None, None, cores
+    try:
+        # the dense leg does not scale to every core of a 2-socket host: try the physical-core count and fractions of it, one
+        # warm-up run (weight conversion, thread pool, page faults) then two timed runs each, and report the best
+        for threads in sorted({cores, max(1, cores // 2), max(1, cores // 4), min(cores, 16)}, reverse=True):
+            torch.set_num_threads(threads)
+            for it in range(3):
+                t0 = time.time()
+                with torch.no_grad():
+                    out = ref.test_image(image, im_info, post=c["post"])
+                t_fwd = time.time() - t0
+                t1 = time.time()
+                sc, boxes = ora.im_detect_post(out["cls_prob"].astype(np.float32), out["bbox_pred"].astype(np.float32),
+                                               out["rois"].astype(np.float32), IM_SCALE, orig)
+                ora.test_net_post(sc, boxes, c["classes"])
+                t_post = time.time() - t1
+                if it > 0 and (best is None or t_fwd + t_post < best):
+                    best, parts, best_threads = t_fwd + t_post, (t_fwd, t_post), threads
+    finally:
+        ora.cpu_nms = saved_nms
+        torch.set_num_threads(old_threads)
+    cores_phys, cores = cores, best_threads
+    return {"value": round(1.0 / best, 4), "unit": "images/sec", "cores": int(cores), "kind": "port",
+            "sample": "1 image %dx%d (%d RoIs), best of 2 timed runs after a warm-up run at the best of {1, 1/2, 1/4, 16} x %d physical "
+                      "cores: torch-CPU f32 dense restatement on %d threads %.2fs (incl. numpy/C proposal_layer) + per-class NMS %.3fs; "
+                      "NMS kernel: %s" % (c["H"], c["W"], c["post"], cores_phys, cores, parts[0], parts[1],
+                         "the reference's Cython cpu_nms (oracle/_ref)" if ref_nms is not None else "oracle_c.c restatement")}
+
+
+def train_bench(args, c, dev, world, rank, dist):
+    """configs[4]: one SGD step per image per GPU; gradients all-reduced over RCCL when world > 1 (frcnn_hip/parallel.py)."""
+    from frcnn_hip.runtime import Session
+    from model.config import cfg
+    from model.train_val import SolverWrapper, synthetic_data_layer
+    cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.TRAIN.DOUBLE_BIAS = 256, 0.0, False      # experiments/cfgs/res101.yml
+    sess = Session(device=dev, seed=cfg.RNG_SEED)
+    net = make_net(c)
+    net.create_architecture("TRAIN", c["classes"], tag="c5", anchor_scales=c["scales"], anchor_ratios=ANCHOR_RATIOS)
+    sess.init_variables(net.variable_specs())
+    ar = None
+    if world > 1:
+        from frcnn_hip import parallel
+        ar = parallel.make_grad_all_reduce()
+    sw = SolverWrapper(sess, net, synthetic_data_layer(c["classes"], seed=cfg.RNG_SEED + rank, image_gain=1 / 256.0), all_reduce=ar,
+                       world_size=world)
+    sw.train_model(max(args.warmup, 1), verbose=False)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sw.train_model(args.steps, verbose=False)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, sess
 
 
 def main():
@@ -88,20 +193,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE.json config (default c2 = configs[1], the metric's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--profile-steps", type=int, default=3, help="steps of the HIP-event pass that feeds `roofline`")
-    ap.add_argument("--batch", type=int, default=4, help="images per launch chain: the dense layers of B images share launches "
-                    "(fills the 256 CUs on the 38x63 layers); a step still counts images")
-    ap.add_argument("--streams", type=int, default=3, help="images in flight per GPU (independent HIP streams + graphs)")
+    ap.add_argument("--profile-steps", type=int, default=3, help="steps of the HIP-event pass that feeds `roofline` / `stages`")
+    ap.add_argument("--batch", type=int, default=0, help="images per launch chain: the launches of B images are shared (fills the 256 "
+                    "CUs on the 38x63 layers); a step still counts images.  0 = the config's default")
+    ap.add_argument("--streams", type=int, default=0, help="launch chains in flight per GPU (independent HIP streams + graphs)")
     ap.add_argument("--reference-order", action="store_true",
                     help="keep the reference op order crop -> 1x1 convs at the block4 entry (default: the 1x1 convs run on the "
                          "feature map and their outputs are cropped; same result up to f32 rounding, 64.5 GFLOP less)")
     ap.add_argument("--mfma", choices=["f32", "bf16x3"], default="f32",
                     help="f32: v_mfma_f32_32x32x2_f32 (default, the headline).  bf16x3: EXPERIMENTAL exact 3-way bf16 split of both "
                          "operands, six bf16 MFMAs per f32 product, f32 accumulate (f32-class error, csrc/conv_igemm_b3.hip)")
+    ap.add_argument("--winograd-f2", default=None, help="comma list of scope tokens run as F(2x2,3x3) instead of F(4x4,3x3) (default: cfg.HIP)")
+    ap.add_argument("--winograd-direct", default=None, help="comma list of scope tokens that keep the direct kernel (default: cfg.HIP)")
     ap.add_argument("--layer-report", default=None, help="write a per-layer table of the event pass to this file")
     args = ap.parse_args()
+    c = CONFIGS[args.config]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -124,25 +233,54 @@ def main():
         frcnn_hip.lib().frcnn_set_tuning(2, 1)
     from frcnn_hip.runtime import Session
     from model.config import cfg
-    from nets.resnet_v1 import resnetv1
 
+    if args.winograd_f2 is not None:
+        cfg.HIP.WINOGRAD_F2_SCOPES = tuple(t for t in args.winograd_f2.split(",") if t)
+    if args.winograd_direct is not None:
+        cfg.HIP.WINOGRAD_DIRECT_SCOPES = tuple(t for t in args.winograd_direct.split(",") if t)
     cfg.USE_GPU_NMS = False           # the reference's CPU/Cython suppression rule (cpu_nms.pyx:65): the path BASELINE.json pins
+    cfg.TEST.RPN_POST_NMS_TOP_N = c["post"]
+    B = args.batch or c["batch"]
+    S = max(1, args.streams or c["streams"])
+    common = {"metric": METRIC, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+              "dtype": "f32" if args.mfma == "f32" else "f32 via exact bf16x3 operand split (6 bf16 MFMAs / product, f32 accumulate)"}
+
+    if args.config == "c5":
+        elapsed, sess = train_bench(args, c, dev, world, rank, dist)
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        if rank == 0:
+            value = world * args.steps / elapsed
+            out = dict(common, value=round(value, 3), ms_per_step=round(1000.0 * elapsed / args.steps, 4),
+                       config={"workload": c["label"] + "; one image per GPU per step", "parallelism": "dp%d (RCCL gradient all-reduce)" % world,
+                               "launch": "eager", "gflop_per_step_reference_graph": c["gflop_ref"]},
+                       roofline={"bound": "mfma", "achieved": round(c["gflop_ref"] * value / world / 1e3, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": round(c["gflop_ref"] * value / world / 1e3 / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                                 "kernel": "whole training step, reference-graph FLOPs (fwd + 2x trainable part) / step time"})
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     sess = Session(device=dev, seed=cfg.RNG_SEED)
-    S = max(1, args.streams)
     nets = []
     for i in range(S):                                   # one Network (= one set of static buffers + one hipGraph) per stream
-        n_ = resnetv1(num_layers=101)
-        n_.create_architecture("TEST", NUM_CLASSES, tag="s%d" % i, anchor_scales=ANCHOR_SCALES, anchor_ratios=ANCHOR_RATIOS)
+        n_ = make_net(c)
+        n_.create_architecture("TEST", c["classes"], tag="s%d" % i, anchor_scales=c["scales"], anchor_ratios=ANCHOR_RATIOS)
         n_._fuse_tail_entry = not args.reference_order
         nets.append(n_)
     net = nets[0]
     sess.init_variables(net.variable_specs())            # weights are shared by all streams
-    im_info = np.array([IM_H, IM_W, IM_SCALE], dtype=np.float32)
-    orig_shape = (int(IM_H / IM_SCALE), int(IM_W / IM_SCALE))
-    image = synth_image(cfg.RNG_SEED + rank)             # every rank its own image
+    im_info = np.array([c["H"], c["W"], IM_SCALE], dtype=np.float32)
+    orig_shape = (int(c["H"] / IM_SCALE), int(c["W"] / IM_SCALE))
+    gain = np.float32(1 / 64.0 if c["net"] == "vgg16" else 1.0)     # VGG has no normalisation: keep 13 random conv layers finite
+    image = synth_image(c, cfg.RNG_SEED + rank) * gain   # every rank its own image
 
     from frcnn_hip import parallel
-    B = max(1, args.batch)
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     recs, views, counts, gathered, imgs = [], [], [], [], []
     for i in range(S):
@@ -151,7 +289,7 @@ def main():
         counts.append(torch.zeros((B,), dtype=torch.int32, device=dev))
         gathered.append(torch.zeros((world,) + tuple(r_.shape), dtype=torch.float32, device=dev) if world > 1 else None)
         with torch.cuda.stream(streams[i]):                 # every (rank, stream, slot) its own image, resident in HBM
-            batch_np = np.concatenate([synth_image(cfg.RNG_SEED + rank + 1000 * i + 100000 * b) for b in range(B)], axis=0)
+            batch_np = np.concatenate([synth_image(c, cfg.RNG_SEED + rank + 1000 * i + 100000 * b) * gain for b in range(B)], axis=0)
             imgs.append(nets[i]._stage_image(sess, batch_np))
     torch.cuda.synchronize()
     calibrate_rpn(sess, nets[0], imgs[0][:1].contiguous(), im_info)   # synthetic-data preparation, outside any timed region
@@ -166,57 +304,52 @@ def main():
                 parallel.set_count(recs[i], counts[i])
                 parallel.all_gather_records(recs[i], gathered[i])
 
-    if True:
+    if args.no_graph:
+        sess.profile = []                                # forward_device runs eagerly while profile is not None
+    for k in range(max(args.warmup, S)):
+        step(k)
         if args.no_graph:
-            sess.profile = []                                # forward_device runs eagerly while profile is not None
-        for k in range(max(args.warmup, S)):
-            step(k)
-            if args.no_graph:
-                sess.profile = []
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            step(k)
-            if args.no_graph:
-                sess.profile = []
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        n_det = int(count_i32[0].item())
-        n_rois = int(net._num_rois[0].item())
-        flops_per_image = sess.flops_last_forward
-
-        # ---- roofline of the dominant kernel (k_conv_igemm): HIP events around every conv launch, on
-        #      the stream the kernels run on, over `profile_steps` further steps of the same workload
-        conv_ms, conv_flops, conv_launches, conv_bytes = 0.0, 0, 0, 0
-        if rank == 0 and args.profile_steps > 0:
-          with torch.cuda.stream(run_stream):
             sess.profile = []
-            for _ in range(args.profile_steps):       # no collective here: only rank 0 runs this pass
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+        if args.no_graph:
+            sess.profile = []
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    n_det = int(count_i32[0].item())
+    n_rois = int(net._num_rois[0].item())
+    flops_per_image = sess.flops_last_forward / B        # launched MFMA FLOPs (Winograd / commuted crop already taken out)
+
+    # ---- HIP-event pass: events around every launch group, on the stream the kernels run on, over `profile_steps` further
+    #      steps of the same workload (a hipGraph replay cannot carry events, so this pass launches eagerly on ONE chain)
+    per_layer, conv = {}, [0.0, 0, 0, 0]
+    if rank == 0 and args.profile_steps > 0:
+        with torch.cuda.stream(run_stream):
+            sess.profile = []
+            for _ in range(args.profile_steps):           # no collective here: only rank 0 runs this pass
                 net.detect_device(sess, img_d, im_info, orig_shape, out=dets_view, count=count_i32)
             run_stream.synchronize()
-            per_layer = {}
-            per_image_scale = 1.0 / B
             for tag, fl, e0, e1, nb in sess.profile:
                 ms = e0.elapsed_time(e1)
-                a = per_layer.setdefault(tag, [0.0, 0, 0])
-                a[0] += ms; a[1] += fl; a[2] += 1
+                a = per_layer.setdefault(tag, [0.0, 0, 0, 0])
+                a[0] += ms; a[1] += fl; a[2] += 1; a[3] += nb
                 if tag.startswith("conv:"):
-                    conv_ms += ms
-                    conv_flops += fl
-                    conv_launches += 1
-                    conv_bytes += nb
+                    conv[0] += ms; conv[1] += fl; conv[2] += 1; conv[3] += nb
             sess.profile = None
-            if args.layer_report:
-                with open(args.layer_report, "w") as f:
-                    f.write("# tag  launches  us/launch  GFLOP/launch  TFLOP/s\n")
-                    for tag, (ms, fl, n) in per_layer.items():
-                        f.write("%-70s %3d %9.1f %9.3f %8.1f\n" % (tag, n, 1000 * ms / n, fl / n / 1e9, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0))
+        if args.layer_report:
+            with open(args.layer_report, "w") as f:
+                f.write("# tag  launches  us/launch  GFLOP/launch  TFLOP/s  GB/s(algorithmic)\n")
+                for tag, (ms, fl, n, nb) in per_layer.items():
+                    f.write("%-70s %3d %9.1f %9.3f %8.1f %8.0f\n" % (tag, n, 1000 * ms / n, fl / n / 1e9, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0,
+                                                                     nb / (ms * 1e-3) / 1e9 if ms > 0 else 0))
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -225,40 +358,58 @@ def main():
 
     if rank == 0:
         value = world * args.steps * B / elapsed
-        out = {
-            "metric": METRIC, "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.mfma == "f32" else "f32 via exact bf16x3 operand split (6 bf16 MFMAs / product, f32 accumulate)",
-            "data": "synthetic",
-            "config": {"workload": "configs[1]: ResNet-101 VOC 600x1000, 300 proposals, 21 classes, A=9, TEST.MODE nms; "
-                                   "image in HBM -> <=100 detections in HBM", "images_per_gpu_per_step": B, "chains_in_flight_per_gpu": S,
-                       "parallelism": "dp%d (one image per GPU, all-gather of detection records)" % world,
-                       "launch": "eager" if args.no_graph else "hipGraph replay", "rois": n_rois, "detections": n_det,
-                       "graph": "reference op order" if args.reference_order else
-                                "block4/unit_1 1x1 convs commuted past the bilinear crop (exact algebra, same outputs to f32 rounding; "
-                                "--reference-order keeps crop -> conv)",
-                       "gflop_per_image_launched": round(flops_per_image / B / 1e9, 2), "gflop_per_image_reference_graph": 622.29},
-        }
-        traffic = None      # HBM bytes per conv launch from the committed rocprofv3 PMC passes of this command (scratch/gpu_pmc2.sh)
-        tpath = os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json")
-        if os.path.exists(tpath) and B == 4 and not args.reference_order:
-            try:
-                traffic = round(json.load(open(tpath))["hbm_bytes_per_launch"])
-            except Exception:
-                traffic = None
-        if conv_launches:
-            ach = conv_flops / (conv_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                               "kernel": "k_conv_igemm (f32 MFMA 32x32x2 implicit GEMM, all tile shapes)",
-                               "algorithmic_bytes_per_launch": conv_bytes // max(conv_launches, 1),
-                               "launches_per_step": conv_launches // args.profile_steps,
-                               "avg_launch_us": round(1000.0 * conv_ms / conv_launches, 2),
-                               "conv_ms_per_image": round(conv_ms / args.profile_steps / B, 3),
-                               "whole_image_frac_of_mfma_roofline": round(flops_per_image / B * value / world / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sess.variables, image, None)
+        out = dict(common, value=round(value, 3), ms_per_step=round(1000.0 * elapsed / args.steps, 4))
+        out["config"] = {"workload": c["label"] + "; image in HBM -> <=100 detections in HBM", "images_per_gpu_per_step": B,
+                         "chains_in_flight_per_gpu": S, "parallelism": "dp%d (one batch per GPU, all-gather of detection records)" % world,
+                         "launch": "eager" if args.no_graph else "hipGraph replay", "rois": n_rois, "detections": n_det,
+                         "nms_rule": "cpu_nms (ovr >= thresh)",
+                         "winograd": {"m": int(cfg.HIP.WINOGRAD_M), "f2_scopes": list(cfg.HIP.WINOGRAD_F2_SCOPES),
+                                      "direct_scopes": list(cfg.HIP.WINOGRAD_DIRECT_SCOPES), "crops_7x7": bool(cfg.HIP.WINOGRAD_7X7)}
+                         if cfg.HIP.WINOGRAD else None,
+                         "graph": "reference op order" if args.reference_order else
+                                  "block4/unit_1 1x1 convs commuted past the bilinear crop (exact algebra, same outputs to f32 rounding; "
+                                  "--reference-order keeps crop -> conv)",
+                         "gflop_per_image_launched": round(flops_per_image / 1e9, 2), "gflop_per_image_reference_graph": c["gflop_ref"]}
+        if conv[2]:
+            steps_p = args.profile_steps
+            ach = conv[1] / (conv[0] * 1e-3) / 1e12
+            traffic, tsrc = None, None      # HBM bytes per conv launch from the committed rocprofv3 PMC passes of this command
+            for name in ("r02_pmc_traffic.json",):
+                tpath = os.path.join(ROOT, "profiles", name)
+                if os.path.exists(tpath) and args.config == "c2" and B == 4 and not args.reference_order:
+                    try:
+                        traffic, tsrc = round(json.load(open(tpath))["hbm_bytes_per_launch"]), "profiles/" + name
+                    except Exception:
+                        traffic = None
+            whole_launched = flops_per_image * value / world / 1e12
+            out["roofline"] = {
+                "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                # frac == frac_launched: FLOPs the conv kernels actually execute / their launch time (event pass, one chain)
+                "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "frac_launched": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
+                # the same kernels credited with the reference graph's direct-convolution FLOPs (SURVEY 8d / BASELINE.md formula):
+                # > 1 is what Winograd and the commuted crop buy, not a kernel-efficiency claim
+                "frac_algorithmic": round(c["gflop_ref"] * value / world / 1e3 / F32_MFMA_PEAK_TFLOPS, 4),
+                # launched FLOPs over the TIMED region's clock (all chains, non-conv stages included)
+                "frac_timed_region_launched": round(whole_launched / F32_MFMA_PEAK_TFLOPS, 4),
+                "traffic": traffic, "traffic_source": tsrc,
+                "kernel": "k_conv_igemm (f32 MFMA 32x32x2 implicit GEMM, all tile shapes; Winograd GEMMs included)",
+                "algorithmic_bytes_per_launch": conv[3] // max(conv[2], 1), "launches_per_step": conv[2] // steps_p,
+                "avg_launch_us": round(1000.0 * conv[0] / conv[2], 2), "conv_ms_per_image": round(conv[0] / steps_p / B, 3)}
+            # the bandwidth-bound stages (north_star: achieved HBM GB/s): algorithmic bytes / event time of the stage
+            stages = {}
+            for tag, key in (("op:proposal_layer", "proposal_layer"), ("op:proposal_layer_tf", "proposal_layer"),
+                             ("op:crop_and_resize", "crop_and_resize"), ("op:detect_post", "detect_post"), ("op:wino_in", "winograd_input_transform"),
+                             ("op:wino_out", "winograd_output_transform"), ("op:maxpool", "maxpool"), ("op:spatial_mean", "spatial_mean"),
+                             ("op:dwconv3x3", "depthwise_conv")):
+                if tag in per_layer:
+                    ms, _, n, nb = per_layer[tag]
+                    stages[key] = {"us_per_image": round(1000.0 * ms / steps_p / B, 2), "launches_per_step": n // steps_p,
+                                   "algorithmic_MB_per_step": round(nb / steps_p / 1e6, 2),
+                                   "achieved_GBs": round(nb / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+                                   "frac_of_hbm_peak": round(nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None}
+            out["stages"] = stages
+        if world == 1 and not args.no_cpu_baseline and c["net"] == "res101":
+            out["cpu_baseline"] = cpu_baseline(sess.variables, image, c)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

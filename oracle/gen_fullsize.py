@@ -97,7 +97,22 @@ def main():
               dets=dets.astype(np.float32), head_sub=feat_nhwc[0, ::4, ::4, :].astype(np.float32),
               head_absmax=np.float64(np.abs(feat_nhwc).max()), fc7_sub=fc7.numpy()[::8].astype(np.float32),
               fc7_absmax=np.float64(fc7.abs().max()))
-    if ref.calibrate:
+    # control: what plain float32 arithmetic (torch-CPU, the same restatement) loses against float64 on THIS network --
+    # the yardstick for "as exact as f32 gets" when the 1e-4 budget is smaller than f32's own noise on a graph
+    ref.calibrate = False
+    c32 = DenseRef(v, c["layers"], c["classes"], c["scales"], c["ratios"], dtype=torch.float32)
+    with torch.no_grad():
+        feat32 = c32.head(image)
+        s32, p32, b32 = c32.rpn(feat32)
+        h32_nhwc = feat32.permute(0, 2, 3, 1).contiguous().numpy()
+        # the f32 tail sees the f32 head (as on the device), cropped at the reference's rois
+        fc32 = c32.tail(ora.crop_and_resize(h32_nhwc[0], rois.astype(np.float32), 16.0, 7))
+        cs32, cp32, bp32 = c32.classify(fc32)
+    fx.update(ctrl_head=fs.rel_err(h32_nhwc, feat_nhwc), ctrl_rpn_cls_score=fs.rel_err(s32, score), ctrl_rpn_cls_prob=fs.rel_err(p32, prob),
+              ctrl_rpn_bbox_pred=fs.rel_err(b32, bbox), ctrl_cls_score=fs.rel_err(cs32, cls_score),
+              ctrl_cls_prob_abs=float(np.abs(cp32 - cls_prob).max()), ctrl_bbox_pred=fs.rel_err(bp32, bbox_pred))
+    print("f32 control vs f64: " + "  ".join("%s %.2e" % (k[5:], float(fx[k])) for k in sorted(fx) if k.startswith("ctrl_")), flush=True)
+    if args.weights == "calibrated":
         names = ref.bn_order
         fx["bn_names"] = np.array(names)
         fx["bn_mean"] = np.concatenate([v[s + "/BatchNorm/moving_mean"] for s in names]).astype(np.float32)

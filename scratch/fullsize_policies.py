@@ -17,7 +17,7 @@ os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 with open(os.path.join(ROOT, "gpurun_out", "fullsize_policies.txt"), "a") as f:
     for config in configs:
         for weights in (("damped", "calibrated") if config == "c2" else ("calibrated",)):
-            for policy in ("direct", "f2", "f4", "f4_rpn_f2", "f4_rpn_block3_f2", "f4_head_f2"):
+            for policy in os.environ.get("POLICIES", "direct,f2,f4,f4_b1_f2,f4_b12_f2,f4_b12_direct,f4_head_f2").split(","):
                 try:
                     line = fs.format_report(fs.run_harness(config, weights, policy, dev))
                 except Exception as e:  # noqa: BLE001

@@ -181,6 +181,7 @@ def test_target_layer_mirrors_reproduce_the_reference_run(dev, golden):
         assert lab.shape == g["at_labels"].shape and np.array_equal(lab, g["at_labels"])
         assert np.array_equal(iw, g["at_inside"]) and np.array_equal(ow, g["at_outside"])
         assert np.abs(tg - g["at_targets"]).max() <= 2e-6
+        np.random.seed(3)                                                      # the reference run re-seeded here (oracle/gen_golden.py)
         rois, sc, labels, btg, biw, bow = proposal_target_layer(g["pt_in_rois"], g["pt_in_scores"], gt, 21)
         assert np.array_equal(rois, g["pt_rois"]) and np.array_equal(sc, g["pt_scores"]) and np.array_equal(labels, g["pt_labels"])
         assert np.array_equal(biw, g["pt_inside"]) and np.array_equal(bow, g["pt_outside"])

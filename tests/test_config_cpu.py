@@ -78,4 +78,6 @@ def test_type_mismatch_and_unknown_keys_are_rejected(tmp_path, restore_cfg):
 def test_device_path_switches_exist_with_documented_defaults():
     h = C.cfg.HIP
     assert h.WINOGRAD is True and h.WINOGRAD_M == 4 and h.WINOGRAD_TRAIN is True and h.WINOGRAD_7X7 is True and h.WINOGRAD_MIN_CIN == 64
-    assert C.cfg.USE_E2E_TF is False and C.cfg.USE_GPU_NMS is True and C.cfg.POOLING_SIZE == 7
+    assert C.cfg.USE_E2E_TF is False and C.cfg.POOLING_SIZE == 7
+    # the session fixture of conftest.py pins USE_GPU_NMS False for the parity suite; the shipped default is the reference's True
+    assert "USE_GPU_NMS=True" in open(C.__file__).read() and C.cfg.USE_GPU_NMS is False

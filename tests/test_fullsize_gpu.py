@@ -26,7 +26,7 @@ SHIPPED = "shipped"
 def _shipped_policy():
     """the cfg.HIP defaults as a harness policy"""
     from model.config import cfg
-    fs.POLICIES[SHIPPED] = {k: cfg.HIP[k] for k in ("WINOGRAD", "WINOGRAD_M", "WINOGRAD_F2_SCOPES", "WINOGRAD_7X7", "WINOGRAD_MIN_CIN")}
+    fs.POLICIES[SHIPPED] = {k: cfg.HIP[k] for k in ("WINOGRAD", "WINOGRAD_M", "WINOGRAD_F2_SCOPES", "WINOGRAD_DIRECT_SCOPES", "WINOGRAD_7X7", "WINOGRAD_MIN_CIN")}
     return SHIPPED
 
 

@@ -198,7 +198,10 @@ def test_batched_forward_equals_single_image_forward(small_net):
     for b, want in enumerate((singles[0], singles[1], singles[0])):
         assert rel_err(p["rpn_cls_prob"][b:b + 1].cpu().numpy(), want["rpn_cls_prob"]) <= 1e-5
         sl = slice(b * per, (b + 1) * per)
-        assert np.allclose(p["rois"][sl].cpu().numpy(), want["rois"], rtol=0, atol=1e-3)
+        got_rois = p["rois"][sl].cpu().numpy()
+        nb = int(net._num_rois[b].item())
+        assert np.all(got_rois[:nb, 0] == b) and np.all(want["rois"][:, 0] == 0)           # rois[:,0] = image index of the batch
+        assert np.allclose(got_rois[:, 1:], want["rois"][:, 1:], rtol=0, atol=1e-3)
         assert rel_err(p["cls_score"][sl].cpu().numpy(), want["cls_score"]) <= 2e-5      # logits (this fixture's are O(1e3))
         assert rel_err(p["bbox_pred"][sl].cpu().numpy(), want["bbox_pred"]) <= 2e-5
     d, c = net.detect_device(sess, batch, im_info, (150, 200))

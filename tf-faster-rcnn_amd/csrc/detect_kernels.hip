@@ -117,39 +117,51 @@ __global__ void k_boxes_scores_key(const float4* __restrict__ in_boxes, const fl
 // them) and zeroes their rank counters.  Reads 8N bytes nine times out of L2; replaces an O(N^2) counting sort
 // over all anchors.
 // ------------------------------------------------------------------------------------------------
-// hist[bin] += 1 for every active lane, one LDS atomic per distinct bin per wave (in the high-byte passes nearly all lanes of
-// a wave hit the same bin: probabilities share their exponent).
-__device__ __forceinline__ void wave_hist_add(int* hist, int bin, bool active) {
-  u64 todo = __ballot(active);
-  while (todo) {
-    const int first = __ffsll((long long)todo) - 1;
-    const int v = __shfl(bin, first, 64);
-    const u64 same = __ballot(active && bin == v);
-    if ((int)(threadIdx.x & 63) == first) atomicAdd(&hist[v], __popcll(same));
-    todo &= ~same;
-  }
-}
-
+#define SEL_LIST 4096
 __global__ __launch_bounds__(1024) void k_select_topk(const u64* __restrict__ keys_all, int N, int K,
                                                       u64* __restrict__ ckeys_all, u32* __restrict__ rank_all, size_t img) {
+  // per-wave histograms (row stride 257 words: the 16 rows start in different LDS banks), summed per pass
+  __shared__ int whist[16 * 257];
   __shared__ int hist[256];
+  __shared__ u64 list[SEL_LIST];             // the keys sharing the selected 16-bit prefix: the last six passes run on these
   __shared__ u64 sel_prefix, sel_mask;
-  __shared__ int sel_k, fill;
-  const int tid = threadIdx.x, lane = tid & 63;
+  __shared__ int sel_k, fill, list_n, gather_flag;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u64* keys = img_ptr(keys_all, img, blockIdx.x);
   u64* ckeys = img_ptr(ckeys_all, img, blockIdx.x);
   u32* rank = img_ptr(rank_all, img, blockIdx.x);
+  int* myhist = whist + wave * 257;
   u64 cut = 0;                                                 // K >= N: every key is selected
   if (K < N) {
-    if (tid == 0) { sel_prefix = 0; sel_mask = 0; sel_k = K; }
+    if (tid == 0) { sel_prefix = 0; sel_mask = 0; sel_k = K; list_n = -1; }
     for (int shift = 56; shift >= 0; shift -= 8) {
-      if (tid < 256) hist[tid] = 0;
+      for (int t = tid; t < 16 * 257; t += 1024) whist[t] = 0;
       __syncthreads();
       const u64 pf = sel_prefix, mk = sel_mask;
-      for (int base = 0; base < N; base += 1024) {               // uniform trip count: wave_hist_add is a wave-level operation
-        const int t = base + tid;
-        const u64 key = (t < N) ? keys[t] : 0ull;
-        wave_hist_add(hist, (int)((key >> shift) & 255), (t < N) && ((key & mk) == pf));
+      const int ln = list_n;
+      if (ln >= 0) {                                           // candidates already gathered into LDS
+        for (int t = tid; t < ln; t += 1024) {
+          const u64 key = list[t];
+          if ((key & mk) == pf) atomicAdd(&myhist[(int)((key >> shift) & 255)], 1);
+        }
+      } else {
+        // 8 independent loads in flight per thread before the (LDS-atomic) histogram updates: a scan of N keys by ONE
+        // workgroup is latency-bound otherwise (N / 1024 dependent round trips to L2 per pass)
+        for (int base = tid; base < N; base += 8 * 1024) {
+          u64 kq[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) kq[q] = (base + q * 1024 < N) ? keys[base + q * 1024] : 0ull;
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (base + q * 1024 < N && (kq[q] & mk) == pf) atomicAdd(&myhist[(int)((kq[q] >> shift) & 255)], 1);
+        }
+      }
+      __syncthreads();
+      if (tid < 256) {
+        int sum = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) sum += whist[w * 257 + tid];
+        hist[tid] = sum;
       }
       __syncthreads();
       if (tid == 0) {
@@ -161,25 +173,45 @@ __global__ __launch_bounds__(1024) void k_select_topk(const u64* __restrict__ ke
         sel_k -= acc;
         sel_prefix |= ((u64)bsel << shift);
         sel_mask |= (255ull << shift);
+        // after the second pass: if the selected 16-bit bucket is small, finish on an LDS copy of it
+        gather_flag = (shift == 48 && hist[bsel] <= SEL_LIST) ? 1 : 0;
+        if (gather_flag) list_n = 0;
       }
       __syncthreads();
+      if (gather_flag) {                                       // workgroup-uniform: written once per pass by thread 0
+        const u64 pf2 = sel_prefix, mk2 = sel_mask;
+        for (int base = tid; base < N; base += 8 * 1024) {
+          u64 kq[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) kq[q] = (base + q * 1024 < N) ? keys[base + q * 1024] : 0ull;
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (base + q * 1024 < N && (kq[q] & mk2) == pf2) list[atomicAdd(&list_n, 1)] = kq[q];
+        }
+        __syncthreads();
+      }
     }
     cut = sel_prefix;                                          // the K-th largest key itself
   }
+  __syncthreads();
   if (tid == 0) fill = 0;
   __syncthreads();
   const int Kc = min(K, N);
-  for (int base = 0; base < N; base += 1024) {
-    const int t = base + tid;
-    const u64 key = (t < N) ? keys[t] : 0ull;
-    const bool f = (t < N) && (key >= cut);
-    const u64 bal = __ballot(f);
-    int wbase = 0;
-    if (lane == 0 && bal) wbase = atomicAdd(&fill, __popcll(bal));
-    wbase = __shfl(wbase, 0, 64);
-    if (f) {
-      const int pos = wbase + __popcll(bal & ((1ull << lane) - 1ull));
-      if (pos < Kc) { ckeys[pos] = key; rank[pos] = 0u; }
+  for (int base = 0; base < N; base += 8 * 1024) {
+    u64 kq[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) kq[q] = (base + q * 1024 + tid < N) ? keys[base + q * 1024 + tid] : 0ull;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const bool f = (base + q * 1024 + tid < N) && (kq[q] >= cut);
+      const u64 bal = __ballot(f);
+      int wbase = 0;
+      if (lane == 0 && bal) wbase = atomicAdd(&fill, __popcll(bal));
+      wbase = __shfl(wbase, 0, 64);
+      if (f) {
+        const int pos = wbase + __popcll(bal & ((1ull << lane) - 1ull));
+        if (pos < Kc) { ckeys[pos] = kq[q]; rank[pos] = 0u; }
+      }
     }
   }
 }

@@ -69,8 +69,14 @@ __C = AttrDict(
     # device-path switches (no reference counterpart): Winograd F(m x m,3x3) for the 3x3 stride-1 convolutions at test
     # time; m = WINOGRAD_M (4 or 2) except scopes containing a WINOGRAD_F2_SCOPES token, which use m = 2.  WINOGRAD_TRAIN: also in
     # the training step (forward and data gradient of those layers; filters transformed on the device every step).
+    # Shipped policy (profiles/r02_fullsize_parity.txt): F(2x2,3x3) in block1 / block2 -- the early layers, whose activations carry a
+    # large common mean, are where the F(4x4,3x3) transforms lose digits (full-size head error 1.8x the float32 control with F(4,3)
+    # everywhere, 1.0x with this policy, for 1.2 % of throughput); F(4x4,3x3) in block3 / RPN / block4 (7x7 scheme).
+    # WINOGRAD_DIRECT_SCOPES: scopes containing one of these tokens keep the direct implicit-GEMM kernel.
     # WINOGRAD_7X7: 7x7 maps (per-RoI crops) use the mixed F(4,3)+F(3,3) scheme (121 instead of 144 products per RoI)
-    HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=64, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=(), WINOGRAD_TRAIN=True, WINOGRAD_7X7=True))
+    HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=64, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=("block1", "block2"), WINOGRAD_DIRECT_SCOPES=(),
+             WINOGRAD_TRAIN=True,
+             WINOGRAD_7X7=True))
 __C.DATA_DIR = osp.abspath(osp.join(__C.ROOT_DIR, 'data'))
 cfg = __C
 

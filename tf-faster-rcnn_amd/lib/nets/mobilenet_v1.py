@@ -68,7 +68,7 @@ class mobilenetv1(Network):
         pad = (1, 1, 1, 1)                                   # SAME (stride 1) == explicit pad 1 (stride 2) for k=3
         OH, OW = ops.conv_out_size(H, 3, stride, 1, 1), ops.conv_out_size(W, 3, stride, 1, 1)
         out = self._sess.buf(self._tag + "/" + dw_scope, (N, OH, OW, C))
-        y = self._sess.mark("op:dwconv3x3", 0, lambda: ops.dwconv3x3(x, w, b, stride, pad, ACT_RELU6, out=out))
+        y = self._sess.mark("op:dwconv3x3", 0, lambda: ops.dwconv3x3(x, w, b, stride, pad, ACT_RELU6, out=out), nbytes=4 * (x.numel() + out.numel()))
         return self._conv(y, "%s/Conv2d_%d_pointwise" % (s, i), 1, act=ACT_RELU6, bn_eps=BN_EPS)
 
     def _image_to_head(self, is_training, reuse=None):
@@ -86,4 +86,4 @@ class mobilenetv1(Network):
         for i in (12, 13):
             net = self._separable(net, i, _SEP[i - 1][0])
         out = self._sess.buf(self._tag + "/fc7", (net.shape[0], net.shape[-1]))
-        return self._sess.mark("op:spatial_mean", 0, lambda: ops.spatial_mean(net, out=out))
+        return self._sess.mark("op:spatial_mean", 0, lambda: ops.spatial_mean(net, out=out), nbytes=4 * (net.numel() + out.numel()))

@@ -80,7 +80,8 @@ class Network(object):
         N, H, W, Cin = x.shape
         wino = (cfg.HIP.WINOGRAD and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1)
                 and residual is None and not fold_w and out_affine is None and not no_bias
-                and Cin % 32 == 0 and Cin >= cfg.HIP.WINOGRAD_MIN_CIN and act in (ACT_NONE, ACT_RELU))
+                and Cin % 32 == 0 and Cin >= cfg.HIP.WINOGRAD_MIN_CIN and act in (ACT_NONE, ACT_RELU)
+                and not any(tok in scope for tok in cfg.HIP.WINOGRAD_DIRECT_SCOPES))
         if wino and self._mode == "TEST":
             return self._conv_winograd(x, scope, act, bn_eps)
         wino = wino and cfg.HIP.WINOGRAD_TRAIN
@@ -138,10 +139,10 @@ class Network(object):
         v = sess.buf(self._tag + "/wino_v", (G, T, Cin))
         mm = sess.buf(self._tag + "/wino_m", (G, T, Cout))
         out = sess.buf(self._tag + "/" + scope, (N, H, W, Cout))
-        sess.mark("op:wino_in", 0, lambda: ops.winograd_input_transform(x, v, m))
+        sess.mark("op:wino_in", 0, lambda: ops.winograd_input_transform(x, v, m), nbytes=4 * (x.numel() + v.numel()))
         sess.mark("conv:" + scope, 2 * G * T * Cout * Cin, lambda: ops.gemm_batched_nt(v, u, mm),
                   nbytes=4 * (v.numel() + u.numel() + mm.numel()))
-        sess.mark("op:wino_out", 0, lambda: ops.winograd_output_transform(mm, b, act, out, m))
+        sess.mark("op:wino_out", 0, lambda: ops.winograd_output_transform(mm, b, act, out, m), nbytes=4 * (mm.numel() + out.numel()))
         return out
 
     # ------------------------------------------------------------------ ImageNet-pretrained weights (train_val.py:177-202)
@@ -189,9 +190,9 @@ class Network(object):
         if name.startswith("rpn_cls_prob"):
             A = self._num_anchors
             out = self._sess.buf(self._tag + "/" + name, bottom.shape[:3] + (2 * A,))
-            return self._sess.mark("op:rpn_softmax", 0, lambda: ops.rpn_softmax(bottom, A, out=out))
+            return self._sess.mark("op:rpn_softmax", 0, lambda: ops.rpn_softmax(bottom, A, out=out), nbytes=8 * out.numel())
         out = self._sess.buf(self._tag + "/" + name, bottom.shape)
-        return self._sess.mark("op:softmax_rows", 0, lambda: ops.softmax_rows(bottom, out=out))
+        return self._sess.mark("op:softmax_rows", 0, lambda: ops.softmax_rows(bottom, out=out), nbytes=8 * out.numel())
 
     # ------------------------------------------------------------------ graph pieces (same names as the reference)
     def _anchor_component(self):
@@ -421,7 +422,8 @@ class Network(object):
         key = (self._tag, self._scope, self._num_classes, self._anchor_scales, self._anchor_ratios, bool(cfg.RESNET.MAX_POOL),
                bool(cfg.USE_GPU_NMS), tuple(image_d.shape), self._im_info[:2], self._mode, cfg.TEST.MODE, self._fuse_tail_entry,
                c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH, cfg.TEST.RPN_TOP_N, cfg.POOLING_SIZE,
-               bool(cfg.HIP.WINOGRAD), int(cfg.HIP.WINOGRAD_MIN_CIN), int(cfg.HIP.WINOGRAD_M), tuple(cfg.HIP.WINOGRAD_F2_SCOPES), bool(cfg.HIP.WINOGRAD_7X7), bool(cfg.USE_E2E_TF))
+               bool(cfg.HIP.WINOGRAD), int(cfg.HIP.WINOGRAD_MIN_CIN), int(cfg.HIP.WINOGRAD_M), tuple(cfg.HIP.WINOGRAD_F2_SCOPES),
+               tuple(cfg.HIP.WINOGRAD_DIRECT_SCOPES), bool(cfg.HIP.WINOGRAD_7X7), bool(cfg.USE_E2E_TF))
         cur = torch.cuda.current_stream(sess.device)
         if not use_graph or sess.profile is not None:
             sess.flops_last_forward = 0

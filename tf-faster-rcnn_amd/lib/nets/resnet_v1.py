@@ -106,7 +106,7 @@ class resnetv1(Network):
                          fold_w=True, real_cin=3)
         N, H, W, C = net.shape
         out = self._sess.buf(self._tag + "/pool1", (N, ops.conv_out_size(H, 3, 2, 1, 1), ops.conv_out_size(W, 3, 2, 1, 1), C))
-        return self._sess.mark("op:maxpool", 0, lambda: ops.maxpool(net, 3, 2, (1, 1, 1, 1), out=out))
+        return self._sess.mark("op:maxpool", 0, lambda: ops.maxpool(net, 3, 2, (1, 1, 1, 1), out=out), nbytes=4 * (net.numel() + out.numel()))
 
     def _image_to_head(self, is_training, reuse=None):
         assert (0 <= cfg.RESNET.FIXED_BLOCKS <= 3)
@@ -139,13 +139,13 @@ class resnetv1(Network):
         for u in range(2, n_units + 1):
             x = self._bottleneck(x, "%s/%s/unit_%d/bottleneck_v1" % (self._scope, name, u), base, stride if u == n_units else 1)
         out = sess.buf(self._tag + "/fc7", (x.shape[0], x.shape[-1]))
-        return sess.mark("op:spatial_mean", 0, lambda: ops.spatial_mean(x, out=out))
+        return sess.mark("op:spatial_mean", 0, lambda: ops.spatial_mean(x, out=out), nbytes=4 * (x.numel() + out.numel()))
 
     def _head_to_tail(self, pool5, is_training, reuse=None):
         fc7 = self._run_blocks(pool5, self._blocks[-1:])
         # average pooling done by reduce_mean (resnet_v1.py:124)
         out = self._sess.buf(self._tag + "/fc7", (fc7.shape[0], fc7.shape[-1]))
-        res = self._sess.mark("op:spatial_mean", 0, lambda: ops.spatial_mean(fc7, out=out))
+        res = self._sess.mark("op:spatial_mean", 0, lambda: ops.spatial_mean(fc7, out=out), nbytes=4 * (fc7.numel() + out.numel()))
         if self._mode == "TRAIN":
             self._tape.append(dict(kind="mean", x=fc7, y=res, name=self._scope + "/fc7_mean"))
             if fc7.data_ptr() in self._requires_grad:

@@ -60,7 +60,7 @@ class vgg16(Network):
                 OH, OW = (H + 1) // 2, (W + 1) // 2
                 out = self._sess.buf(self._tag + "/pool%d" % (bi + 1), (N, OH, OW, C))
                 x = net
-                net = self._sess.mark("op:maxpool", 0, lambda: ops.maxpool(x, 2, 2, (0, H % 2, 0, W % 2), out=out))
+                net = self._sess.mark("op:maxpool", 0, lambda: ops.maxpool(x, 2, 2, (0, H % 2, 0, W % 2), out=out), nbytes=4 * (x.numel() + out.numel()))
         self._act_summaries.append(net)
         self._layers['head'] = net
         return net
