@@ -217,7 +217,8 @@ int frcnn_conv2d_nhwc_ws(const float* x_d, int N, int H, int W, int Cin, const f
                          int KW, int stride, int pad_top, int pad_left, int act, int fold_w, void* ws, size_t ws_bytes,
                          void* stream);
 
-/* Tuning knobs for A/B experiments: key 0 = force conv tile configuration id (-1 = automatic); key 1 = ablation bits;
+/* Tuning knobs for A/B experiments (process-wide debugging switches read at launch time: set them while no other thread is
+ * launching; they are NOT part of the thread-safety contract above and no product path changes them): key 0 = force conv tile configuration id (-1 = automatic); key 1 = ablation bits;
  * key 2 = 1 enables the EXPERIMENTAL bf16x3 split-operand MFMA path for every non-stem conv (f32 in/out, f32-class
  * accuracy, see csrc/conv_igemm_b3.hip); key 3 = force its tile configuration. */
 int frcnn_set_tuning(int key, int value);

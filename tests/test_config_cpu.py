@@ -81,3 +81,32 @@ def test_device_path_switches_exist_with_documented_defaults():
     assert C.cfg.USE_E2E_TF is False and C.cfg.POOLING_SIZE == 7
     # the session fixture of conftest.py pins USE_GPU_NMS False for the parity suite; the shipped default is the reference's True
     assert "USE_GPU_NMS=True" in open(C.__file__).read() and C.cfg.USE_GPU_NMS is False
+
+
+def test_unsupported_modes_and_values_raise_instead_of_being_ignored():
+    """TRAIN mode exists for the ResNet family only; config values the kernels hard-code are refused."""
+    import pytest
+    from nets.mobilenet_v1 import mobilenetv1
+    from nets.resnet_v1 import resnetv1
+    from nets.vgg16 import vgg16
+    for net in (mobilenetv1(), vgg16()):
+        net.create_architecture("TEST", 21, tag="t")
+        with pytest.raises(NotImplementedError, match="TRAIN mode"):
+            net.create_architecture("TRAIN", 21, tag="t")
+    resnetv1(50).create_architecture("TRAIN", 21, tag="t")
+    old = (C.cfg.TEST.BBOX_REG, C.cfg.TRAIN.RPN_POSITIVE_WEIGHT, C.cfg.RESNET.MAX_POOL)
+    try:
+        C.cfg.TEST.BBOX_REG = False
+        with pytest.raises(NotImplementedError, match="TEST.BBOX_REG"):
+            resnetv1(50).create_architecture("TEST", 21, tag="t")
+        C.cfg.TEST.BBOX_REG = True
+        C.cfg.TRAIN.RPN_POSITIVE_WEIGHT = 0.5
+        with pytest.raises(NotImplementedError, match="RPN_POSITIVE_WEIGHT"):
+            resnetv1(50).create_architecture("TRAIN", 21, tag="t")
+        C.cfg.TRAIN.RPN_POSITIVE_WEIGHT = -1.0
+        C.cfg.RESNET.MAX_POOL = True
+        resnetv1(50).create_architecture("TEST", 21, tag="t")
+        with pytest.raises(NotImplementedError, match="MAX_POOL"):
+            resnetv1(50).create_architecture("TRAIN", 21, tag="t")
+    finally:
+        C.cfg.TEST.BBOX_REG, C.cfg.TRAIN.RPN_POSITIVE_WEIGHT, C.cfg.RESNET.MAX_POOL = old

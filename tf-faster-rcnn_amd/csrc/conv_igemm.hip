@@ -27,6 +27,7 @@
 // lib/nets/resnet_v1.py:80-125 (7x7/2 stem via fold_w, bottleneck 1x1 / 3x3 / conv2d_same
 // stride 2, projection and subsample shortcuts), vgg16.py:26-60.
 #include "common.h"
+#include <mutex>
 #include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -355,12 +356,12 @@ static int launch_conv(ConvParams p, hipStream_t st) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   constexpr size_t ring = sizeof(float) * NS * (BM + BN) * 32, epi = sizeof(float) * BM * BN;
   constexpr size_t lds = ring > epi ? ring : epi;     // the epilogue tile reuses the ring memory
-  static bool attr_set = false;
   auto kern = k_conv_igemm<BM, BN, WM, WN, NS, FOLDW, ILV, RF>;
-  if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  // once per instantiation, safe when several host threads drive distinct streams ("distinct streams are thread-safe")
+  static std::once_flag attr_once;
+  static hipError_t attr_rc = hipSuccess;
+  std::call_once(attr_once, [&] { attr_rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+  HIP_TRY(attr_rc);
   p.mtiles = cdiv(p.M, BM);
   p.ntiles = cdiv(p.Cout, BN);
   hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles, p.batch, p.splits), dim3(NT), lds, st, p);

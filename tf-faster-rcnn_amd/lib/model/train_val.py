@@ -47,8 +47,9 @@ def remove_snapshot(np_paths, ss_paths):
 
 
 class SolverWrapper(object):
-    def __init__(self, sess, network, data_layer, all_reduce=None, world_size=1):
+    def __init__(self, sess, network, data_layer, all_reduce=None, world_size=1, write_snapshots=True):
         self.sess, self.net, self.data_layer = sess, network, data_layer
+        self.write_snapshots = bool(write_snapshots)               # data-parallel runs: every rank READS snapshots, rank 0 writes them
         self.state = TrainState(sess, network, momentum=cfg.TRAIN.MOMENTUM, weight_decay=cfg.TRAIN.WEIGHT_DECAY,
                                 double_bias=cfg.TRAIN.DOUBLE_BIAS, bias_decay=cfg.TRAIN.BIAS_DECAY)
         self.state.all_reduce, self.state.world_size = all_reduce, world_size
@@ -132,7 +133,7 @@ class SolverWrapper(object):
                 print('iter: %d / %d, total loss: %.6f\n >>> rpn_loss_cls: %.6f\n >>> rpn_loss_box: %.6f\n >>> loss_cls: %.6f\n'
                       ' >>> loss_box: %.6f\n >>> lr: %f' % (it, max_iters, total_loss, rpn_loss_cls, rpn_loss_box, loss_cls, loss_box, lr))
                 print('speed: {:.3f}s / iter'.format((time.time() - t0) / (it - start_iter)))
-            if snapshot_dir is not None and it % cfg.TRAIN.SNAPSHOT_ITERS == 0:
+            if snapshot_dir is not None and self.write_snapshots and it % cfg.TRAIN.SNAPSHOT_ITERS == 0:
                 self.snapshot(it, snapshot_dir)
         if history:
             import torch
@@ -155,10 +156,13 @@ def synthetic_data_layer(num_classes, seed=3, height=600, width=1000, scale=1.6,
 
 
 def train_net(network, sess, data_layer, max_iters=40000, all_reduce=None, world_size=1, pretrained_model=None, output_dir=None,
-              resume=None):
+              resume=None, write_snapshots=True):
     """Train a Faster R-CNN network (reference signature minus imdb/roidb): pretrained_model = ImageNet checkpoint prefix
-    (train_val.py:177-202), output_dir = where snapshots go every cfg.TRAIN.SNAPSHOT_ITERS, resume = (ckpt, pkl)."""
-    sw = SolverWrapper(sess, network, data_layer, all_reduce=all_reduce, world_size=world_size)
+    (train_val.py:177-202), output_dir = where snapshots go every cfg.TRAIN.SNAPSHOT_ITERS, resume = (ckpt, pkl).
+    Data-parallel runs pass the SAME output_dir to every rank (all replicas must resume from the same snapshot: weights,
+    Momentum slots, iteration and sampling seed -- otherwise they diverge and issue different numbers of all-reduces) and
+    write_snapshots = (rank == 0)."""
+    sw = SolverWrapper(sess, network, data_layer, all_reduce=all_reduce, world_size=world_size, write_snapshots=write_snapshots)
     start = 0
     if resume is None and output_dir is not None and os.path.isdir(output_dir):
         lsf, nfiles, sfiles = find_previous(output_dir)            # train_val.py:243-252: continue from the newest snapshot

@@ -375,8 +375,28 @@ class Network(object):
         cls_prob, bbox_pred = self._region_classification(fc7, is_training)
         return rois, cls_prob, bbox_pred
 
+    _trainable_on_device = False          # subclasses whose whole TRAIN graph has a reverse sweep (frcnn_hip/train.py) set True
+
+    @staticmethod
+    def _check_supported_cfg(mode):
+        """Config keys the kernels implement for ONE value only: refuse the others instead of silently ignoring them."""
+        t = cfg.TRAIN
+        fixed = [("TRAIN.RPN_CLOBBER_POSITIVES", t.RPN_CLOBBER_POSITIVES, False), ("TRAIN.RPN_POSITIVE_WEIGHT", float(t.RPN_POSITIVE_WEIGHT), -1.0),
+                 ("TRAIN.RPN_BBOX_INSIDE_WEIGHTS", tuple(t.RPN_BBOX_INSIDE_WEIGHTS), (1.0, 1.0, 1.0, 1.0)),
+                 ("TRAIN.BBOX_INSIDE_WEIGHTS", tuple(t.BBOX_INSIDE_WEIGHTS), (1.0, 1.0, 1.0, 1.0)), ("TRAIN.USE_GT", t.USE_GT, False),
+                 ("TRAIN.TRUNCATED", t.TRUNCATED, False), ("TEST.BBOX_REG", cfg.TEST.BBOX_REG, True), ("POOLING_MODE", cfg.POOLING_MODE, "crop")]
+        bad = ["%s = %r (only %r is implemented)" % (k, v, want) for k, v, want in fixed if v != want]
+        if bad:
+            raise NotImplementedError("unsupported configuration for the HIP path: " + "; ".join(bad))
+
     def create_architecture(self, mode, num_classes, tag=None, anchor_scales=(8, 16, 32), anchor_ratios=(0.5, 1, 2)):
         assert tag is not None
+        self._check_supported_cfg(mode)
+        if mode == "TRAIN" and not self._trainable_on_device:
+            raise NotImplementedError("%s: TRAIN mode is provided for the ResNet family only (no backward for depthwise conv / "
+                                      "crop + 2x2 max pool / dropout); TEST mode works" % type(self).__name__)
+        if mode == "TRAIN" and cfg.RESNET.MAX_POOL:
+            raise NotImplementedError("RESNET.MAX_POOL in TRAIN mode: the 14x14 crop + 2x2 max has no max-routed backward")
         self._tag = tag
         self._num_classes = num_classes
         self._mode = mode
@@ -514,6 +534,8 @@ class Network(object):
         ops.ws_scope = self._tag
         B = image_d.shape[0]
         R, C = self._rois_per_image, self._num_classes
+        # rows of the output: test.py:176-180 keeps every detection that TIES the max_per_image-th score, so the list can exceed
+        # max_per_image; the default buffer holds 28 extra rows (a 128-row record), `count` reports the true number
         max_out = None if out is None else out.shape[-2]
         if B > 1:
             max_out = (max_per_image + 28) if out is None else max_out

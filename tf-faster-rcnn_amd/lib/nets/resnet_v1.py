@@ -29,6 +29,7 @@ def _same_pad(k, stride):
 
 class resnetv1(Network):
     _rgb_first_conv = "/conv1"
+    _trainable_on_device = True
     def __init__(self, num_layers=50):
         Network.__init__(self)
         self._feat_stride = [16, ]

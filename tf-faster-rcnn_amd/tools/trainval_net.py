@@ -70,5 +70,7 @@ if __name__ == '__main__':
         pretrained = args.weight                                        # ImageNet checkpoint: restore + fix_variables
     data = synthetic_data_layer(num_classes, seed=cfg.RNG_SEED + 1000 * rank, image_gain=1.0 / 256.0)
     out_dir = getattr(args, 'output_dir', None)
+    # every rank resumes from the snapshots in out_dir (same weights, Momentum slots, iteration and sampling seed on all replicas);
+    # only rank 0 writes new ones
     train_net(net, sess, data, max_iters=args.max_iters, all_reduce=all_reduce, world_size=world, pretrained_model=pretrained,
-              output_dir=out_dir if rank == 0 else None)
+              output_dir=out_dir, write_snapshots=(rank == 0))
