@@ -217,6 +217,16 @@ int frcnn_conv2d_nhwc_ws(const float* x_d, int N, int H, int W, int Cin, const f
                          int KW, int stride, int pad_top, int pad_left, int act, int fold_w, void* ws, size_t ws_bytes,
                          void* stream);
 
+/* 1x1 convolution fused with the mean over consecutive row groups -- the tail's last convolution followed by reduce_mean over
+ * the 7x7 positions of every RoI (lib/nets/resnet_v1.py:115-125: block4/unit_3/conv3 + `tf.reduce_mean(fc7, axis=[1, 2])`;
+ * mobilenet_v1.py:240-250).  x_d [M,Cin], w_d packed [Cout][Cin], residual_d [M,Cout] or NULL:
+ *   mean_out_d [M/group_rows, Cout] = mean over each group of act(x W^T + bias + residual);
+ * the [M,Cout] tensor is never written (C2: 482 MB stored + 482 MB re-read per 4-image batch otherwise).  Deterministic
+ * (fixed summation order).  M % group_rows == 0, 43 <= group_rows, Cin % 32 == 0, Cout % 4 == 0. */
+size_t frcnn_conv1x1_mean_workspace_bytes(int M, int Cout);
+int frcnn_conv1x1_mean(const float* x_d, int M, int Cin, const float* w_d, const float* bias_d, const float* residual_d, int Cout,
+                       int act, int group_rows, float* mean_out_d, void* ws, size_t ws_bytes, void* stream);
+
 /* Tuning knobs for A/B experiments (process-wide debugging switches read at launch time: set them while no other thread is
  * launching; they are NOT part of the thread-safety contract above and no product path changes them): key 0 = force conv tile configuration id (-1 = automatic); key 1 = ablation bits;
  * key 2 = 1 enables the EXPERIMENTAL bf16x3 split-operand MFMA path for every non-stem conv (f32 in/out, f32-class

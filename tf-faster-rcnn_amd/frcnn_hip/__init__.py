@@ -62,6 +62,8 @@ SIGNATURES = {
     "frcnn_conv2d_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "frcnn_conv2d_nhwc_ws": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "frcnn_conv1x1_mean_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "frcnn_conv1x1_mean": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
     "frcnn_crc32c": (ctypes.c_uint32, [_P, c_size_t, ctypes.c_uint32]),
     "frcnn_snappy_uncompress": (c_longlong, [_P, c_size_t, _P, c_size_t]),
     "frcnn_prep_image_shape": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P]),

@@ -330,6 +330,22 @@ def conv2d(x, w_packed, bias, KH, KW, stride=1, pad=(0, 0, 0, 0), act=ACT_NONE, 
     return out
 
 
+def conv1x1_mean(x, w_packed, bias, group_rows, act=ACT_NONE, residual=None, out=None):
+    """mean over consecutive `group_rows` rows of act(x W^T + bias + residual) without writing the [M,Cout] tensor:
+    x [..., Cin] (M rows), w_packed [Cout,1,1,Cin] -> [M/group_rows, Cout] (frcnn_conv1x1_mean)."""
+    _chk(x), _chk(w_packed)
+    Cin = x.shape[-1]
+    M = x.numel() // Cin
+    Cout = w_packed.shape[0]
+    out = torch.empty((M // group_rows, Cout), dtype=torch.float32, device=x.device) if out is None else out
+    if residual is not None:
+        _chk(residual)
+    ws = workspace(lib().frcnn_conv1x1_mean_workspace_bytes(M, Cout), x.device, "conv_mean")
+    call("frcnn_conv1x1_mean", _ptr(x), M, Cin, _ptr(w_packed), _ptr(bias), _ptr(residual), Cout, int(act), int(group_rows), _ptr(out),
+         _ptr(ws), ws.numel(), _stream())
+    return out
+
+
 def prep_image_shape(h, w, target_size, max_size):
     """HOST: (im_scale, OH, OW) of _get_image_blob / prep_im_for_blob for an h x w image."""
     sc, oh, ow = ctypes.c_double(), ctypes.c_int(), ctypes.c_int()

@@ -73,10 +73,11 @@ __C = AttrDict(
     # large common mean, are where the F(4x4,3x3) transforms lose digits (full-size head error 1.8x the float32 control with F(4,3)
     # everywhere, 1.0x with this policy, for 1.2 % of throughput); F(4x4,3x3) in block3 / RPN / block4 (7x7 scheme).
     # WINOGRAD_DIRECT_SCOPES: scopes containing one of these tokens keep the direct implicit-GEMM kernel.
+    # FUSE_TAIL_MEAN: TEST mode, the tail's last 1x1 convolution + reduce_mean in one kernel (frcnn_conv1x1_mean).
     # WINOGRAD_7X7: 7x7 maps (per-RoI crops) use the mixed F(4,3)+F(3,3) scheme (121 instead of 144 products per RoI)
     HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=64, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=("block1", "block2"), WINOGRAD_DIRECT_SCOPES=(),
              WINOGRAD_TRAIN=True,
-             WINOGRAD_7X7=True))
+             WINOGRAD_7X7=True, FUSE_TAIL_MEAN=True))
 __C.DATA_DIR = osp.abspath(osp.join(__C.ROOT_DIR, 'data'))
 cfg = __C
 

@@ -145,6 +145,18 @@ class Network(object):
         sess.mark("op:wino_out", 0, lambda: ops.winograd_output_transform(mm, b, act, out, m), nbytes=4 * (mm.numel() + out.numel()))
         return out
 
+    def _conv1x1_mean(self, x, scope, group_rows, act=ACT_RELU, bn_eps=None, residual=None, name="fc7"):
+        """The tail's last 1x1 convolution fused with reduce_mean over the P*P positions of every RoI (resnet_v1.py:115-125,
+        mobilenet_v1.py:240-250), TEST mode: the [R*P*P, Cout] tensor is never written (frcnn_conv1x1_mean)."""
+        sess = self._sess
+        w, b = sess.conv_params(scope, bn_eps=bn_eps)
+        Cin, Cout = x.shape[-1], w.shape[0]
+        M = x.numel() // Cin
+        out = sess.buf(self._tag + "/" + name, (M // group_rows, Cout))
+        sess.mark("conv:" + scope, 2 * M * Cout * Cin, lambda: ops.conv1x1_mean(x, w, b, group_rows, act, residual, out=out),
+                  nbytes=4 * (x.numel() + w.numel() + out.numel() + (M * Cout if residual is not None else 0)))
+        return out
+
     # ------------------------------------------------------------------ ImageNet-pretrained weights (train_val.py:177-202)
     _rgb_first_conv = None                   # scope tail of the stem conv whose input channels are RGB in the released weights
 
@@ -443,7 +455,7 @@ class Network(object):
                bool(cfg.USE_GPU_NMS), tuple(image_d.shape), self._im_info[:2], self._mode, cfg.TEST.MODE, self._fuse_tail_entry,
                c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH, cfg.TEST.RPN_TOP_N, cfg.POOLING_SIZE,
                bool(cfg.HIP.WINOGRAD), int(cfg.HIP.WINOGRAD_MIN_CIN), int(cfg.HIP.WINOGRAD_M), tuple(cfg.HIP.WINOGRAD_F2_SCOPES),
-               tuple(cfg.HIP.WINOGRAD_DIRECT_SCOPES), bool(cfg.HIP.WINOGRAD_7X7), bool(cfg.USE_E2E_TF))
+               tuple(cfg.HIP.WINOGRAD_DIRECT_SCOPES), bool(cfg.HIP.WINOGRAD_7X7), bool(cfg.HIP.FUSE_TAIL_MEAN), bool(cfg.USE_E2E_TF))
         cur = torch.cuda.current_stream(sess.device)
         if not use_graph or sess.profile is not None:
             sess.flops_last_forward = 0

@@ -70,7 +70,9 @@ class resnetv1(Network):
         return self._blocks[3][1] * 4
 
     # ---- graph -----------------------------------------------------------------------------------
-    def _bottleneck(self, x, prefix, base, stride):
+    def _bottleneck(self, x, prefix, base, stride, mean_rows=0):
+        """mean_rows > 0 (TEST mode, last unit of the tail): returns mean over every `mean_rows` consecutive pixels of the unit's
+        output instead of the output itself (conv3 + residual + ReLU + reduce_mean in one kernel)."""
         depth = base * 4
         cin = x.shape[-1]
         if cin != depth:
@@ -81,6 +83,8 @@ class resnetv1(Network):
         r = self._conv(x, prefix + "/conv1", 1, 1, act=ACT_RELU, bn_eps=BN_EPS)
         pad = (1, 1, 1, 1) if stride == 1 else _same_pad(3, stride)
         r = self._conv(r, prefix + "/conv2", 3, stride, pad, act=ACT_RELU, bn_eps=BN_EPS)
+        if mean_rows and res_stride == 1 and cfg.HIP.FUSE_TAIL_MEAN:
+            return self._conv1x1_mean(r, prefix + "/conv3", mean_rows, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut)
         return self._conv(r, prefix + "/conv3", 1, 1, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut, res_stride=res_stride)
 
     def _run_blocks(self, x, blocks):
@@ -137,12 +141,23 @@ class resnetv1(Network):
         r = self._crop_images(c1_map, rois, c1_out, bias=b_c1, act=ACT_RELU)
         r = self._conv(r, prefix + "/conv2", 3, 1, (1, 1, 1, 1), act=ACT_RELU, bn_eps=BN_EPS)
         x = self._conv(r, prefix + "/conv3", 1, 1, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut, res_stride=1)
+        fused = bool(cfg.HIP.FUSE_TAIL_MEAN) and stride == 1 and n_units >= 2
         for u in range(2, n_units + 1):
-            x = self._bottleneck(x, "%s/%s/unit_%d/bottleneck_v1" % (self._scope, name, u), base, stride if u == n_units else 1)
+            x = self._bottleneck(x, "%s/%s/unit_%d/bottleneck_v1" % (self._scope, name, u), base, stride if u == n_units else 1,
+                                 mean_rows=P * P if (fused and u == n_units) else 0)
+        if fused:
+            return x                                          # [R, 2048]: the mean came out of the last conv3's epilogue
         out = sess.buf(self._tag + "/fc7", (x.shape[0], x.shape[-1]))
         return sess.mark("op:spatial_mean", 0, lambda: ops.spatial_mean(x, out=out), nbytes=4 * (x.numel() + out.numel()))
 
     def _head_to_tail(self, pool5, is_training, reuse=None):
+        name, base, n_units, stride = self._blocks[-1]
+        if self._mode == "TEST" and cfg.HIP.FUSE_TAIL_MEAN and stride == 1:
+            x = pool5
+            hw = pool5.shape[1] * pool5.shape[2]
+            for u in range(1, n_units + 1):
+                x = self._bottleneck(x, "%s/%s/unit_%d/bottleneck_v1" % (self._scope, name, u), base, 1, mean_rows=hw if u == n_units else 0)
+            return x
         fc7 = self._run_blocks(pool5, self._blocks[-1:])
         # average pooling done by reduce_mean (resnet_v1.py:124)
         out = self._sess.buf(self._tag + "/fc7", (fc7.shape[0], fc7.shape[-1]))
