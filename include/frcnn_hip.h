@@ -378,6 +378,12 @@ int frcnn_crop_and_resize_bwd(const float* dout_d, int H, int W, int C, const fl
  * scale_d / w_folded_d may be NULL (biases, fc). */
 int frcnn_sgd_momentum(float* w_d, float* acc_d, float* w_folded_d, const float* grad_d, const float* scale_d,
                        long long n, int K, float lr, float momentum, float weight_decay, float grad_scale, void* stream);
+/* The same update for `count` tensors in ONE launch.  desc_table_d: device array of `count` descriptors of frcnn_sgd_desc_bytes()
+ * bytes each, laid out as { float* w; float* acc; float* w_folded (or NULL); const float* grad; const float* scale (or NULL);
+ * long long n; int K; float lr_mult; float weight_decay; int pad; } -- lr_mult = 2 for biases under TRAIN.DOUBLE_BIAS
+ * (lib/model/train_val.py:132-141), 1 otherwise.  Element-wise identical to frcnn_sgd_momentum. */
+size_t frcnn_sgd_desc_bytes(void);
+int frcnn_sgd_momentum_multi(const void* desc_table_d, int count, float lr, float momentum, float grad_scale, void* stream);
 /* out (+)= scale * sum(w^2)   (slim l2_regularizer value); ws >= 2 KiB. */
 int frcnn_sumsq(const float* w_d, long long n, double scale, float* out_d, int accumulate, void* ws, size_t ws_bytes, void* stream);
 /* The same over `count` tensors in two launches: ptr_table_d = device array of `count` float pointers, sizes_d = their

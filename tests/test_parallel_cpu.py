@@ -34,8 +34,18 @@ def _worker(rank, world, port, q):
         parallel.set_count(rec, torch.tensor([n], dtype=torch.int32))
         out = parallel.unpack_records(parallel.all_gather_records(rec))
         flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)          # training exchange: bucketed gradient sum
-        parallel.make_grad_all_reduce(bucket_bytes=1024)(flat)
+        parallel.make_grad_all_reduce(bucket_bytes=1024, overlap=False)(flat)
         assert torch.equal(flat, torch.arange(1000, dtype=torch.float32) * 3)
+        # the overlapped form: ranges are handed over back to front while "the reverse sweep" is still running
+        flat2 = torch.arange(5000, dtype=torch.float32) * (rank + 1)
+        ar = parallel.make_grad_all_reduce(bucket_bytes=4096)                  # 1024-element buckets, BucketedAllReduce
+        inflight = []
+        for off in (4100, 2600, 1500, 700, 0):                                  # parameters in reverse forward order
+            ar.ready(flat2, flat2[off:].data_ptr())
+            inflight.append(len(ar.handles))
+        assert inflight == [0, 2, 3, 4, 4], inflight                            # 900 final: nothing yet; 2400: two buckets; ...
+        ar.finish(flat2)
+        assert torch.equal(flat2, torch.arange(5000, dtype=torch.float32) * 3) and ar.handles == []
         q.put((rank, mine, [o.tolist() for o in out], dets.tolist()))
         dist.barrier()
     finally:

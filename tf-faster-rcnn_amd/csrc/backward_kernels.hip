@@ -271,6 +271,32 @@ extern "C" int frcnn_sgd_momentum(float* w_d, float* acc_d, float* w_folded_d, c
   return FRCNN_OK;
 }
 
+// The same update for EVERY parameter tensor in one launch (the per-tensor form is ~150 launches per ResNet-152 step): a device
+// table of descriptors, grid = (SGD_BLOCKS, count), block (b, t) walks tensor t with a grid stride.  lr and the mean-over-replicas
+// factor are launch arguments (they change per step); per-tensor lr multiplier (DOUBLE_BIAS) and weight decay sit in the table.
+struct SgdDesc { float* w; float* acc; float* wf; const float* grad; const float* scale; long long n; int K; float lr_mult; float wd; int pad; };
+#define SGD_BLOCKS 32
+__global__ __launch_bounds__(256) void k_sgd_multi(const SgdDesc* __restrict__ table, float lr, float mom, float grad_scale) {
+  const SgdDesc d = table[blockIdx.y];
+  const float lr_t = lr * d.lr_mult;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (long long)SGD_BLOCKS * 256) {
+    const float s = d.scale ? d.scale[i / d.K] : 1.f;
+    const float g = grad_scale * d.grad[i] * s + d.wd * d.w[i];
+    const float a = mom * d.acc[i] + g;
+    const float nw = d.w[i] - lr_t * a;
+    d.acc[i] = a; d.w[i] = nw;
+    if (d.wf) d.wf[i] = nw * s;
+  }
+}
+extern "C" size_t frcnn_sgd_desc_bytes(void) { return sizeof(SgdDesc); }
+extern "C" int frcnn_sgd_momentum_multi(const void* desc_table_d, int count, float lr, float momentum, float grad_scale, void* stream) {
+  if (!desc_table_d || count <= 0 || count > 65535) return FRCNN_E_ARG;
+  hipLaunchKernelGGL(k_sgd_multi, dim3(SGD_BLOCKS, count), dim3(256), 0, (hipStream_t)stream, (const SgdDesc*)desc_table_d, lr, momentum,
+                     grad_scale);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
 // sum of squares (L2 regulariser value, slim l2_regularizer = wd * sum(w^2) / 2): deterministic two-stage
 __global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ w, long long n, double* __restrict__ partial) {
   __shared__ double sh[4];

@@ -147,13 +147,26 @@ __global__ __launch_bounds__(1024) void k_select_topk(const u64* __restrict__ ke
       } else {
         // 8 independent loads in flight per thread before the (LDS-atomic) histogram updates: a scan of N keys by ONE
         // workgroup is latency-bound otherwise (N / 1024 dependent round trips to L2 per pass)
-        for (int base = tid; base < N; base += 8 * 1024) {
+        for (int base = tid - lane; base < N; base += 8 * 1024) {          // wave-uniform trip count (ballots inside)
           u64 kq[8];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) kq[q] = (base + q * 1024 < N) ? keys[base + q * 1024] : 0ull;
+          for (int q = 0; q < 8; ++q) kq[q] = (base + q * 1024 + lane < N) ? keys[base + q * 1024 + lane] : 0ull;
 #pragma unroll
-          for (int q = 0; q < 8; ++q)
-            if (base + q * 1024 < N && (kq[q] & mk) == pf) atomicAdd(&myhist[(int)((kq[q] >> shift) & 255)], 1);
+          for (int q = 0; q < 8; ++q) {
+            const bool on = (base + q * 1024 + lane < N) && (kq[q] & mk) == pf;
+            const int bin = (int)((kq[q] >> shift) & 255);
+            // the high-byte passes put (nearly) every lane of a wave into ONE bin (probabilities share sign + exponent): 64
+            // same-address LDS atomics serialise, so a wave whose active lanes agree sends a single add
+            const u64 act = __ballot(on);
+            if (!act) continue;
+            const int first = __ffsll((long long)act) - 1;
+            const int v0 = __shfl(bin, first, 64);
+            if (__ballot(on && bin == v0) == act) {
+              if (lane == first) atomicAdd(&myhist[v0], __popcll(act));
+            } else if (on) {
+              atomicAdd(&myhist[bin], 1);
+            }
+          }
         }
       }
       __syncthreads();
@@ -351,7 +364,8 @@ __device__ __forceinline__ void reduce_finish(const ReduceOut& o, int b, int max
   if (o.write_rois) {
     for (int p = n + (int)threadIdx.x; p < max_keep; p += nthreads) {
       float* r = o.rois + 5 * ((size_t)b * max_keep + p);
-      r[0] = r[1] = r[2] = r[3] = r[4] = 0.0f;
+      r[0] = (float)b;                                    // padding rows stay inside their own image (box_ind of the crop)
+      r[1] = r[2] = r[3] = r[4] = 0.0f;
       o.scores[(size_t)b * max_keep + p] = 0.0f;
     }
   }
@@ -1095,6 +1109,7 @@ extern "C" int frcnn_im_detect_boxes(const float* rois_d, const float* bbox_pred
 }
 
 #define PC_MAXR 1024
+#define PC_THREADS 1024          // the 64x64-IoU mask rows of a class are the bulk of the work: spread them over 16 waves
 
 // dynamic LDS: sboxes float4[Rp] | sscores float[Rp] | union { keys u64[Rp] + boxes float4[Rp] ; mask u64[Rp * Rp/64] }
 static size_t perclass_lds_bytes(int R) {
@@ -1104,7 +1119,7 @@ static size_t perclass_lds_bytes(int R) {
 }
 
 template <int RULE>
-__global__ __launch_bounds__(256) void k_perclass_nms(const float* __restrict__ prob_all, const float* __restrict__ bbox_pred_all,
+__global__ __launch_bounds__(PC_THREADS) void k_perclass_nms(const float* __restrict__ prob_all, const float* __restrict__ bbox_pred_all,
                                                       const float* __restrict__ rois_all, const int* __restrict__ num_rois,
                                                       int R, int C, double im_scale, float hi_x, float hi_y, float thr,
                                                       float score_thresh, float* __restrict__ cls_dets_all,
@@ -1128,7 +1143,7 @@ __global__ __launch_bounds__(256) void k_perclass_nms(const float* __restrict__ 
   const int nr = num_rois ? min(num_rois[img], R) : R;
   if (tid == 0) nvalid_s = 0;
   __syncthreads();
-  for (int r = tid; r < R; r += 256) {
+  for (int r = tid; r < R; r += PC_THREADS) {
     const float s = prob[(size_t)r * C + j];
     const bool valid = (r < nr) && (s > score_thresh);                                   // test.py:163
     float4 b = make_float4(0, 0, 0, 0);
@@ -1147,7 +1162,7 @@ __global__ __launch_bounds__(256) void k_perclass_nms(const float* __restrict__ 
   }
   __syncthreads();
   const int nv = nvalid_s;
-  for (int r = tid; r < R; r += 256) {
+  for (int r = tid; r < R; r += PC_THREADS) {
     const u64 mine = keys[r];
     int rk = 0;
     for (int q = 0; q < R; ++q) rk += (keys[q] > mine) ? 1 : 0;
@@ -1158,7 +1173,7 @@ __global__ __launch_bounds__(256) void k_perclass_nms(const float* __restrict__ 
   }
   __syncthreads();                                      // keys / boxes dead from here: the mask takes their place
   const int words = (nv + 63) / 64;
-  for (int t = tid; t < nv * words; t += 256) {
+  for (int t = tid; t < nv * words; t += PC_THREADS) {
     const int i = t / words, w = t % words;
     u64 bits = 0;
     if (w >= (i >> 6)) {
@@ -1298,7 +1313,7 @@ extern "C" int frcnn_detect_post_batched(const float* cls_prob_d, const float* b
   auto kern = rule == NMS_RULE_GPU ? k_perclass_nms<NMS_RULE_GPU> : k_perclass_nms<NMS_RULE_CPU>;
   if (lds > 48 * 1024)      // beyond the default dynamic-LDS limit (R > ~512); not a stream operation, legal during capture
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(nfg, B), dim3(256), lds, st, cls_prob_d, bbox_pred_d, rois_d, num_rois_d, R, C, im_scale,
+  hipLaunchKernelGGL(kern, dim3(nfg, B), dim3(PC_THREADS), lds, st, cls_prob_d, bbox_pred_d, rois_d, num_rois_d, R, C, im_scale,
                      (float)(im_w - 1), (float)(im_h - 1), thr, score_thresh, cls_dets, cls_count);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(k_final_select, dim3(B), dim3(1024), 0, st, cls_dets, cls_count, nfg, R, max_per_image, out_dets_d,

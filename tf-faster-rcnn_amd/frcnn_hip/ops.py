@@ -690,6 +690,23 @@ def sgd_momentum(w, acc, w_folded, grad, scale, K, lr, momentum, weight_decay, g
          float(momentum), float(weight_decay), float(grad_scale), _stream())
 
 
+def sgd_desc_table(entries, device):
+    """entries: list of (w, acc, w_folded or None, grad, scale or None, K, lr_mult, weight_decay) tensors / numbers ->
+    uint8 device tensor holding the SgdDesc array of frcnn_sgd_momentum_multi."""
+    import struct
+    nb = lib().frcnn_sgd_desc_bytes()
+    assert nb == 64, nb
+    raw = bytearray()
+    for w, acc, wf, grad, scale, K, lr_mult, wd in entries:
+        raw += struct.pack("<QQQQQqiffi", w.data_ptr(), acc.data_ptr(), 0 if wf is None else wf.data_ptr(), grad.data_ptr(),
+                           0 if scale is None else scale.data_ptr(), int(w.numel()), int(K), float(lr_mult), float(wd), 0)
+    return torch.frombuffer(raw, dtype=torch.uint8).clone().to(device)
+
+
+def sgd_momentum_multi(table, count, lr, momentum, grad_scale=1.0):
+    call("frcnn_sgd_momentum_multi", _ptr(table), int(count), float(lr), float(momentum), float(grad_scale), _stream())
+
+
 def sumsq(w, scale, out, accumulate):
     ws = workspace(4096, w.device, "sumsq")
     call("frcnn_sumsq", _ptr(w), w.numel(), float(scale), _ptr(out), 1 if accumulate else 0, _ptr(ws), ws.numel(), _stream())

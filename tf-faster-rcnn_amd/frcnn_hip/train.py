@@ -148,6 +148,11 @@ class TrainState(object):
                 ops.conv2d(gyT.view(1, 1, Cout, Mp), xT.view(xT.shape[0], 1, 1, Mp), None, 1, 1, out=p.grad_w.view(1, 1, Cout, p.K))
                 if p.bias is not None:
                     ops.colsum(gy.view(M, Cout), p.grad_b)
+                ar = getattr(self, "all_reduce", None)
+                if ar is not None and getattr(self, "world_size", 1) > 1 and hasattr(ar, "ready"):
+                    # this parameter's gradient is enqueued: everything from its offset to the end of the flat buffer is final
+                    # (the tape is walked backwards and the buffer is laid out in forward order)
+                    ar.ready(self.flat, p.grad_w.data_ptr())
             if x.data_ptr() in needs:
                 gx, had = accumulate_into(x, x.shape, sc + "/in")
                 wf = sess.conv_info[sc]["w"]
@@ -172,17 +177,26 @@ class TrainState(object):
 
     # ---- solver --------------------------------------------------------------------------------------
     def apply(self, lr, world_size=1, all_reduce=None):
-        """acc = m*acc + g ; w -= lr*acc (train_val.py:128-145).  all_reduce: callable(flat_tensor) summing the
-        flat gradient over the ranks (RCCL); the mean over replicas is folded into the SGD kernel."""
+        """acc = m*acc + g ; w -= lr*acc (train_val.py:128-145) for every parameter in ONE launch.  Data parallel: the flat
+        gradient is summed over the ranks (RCCL) -- bucket by bucket during the reverse sweep when `all_reduce` has the
+        bucketed interface (parallel.BucketedAllReduce: backward() hands it every finished range), otherwise in one call
+        here -- and the mean over replicas is folded into the SGD kernel (grad_scale = 1 / world_size)."""
         if all_reduce is not None and world_size > 1:
-            all_reduce(self.flat)
+            if hasattr(all_reduce, "finish"):
+                all_reduce.finish(self.flat)              # ranges not yet handed over + wait for the ones in flight
+            else:
+                all_reduce(self.flat)
         gs = 1.0 / float(world_size)
-        for p in self.params.values():
-            ops.sgd_momentum(p.w, p.acc_w, p.wf if p.scale is not None else None, p.grad_w, p.scale, p.K, lr, self.momentum,
-                             self.weight_decay, gs)
-            if p.bias is not None:
-                ops.sgd_momentum(p.bias, p.acc_b, None, p.grad_b, None, p.bias.numel(), lr * (2.0 if self.double_bias else 1.0),
-                                 self.momentum, self.weight_decay if self.bias_decay else 0.0, gs)
+        if getattr(self, "_sgd_table", None) is None:
+            entries = []
+            for p in self.params.values():
+                entries.append((p.w, p.acc_w, p.wf if p.scale is not None else None, p.grad_w, p.scale, p.K, 1.0, self.weight_decay))
+                if p.bias is not None:
+                    entries.append((p.bias, p.acc_b, None, p.grad_b, None, p.bias.numel(), 2.0 if self.double_bias else 1.0,
+                                    self.weight_decay if self.bias_decay else 0.0))
+            self._sgd_count = len(entries)
+            self._sgd_table = ops.sgd_desc_table(entries, self.sess.device)
+        ops.sgd_momentum_multi(self._sgd_table, self._sgd_count, lr, self.momentum, gs)
 
     # ---- checkpoint view (tf.train.Saver saves the variables AND the optimizer slots `<variable>/Momentum`) ----------
     def _names(self, p):
