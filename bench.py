@@ -208,6 +208,9 @@ def main():
                          "operands, six bf16 MFMAs per f32 product, f32 accumulate (f32-class error, csrc/conv_igemm_b3.hip)")
     ap.add_argument("--winograd-f2", default=None, help="comma list of scope tokens run as F(2x2,3x3) instead of F(4x4,3x3) (default: cfg.HIP)")
     ap.add_argument("--winograd-direct", default=None, help="comma list of scope tokens that keep the direct kernel (default: cfg.HIP)")
+    ap.add_argument("--crop-slabs", type=int, default=-1, help="A/B knob: channel-slab count of the crop kernels (frcnn_detect_set_tuning key 4)")
+    ap.add_argument("--overlap", action="store_true", help="A/B knob: tail-entry 1x1 convs on a graph branch beside the proposal layer (cfg.HIP.OVERLAP_TAIL_ENTRY)")
+    ap.add_argument("--fused-mean", action="store_true", help="A/B knob: the tail's last conv3 + reduce_mean in one kernel (cfg.HIP.FUSE_TAIL_MEAN)")
     ap.add_argument("--layer-report", default=None, help="write a per-layer table of the event pass to this file")
     args = ap.parse_args()
     c = CONFIGS[args.config]
@@ -238,6 +241,12 @@ def main():
         cfg.HIP.WINOGRAD_F2_SCOPES = tuple(t for t in args.winograd_f2.split(",") if t)
     if args.winograd_direct is not None:
         cfg.HIP.WINOGRAD_DIRECT_SCOPES = tuple(t for t in args.winograd_direct.split(",") if t)
+    if args.crop_slabs > 0:
+        frcnn_hip.lib().frcnn_detect_set_tuning(4, args.crop_slabs)
+    if args.overlap:
+        cfg.HIP.OVERLAP_TAIL_ENTRY = True
+    if args.fused_mean:
+        cfg.HIP.FUSE_TAIL_MEAN = True
     cfg.USE_GPU_NMS = False           # the reference's CPU/Cython suppression rule (cpu_nms.pyx:65): the path BASELINE.json pins
     cfg.TEST.RPN_POST_NMS_TOP_N = c["post"]
     B = args.batch or c["batch"]

@@ -73,11 +73,17 @@ __C = AttrDict(
     # large common mean, are where the F(4x4,3x3) transforms lose digits (full-size head error 1.8x the float32 control with F(4,3)
     # everywhere, 1.0x with this policy, for 1.2 % of throughput); F(4x4,3x3) in block3 / RPN / block4 (7x7 scheme).
     # WINOGRAD_DIRECT_SCOPES: scopes containing one of these tokens keep the direct implicit-GEMM kernel.
-    # FUSE_TAIL_MEAN: TEST mode, the tail's last 1x1 convolution + reduce_mean in one kernel (frcnn_conv1x1_mean).
+    # OVERLAP_TAIL_ENTRY: the tail-entry 1x1 convolutions run on a side stream / graph branch beside RPN + proposal layer.  Measured
+    # (profiles/r02_c_sweep.txt): slower -- 315 vs 322 images/s in the pipeline, 5.11 vs 4.99 ms single image -- so it stays off.
+    # FUSE_TAIL_MEAN: TEST mode, the tail's last 1x1 convolution + reduce_mean in one kernel (frcnn_conv1x1_mean): +0.7 % images/s
+    # (profiles/r02_c_sweep.txt), but the 49 rows of a RoI are then added in an order that depends on where the RoI falls inside the
+    # 128-row GEMM tiles, i.e. on its slot in the batch: fc7 moves by an ulp between slots and tie-breaks between equal scores can
+    # change.  Off by default: the same image gives bit-identical detections in every batch slot
+    # (tests/test_network_gpu.py::test_batched_forward_equals_single_image_forward).
     # WINOGRAD_7X7: 7x7 maps (per-RoI crops) use the mixed F(4,3)+F(3,3) scheme (121 instead of 144 products per RoI)
     HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=64, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=("block1", "block2"), WINOGRAD_DIRECT_SCOPES=(),
              WINOGRAD_TRAIN=True,
-             WINOGRAD_7X7=True, FUSE_TAIL_MEAN=True))
+             WINOGRAD_7X7=True, FUSE_TAIL_MEAN=False, OVERLAP_TAIL_ENTRY=False))
 __C.DATA_DIR = osp.abspath(osp.join(__C.ROOT_DIR, 'data'))
 cfg = __C
 

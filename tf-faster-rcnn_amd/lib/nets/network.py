@@ -369,16 +369,49 @@ class Network(object):
     def _head_to_tail(self, pool5, is_training, reuse=None):
         raise NotImplementedError
 
+    # ------------------------------------------------------------------ fork / join inside one launch chain
+    def _fork(self, fn):
+        """Run fn() on the network's side stream, ordered after everything enqueued so far on the current stream.  Inside a
+        stream capture the side stream joins the capture (event fork), so the hipGraph gets two concurrent branches."""
+        sess = self._sess
+        main = torch.cuda.current_stream(sess.device)
+        side = sess.side_stream(self._tag)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        scope = ops.ws_scope
+        ops.ws_scope = self._tag + "/side"                 # scratch (split-K partials ...) must not be shared between live streams
+        try:
+            with torch.cuda.stream(side):
+                res = fn()
+                self._join_event = torch.cuda.Event()
+                self._join_event.record(side)
+        finally:
+            ops.ws_scope = scope
+        return res
+
+    def _join(self):
+        torch.cuda.current_stream(self._sess.device).wait_event(self._join_event)
+        self._join_event = None
+
     def _build_network(self, is_training=True):
         self._tape = []
         self._requires_grad = set()
         net_conv = self._image_to_head(is_training)
         self._anchor_component()
+        fused = self._fuse_tail_entry and not is_training and hasattr(self, "_fused_tail_entry")
+        maps = None
+        if fused and cfg.HIP.OVERLAP_TAIL_ENTRY and hasattr(self, "_fused_tail_maps"):
+            # the two 1x1 convolutions of the tail's entry read only the head: they run beside RPN + proposal layer (whose
+            # select / sort / NMS kernels occupy a handful of CUs) instead of after them
+            maps = self._fork(lambda: self._fused_tail_maps(net_conv))
         rois = self._region_proposal(net_conv, is_training)
+        if maps is not None:
+            self._join()
         if cfg.POOLING_MODE != "crop":
             raise NotImplementedError
-        if self._fuse_tail_entry and not is_training and hasattr(self, "_fused_tail_entry"):
-            fc7 = self._fused_tail_entry(net_conv, rois)          # crop commuted past the first 1x1 convs (exact algebra)
+        if fused:
+            fc7 = self._fused_tail_entry(net_conv, rois, maps)          # crop commuted past the first 1x1 convs (exact algebra)
         else:
             pool5 = self._crop_pool_layer(net_conv, rois, "pool5")
             self._layers["pool5"] = pool5
@@ -455,7 +488,7 @@ class Network(object):
                bool(cfg.USE_GPU_NMS), tuple(image_d.shape), self._im_info[:2], self._mode, cfg.TEST.MODE, self._fuse_tail_entry,
                c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH, cfg.TEST.RPN_TOP_N, cfg.POOLING_SIZE,
                bool(cfg.HIP.WINOGRAD), int(cfg.HIP.WINOGRAD_MIN_CIN), int(cfg.HIP.WINOGRAD_M), tuple(cfg.HIP.WINOGRAD_F2_SCOPES),
-               tuple(cfg.HIP.WINOGRAD_DIRECT_SCOPES), bool(cfg.HIP.WINOGRAD_7X7), bool(cfg.HIP.FUSE_TAIL_MEAN), bool(cfg.USE_E2E_TF))
+               tuple(cfg.HIP.WINOGRAD_DIRECT_SCOPES), bool(cfg.HIP.WINOGRAD_7X7), bool(cfg.HIP.FUSE_TAIL_MEAN), bool(cfg.HIP.OVERLAP_TAIL_ENTRY), bool(cfg.USE_E2E_TF))
         cur = torch.cuda.current_stream(sess.device)
         if not use_graph or sess.profile is not None:
             sess.flops_last_forward = 0
