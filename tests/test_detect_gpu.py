@@ -12,6 +12,17 @@ pytestmark = pytest.mark.gpu
 f32 = np.float32
 
 
+BOX_TOL = 4 * float(np.spacing(np.float32(2048.0)))      # 9.8e-4 px = 4 ulp at the pre-clip magnitude of the widest decoded boxes
+                                                           # (device expf vs np.exp differ by <= 2 ulp of exp(dw) * w); the measured
+                                                           # maxima are printed (pytest -s) and are ~1 ulp of the coordinate itself
+
+
+def boxes_close(got, want, what):
+    err = float(np.abs(np.asarray(got, dtype=np.float64) - np.asarray(want, dtype=np.float64)).max()) if np.size(want) else 0.0
+    print("%s: max |box - reference| = %.3g px (bound %.3g)" % (what, err, BOX_TOL))
+    return err <= BOX_TOL
+
+
 def T(a, dev, dtype=None):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev) if dtype is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype)
 
@@ -127,7 +138,7 @@ def test_proposal_top_layer_vs_reference_golden(dev, golden):
     base = ops.generate_anchors(16)
     rois, scores = ops.proposal_top_layer(T(prob, dev), T(dl, dev), 600, 1000, 16, T(base, dev), 5000)
     assert np.array_equal(scores.cpu().numpy(), g["top_38x63_a9_scores"])
-    assert np.allclose(rois.cpu().numpy(), g["top_38x63_a9_rois"], rtol=0, atol=1e-3)
+    assert boxes_close(rois.cpu().numpy(), g["top_38x63_a9_rois"], "proposal_top_layer vs reference golden")
 
 
 def test_proposal_layer_other_seeds_vs_oracle(dev):
@@ -135,7 +146,7 @@ def test_proposal_layer_other_seeds_vs_oracle(dev):
         prob, dl, rois, scores, n = _proposal_case(dev, 38, 63, (8, 16, 32), "TEST", 300, (600, 1000, 1.6), seed=seed)
         anc, _ = ora.generate_anchors_pre(38, 63, 16)
         wr, ws = ora.proposal_layer(prob, dl, np.array([600, 1000, 1.6], dtype=f32), "TEST", [16], anc, 9)
-        assert n == wr.shape[0] and np.array_equal(scores[:n], ws) and np.allclose(rois[:n], wr, rtol=0, atol=1e-3)
+        assert n == wr.shape[0] and np.array_equal(scores[:n], ws) and boxes_close(rois[:n], wr, "proposal_layer vs oracle")
 
 
 @pytest.mark.parametrize("H,W,C,R,pool,mp", [(38, 63, 1024, 300, 7, False), (38, 63, 512, 64, 7, True), (50, 84, 256, 100, 7, False),
@@ -166,7 +177,7 @@ def test_detect_post_vs_reference_golden(dev, golden, tag, R, C, W, H):
     got = dets[:n].cpu().numpy()
     assert n == want.shape[0]
     assert np.array_equal(got[:, 4:], want[:, 4:])                    # scores + classes: bit-exact => same keep sets
-    assert np.allclose(got[:, :4], want[:, :4], rtol=0, atol=1e-3)
+    assert boxes_close(got[:, :4], want[:, :4], "detect_post vs reference golden " + tag)
 
 
 def test_detect_post_num_rois_and_no_cap(dev):
@@ -222,7 +233,7 @@ def test_host_mirror_seams_numpy_in_numpy_out(dev, golden):
     prob, dl = synth.rpn_outputs(38, 63, 9, seed=3)
     blob, sc = proposal_layer(prob, dl, np.array([600, 1000, 1.6], dtype=f32), b"TEST", [16, ], anc, 9)
     assert np.array_equal(sc, golden["proposal"]["test_38x63_a9_scores"])
-    assert np.allclose(blob, golden["proposal"]["test_38x63_a9_rois"], rtol=0, atol=1e-3)
+    assert boxes_close(blob, golden["proposal"]["test_38x63_a9_rois"], "proposal_layer mirror vs reference golden")
 
 
 # ------------------------------------------------------------------------------------------------ USE_E2E_TF graph
@@ -274,7 +285,7 @@ def test_proposal_layer_tf_vs_reference_golden(dev, golden, tag, H, W, scales, p
     want_r, want_s = g["tf_" + tag + "_rois"], g["tf_" + tag + "_scores"]
     assert n == want_r.shape[0]
     assert np.array_equal(scores[:n], want_s)                                     # same anchors selected, same order
-    assert np.allclose(rois[:n], want_r, rtol=0, atol=1e-3)
+    assert boxes_close(rois[:n], want_r, "proposal_layer_tf vs reference golden " + tag)
     assert np.all(rois[n:] == 0) and np.all(scores[n:] == 0)
 
 

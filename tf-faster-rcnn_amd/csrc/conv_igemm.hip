@@ -45,6 +45,7 @@ struct ConvParams {
   int dbg;                         // unused by the kernels (kept for the tuning ABI); run-time switches in the hot loop cost MFMA issue slots
   int splits, kchunk;              // split-K: grid.z = splits, each covers kchunk slabs and writes raw partial sums to y + z*gz
   long long gz;
+  int stagger, stagger_slots;      // > 0: workgroup in residency slot s of its CU (first dispatch round) starts s * stagger shader cycles late
   int mean_group;                  // MEAN kernels: rows per group (49 = the 7x7 positions of one RoI); y is NOT written,
   float* mean_part;                // per-(m-tile, group slot) column sums go here: [mtiles][MEAN_SLOTS][Cout]
 };
@@ -93,6 +94,18 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (p.stagger > 0) {
+    // Phase-shift the co-resident workgroups of a CU.  Every workgroup of a launch starts at the same time and does the same
+    // amount of work, so the (LDS-limited) workgroups sharing a CU reach their prologue / epilogue -- the phases without MFMA
+    // issue -- together and the matrix pipe idles; an initial delay of slot * (tile time / slots) for the workgroups of the
+    // first dispatch round (observed placement: block b -> XCD b % 8, CU (b / 8) % 32, slot (b / 8) / 32) makes one's
+    // epilogue overlap the others' main loops for the rest of the launch.
+    const unsigned slot = blockIdx.x >> 8;               // 256 CUs: blocks [256 s, 256 s + 256) fill residency slot s
+    if (blockIdx.y == 0 && blockIdx.z == 0 && slot > 0 && slot < (unsigned)p.stagger_slots) {
+      const long long t0 = clock64(), wait = (long long)p.stagger * slot;
+      while (clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
+  }
   // XCD-aware tile order (observed placement: block b -> XCD b % 8): consecutive tiles of one XCD
   // share an activation slab; bijective for any grid size.
   const int nwg = p.mtiles * p.ntiles;
@@ -422,7 +435,7 @@ static int launch_conv(ConvParams p, hipStream_t st) {
 
 // tuning knob (experiments / A-B runs): key 0 = force a tile configuration id for every non-stem conv
 // (-1 = automatic choice).
-static int g_force_cfg = -1, g_dbg = 0, g_b3 = 0, g_b3_cfg = -1;
+static int g_force_cfg = -1, g_dbg = 0, g_b3 = 0, g_b3_cfg = -1, g_stagger = 0;
 int frcnn_conv2d_b3_dispatch(const float* x_d, int N, int H, int W, int Cin, const float* w_d, const float* bias_d,
                              const float* residual_d, int RH, int RW, int res_stride, float* y_d, int OH, int OW, int Cout,
                              int KH, int KW, int stride, int pad_top, int pad_left, int act, int cfg, hipStream_t st);
@@ -431,6 +444,7 @@ extern "C" int frcnn_set_tuning(int key, int value) {
   if (key == 1) { g_dbg = value; return FRCNN_OK; }
   if (key == 2) { g_b3 = value; return FRCNN_OK; }          // experimental bf16x3 split-operand path (conv_igemm_b3.hip)
   if (key == 3) { g_b3_cfg = value; return FRCNN_OK; }
+  if (key == 5) { g_stagger = value; return FRCNN_OK; }        // 0 off; n > 0: second-slot workgroups start n/8 of a tile late
   return FRCNN_E_ARG;
 }
 
@@ -562,7 +576,7 @@ static int conv2d_impl(const float* x_d, int N, int H, int W, int Cin, const flo
   p.gx = p.gw = p.gy = p.gz = 0;
   p.batch = 1;
   p.splits = 1; p.kchunk = p.nsteps;
-  p.mean_group = 0; p.mean_part = nullptr;
+  p.mean_group = 0; p.mean_part = nullptr; p.stagger = 0; p.stagger_slots = 0;
   p.dbg = g_dbg;
   hipStream_t st = (hipStream_t)stream;
   if (fold_w) return launch_conv<128, 64, 32, 64, 3, true>(p, st);
@@ -590,7 +604,18 @@ static int conv2d_impl(const float* x_d, int N, int H, int W, int Cin, const flo
   // for the per-RoI tail (M = 14700), 64x64 tiles with a shallow ring (32 KB LDS -> up to 5
   // workgroups per CU) for the 38x63 / 75x125 / 150x250 feature maps.
   const long long big = (long long)cdiv(p.M, 128) * cdiv(Cout, 128);
-  if (Cout >= 96 && big >= 384 && p.nsteps >= 8) return launch_cfg(Cout >= 1024 ? 21 : 20, p, st);   // reads-first; 8 waves help the residual epilogue
+  if (Cout >= 96 && big >= 384 && p.nsteps >= 8) {
+    // a 128x128 tile keeps each SIMD's matrix pipe busy for nsteps * 64 MFMAs * 64 cycles; two workgroups share a CU
+    if (g_stagger > 0 && big >= 1024) {
+      p.stagger = (int)min((long long)p.nsteps * 8192 * g_stagger / 8, (long long)1 << 30);
+      p.stagger_slots = 2;
+    }
+    return launch_cfg(Cout >= 1024 ? 21 : 20, p, st);   // reads-first; 8 waves help the residual epilogue
+  }
+  if (g_stagger > 0 && (g_stagger & 16) && Cout > 32 && (long long)cdiv(p.M, 64) * cdiv(Cout, 64) >= 1280) {
+    p.stagger = p.nsteps * 1024;                         // 64x64 tiles: 5 workgroups per CU (32 KB LDS), one fifth of a tile apart
+    p.stagger_slots = 5;
+  }
   if (Cout > 32) return launch_cfg(15, p, st);
   return launch_cfg(4, p, st);
 }
@@ -632,7 +657,7 @@ extern "C" int frcnn_conv1x1_mean(const float* x_d, int M, int Cin, const float*
   p.M = M; p.Ktot = Cin; p.nsteps = Cin / 32; p.mtiles = p.ntiles = 0;
   p.gx = p.gw = p.gy = p.gz = 0;
   p.batch = 1; p.splits = 1; p.kchunk = p.nsteps; p.dbg = 0;
-  p.mean_group = group_rows; p.mean_part = (float*)ws;
+  p.mean_group = group_rows; p.mean_part = (float*)ws; p.stagger = 0; p.stagger_slots = 0;
   hipStream_t st = (hipStream_t)stream;
   const int rc = Cout >= 1024 ? launch_conv<128, 128, 32, 64, 2, false, false, true, true>(p, st)
                               : launch_conv<128, 128, 64, 64, 2, false, false, true, true>(p, st);
@@ -660,7 +685,7 @@ extern "C" int frcnn_gemm_batched_nt(const float* x_d, const float* w_d, float* 
   p.dbg = 0;
   p.batch = G;
   p.splits = 1; p.kchunk = p.nsteps;
-  p.mean_group = 0; p.mean_part = nullptr;
+  p.mean_group = 0; p.mean_part = nullptr; p.stagger = 0; p.stagger_slots = 0;
   const long long big = (long long)cdiv(M, 128) * cdiv(N, 128) * G;
   if (g_force_cfg >= 0) return launch_cfg(g_force_cfg, p, (hipStream_t)stream);
   return (N >= 96 && big >= 384 && p.nsteps >= 8) ? launch_cfg(N >= 1024 ? 21 : 20, p, (hipStream_t)stream)
