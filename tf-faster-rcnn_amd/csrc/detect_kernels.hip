@@ -117,6 +117,32 @@ __global__ void k_boxes_scores_key(const float4* __restrict__ in_boxes, const fl
 // them) and zeroes their rank counters.  Reads 8N bytes nine times out of L2; replaces an O(N^2) counting sort
 // over all anchors.
 // ------------------------------------------------------------------------------------------------
+// One radix-select step over a 256-bin histogram: the bin that holds the k-th largest key and the number of keys in the bins
+// above it.  Parallel suffix sum (shuffles inside the four 64-bin waves, then the wave totals); a serial walk by one thread
+// costs ~10 us of dependent LDS round trips per pass.  Called by EVERY thread of the workgroup (barriers inside); k must not
+// exceed the histogram total.
+__device__ __forceinline__ void pick_bin(const int* hist, int k, int* wtot, int* out_bin, int* out_above) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int h = 0, x = 0;
+  if (tid < 256) {
+    h = hist[tid];
+    x = h;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int y = __shfl_down(x, off, 64);
+      if (lane + off < 64) x += y;                       // inclusive suffix sum inside the wave
+    }
+    if (lane == 0) wtot[wave] = x;
+  }
+  __syncthreads();
+  if (tid < 256) {
+    int above = 0;
+    for (int w = wave + 1; w < 4; ++w) above += wtot[w];
+    const int excl = x - h + above;                      // keys in bins > tid
+    if (excl < k && k <= excl + h) { *out_bin = tid; *out_above = excl; }
+  }
+  __syncthreads();
+}
+
 #define SEL_LIST 4096
 __global__ __launch_bounds__(1024) void k_select_topk(const u64* __restrict__ keys_all, int N, int K,
                                                       u64* __restrict__ ckeys_all, u32* __restrict__ rank_all, size_t img) {
@@ -125,7 +151,8 @@ __global__ __launch_bounds__(1024) void k_select_topk(const u64* __restrict__ ke
   __shared__ int hist[256];
   __shared__ u64 list[SEL_LIST];             // the keys sharing the selected 16-bit prefix: the last six passes run on these
   __shared__ u64 sel_prefix, sel_mask;
-  __shared__ int sel_k, fill, list_n, gather_flag;
+  __shared__ int sel_k, fill, list_n, gather_flag, pick_b, pick_a;
+  __shared__ int wtot[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u64* keys = img_ptr(keys_all, img, blockIdx.x);
   u64* ckeys = img_ptr(ckeys_all, img, blockIdx.x);
@@ -177,13 +204,10 @@ __global__ __launch_bounds__(1024) void k_select_topk(const u64* __restrict__ ke
         hist[tid] = sum;
       }
       __syncthreads();
+      pick_bin(hist, sel_k, wtot, &pick_b, &pick_a);
       if (tid == 0) {
-        int acc = 0, bsel = 255;
-        for (; bsel > 0; --bsel) {
-          if (acc + hist[bsel] >= sel_k) break;
-          acc += hist[bsel];
-        }
-        sel_k -= acc;
+        const int bsel = pick_b;
+        sel_k -= pick_a;
         sel_prefix |= ((u64)bsel << shift);
         sel_mask |= (255ull << shift);
         // after the second pass: if the selected 16-bit bucket is small, finish on an LDS copy of it
@@ -1207,7 +1231,8 @@ __global__ __launch_bounds__(1024) void k_final_select(const float* __restrict__
   __shared__ int hist[256];
   __shared__ int wave_off[16];
   __shared__ u32 sel_prefix, sel_mask;
-  __shared__ int sel_k, total_s, running_s;
+  __shared__ int sel_k, total_s, running_s, pick_b, pick_a;
+  __shared__ int wtot[4];
   const int img = blockIdx.x;
   const float* cls_dets = cls_dets_all + (size_t)img * nfg * R * 5;
   const int* cls_count = cls_count_all + (size_t)img * nfg;
@@ -1234,14 +1259,10 @@ __global__ __launch_bounds__(1024) void k_final_select(const float* __restrict__
         }
       }
       __syncthreads();
+      pick_bin(hist, sel_k, wtot, &pick_b, &pick_a);
       if (tid == 0) {
-        int acc = 0, b = 255;
-        for (; b > 0; --b) {
-          if (acc + hist[b] >= sel_k) break;
-          acc += hist[b];
-        }
-        sel_k -= acc;
-        sel_prefix |= ((u32)b << shift);
+        sel_k -= pick_a;
+        sel_prefix |= ((u32)pick_b << shift);
         sel_mask |= (255u << shift);
       }
       __syncthreads();
