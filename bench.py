@@ -208,6 +208,7 @@ def main():
                          "operands, six bf16 MFMAs per f32 product, f32 accumulate (f32-class error, csrc/conv_igemm_b3.hip)")
     ap.add_argument("--winograd-f2", default=None, help="comma list of scope tokens run as F(2x2,3x3) instead of F(4x4,3x3) (default: cfg.HIP)")
     ap.add_argument("--winograd-direct", default=None, help="comma list of scope tokens that keep the direct kernel (default: cfg.HIP)")
+    ap.add_argument("--no-stream-gemm", action="store_true", help="A/B knob: frcnn_set_tuning key 6 = 0 (short-K GEMMs on k_conv_igemm instead of k_gemm_stream)")
     ap.add_argument("--stagger", type=int, default=0, help="A/B knob: frcnn_set_tuning key 5 (second-slot workgroups of the big GEMM launches "
                     "start n/8 of a tile late)")
     ap.add_argument("--crop-slabs", type=int, default=-1, help="A/B knob: channel-slab count of the crop kernels (frcnn_detect_set_tuning key 4)")
@@ -245,6 +246,8 @@ def main():
         cfg.HIP.WINOGRAD_DIRECT_SCOPES = tuple(t for t in args.winograd_direct.split(",") if t)
     if args.stagger:
         frcnn_hip.lib().frcnn_set_tuning(5, args.stagger)
+    if args.no_stream_gemm:
+        frcnn_hip.lib().frcnn_set_tuning(6, 0)
     if args.crop_slabs > 0:
         frcnn_hip.lib().frcnn_detect_set_tuning(4, args.crop_slabs)
     if args.overlap:

@@ -433,9 +433,298 @@ static int launch_conv(ConvParams p, hipStream_t st) {
   return FRCNN_OK;
 }
 
+// ---- streaming (persistent) GEMM ---------------------------------------------------------------------------------------
+// For the 1x1 / stride-1 convolutions and the batched Winograd products (plain "NT" GEMMs: A[M][K] activations, W[N][K] filter,
+// Y[M][N]).  Same slab ring, fragment layout and MFMA order as k_conv_igemm, but a workgroup is a RESIDENT worker that walks a
+// static list of output tiles and treats (tile, k-slab) as ONE stream:
+//   * the ring never drains: slab 0 of the next tile is issued while the last slab of the current tile is being multiplied, so the
+//     load-latency prologue is paid once per workgroup instead of once per tile (a block3 tile is only 8 slabs = 128 MFMAs/wave);
+//   * the epilogue writes straight from the accumulator registers (lane = output column: each store instruction covers two
+//     128-byte row segments), so it needs neither the LDS tile nor its two barriers, and the waves of a workgroup finish a tile
+//     independently while the next tile's slab is already landing;
+//   * with RESPF the residual rows of the tile are requested before the MFMAs of its last slab, not after them;
+//   * no workgroup launch / LDS allocation per tile.
+// The host requires N % BN == 0; the M tail is handled without predicates (clamped source rows, range-checked buffer stores).
+// Schedule: workgroup b lives on XCD b % 8 (observed placement); XCD x owns a contiguous range of the m-major tile list and its
+// workgroups take that range round-robin, so concurrently running workgroups of an XCD share activation rows in its L2.
+// The per-element summation order is the one of k_conv_igemm (results are bit-identical to it).
+struct GemmParams {
+  const float* x; const float* w; const float* bias; const float* res; float* y;
+  int M, N, K, nsteps, mtiles, ntiles, batch, act;
+  long long gx, gw, gy;                                 // element strides per batch entry
+};
+
+template <int BM, int BN, int WM, int WN, bool ILV, bool RF, bool RESPF>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_gemm_stream(const GemmParams p) {
+  constexpr int NW = (BM / WM) * (BN / WN);
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int LA = BM / 8 / NW, LB = BN / 8 / NW;
+  constexpr int G = LA + LB;
+  constexpr int SLAB = (BM + BN) * 32;
+  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile/wave mismatch");
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // [2][BM+BN][32]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int per = p.mtiles * p.ntiles, T = per * p.batch;
+  const int xcd = blockIdx.x & 7, wx = blockIdx.x >> 3, W8 = gridDim.x >> 3;       // host: gridDim.x % 8 == 0
+  const int tq = T / 8, tr = T % 8, tn = tq + (xcd < tr ? 1 : 0);
+  const int t_end = (xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq) + tn;
+  int tile = __builtin_amdgcn_readfirstlane(t_end - tn + wx);
+  if (tile >= t_end) return;                                                       // uniform per workgroup
+
+  const int wm0 = (wave / (BN / WN)) * WM, wn0 = (wave % (BN / WN)) * WN;
+  const int lrow = lane >> 3, lpos = lane & 7;
+  // per-lane slab sources: row (wave*L + t)*8 + lrow of the tile, swizzled 16-byte chunk; the tile / slab position is added on top
+  int a_lane[LA], b_lane[LB];
+#pragma unroll
+  for (int t = 0; t < LB; ++t) {
+    const int row = (wave * LB + t) * 8 + lrow;
+    b_lane[t] = row * p.K + (lpos ^ (((BM + row) >> 1) & 7)) * 4;
+  }
+  const float* ia = p.x; const float* ib = p.w;      // issue side (wave-uniform): next slab of the tile whose slabs are being issued
+  int i_bm0 = 0, i_bn0 = 0, i_g = 0;
+  auto set_tile = [&](int tl) {
+    const int g = tl / per, rem = tl - g * per;
+    const int mt = rem / p.ntiles, nt = rem - mt * p.ntiles;
+    i_bm0 = mt * BM; i_bn0 = nt * BN; i_g = g;
+    ia = p.x + (size_t)g * p.gx + (size_t)i_bm0 * p.K;
+    ib = p.w + (size_t)g * p.gw + (size_t)i_bn0 * p.K;
+    // rows past M (last m-tile only) re-read row M-1: direct-to-LDS loads cannot be predicated; their products are never stored
+#pragma unroll
+    for (int t = 0; t < LA; ++t) {
+      const int row = (wave * LA + t) * 8 + lrow;
+      a_lane[t] = (min(row, p.M - 1 - i_bm0)) * p.K + (lpos ^ ((row >> 1) & 7)) * 4;
+    }
+  };
+  const unsigned lds0 = (unsigned)(size_t)(LDS_AS float*)smem;
+  auto issue_one = [&](int buf, int t) {
+    const unsigned sb = lds0 + (unsigned)(buf * SLAB * 4);
+    if (t < LA) glds16(ia + a_lane[t], __builtin_amdgcn_readfirstlane(sb + (wave * LA + t) * 1024));
+    else glds16(ib + b_lane[t - LA], __builtin_amdgcn_readfirstlane(sb + BM * 128 + (wave * LB + (t - LA)) * 1024));
+  };
+  auto advance_k = [&]() { ia += 32; ib += 32; };
+  auto issue_slab = [&](int buf) {
+#pragma unroll
+    for (int t = 0; t < G; ++t) issue_one(buf, t);
+    advance_k();
+  };
+
+  constexpr bool KSPLIT = (TM * TN == 1);
+  f32x16 acc[TM][TN], acc2[TM][TN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acc2[i][j][r] = 0.f; }
+  };
+  zero_acc();
+  const int frow = lane & 31, khalf = lane >> 5;
+  int koff[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) koff[s] = ((2 * s + khalf) ^ ((frow >> 1) & 7)) * 4;
+  const int a_row0 = (wm0 + frow) * 32, b_row0 = (BM + wn0 + frow) * 32;
+
+  // compute side: the tile whose slabs are being multiplied (the issue side runs one slab ahead and crosses into the next tile)
+  int c_bm0, c_bn0, c_g;
+  float rv[RESPF ? TM : 1][RESPF ? TN : 1][16];
+  // Output / residual element of accumulator register r of sub-tile (i, j): row (r&3) + 8*(r>>2) + 4*khalf, column frow.  Addressed
+  // with raw buffer instructions: a wave-uniform descriptor per sub-tile whose range ends at the end of the tensor -- rows past M
+  // are dropped (stores) / read as zero (loads) by the hardware range check, so the M tail needs no predicate -- and a per-lane
+  // byte offset = (tile-invariant lane part) + (scalar row part).
+  const int lane_off = (4 * khalf * p.N + frow) * 4;
+  auto sub_base = [&](int i, int j) { return (long long)(c_bm0 + wm0 + i * 32) * p.N + (long long)(c_bn0 + wn0 + j * 32); };
+  auto row_soff = [&](int r) { return ((r & 3) + 8 * (r >> 2)) * p.N * 4; };
+  auto rsrc_of = [&](const float* tensor, long long sbase) {
+    const long long left = ((long long)p.M * p.N - sbase) * 4;                       // bytes from the sub-tile origin to the tensor end
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(tensor + sbase), 0, (int)max(0ll, min(left, 0x7fffffffll)), 0x00020000);
+  };
+  auto prefetch_res = [&]() {
+    if (!RESPF || !p.res) return;
+    int lo = lane_off;
+    asm volatile("" : "+v"(lo));             // opaque per tile: keeps the 16 row offsets out of the registers that live through the main loop
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const auto rr = rsrc_of(p.res + (size_t)c_g * p.gy, sub_base(i, j));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[RESPF ? i : 0][RESPF ? j : 0][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, lo + row_soff(r), 0, 0));
+      }
+  };
+
+  // The multiply part of one slab: fragment reads of slab `cur`, the direct-to-LDS loads of the stream's next slab, 64 * TM * TN
+  // MFMAs.  ONE code instance for every slab of every tile (no branch inside: a branch would split the block and the compiler
+  // would then serialise fragment reads and MFMAs).
+  auto slab_body = [&](int cur) {
+    const int nbuf = cur ^ 1;
+    const float* sb = smem + cur * SLAB;
+    float4 a[4][TM], b[4][TN];
+    auto read_frag = [&](int q) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[q][i] = *(const float4*)(sb + a_row0 + i * 1024 + koff[q]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[q][j] = *(const float4*)(sb + b_row0 + j * 1024 + koff[q]);
+    };
+    auto mfma_group = [&](int q) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float av = e == 0 ? a[q][i].x : e == 1 ? a[q][i].y : e == 2 ? a[q][i].z : a[q][i].w;
+            const float bv = e == 0 ? b[q][j].x : e == 1 ? b[q][j].y : e == 2 ? b[q][j].z : b[q][j].w;
+            if (KSPLIT && (e & 1)) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc2[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+          }
+    };
+    if (ILV) {
+      read_frag(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < 3) read_frag(q + 1);
+#pragma unroll
+        for (int t = (q * G) / 4; t < ((q + 1) * G) / 4; ++t) issue_one(nbuf, t);
+        mfma_group(q);
+      }
+      advance_k();
+    } else {
+      constexpr int RF_FIRST = !RF ? 0 : (TM * TN == 1 ? 4 : 1);
+#pragma unroll
+      for (int q = 0; q < RF_FIRST; ++q) read_frag(q);
+      issue_slab(nbuf);
+#pragma unroll
+      for (int q = RF_FIRST; q < 4; ++q) read_frag(q);
+      if (TM * TN == 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mfma_group(q);
+    }
+  };
+
+  // epilogue from registers: D of a 32x32 MFMA tile -- lane holds column lane&31, register r holds row (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // No predicates; the activation is a clamp to [lo, hi] (ReLU: [0, inf), ReLU6: [0, 6]); the residual case is
+  // a separate straight-line instantiation.
+  const float act_lo = p.act == FRCNN_ACT_NONE ? -__builtin_inff() : 0.f;
+  const float act_hi = p.act == FRCNN_ACT_RELU6 ? 6.f : __builtin_inff();
+  auto finish = [&](auto res_c) {
+    constexpr bool RES = decltype(res_c)::value;
+    float* const py = p.y + (size_t)c_g * p.gy;
+    int lo = lane_off;
+    asm volatile("" : "+v"(lo));
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float bv = p.bias ? p.bias[c_bn0 + wn0 + j * 32 + frow] : 0.f;
+        const long long sbase = sub_base(i, j);
+        float v[16];
+        if (RES && !RESPF) {
+          const auto rr = rsrc_of(p.res + (size_t)c_g * p.gy, sbase);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, lo + row_soff(r), 0, 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float t = (KSPLIT ? acc[i][j][r] + acc2[i][j][r] : acc[i][j][r]) + bv;
+          if (RES) t += RESPF ? rv[RESPF ? i : 0][RESPF ? j : 0][r] : v[r];
+          v[r] = fminf(fmaxf(t, act_lo), act_hi);
+        }
+        const auto ry = rsrc_of(py, sbase);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), ry, lo + row_soff(r), 0, 0);
+      }
+  };
+
+  set_tile(tile);
+  c_bm0 = i_bm0; c_bn0 = i_bn0; c_g = i_g;
+  issue_slab(0);
+  int cur = 0, step = 0;
+  for (;;) {
+    wait_vmcnt<0>();                         // slab `step` of the current tile has landed (this wave's share)
+    __builtin_amdgcn_s_barrier();            // ... everybody's share; and every wave is done reading the other ring slot
+    const bool last = step + 1 == p.nsteps;  // wave-uniform
+    int next = tile;
+    if (last) {
+      // the stream crosses into the next tile: its slab 0 is issued under this slab's MFMAs (the final tile re-requests its own
+      // slab 0 -- in-bounds, never read -- so that the multiply part stays one branch-free code instance)
+      next = __builtin_amdgcn_readfirstlane(tile + W8);
+      set_tile(next < t_end ? next : tile);
+      prefetch_res();
+    }
+    slab_body(cur);
+    cur ^= 1;
+    if (!last) { ++step; continue; }
+    if (p.res) finish(std::true_type{}); else finish(std::false_type{});
+    if (next >= t_end) break;
+    zero_acc();
+    step = 0; tile = next; c_bm0 = i_bm0; c_bn0 = i_bn0; c_g = i_g;
+  }
+  wait_vmcnt<0>();                           // the dummy prefetch must not land in a later workgroup's LDS
+}
+
+template <int BM, int BN, int WM, int WN, bool ILV, bool RF, bool RESPF>
+static int launch_stream(const ConvParams& c, hipStream_t st) {
+  constexpr int NT = (BM / WM) * (BN / WN) * 64;
+  constexpr size_t lds = sizeof(float) * 2 * (BM + BN) * 32;
+  auto kern = k_gemm_stream<BM, BN, WM, WN, ILV, RF, RESPF>;
+  static std::once_flag once;
+  static hipError_t rc0 = hipSuccess;
+  static int slots = 0;                     // resident workgroups on the device
+  std::call_once(once, [&] {
+    rc0 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int per_cu = 0, dev = 0, cus = 0;
+    if (rc0 == hipSuccess) rc0 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, NT, lds);
+    if (rc0 == hipSuccess) rc0 = hipGetDevice(&dev);
+    if (rc0 == hipSuccess) rc0 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    slots = per_cu * cus;
+  });
+  HIP_TRY(rc0);
+  const bool plain = c.KH == 1 && c.KW == 1 && c.stride == 1 && c.pad_top == 0 && c.pad_left == 0 && c.OH == c.H && c.OW == c.W;
+  if (slots < 8 || !plain || c.Cout % BN || c.splits != 1 || (c.res && c.res_stride != 1) || (long long)c.M * c.Cout >= (1ll << 31) ||
+      (long long)c.M * c.Cin >= (1ll << 31) || (long long)c.Cout * c.Cin >= (1ll << 31))
+    return FRCNN_E_UNSUPPORTED;
+  GemmParams p;
+  p.x = c.x; p.w = c.w; p.bias = c.bias; p.res = c.res; p.y = c.y;
+  p.mtiles = cdiv(c.M, BM); p.M = c.M; p.N = c.Cout; p.K = c.Cin; p.nsteps = c.Cin / 32;
+  p.ntiles = c.Cout / BN; p.batch = c.batch; p.act = c.act;
+  p.gx = c.gx; p.gw = c.gw; p.gy = c.gy;
+  const long long T = (long long)p.mtiles * p.ntiles * p.batch;
+  if (T >= (1ll << 30)) return FRCNN_E_UNSUPPORTED;
+  const int grid = (int)min((long long)(slots / 8) * 8, ((T + 7) / 8) * 8);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, p);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// streaming configurations (ids 100+ of tuning key 0)
+static int launch_stream_cfg(int id, const ConvParams& p, hipStream_t st) {
+  switch (id) {
+    case 100: return launch_stream<64, 64, 32, 32, true, false, false>(p, st);      // cfg 15
+    case 101: return launch_stream<64, 64, 32, 32, true, false, true>(p, st);
+    case 102: return launch_stream<128, 128, 64, 64, false, true, false>(p, st);    // cfg 20
+    case 103: return launch_stream<128, 128, 64, 64, false, true, true>(p, st);
+    case 104: return launch_stream<128, 128, 32, 64, false, true, false>(p, st);    // cfg 21
+    case 105: return launch_stream<128, 128, 32, 64, false, true, true>(p, st);
+    case 106: return launch_stream<128, 64, 32, 32, true, false, false>(p, st);     // 8 single-tile waves, 48 KB
+    case 107: return launch_stream<128, 64, 32, 32, true, false, true>(p, st);
+    case 108: return launch_stream<64, 128, 32, 32, true, false, false>(p, st);
+    case 109: return launch_stream<64, 128, 32, 32, true, false, true>(p, st);
+    case 110: return launch_stream<128, 64, 64, 32, false, true, true>(p, st);      // 4 waves x 2 accumulators
+    case 111: return launch_stream<64, 128, 32, 64, false, true, true>(p, st);
+    case 112: return launch_stream<32, 64, 32, 32, true, false, false>(p, st);       // 2 single-tile waves, 24 KB
+    case 113: return launch_stream<64, 32, 32, 32, true, false, false>(p, st);
+    case 114: return launch_stream<32, 128, 32, 32, true, false, false>(p, st);      // 4 single-tile waves, 40 KB
+    case 115: return launch_stream<32, 64, 32, 32, false, true, false>(p, st);
+    default: return FRCNN_E_ARG;
+  }
+}
+
 // tuning knob (experiments / A-B runs): key 0 = force a tile configuration id for every non-stem conv
 // (-1 = automatic choice).
-static int g_force_cfg = -1, g_dbg = 0, g_b3 = 0, g_b3_cfg = -1, g_stagger = 0;
+static int g_force_cfg = -1, g_dbg = 0, g_b3 = 0, g_b3_cfg = -1, g_stagger = 0, g_stream = 1;
 int frcnn_conv2d_b3_dispatch(const float* x_d, int N, int H, int W, int Cin, const float* w_d, const float* bias_d,
                              const float* residual_d, int RH, int RW, int res_stride, float* y_d, int OH, int OW, int Cout,
                              int KH, int KW, int stride, int pad_top, int pad_left, int act, int cfg, hipStream_t st);
@@ -445,6 +734,7 @@ extern "C" int frcnn_set_tuning(int key, int value) {
   if (key == 2) { g_b3 = value; return FRCNN_OK; }          // experimental bf16x3 split-operand path (conv_igemm_b3.hip)
   if (key == 3) { g_b3_cfg = value; return FRCNN_OK; }
   if (key == 5) { g_stagger = value; return FRCNN_OK; }        // 0 off; n > 0: second-slot workgroups start n/8 of a tile late
+  if (key == 6) { g_stream = value; return FRCNN_OK; }         // 0: never dispatch to k_gemm_stream (A/B runs)
   return FRCNN_E_ARG;
 }
 
@@ -582,6 +872,7 @@ static int conv2d_impl(const float* x_d, int N, int H, int W, int Cin, const flo
   if (fold_w) return launch_conv<128, 64, 32, 64, 3, true>(p, st);
   if (g_b3) return frcnn_conv2d_b3_dispatch(x_d, N, H, W, Cin, w_d, bias_d, residual_d, RH, RW, res_stride, y_d, OH, OW, Cout, KH,
                                             KW, stride, pad_top, pad_left, act, g_b3_cfg, st);
+  if (g_force_cfg >= 100) return launch_stream_cfg(g_force_cfg, p, st);
   if (g_force_cfg >= 0) return launch_cfg(g_force_cfg, p, st);
   if (ws) {
     const int S = plan_splits(p.M, Cout, p.nsteps);
@@ -603,6 +894,18 @@ static int conv2d_impl(const float* x_d, int N, int H, int W, int Cin, const flo
   // and (b) the per-slab barrier/ds_read overhead: 128x128 tiles with 8 waves (2 accumulators each)
   // for the per-RoI tail (M = 14700), 64x64 tiles with a shallow ring (32 KB LDS -> up to 5
   // workgroups per CU) for the 38x63 / 75x125 / 150x250 feature maps.
+  // Short-K pointwise convolutions (bottleneck conv3: K = Cin <= 256 into a 4x wider output + residual): a tile is only <= 8 slabs
+  // (<= 128 MFMAs per wave), so per-tile launch / prologue / LDS-staged epilogue cost as much as the multiply -> resident
+  // streaming workers with register epilogues (profiles/r02_h_stream_sweep.txt: 64.5 -> 51 us on 9576 x 1024 x 256).
+  if (g_stream && p.nsteps <= 8 && stride == 1 && KH == 1 && KW == 1 && (!residual_d || p.res_stride == 1)) {
+    if (Cout % 128 == 0 && (long long)cdiv(p.M, 64) * (Cout / 128) >= 512) {
+      const int rc = launch_stream_cfg(108, p, st);
+      if (rc != FRCNN_E_UNSUPPORTED) return rc;
+    } else if (Cout == 64 && cdiv(p.M, 128) >= 512) {
+      const int rc = launch_stream_cfg(106, p, st);
+      if (rc != FRCNN_E_UNSUPPORTED) return rc;
+    }
+  }
   const long long big = (long long)cdiv(p.M, 128) * cdiv(Cout, 128);
   if (Cout >= 96 && big >= 384 && p.nsteps >= 8) {
     // a 128x128 tile keeps each SIMD's matrix pipe busy for nsteps * 64 MFMAs * 64 cycles; two workgroups share a CU
@@ -687,7 +990,12 @@ extern "C" int frcnn_gemm_batched_nt(const float* x_d, const float* w_d, float* 
   p.splits = 1; p.kchunk = p.nsteps;
   p.mean_group = 0; p.mean_part = nullptr; p.stagger = 0; p.stagger_slots = 0;
   const long long big = (long long)cdiv(M, 128) * cdiv(N, 128) * G;
+  if (g_force_cfg >= 100) return launch_stream_cfg(g_force_cfg, p, (hipStream_t)stream);
   if (g_force_cfg >= 0) return launch_cfg(g_force_cfg, p, (hipStream_t)stream);
+  if (g_stream && p.nsteps <= 8 && N % 128 == 0 && (long long)cdiv(M, 64) * (N / 128) * G >= 512) {      // short-K batched products
+    const int rc = launch_stream_cfg(108, p, (hipStream_t)stream);
+    if (rc != FRCNN_E_UNSUPPORTED) return rc;
+  }
   return (N >= 96 && big >= 384 && p.nsteps >= 8) ? launch_cfg(N >= 1024 ? 21 : 20, p, (hipStream_t)stream)
                                                  : launch_cfg(N > 32 ? 15 : 4, p, (hipStream_t)stream);
 }
