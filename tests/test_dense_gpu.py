@@ -400,3 +400,76 @@ def test_conv1x1_mean_equals_conv_then_mean(dev, R, Cin, Cout, act, with_res):
     assert np.abs(got - two).max() <= 2e-6 * scale and np.abs(got - ref).max() <= 2e-5 * scale
     again = ops.conv1x1_mean(xd, wd, bd, 49, act, rd).cpu().numpy()
     assert np.array_equal(got, again)                                   # deterministic summation order
+
+
+STREAM_CASES = [
+    # M, Cin, Cout, act, residual: shapes the dispatcher gives to k_gemm_stream (short K, wide output, >= 512 tiles), with an M tail
+    (64 * 530 + 37, 64, 256, 1, True),        # bottleneck conv3 class: 64x128 tiles, last m-tile 37 rows
+    (64 * 300 + 1, 256, 512, 0, False),       # no residual / no activation, 1-row tail
+    (128 * 520 + 90, 128, 64, 2, True),       # Cout = 64 class (128x64 tiles), ReLU6
+]
+
+
+@pytest.mark.parametrize("case", STREAM_CASES, ids=[str(i) for i in range(len(STREAM_CASES))])
+def test_pointwise_conv_streaming_gemm(dev, case):
+    """k_gemm_stream (resident workgroups, register epilogue through range-checked buffer stores) vs float64, and bit-identical to
+    k_conv_igemm's single-tile-wave configuration (same per-element summation order), rows past M untouched."""
+    from frcnn_hip import ops, lib
+    M, Cin, Cout, act, with_res = case
+    rng = np.random.RandomState(M % 1000 + Cout)
+    x = rng.randn(1, 1, M, Cin).astype(np.float32)
+    w = (rng.randn(1, 1, Cin, Cout) / np.sqrt(Cin)).astype(np.float32)
+    b = rng.randn(Cout).astype(np.float32)
+    r = rng.randn(1, 1, M, Cout).astype(np.float32) if with_res else None
+    want = ref_conv(x, w, b, 1, (0, 0, 0, 0), act, r, 1)
+    wp = T(ops.pack_filter_hwio(w), dev)
+    xd, bd, rd = T(x, dev), T(b, dev), (T(r, dev) if with_res else None)
+    guard = torch.full((M + 256, Cout), 7.25, dtype=torch.float32, device=dev)       # rows past M must stay untouched
+    out = guard[:M].view(1, 1, M, Cout)
+    L = lib()
+    try:
+        L.frcnn_set_tuning(6, 1)
+        ops.conv2d(xd, wp, bd, 1, 1, 1, (0, 0, 0, 0), act, rd, 1, out=out)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().copy()
+        assert bool((guard[M:] == 7.25).all()), "store past the last row"
+        L.frcnn_set_tuning(0, 15)                                                    # k_conv_igemm <64,64,32,32> (k split over two accumulators)
+        ref15 = ops.conv2d(xd, wp, bd, 1, 1, 1, (0, 0, 0, 0), act, rd, 1)
+        torch.cuda.synchronize()
+    finally:
+        L.frcnn_set_tuning(0, -1)
+    scale = max(1.0, float(np.abs(want).max()))
+    assert float(np.abs(got - want).max()) <= 2e-5 * scale
+    assert np.array_equal(got, ref15.cpu().numpy())
+
+
+@pytest.mark.parametrize("cfg,base", [(100, 15), (101, 15), (102, 20), (104, 21), (105, 21), (106, 15), (107, 15), (108, 15), (109, 15),
+                                      (110, 20), (111, 20), (112, 15), (114, 15)])
+def test_streaming_gemm_configurations_bit_identical_to_igemm(dev, cfg, base):
+    """every k_gemm_stream instantiation (tile shapes, residual prefetch on/off) against the k_conv_igemm configuration with the
+    same accumulator structure, on a conv with residual + ReLU and on a batched product, both with M tails."""
+    from frcnn_hip import ops, lib
+    rng = np.random.RandomState(cfg)
+    M, Cin, Cout = 128 * 41 + 77, 96, 256
+    x = T(rng.randn(1, 1, M, Cin).astype(np.float32), dev)
+    wp = T((rng.randn(Cout, 1, 1, Cin) / np.sqrt(Cin)).astype(np.float32), dev)
+    b = T(rng.randn(Cout).astype(np.float32), dev)
+    r = T(rng.randn(1, 1, M, Cout).astype(np.float32), dev)
+    G, Mg, N, K = 5, 64 * 9 + 13, 128, 64
+    xg = T(rng.randn(G, Mg, K).astype(np.float32), dev)
+    wg = T(rng.randn(G, N, K).astype(np.float32), dev)
+    L = lib()
+    res = {}
+    try:
+        for c in (cfg, base):
+            L.frcnn_set_tuning(0, c)
+            y = ops.conv2d(x, wp, b, 1, 1, 1, (0, 0, 0, 0), 1, r, 1)
+            yg = ops.gemm_batched_nt(xg, wg, torch.full((G, Mg, N), float("nan"), dtype=torch.float32, device=dev))
+            torch.cuda.synchronize()
+            res[c] = (y.cpu().numpy(), yg.cpu().numpy())
+    finally:
+        L.frcnn_set_tuning(0, -1)
+    assert np.array_equal(res[cfg][0], res[base][0])
+    assert np.array_equal(res[cfg][1], res[base][1])
+    want = torch.einsum("gmk,gnk->gmn", xg.double().cpu(), wg.double().cpu()).numpy()
+    assert float(np.abs(res[cfg][1] - want).max()) <= 2e-5 * max(1.0, float(np.abs(want).max()))
