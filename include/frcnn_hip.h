@@ -365,6 +365,25 @@ int frcnn_conv2d_dgrad_strided(const float* dy_d, int N, int OH, int OW, int Cou
                                int Cin, int stride, int pad_top, int pad_left, float* dx_d, int H, int W,
                                int accumulate, void* stream);
 int frcnn_relu_bwd(float* grad_d, const float* y_d, long long n, void* stream);              /* grad *= (y > 0) */
+int frcnn_relu6_bwd(float* grad_d, const float* y_d, long long n, void* stream);             /* grad *= (0 < y < 6) */
+/* Reverse-sweep pieces of the VGG16 / MobileNet-v1 TRAIN graphs (lib/nets/vgg16.py:26-60, mobilenet_v1.py:114-172):
+ *   frcnn_maxpool_bwd:      gradient of slim.max_pool2d (padding at the bottom / right only): a window's gradient goes to its first
+ *                           maximum in (row, column) order; dx is written, overlapping windows (k > stride) are summed.
+ *   frcnn_dropout:          tf.nn.dropout, y = x / keep_prob * floor(keep_prob + u(seed, i)); the same call on dy is the backward
+ *                           pass (the mask is a counter-based function of (seed, element index), never stored).  In-place allowed.
+ *   frcnn_dwconv3x3_dgrad:  data gradient of frcnn_dwconv3x3_nhwc (w = the forward filter [3][3][C]).
+ *   frcnn_dwconv3x3_wgrad:  filter gradient [3][3][C], optionally times scale[c] (chain rule through a frozen-BN fold); two
+ *                           deterministic stages through a workspace of frcnn_dwconv3x3_wgrad_workspace_bytes bytes.
+ *   frcnn_dwconv3x3_refold: wf[tap][c] = w[tap][c] * scale[c] (forward filter from the master copy after a solver step). */
+int frcnn_maxpool_bwd(const float* x_d, int N, int H, int W, int C, int k, int stride, const float* y_d, const float* dy_d,
+                      int OH, int OW, float* dx_d, void* stream);
+int frcnn_dropout(const float* x_d, long long n, unsigned long long seed, float keep_prob, float* y_d, void* stream);
+int frcnn_dwconv3x3_dgrad(const float* g_d, int N, int OH, int OW, int C, const float* w_d, float* dx_d, int H, int W, int stride,
+                          int pad_top, int pad_left, int accumulate, void* stream);
+size_t frcnn_dwconv3x3_wgrad_workspace_bytes(int N, int OH, int OW, int C);
+int frcnn_dwconv3x3_wgrad(const float* g_d, const float* x_d, int N, int H, int W, int C, int OH, int OW, int stride, int pad_top,
+                          int pad_left, const float* scale_d, float* dw_d, void* ws, size_t ws_bytes, void* stream);
+int frcnn_dwconv3x3_refold(const float* w_d, const float* scale_d, int C, float* wf_d, void* stream);
 int frcnn_add_strided(const float* src_d, int N, int OH, int OW, int C, float* dst_d, int H, int W, int stride,
                       int accumulate, void* stream);                                        /* skip / subsample gradient */
 int frcnn_spatial_mean_bwd(const float* dy_d, int N, int HW, int C, float* dx_d, void* stream);

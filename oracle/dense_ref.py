@@ -185,6 +185,11 @@ class TrainRef(DenseRef):
         t = self._cache[name]
         return t.permute(3, 2, 0, 1) if t.ndim == 4 else t
 
+    def train_tail(self, feat, rois):
+        """RoI pooling + per-RoI tail as differentiable torch ops (resnet: direct 7x7 crop, resnet_v1.py:55-76,115-125)."""
+        pool5 = crop_and_resize_torch(feat, rois, 16.0, 7)
+        return self.run_blocks(pool5, self.blocks[3:]).mean(dim=(2, 3))
+
     def losses(self, image_nhwc, rois, at, pt, sigma_rpn=3.0):
         feat = self.head(image_nhwc)
         s, A = self.scope, self.A
@@ -201,8 +206,7 @@ class TrainRef(DenseRef):
         d = lambda k, src: _t(np.asarray(src[k]), self.dtype)
         rpn_box = sl1(bbox.permute(0, 2, 3, 1), d("rpn_bbox_targets", at), d("rpn_bbox_inside_weights", at),
                       d("rpn_bbox_outside_weights", at), sigma_rpn)
-        pool5 = crop_and_resize_torch(feat, rois, 16.0, 7)
-        fc7 = self.run_blocks(pool5, self.blocks[3:]).mean(dim=(2, 3))
+        fc7 = self.train_tail(feat, rois)
         cls_score = fc7 @ self.w(s + "/cls_score/weights") + self.w(s + "/cls_score/biases")
         bbox_pred = fc7 @ self.w(s + "/bbox_pred/weights") + self.w(s + "/bbox_pred/biases")
         ce = F.cross_entropy(cls_score, torch.from_numpy(np.asarray(pt["labels"]).ravel()).long())
@@ -264,6 +268,54 @@ class MobileNetRef(DenseRef):
 
     def tail(self, pool5_nhwc):
         x = _t(pool5_nhwc, self.dtype).permute(0, 3, 1, 2)
+        for i in (12, 13):
+            x = self.sep(x, i, self.SEP[i - 1][0])
+        return x.mean(dim=(2, 3))
+
+
+class VGG16TrainRef(TrainRef, VGG16Ref):
+    """VGG16 TRAIN graph (vgg16.py:26-60, network.py:141-157): 14x14 crop + 2x2 max, fc6 / fc7 with dropout; the two dropout
+    masks (already divided by keep_prob) are given as constants, like the sampled rois / targets."""
+
+    def __init__(self, variables, num_classes, anchor_scales, anchor_ratios, trainable, masks, dtype=torch.float64):
+        VGG16Ref.__init__(self, variables, num_classes, anchor_scales, anchor_ratios, dtype)
+        self.trainable = trainable
+        self.masks = [_t(m, dtype) for m in masks]
+
+    def train_tail(self, feat, rois):
+        s = self.scope
+        pool5 = F.max_pool2d(crop_and_resize_torch(feat, rois, 16.0, 14), 2, 2)                   # [R,C,7,7]
+        x = pool5.permute(0, 2, 3, 1).reshape(pool5.shape[0], -1)                                  # slim.flatten: (h, w, c)
+        x = F.relu(x @ self.w(s + "/fc6/weights") + self.w(s + "/fc6/biases")) * self.masks[0]
+        return F.relu(x @ self.w(s + "/fc7/weights") + self.w(s + "/fc7/biases")) * self.masks[1]
+
+
+class MobileNetTrainRef(TrainRef, MobileNetRef):
+    """MobileNet-v1 TRAIN graph (mobilenet_v1.py:214-250): frozen batch norm everywhere, layers >= FIXED_LAYERS train their
+    depthwise and pointwise filters."""
+
+    def __init__(self, variables, num_classes, anchor_scales, anchor_ratios, trainable, dtype=torch.float64):
+        MobileNetRef.__init__(self, variables, num_classes, anchor_scales, anchor_ratios, dtype)
+        self.trainable = trainable
+
+    def w_dw(self, scope):
+        name = scope + "/depthwise_weights"
+        if name not in self._cache:
+            t = _t(self.v[name], self.dtype)                                                       # [3,3,C,1]
+            if self.trainable(scope):
+                t.requires_grad_(True)
+            self._cache[name] = t
+        return self._cache[name].permute(2, 3, 0, 1)                                               # [C,1,3,3]
+
+    def sep(self, x, i, stride):
+        dw = "%s/Conv2d_%d_depthwise" % (self.scope, i)
+        x = F.conv2d(F.pad(x, (1, 1, 1, 1)), self.w_dw(dw), stride=stride, groups=x.shape[1])
+        x = self.bn(x, dw, eps=1e-3).clamp(0, 6)
+        pw = "%s/Conv2d_%d_pointwise" % (self.scope, i)
+        return self.bn(F.conv2d(x, self.w(pw + "/weights")), pw, eps=1e-3).clamp(0, 6)
+
+    def train_tail(self, feat, rois):
+        x = F.max_pool2d(crop_and_resize_torch(feat, rois, 16.0, 14), 2, 2)
         for i in (12, 13):
             x = self.sep(x, i, self.SEP[i - 1][0])
         return x.mean(dim=(2, 3))

@@ -84,15 +84,25 @@ def test_device_path_switches_exist_with_documented_defaults():
 
 
 def test_unsupported_modes_and_values_raise_instead_of_being_ignored():
-    """TRAIN mode exists for the ResNet family only; config values the kernels hard-code are refused."""
+    """Every network builds in TEST and TRAIN mode; config values the kernels hard-code are refused."""
     import pytest
     from nets.mobilenet_v1 import mobilenetv1
     from nets.resnet_v1 import resnetv1
     from nets.vgg16 import vgg16
     for net in (mobilenetv1(), vgg16()):
         net.create_architecture("TEST", 21, tag="t")
-        with pytest.raises(NotImplementedError, match="TRAIN mode"):
-            net.create_architecture("TRAIN", 21, tag="t")
+        net.create_architecture("TRAIN", 21, tag="t")
+    old_m = (C.cfg.MOBILENET.REGU_DEPTH, C.cfg.MOBILENET.FIXED_LAYERS)
+    try:
+        C.cfg.MOBILENET.REGU_DEPTH = True
+        with pytest.raises(NotImplementedError, match="REGU_DEPTH"):
+            mobilenetv1().create_architecture("TRAIN", 21, tag="t")
+        mobilenetv1().create_architecture("TEST", 21, tag="t")
+        C.cfg.MOBILENET.REGU_DEPTH, C.cfg.MOBILENET.FIXED_LAYERS = False, 0
+        with pytest.raises(NotImplementedError, match="FIXED_LAYERS"):
+            mobilenetv1().create_architecture("TRAIN", 21, tag="t")
+    finally:
+        C.cfg.MOBILENET.REGU_DEPTH, C.cfg.MOBILENET.FIXED_LAYERS = old_m
     resnetv1(50).create_architecture("TRAIN", 21, tag="t")
     old = (C.cfg.TEST.BBOX_REG, C.cfg.TRAIN.RPN_POSITIVE_WEIGHT, C.cfg.RESNET.MAX_POOL)
     try:
@@ -104,9 +114,8 @@ def test_unsupported_modes_and_values_raise_instead_of_being_ignored():
         with pytest.raises(NotImplementedError, match="RPN_POSITIVE_WEIGHT"):
             resnetv1(50).create_architecture("TRAIN", 21, tag="t")
         C.cfg.TRAIN.RPN_POSITIVE_WEIGHT = -1.0
-        C.cfg.RESNET.MAX_POOL = True
+        C.cfg.RESNET.MAX_POOL = True                       # 14x14 crop + 2x2 max: fused kernel in TEST, two tape records in TRAIN
         resnetv1(50).create_architecture("TEST", 21, tag="t")
-        with pytest.raises(NotImplementedError, match="MAX_POOL"):
-            resnetv1(50).create_architecture("TRAIN", 21, tag="t")
+        resnetv1(50).create_architecture("TRAIN", 21, tag="t")
     finally:
         C.cfg.TEST.BBOX_REG, C.cfg.TRAIN.RPN_POSITIVE_WEIGHT, C.cfg.RESNET.MAX_POOL = old

@@ -296,3 +296,176 @@ def test_snapshot_and_resume_continue_the_same_run(dev, tmp_path):
         assert np.allclose(first, full[:2], rtol=1e-3, atol=0) and np.allclose(rest, full[2:], rtol=5e-2, atol=0), (first + rest, full)
     finally:
         (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.SNAPSHOT_ITERS, cfg.TRAIN.STEPSIZE, cfg.TRAIN.DISPLAY) = old
+
+
+def _train_once(dev, net, tag, batch=64):
+    from frcnn_hip.runtime import Session
+    from frcnn_hip.train import TrainState
+    from model.config import cfg
+    SC, RT = (4, 8, 16), (0.5, 1, 2)
+    sess = Session(device=dev, seed=5)
+    net.create_architecture("TRAIN", 21, tag=tag, anchor_scales=SC, anchor_ratios=RT)
+    sess.init_variables(net.variable_specs())
+    rng = np.random.RandomState(2)
+    H, W = 128, 160
+    image = ((rng.rand(1, H, W, 3) * 255.0).astype(np.float32) - cfg.PIXEL_MEANS.astype(np.float32)) * np.float32(1 / 256.0)
+    gt = np.array([[16, 16, 79, 79, 3], [60, 30, 150, 110, 7], [5, 70, 60, 120, 12]], dtype=np.float32)
+    blobs = dict(data=image, im_info=np.array([H, W, 1.0], dtype=np.float32), gt_boxes=gt)
+    losses = net.train_forward(sess, blobs)
+    ts = TrainState(sess, net, momentum=0.9, weight_decay=1e-4).build()
+    ts.winograd = None
+    ts.backward(net._loss_seeds)
+    torch.cuda.synchronize()
+    return sess, ts, blobs, image, losses, (SC, RT)
+
+
+def _check_param_grads(net, ts, ref, scopes, tol=2e-3):
+    for sc in scopes:
+        scope = net._scope + sc
+        p = ts.params[scope]
+        if getattr(p, "dw", False):
+            want = ref._cache[scope + "/depthwise_weights"].grad.numpy()[:, :, :, 0]       # [3,3,C]
+            got = p.grad_w.cpu().numpy()                                                    # chain rule through the fold already applied
+        else:
+            g = ref._cache[scope + "/weights"].grad.numpy()
+            if g.ndim == 2:
+                g = g[None, None]
+            want = np.transpose(g, (3, 0, 1, 2))
+            got = p.grad_w.cpu().numpy()
+            if p.scale is not None:
+                got = got * p.scale.cpu().numpy()[:, None, None, None]
+        assert np.abs(want).max() > 0, sc
+        err = np.abs(got - want).max() / np.abs(want).max()
+        assert err <= tol, (sc, err)
+        if p.bias is not None:
+            gb = ref._cache[scope + "/biases"].grad.numpy()
+            assert np.abs(p.grad_b.cpu().numpy() - gb).max() <= tol * max(np.abs(gb).max(), 1e-12), sc
+
+
+def test_vgg16_train_step_matches_torch_autograd(dev):
+    """VGG16 TRAIN graph (vgg16.py:26-60): max pools, 14x14 crop + 2x2 max, fc6 / fc7 with dropout -- forward losses and
+    parameter gradients vs torch float64 autograd; the device's dropout masks and sampled rois / targets are the reference's constants."""
+    from dense_ref import VGG16TrainRef
+    from frcnn_hip import ops
+    from model.config import cfg
+    from nets.vgg16 import vgg16
+    old = (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO)
+    cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO = 64, 0.0
+    try:
+        net = vgg16()
+        sess, ts, blobs, image, losses, (SC, RT) = _train_once(dev, net, "train_vgg")
+        pt, at = net._proposal_targets, net._anchor_targets
+        drops = [r for r in net._tape if r["kind"] == "dropout"]
+        assert len(drops) == 2
+        masks = []
+        for r in drops:
+            m = ops.dropout(torch.ones_like(r["x"]), r["seed"], r["keep"]).view(-1, 4096).cpu().numpy()
+            assert set(np.unique(m)) <= {0.0, 2.0} and 0.45 < (m > 0).mean() < 0.55
+            got = r["y"].view(-1, 4096).cpu().numpy()
+            assert np.array_equal(got, r["x"].view(-1, 4096).cpu().numpy() / np.float32(0.5) * (m > 0))
+            masks.append(m)
+        assert not np.array_equal(masks[0], masks[1])
+        ref = VGG16TrainRef(sess.variables, 21, SC, RT, net.trainable_scope, masks)
+        to_np = lambda d_: {k: v.cpu().numpy() for k, v in d_.items()}
+        rl = ref.losses(image, pt["rois"].cpu().numpy(), to_np(at), to_np(pt))
+        for k in ("rpn_cross_entropy", "rpn_loss_box", "cross_entropy", "loss_box"):
+            assert abs(losses[k].item() - rl[k].item()) <= 1e-4 * max(1.0, abs(rl[k].item())), k
+        sum(rl.values()).backward()
+        _check_param_grads(net, ts, ref, ("/cls_score", "/bbox_pred", "/rpn_cls_score", "/rpn_bbox_pred", "/rpn_conv/3x3", "/fc7", "/fc6",
+                                          "/conv5/conv5_3", "/conv5/conv5_1", "/conv4/conv4_3", "/conv4/conv4_1", "/conv3/conv3_2", "/conv3/conv3_1"))
+        assert not any("/conv1/" in s or "/conv2/" in s for s in ts.params)
+        ts.lr = 0.001
+        out = net.train_step(sess, blobs, ts)
+        assert len(out) == 5 and all(np.isfinite(out)) and out[4] > sum(out[:4])
+        net.train_forward(sess, blobs)                                                                      # the forward of the NEXT step
+        assert [r["seed"] for r in net._tape if r["kind"] == "dropout"] != [r["seed"] for r in drops]      # a new mask every step
+    finally:
+        cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO = old
+
+
+def test_mobilenet_train_step_matches_torch_autograd(dev):
+    """MobileNet-v1 TRAIN graph (mobilenet_v1.py:214-250): depthwise / pointwise layers >= FIXED_LAYERS train (frozen BN folded,
+    ReLU6), 14x14 crop + 2x2 max, two per-RoI layers + mean -- losses, pointwise and depthwise filter gradients vs float64 autograd,
+    one solver step on a depthwise filter."""
+    from dense_ref import MobileNetTrainRef
+    from model.config import cfg
+    from nets.mobilenet_v1 import mobilenetv1
+    old = (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO)
+    cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO = 64, 0.0
+    try:
+        net = mobilenetv1()
+        sess, ts, blobs, image, losses, (SC, RT) = _train_once(dev, net, "train_mob")
+        pt, at = net._proposal_targets, net._anchor_targets
+        ref = MobileNetTrainRef(sess.variables, 21, SC, RT, net.trainable_scope)
+        to_np = lambda d_: {k: v.cpu().numpy() for k, v in d_.items()}
+        rl = ref.losses(image, pt["rois"].cpu().numpy(), to_np(at), to_np(pt))
+        for k in ("rpn_cross_entropy", "rpn_loss_box", "cross_entropy", "loss_box"):
+            assert abs(losses[k].item() - rl[k].item()) <= 1e-4 * max(1.0, abs(rl[k].item())), k
+        sum(rl.values()).backward()
+        _check_param_grads(net, ts, ref, ("/cls_score", "/bbox_pred", "/rpn_cls_score", "/rpn_conv/3x3",
+                                          "/Conv2d_13_pointwise", "/Conv2d_13_depthwise", "/Conv2d_12_pointwise", "/Conv2d_12_depthwise",
+                                          "/Conv2d_11_pointwise", "/Conv2d_11_depthwise", "/Conv2d_6_pointwise", "/Conv2d_6_depthwise",
+                                          "/Conv2d_5_pointwise", "/Conv2d_5_depthwise"))
+        fixed = ["/Conv2d_%d_" % i for i in range(0, cfg.MOBILENET.FIXED_LAYERS)]
+        assert not any(f in s for s in ts.params for f in fixed) and net._scope + "/Conv2d_0" not in ts.params
+        # solver step on a depthwise filter: no L2 term (MOBILENET.REGU_DEPTH False), folded copy refreshed
+        p = ts.params[net._scope + "/Conv2d_6_depthwise"]
+        w0, g0 = p.w.cpu().numpy().copy(), p.grad_w.cpu().numpy().copy()
+        q = ts.params[net._scope + "/Conv2d_6_pointwise"]
+        qw0, qg0 = q.w.cpu().numpy().copy(), (q.grad_w * q.scale.view(-1, 1, 1, 1)).cpu().numpy()
+        ts.apply(lr=0.01)
+        w1 = p.w.cpu().numpy()
+        assert np.allclose(w1, w0 - 0.01 * g0, rtol=1e-5, atol=1e-8)
+        assert np.allclose(p.wf.cpu().numpy(), w1 * p.scale.cpu().numpy()[None, None, :], rtol=1e-6, atol=1e-9)
+        assert np.allclose(q.w.cpu().numpy(), qw0 - 0.01 * (qg0 + cfg.MOBILENET.WEIGHT_DECAY * qw0), rtol=1e-5, atol=1e-8)   # backbone coefficient
+        ts.lr = 0.001
+        out = net.train_step(sess, blobs, ts)
+        assert len(out) == 5 and all(np.isfinite(out)) and out[4] > sum(out[:4])
+        exp = ts.export_variables(slots=True)
+        name = net._scope + "/Conv2d_6_depthwise/depthwise_weights"
+        assert exp[name].shape == (3, 3, p.w.shape[-1], 1) and exp[name + "/Momentum"].shape == exp[name].shape
+    finally:
+        cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO = old
+
+
+def test_maxpool_and_depthwise_gradients_vs_torch(dev):
+    """frcnn_maxpool_bwd (2x2/2 'SAME' on odd sizes; 3x3/2 overlapping windows) and the depthwise data / filter gradients
+    (stride 1 and 2) against torch float64 autograd."""
+    from frcnn_hip import ops
+    rng = np.random.RandomState(4)
+    for (H, W, k, s) in ((37, 25, 2, 2), (14, 14, 2, 2), (19, 23, 3, 2)):
+        x = rng.randn(2, H, W, 8).astype(np.float32)
+        x[0, :4, :4] = 0.5                                                        # ties: the first maximum takes the gradient
+        OH, OW = -(-(H - (k - s)) // s) if k > s else -(-H // s), -(-(W - (k - s)) // s) if k > s else -(-W // s)
+        xt = torch.from_numpy(x).double().permute(0, 3, 1, 2).requires_grad_(True)
+        if k == s:
+            yt = torch.nn.functional.max_pool2d(xt, k, s, ceil_mode=True)
+        else:
+            yt = torch.nn.functional.max_pool2d(xt, k, s)
+        OH, OW = yt.shape[2], yt.shape[3]
+        g = rng.randn(2, OH, OW, 8).astype(np.float32)
+        yt.backward(torch.from_numpy(g).double().permute(0, 3, 1, 2))
+        xd = torch.from_numpy(x).to(dev)
+        pad = (0, (OH - 1) * s + k - H, 0, (OW - 1) * s + k - W)
+        yd = ops.maxpool(xd, k, s, pad)
+        assert np.array_equal(yd.cpu().numpy(), yt.detach().permute(0, 2, 3, 1).numpy().astype(np.float32))
+        dx = ops.maxpool_bwd(xd, yd, torch.from_numpy(g).to(dev), k, s, torch.empty_like(xd))
+        assert np.allclose(dx.cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy(), rtol=1e-6, atol=1e-6), (H, W, k, s)
+    for stride in (1, 2):
+        N, H, W, C = 2, 17, 21, 32
+        x = rng.randn(N, H, W, C).astype(np.float32)
+        w = rng.randn(3, 3, C).astype(np.float32)
+        scale = (rng.rand(C) + 0.5).astype(np.float32)
+        xt = torch.from_numpy(x).double().permute(0, 3, 1, 2).requires_grad_(True)
+        wt = torch.from_numpy(w).double().requires_grad_(True)                                      # master filter
+        wf = (wt * torch.from_numpy(scale).double()[None, None, :]).permute(2, 0, 1)[:, None]       # folded, [C,1,3,3]
+        yt = torch.nn.functional.conv2d(torch.nn.functional.pad(xt, (1, 1, 1, 1)), wf, stride=stride, groups=C)
+        g = rng.randn(N, yt.shape[2], yt.shape[3], C).astype(np.float32)
+        yt.backward(torch.from_numpy(g).double().permute(0, 3, 1, 2))
+        gd, xd = torch.from_numpy(g).to(dev), torch.from_numpy(x).to(dev)
+        wfd = torch.from_numpy(w * scale[None, None, :]).to(dev)
+        dx = ops.dwconv3x3_dgrad(gd, wfd, stride, (1, 1, 1, 1), torch.empty_like(xd))
+        assert np.allclose(dx.cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy(), rtol=1e-5, atol=1e-5)
+        dw = ops.dwconv3x3_wgrad(gd, xd, stride, (1, 1, 1, 1), torch.from_numpy(scale).to(dev), torch.empty((3, 3, C), device=dev))
+        want = wt.grad.numpy()
+        assert np.abs(dw.cpu().numpy() - want).max() <= 1e-5 * np.abs(want).max()

@@ -360,3 +360,219 @@ extern "C" int frcnn_sumsq(const float* w_d, long long n, double scale, float* o
   LAUNCH_CHECK();
   return FRCNN_OK;
 }
+
+// =====================================================================================================================
+// Reverse-sweep pieces of the VGG16 and MobileNet-v1 TRAIN graphs (lib/nets/vgg16.py:26-60, mobilenet_v1.py:114-172).
+// All bandwidth-bound, float4 over channels.
+// =====================================================================================================================
+
+// ---- tf.nn.relu6 gradient: grad *= (0 < y < 6) --------------------------------------------------------------------
+__global__ void k_relu6_bwd(float4* __restrict__ g, const float4* __restrict__ y, long long n4) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 a = g[i];
+  const float4 b = y[i];
+  a.x = (b.x > 0.f && b.x < 6.f) ? a.x : 0.f; a.y = (b.y > 0.f && b.y < 6.f) ? a.y : 0.f;
+  a.z = (b.z > 0.f && b.z < 6.f) ? a.z : 0.f; a.w = (b.w > 0.f && b.w < 6.f) ? a.w : 0.f;
+  g[i] = a;
+}
+extern "C" int frcnn_relu6_bwd(float* grad_d, const float* y_d, long long n, void* stream) {
+  if (!grad_d || !y_d || n <= 0 || (n & 3)) return FRCNN_E_ARG;
+  hipLaunchKernelGGL(k_relu6_bwd, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (float4*)grad_d, (const float4*)y_d, n / 4);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// ---- max pool gradient (slim.max_pool2d 'SAME' with bottom/right padding only, vgg16.py:29-41; network.py:156) ---------------
+// Gather form, one thread per input element quad: for every window that covers the element, the window's gradient goes to
+// its FIRST maximum in (row, column) scan order (the arg-max the forward max would report); windows may overlap (k > stride).
+__global__ void k_maxpool_bwd(const float4* __restrict__ x, int N, int H, int W, int C4, int k, int stride, const float4* __restrict__ y,
+                              const float4* __restrict__ dy, int OH, int OW, float4* __restrict__ dx) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long tot = (long long)N * H * W * C4;
+  if (t >= tot) return;
+  const int c4 = (int)(t % C4);
+  long long pix = t / C4;
+  const int iw = (int)(pix % W); pix /= W;
+  const int ih = (int)(pix % H);
+  const int img = (int)(pix / H);
+  const float4 xv = x[t];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int oh_lo = max(0, (ih - k + stride) / stride), oh_hi = min(OH - 1, ih / stride);     // ceil((ih-k+1)/stride) for ih-k+1 > 0
+  const int ow_lo = max(0, (iw - k + stride) / stride), ow_hi = min(OW - 1, iw / stride);
+  for (int oh = oh_lo; oh <= oh_hi; ++oh)
+    for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+      const size_t o = ((size_t)(img * OH + oh) * OW + ow) * C4 + c4;
+      const float4 m = y[o], g = dy[o];
+      bool mx = xv.x == m.x, my = xv.y == m.y, mz = xv.z == m.z, mw = xv.w == m.w;
+      // an earlier element of the same window with the same value takes the gradient instead
+      const int ry = ih - oh * stride, rx = iw - ow * stride;
+      for (int a = 0; a <= ry; ++a)
+        for (int b = 0; b < (a == ry ? rx : k); ++b) {
+          const int jh = oh * stride + a, jw = ow * stride + b;
+          if (jh >= H || jw >= W) continue;
+          const float4 e = x[((size_t)(img * H + jh) * W + jw) * C4 + c4];
+          mx = mx && !(e.x == m.x); my = my && !(e.y == m.y); mz = mz && !(e.z == m.z); mw = mw && !(e.w == m.w);
+        }
+      acc.x += mx ? g.x : 0.f; acc.y += my ? g.y : 0.f; acc.z += mz ? g.z : 0.f; acc.w += mw ? g.w : 0.f;
+    }
+  dx[t] = acc;
+}
+extern "C" int frcnn_maxpool_bwd(const float* x_d, int N, int H, int W, int C, int k, int stride, const float* y_d, const float* dy_d,
+                                 int OH, int OW, float* dx_d, void* stream) {
+  if (!x_d || !y_d || !dy_d || !dx_d || N <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || stride <= 0 || OH <= 0 || OW <= 0) return FRCNN_E_ARG;
+  if (C % 4 || stride > k) return FRCNN_E_UNSUPPORTED;
+  const long long tot = (long long)N * H * W * (C / 4);
+  hipLaunchKernelGGL(k_maxpool_bwd, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x_d, N, H, W, C / 4,
+                     k, stride, (const float4*)y_d, (const float4*)dy_d, OH, OW, (float4*)dx_d);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// ---- dropout (slim.dropout(keep_prob = 0.5, is_training = True), vgg16.py:52-58 = tf.nn.dropout: x / keep_prob * floor(keep_prob + u)) ----
+// u = a counter-based uniform of (seed, element index): the mask is recomputed in the backward pass, never stored.  TF's own
+// random stream is not reproducible outside TF; tests feed the device mask to the float64 reference as a constant.
+__device__ __forceinline__ float dropout_keep(unsigned long long seed, unsigned long long idx, float keep_prob) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1ull);            // splitmix64 finaliser
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  const float u = (float)(z >> 40) * (1.0f / 16777216.0f);                         // [0, 1)
+  return floorf(keep_prob + u);                                                    // 1 with probability keep_prob
+}
+__global__ void k_dropout(const float* __restrict__ x, long long n, unsigned long long seed, float keep_prob, float* __restrict__ y) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = x[i] / keep_prob * dropout_keep(seed, (unsigned long long)i, keep_prob);
+}
+// forward and backward are the same map (y = x * mask / keep_prob, dx = dy * mask / keep_prob); in-place allowed
+extern "C" int frcnn_dropout(const float* x_d, long long n, unsigned long long seed, float keep_prob, float* y_d, void* stream) {
+  if (!x_d || !y_d || n <= 0 || !(keep_prob > 0.f) || keep_prob > 1.f) return FRCNN_E_ARG;
+  hipLaunchKernelGGL(k_dropout, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_d, n, seed, keep_prob, y_d);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// ---- depthwise 3x3 gradients (mobilenet_v1.py:21-49, 146-160) -----------------------------------------------------------------
+// data gradient: dx[n,ih,iw,c] = sum over taps (dy,dx) with oh*s - pt + dy == ih: g[n,oh,ow,c] * w[dy][dx][c]
+__global__ void k_dwconv3x3_dgrad(const float4* __restrict__ g, int N, int OH, int OW, int C4, const float4* __restrict__ w,
+                                  float4* __restrict__ dx, int H, int W, int stride, int pt, int pl, int accumulate) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long tot = (long long)N * H * W * C4;
+  if (t >= tot) return;
+  const int c4 = (int)(t % C4);
+  long long pix = t / C4;
+  const int iw = (int)(pix % W); pix /= W;
+  const int ih = (int)(pix % H);
+  const int img = (int)(pix / H);
+  float4 a = accumulate ? dx[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int dy = 0; dy < 3; ++dy) {
+    const int th = ih + pt - dy;
+    if (th < 0 || th % stride) continue;
+    const int oh = th / stride;
+    if (oh >= OH) continue;
+    for (int dxk = 0; dxk < 3; ++dxk) {
+      const int tw = iw + pl - dxk;
+      if (tw < 0 || tw % stride) continue;
+      const int ow = tw / stride;
+      if (ow >= OW) continue;
+      const float4 v = g[((size_t)(img * OH + oh) * OW + ow) * C4 + c4];
+      const float4 f = w[(dy * 3 + dxk) * C4 + c4];
+      a.x = fmaf(v.x, f.x, a.x); a.y = fmaf(v.y, f.y, a.y); a.z = fmaf(v.z, f.z, a.z); a.w = fmaf(v.w, f.w, a.w);
+    }
+  }
+  dx[t] = a;
+}
+extern "C" int frcnn_dwconv3x3_dgrad(const float* g_d, int N, int OH, int OW, int C, const float* w_d, float* dx_d, int H, int W, int stride,
+                                     int pad_top, int pad_left, int accumulate, void* stream) {
+  if (!g_d || !w_d || !dx_d || N <= 0 || OH <= 0 || OW <= 0 || C <= 0 || H <= 0 || W <= 0 || stride <= 0) return FRCNN_E_ARG;
+  if (C % 4) return FRCNN_E_UNSUPPORTED;
+  const long long tot = (long long)N * H * W * (C / 4);
+  hipLaunchKernelGGL(k_dwconv3x3_dgrad, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)g_d, N, OH, OW,
+                     C / 4, (const float4*)w_d, (float4*)dx_d, H, W, stride, pad_top, pad_left, accumulate);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// filter gradient: dW[tap][c] = scale[c] * sum_{n,oh,ow} g[n,oh,ow,c] * x[n, oh*s-pt+dy, ow*s-pl+dx, c]   (scale: chain rule through
+// the frozen-BN fold, may be null).  Two deterministic stages: workgroup (64-channel group, pixel chunk) -> partial[chunk][9][C],
+// then an in-order sum over the chunks.  256 threads = 16 channel quads x 16 pixel lanes (a wave reads 256-byte runs).
+#define DWG_CHUNK 4096
+__global__ __launch_bounds__(256) void k_dwconv3x3_wgrad(const float4* __restrict__ g, const float4* __restrict__ x, int N, int H, int W,
+                                                         int C4, int OH, int OW, int stride, int pt, int pl, float4* __restrict__ partial) {
+  __shared__ float4 red[16][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c4 = blockIdx.x * 16 + tx;
+  const long long M = (long long)N * OH * OW;
+  const long long m0 = (long long)blockIdx.y * DWG_CHUNK, m1 = min(M, m0 + DWG_CHUNK);
+  float4 acc[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c4 < C4)
+    for (long long m = m0 + ty; m < m1; m += 16) {
+      const int ow = (int)(m % OW), oh = (int)((m / OW) % OH), img = (int)(m / ((long long)OW * OH));
+      const float4 gv = g[(size_t)m * C4 + c4];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int ih = oh * stride - pt + dy;
+#pragma unroll
+        for (int dxk = 0; dxk < 3; ++dxk) {
+          const int iw = ow * stride - pl + dxk;
+          if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+            const float4 v = x[((size_t)(img * H + ih) * W + iw) * C4 + c4];
+            float4& a = acc[dy * 3 + dxk];
+            a.x = fmaf(gv.x, v.x, a.x); a.y = fmaf(gv.y, v.y, a.y); a.z = fmaf(gv.z, v.z, a.z); a.w = fmaf(gv.w, v.w, a.w);
+          }
+        }
+      }
+    }
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    red[ty][tx] = acc[q];
+    __syncthreads();
+    if (ty == 0 && c4 < C4) {
+      float4 s = red[0][tx];
+      for (int r = 1; r < 16; ++r) { const float4 v = red[r][tx]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+      partial[((size_t)blockIdx.y * 9 + q) * C4 + c4] = s;
+    }
+    __syncthreads();
+  }
+}
+__global__ void k_dwconv3x3_wgrad_finish(const float4* __restrict__ partial, int chunks, int C4, const float4* __restrict__ scale,
+                                         float4* __restrict__ dw) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 9 * C4) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = 0; c < chunks; ++c) { const float4 v = partial[(size_t)c * 9 * C4 + t]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+  if (scale) { const float4 k = scale[t % C4]; s.x *= k.x; s.y *= k.y; s.z *= k.z; s.w *= k.w; }
+  dw[t] = s;
+}
+extern "C" size_t frcnn_dwconv3x3_wgrad_workspace_bytes(int N, int OH, int OW, int C) {
+  if (N <= 0 || OH <= 0 || OW <= 0 || C <= 0) return 256;
+  return (size_t)cdiv((long long)N * OH * OW, DWG_CHUNK) * 9 * (size_t)C * sizeof(float);
+}
+extern "C" int frcnn_dwconv3x3_wgrad(const float* g_d, const float* x_d, int N, int H, int W, int C, int OH, int OW, int stride, int pad_top,
+                                     int pad_left, const float* scale_d, float* dw_d, void* ws, size_t ws_bytes, void* stream) {
+  if (!g_d || !x_d || !dw_d || !ws || N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || stride <= 0) return FRCNN_E_ARG;
+  if (C % 4) return FRCNN_E_UNSUPPORTED;
+  if (frcnn_dwconv3x3_wgrad_workspace_bytes(N, OH, OW, C) > ws_bytes) return FRCNN_E_WS;
+  const int chunks = (int)cdiv((long long)N * OH * OW, DWG_CHUNK), C4 = C / 4;
+  hipLaunchKernelGGL(k_dwconv3x3_wgrad, dim3(cdiv(C4, 16), chunks), dim3(256), 0, (hipStream_t)stream, (const float4*)g_d, (const float4*)x_d,
+                     N, H, W, C4, OH, OW, stride, pad_top, pad_left, (float4*)ws);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_dwconv3x3_wgrad_finish, dim3(cdiv(9 * C4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)ws, chunks, C4,
+                     (const float4*)scale_d, (float4*)dw_d);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// forward filter of a depthwise layer from its master copy: wf[tap][c] = w[tap][c] * scale[c] (after the solver step)
+__global__ void k_dw_refold(const float* __restrict__ w, const float* __restrict__ scale, int C, float* __restrict__ wf) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < 9 * C) wf[t] = w[t] * scale[t % C];
+}
+extern "C" int frcnn_dwconv3x3_refold(const float* w_d, const float* scale_d, int C, float* wf_d, void* stream) {
+  if (!w_d || !scale_d || !wf_d || C <= 0) return FRCNN_E_ARG;
+  hipLaunchKernelGGL(k_dw_refold, dim3(cdiv(9 * C, 256)), dim3(256), 0, (hipStream_t)stream, w_d, scale_d, C, wf_d);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}

@@ -6,7 +6,7 @@ library is missing or a call fails, an exception is raised.
 """
 import ctypes
 import os
-from ctypes import c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
+from ctypes import c_double, c_float, c_int, c_longlong, c_size_t, c_ulonglong, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libfrcnn_hip.so")
@@ -104,6 +104,13 @@ SIGNATURES = {
     "frcnn_conv2d_dgrad_strided": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int,
                                            c_int, c_int, _P]),
     "frcnn_relu_bwd": (c_int, [_P, _P, c_longlong, _P]),
+    "frcnn_relu6_bwd": (c_int, [_P, _P, c_longlong, _P]),
+    "frcnn_maxpool_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P]),
+    "frcnn_dropout": (c_int, [_P, c_longlong, c_ulonglong, c_float, _P, _P]),
+    "frcnn_dwconv3x3_dgrad": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "frcnn_dwconv3x3_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "frcnn_dwconv3x3_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
+    "frcnn_dwconv3x3_refold": (c_int, [_P, _P, c_int, _P, _P]),
     "frcnn_add_strided": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "frcnn_spatial_mean_bwd": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "frcnn_colsum": (c_int, [_P, c_int, c_int, _P, _P]),

@@ -658,6 +658,51 @@ def relu_bwd(grad, y):
     return grad
 
 
+def relu6_bwd(grad, y):
+    _chk(grad), _chk(y)
+    call("frcnn_relu6_bwd", _ptr(grad), _ptr(y), grad.numel(), _stream())
+    return grad
+
+
+def maxpool_bwd(x, y, dy, k, stride, dx):
+    """gradient of maxpool(x) (padding bottom / right only) into dx (written)."""
+    _chk(x), _chk(y), _chk(dy), _chk(dx)
+    N, H, W, C = x.shape
+    call("frcnn_maxpool_bwd", _ptr(x), N, H, W, C, int(k), int(stride), _ptr(y), _ptr(dy), y.shape[1], y.shape[2], _ptr(dx), _stream())
+    return dx
+
+
+def dropout(x, seed, keep_prob, out=None):
+    """tf.nn.dropout with a counter-based mask of (seed, element index); the same call on a gradient is the backward pass."""
+    _chk(x)
+    out = torch.empty_like(x) if out is None else out
+    call("frcnn_dropout", _ptr(x), x.numel(), int(seed) & 0xFFFFFFFFFFFFFFFF, float(keep_prob), _ptr(out), _stream())
+    return out
+
+
+def dwconv3x3_dgrad(g, w, stride, pad, dx, accumulate=False):
+    _chk(g), _chk(w), _chk(dx)
+    N, OH, OW, C = g.shape
+    call("frcnn_dwconv3x3_dgrad", _ptr(g), N, OH, OW, C, _ptr(w), _ptr(dx), dx.shape[1], dx.shape[2], int(stride), int(pad[0]), int(pad[2]),
+         1 if accumulate else 0, _stream())
+    return dx
+
+
+def dwconv3x3_wgrad(g, x, stride, pad, scale, dw):
+    _chk(g), _chk(x), _chk(dw)
+    N, OH, OW, C = g.shape
+    ws = workspace(lib().frcnn_dwconv3x3_wgrad_workspace_bytes(N, OH, OW, C), g.device, "dw_wgrad")
+    call("frcnn_dwconv3x3_wgrad", _ptr(g), _ptr(x), N, x.shape[1], x.shape[2], C, OH, OW, int(stride), int(pad[0]), int(pad[2]), _ptr(scale),
+         _ptr(dw), _ptr(ws), ws.numel(), _stream())
+    return dw
+
+
+def dwconv3x3_refold(w, scale, wf):
+    _chk(w), _chk(scale), _chk(wf)
+    call("frcnn_dwconv3x3_refold", _ptr(w), _ptr(scale), w.shape[-1], _ptr(wf), _stream())
+    return wf
+
+
 def add_strided(src, dst, stride, accumulate):
     _chk(src), _chk(dst)
     N, OH, OW, C = src.shape

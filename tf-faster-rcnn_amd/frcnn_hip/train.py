@@ -11,7 +11,7 @@ fold) and the folded copy is refreshed inside the SGD kernel.
 import numpy as np
 import torch
 
-from . import ACT_NONE, ACT_RELU, ops
+from . import ACT_NONE, ACT_RELU, ACT_RELU6, ops
 
 
 class Param(object):
@@ -40,6 +40,24 @@ class Param(object):
         self.grad_b = flat_b
 
 
+class DwParam(object):
+    """One trainable depthwise 3x3 filter (MobileNet): master copy [3,3,C] as in the variable `depthwise_weights` [3,3,C,1], the
+    forward filter is master * scale[c] (frozen-BN fold, refreshed after every solver step); no bias (the BN shift is frozen)."""
+    dw = True
+
+    def __init__(self, scope, wf, scale_np, flat_w, master_np):
+        dev = wf.device
+        self.scope = scope
+        self.wf = wf
+        self.scale = torch.from_numpy(np.ascontiguousarray(scale_np, dtype=np.float32)).to(dev)
+        self.w = torch.from_numpy(np.ascontiguousarray(master_np, dtype=np.float32)).to(dev)
+        ops.dwconv3x3_refold(self.w, self.scale, self.wf)
+        self.K = self.w.numel()
+        self.acc_w = torch.zeros_like(self.w)
+        self.grad_w = flat_w.view(self.w.shape)
+        self.bias = self.acc_b = self.grad_b = None
+
+
 class TrainState(object):
     """Owns the parameters, their momentum buffers and ONE flat gradient buffer (so data-parallel
     training is a single RCCL all-reduce, or a few bucketed ones, over contiguous memory)."""
@@ -55,26 +73,32 @@ class TrainState(object):
     def build(self):
         """Call after one TRAIN forward (which packs every filter and fills net._tape)."""
         sess, net = self.sess, self.net
-        scopes = []
+        scopes = []                                             # (kind, scope) in forward order: the flat buffer follows the tape
         for rec in net._tape:
-            if rec["kind"] == "conv" and net.trainable_scope(rec["scope"]) and rec["scope"] not in scopes:
-                scopes.append(rec["scope"])
+            if rec["kind"] in ("conv", "dwconv") and net.trainable_scope(rec["scope"]) and (rec["kind"], rec["scope"]) not in scopes:
+                scopes.append((rec["kind"], rec["scope"]))
         total = 0
         sizes = []
-        for sc in scopes:
-            info = sess.conv_info[sc]
-            nb = info["b"].numel() if (info["b"] is not None and not info["bn"]) else 0
-            sizes.append((info["w"].numel(), nb))
-            total += info["w"].numel() + nb
+        for kind, sc in scopes:
+            if kind == "dwconv":
+                sizes.append((sess.packed[("dw", sc)][0].numel(), 0))
+            else:
+                info = sess.conv_info[sc]
+                sizes.append((info["w"].numel(), info["b"].numel() if (info["b"] is not None and not info["bn"]) else 0))
+            total += sum(sizes[-1])
         self.flat = torch.zeros((total,), dtype=torch.float32, device=sess.device)
         off = 0
-        for sc, (nw, nb) in zip(scopes, sizes):
-            info = sess.conv_info[sc]
+        for (kind, sc), (nw, nb) in zip(scopes, sizes):
             fw = self.flat[off:off + nw]
             off += nw
             fb = self.flat[off:off + nb] if nb else None
             off += nb
-            self.params[sc] = Param(sc, info["w"], info["b"], info["scale"], nb > 0, fw, fb, sess.variables.get(sc + "/weights"))
+            if kind == "dwconv":
+                scale, _ = sess.fold_bn(sc, net.dw_bn_eps)
+                self.params[sc] = DwParam(sc, sess.packed[("dw", sc)][0], scale, fw, sess.variables[sc + "/depthwise_weights"][:, :, :, 0])
+            else:
+                info = sess.conv_info[sc]
+                self.params[sc] = Param(sc, info["w"], info["b"], info["scale"], nb > 0, fw, fb, sess.variables.get(sc + "/weights"))
         self.reg_scopes = [sc for sc in sess.conv_info]            # slim regularises every conv/fc weight, frozen or not
         return self
 
@@ -116,6 +140,41 @@ class TrainState(object):
                     gx.zero_()
                 ops.crop_and_resize_bwd(gy.view(rec["y"].shape), rec["rois"], rec["stride"], gx)
                 continue
+            if kind == "maxpool":
+                gy = grads.get(rec["y"].data_ptr())
+                x = rec["x"]
+                if gy is None or x.data_ptr() not in needs:
+                    continue
+                gx, had = accumulate_into(x, x.shape, rec["name"] + "/in")
+                assert not had
+                ops.maxpool_bwd(x, rec["y"], gy.view(rec["y"].shape), rec["k"], rec["stride"], gx)
+                continue
+            if kind == "dropout":
+                gy = grads.get(rec["y"].data_ptr())
+                x = rec["x"]
+                if gy is None or x.data_ptr() not in needs:
+                    continue
+                gx, had = accumulate_into(x, x.shape, rec["name"] + "/in")
+                assert not had
+                ops.dropout(gy.view(x.shape), rec["seed"], rec["keep"], out=gx)      # same mask, same 1 / keep_prob
+                continue
+            if kind == "dwconv":
+                y, x, sc = rec["y"], rec["x"], rec["scope"]
+                gy = grads.get(y.data_ptr())
+                if gy is None:
+                    continue
+                gy = gy.view(y.shape)
+                (ops.relu6_bwd if rec["act"] == ACT_RELU6 else ops.relu_bwd)(gy, y)
+                p = self.params.get(sc)
+                if p is not None:
+                    ops.dwconv3x3_wgrad(gy, x, rec["stride"], rec["pad"], p.scale, p.grad_w)
+                    ar = getattr(self, "all_reduce", None)
+                    if ar is not None and getattr(self, "world_size", 1) > 1 and hasattr(ar, "ready"):
+                        ar.ready(self.flat, p.grad_w.data_ptr())
+                if x.data_ptr() in needs:
+                    gx, had = accumulate_into(x, x.shape, sc + "/in")
+                    ops.dwconv3x3_dgrad(gy, sess.packed[("dw", sc)][0], rec["stride"], rec["pad"], gx, accumulate=had)
+                continue
             # ---- convolution record -------------------------------------------------------------------
             y, x, sc = rec["y"], rec["x"], rec["scope"]
             gy = grads.get(y.data_ptr())
@@ -124,6 +183,8 @@ class TrainState(object):
             gy = gy.view(y.shape)
             if rec["act"] == ACT_RELU:
                 ops.relu_bwd(gy, y)
+            elif rec["act"] == ACT_RELU6:
+                ops.relu6_bwd(gy, y)
             res = rec["residual"]
             if res is not None and res.data_ptr() in needs:
                 gr, had = accumulate_into(res, res.shape, sc + "/res")
@@ -190,13 +251,24 @@ class TrainState(object):
         if getattr(self, "_sgd_table", None) is None:
             entries = []
             for p in self.params.values():
-                entries.append((p.w, p.acc_w, p.wf if p.scale is not None else None, p.grad_w, p.scale, p.K, 1.0, self.weight_decay))
+                if getattr(p, "dw", False):          # gradient already carries the BN-fold scale; no L2 term (MOBILENET.REGU_DEPTH False)
+                    entries.append((p.w, p.acc_w, None, p.grad_w, None, p.K, 1.0, 0.0))
+                    continue
+                wd = self._wd(p.scope)
+                entries.append((p.w, p.acc_w, p.wf if p.scale is not None else None, p.grad_w, p.scale, p.K, 1.0, wd))
                 if p.bias is not None:
                     entries.append((p.bias, p.acc_b, None, p.grad_b, None, p.bias.numel(), 2.0 if self.double_bias else 1.0,
-                                    self.weight_decay if self.bias_decay else 0.0))
+                                    wd if self.bias_decay else 0.0))
             self._sgd_count = len(entries)
             self._sgd_table = ops.sgd_desc_table(entries, self.sess.device)
         ops.sgd_momentum_multi(self._sgd_table, self._sgd_count, lr, self.momentum, gs)
+        for p in self.params.values():
+            if getattr(p, "dw", False):
+                ops.dwconv3x3_refold(p.w, p.scale, p.wf)
+
+    def _wd(self, scope):
+        wd = self.net.weight_decay_for(scope) if hasattr(self.net, "weight_decay_for") else None
+        return self.weight_decay if wd is None else wd
 
     # ---- checkpoint view (tf.train.Saver saves the variables AND the optimizer slots `<variable>/Momentum`) ----------
     def _names(self, p):
@@ -208,6 +280,11 @@ class TrainState(object):
         accumulators under `<name>/Momentum` (MomentumOptimizer's slot name)."""
         out = {}
         for p in self.params.values():
+            if getattr(p, "dw", False):
+                name = p.scope + "/depthwise_weights"
+                for suffix, t in (("", p.w),) + ((("/Momentum", p.acc_w),) if slots else ()):
+                    out[name + suffix] = t.detach().cpu().numpy().reshape(self.sess.variables[name].shape).copy()
+                continue
             wname, bname = self._names(p)
             ref = self.sess.variables[wname]
             for suffix, t in (("", p.w),) + ((("/Momentum", p.acc_w),) if slots else ()):
@@ -226,6 +303,10 @@ class TrainState(object):
         """Restore the momentum accumulators written by export_variables(slots=True)."""
         get = reader_or_dict.get_tensor if hasattr(reader_or_dict, "get_tensor") else reader_or_dict.__getitem__
         for p in self.params.values():
+            if getattr(p, "dw", False):
+                acc = np.asarray(get(p.scope + "/depthwise_weights/Momentum"), dtype=np.float32)
+                p.acc_w.copy_(torch.from_numpy(np.ascontiguousarray(acc.reshape(tuple(p.w.shape)))))
+                continue
             wname, bname = self._names(p)
             acc = np.asarray(get(wname + "/Momentum"), dtype=np.float32)
             kh, kw = p.w.shape[1], p.w.shape[2]
@@ -237,21 +318,23 @@ class TrainState(object):
     def regularization_loss(self, out):
         """slim l2_regularizer(WEIGHT_DECAY): wd * sum(w^2)/2 over every conv / fc weight (network.py:315-317), all tensors in
         two launches (the master tensors are static, so the pointer table is built once)."""
-        if getattr(self, "_reg_table", None) is None:
-            tensors = []
+        if getattr(self, "_reg_tables", None) is None:
+            groups = {}                                              # L2 coefficient -> tensors (MobileNet: backbone vs heads)
             for sc in self.reg_scopes:
                 p = self.params.get(sc)
                 if p is not None:
-                    tensors.append(p.w)
-                    continue
-                info = self.sess.conv_info[sc]
-                if "w_master" not in info:
-                    info["w_master"] = info["w"] if info["scale"] is None else \
-                        (info["w"] / torch.from_numpy(info["scale"]).to(info["w"].device).view(-1, 1, 1, 1)).contiguous()
-                tensors.append(info["w_master"])
+                    t = p.w
+                else:
+                    info = self.sess.conv_info[sc]
+                    if "w_master" not in info:
+                        info["w_master"] = info["w"] if info["scale"] is None else \
+                            (info["w"] / torch.from_numpy(info["scale"]).to(info["w"].device).view(-1, 1, 1, 1)).contiguous()
+                    t = info["w_master"]
+                groups.setdefault(self._wd(sc), []).append(t)
             dev = self.sess.device
-            self._reg_keep = tensors
-            self._reg_table = (torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64, device=dev),
-                               torch.tensor([t.numel() for t in tensors], dtype=torch.int64, device=dev))
-        ops.sumsq_multi(self._reg_table[0], self._reg_table[1], 0.5 * self.weight_decay, out, False)
+            self._reg_keep = groups
+            self._reg_tables = [(wd, torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64, device=dev),
+                                 torch.tensor([t.numel() for t in ts], dtype=torch.int64, device=dev)) for wd, ts in groups.items()]
+        for i, (wd, ptrs, sizes) in enumerate(self._reg_tables):
+            ops.sumsq_multi(ptrs, sizes, 0.5 * wd, out, i > 0)
         return out

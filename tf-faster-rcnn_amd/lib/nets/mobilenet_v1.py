@@ -18,6 +18,7 @@ _SEP = [(1, 64), (2, 128), (1, 128), (2, 256), (1, 256), (2, 512), (1, 512), (1,
 
 class mobilenetv1(Network):
     _rgb_first_conv = "/Conv2d_0"
+    dw_bn_eps = BN_EPS
 
     def _fix_one(self, name, value):
         # mobilenet_v1.py:266-278: tf.reverse(Conv2d_0_rgb / (255.0 / 2.0), [2]) -- the released weights expect [-1,1] inputs
@@ -69,7 +70,33 @@ class mobilenetv1(Network):
         OH, OW = ops.conv_out_size(H, 3, stride, 1, 1), ops.conv_out_size(W, 3, stride, 1, 1)
         out = self._sess.buf(self._tag + "/" + dw_scope, (N, OH, OW, C))
         y = self._sess.mark("op:dwconv3x3", 0, lambda: ops.dwconv3x3(x, w, b, stride, pad, ACT_RELU6, out=out), nbytes=4 * (x.numel() + out.numel()))
+        if self._mode == "TRAIN":
+            self._tape.append(dict(kind="dwconv", scope=dw_scope, x=x, y=out, stride=stride, pad=pad, act=ACT_RELU6))
+            if self.trainable_scope(dw_scope) or x.data_ptr() in self._requires_grad:
+                self._requires_grad.add(out.data_ptr())
         return self._conv(y, "%s/Conv2d_%d_pointwise" % (s, i), 1, act=ACT_RELU6, bn_eps=BN_EPS)
+
+    _trainable_on_device = True
+
+    def create_architecture(self, mode, num_classes, tag=None, anchor_scales=(8, 16, 32), anchor_ratios=(0.5, 1, 2)):
+        if mode == "TRAIN":
+            if cfg.MOBILENET.REGU_DEPTH:
+                raise NotImplementedError("MOBILENET.REGU_DEPTH = True (only False is implemented: no L2 term on the depthwise filters)")
+            if cfg.MOBILENET.FIXED_LAYERS < 1:
+                raise NotImplementedError("MOBILENET.FIXED_LAYERS = 0: the channel-folded stem filter has no trainable master copy")
+        return Network.create_architecture(self, mode, num_classes, tag, anchor_scales, anchor_ratios)
+
+    def trainable_scope(self, scope):
+        """mobilenet_v1.py:214-236: layers below cfg.MOBILENET.FIXED_LAYERS are built with is_training=False (trainable=False);
+        batch-norm parameters never train (mobilenet_v1.py:176-183)."""
+        tail = scope[len(self._scope):]
+        if tail.startswith("/Conv2d_"):
+            return int(tail[len("/Conv2d_"):].split("_")[0]) >= cfg.MOBILENET.FIXED_LAYERS
+        return True
+
+    def weight_decay_for(self, scope):
+        # mobilenet_v1.py:186: the backbone's own regulariser coefficient; RPN / heads keep cfg.TRAIN.WEIGHT_DECAY
+        return float(cfg.MOBILENET.WEIGHT_DECAY) if scope[len(self._scope):].startswith("/Conv2d_") else None
 
     def _image_to_head(self, is_training, reuse=None):
         assert (0 <= cfg.MOBILENET.FIXED_LAYERS <= 12)
@@ -86,4 +113,9 @@ class mobilenetv1(Network):
         for i in (12, 13):
             net = self._separable(net, i, _SEP[i - 1][0])
         out = self._sess.buf(self._tag + "/fc7", (net.shape[0], net.shape[-1]))
-        return self._sess.mark("op:spatial_mean", 0, lambda: ops.spatial_mean(net, out=out), nbytes=4 * (net.numel() + out.numel()))
+        res = self._sess.mark("op:spatial_mean", 0, lambda: ops.spatial_mean(net, out=out), nbytes=4 * (net.numel() + out.numel()))
+        if self._mode == "TRAIN":
+            self._tape.append(dict(kind="mean", x=net, y=res, name=self._scope + "/fc7_mean"))
+            if net.data_ptr() in self._requires_grad:
+                self._requires_grad.add(res.data_ptr())
+        return res

@@ -321,9 +321,42 @@ class Network(object):
         return out
 
     def _crop_pool_layer(self, bottom, rois, name):
-        # network.py:141-157: 14x14 crop + 2x2 max pool (fused in the kernel)
-        out = self._sess.buf(self._tag + "/" + name, (rois.shape[0], cfg.POOLING_SIZE, cfg.POOLING_SIZE, bottom.shape[-1]))
-        return self._crop_images(bottom, rois, out, max_pool=True)
+        # network.py:141-157: 14x14 crop + 2x2 max pool (TEST: fused in one kernel)
+        return self._crop_pool(bottom, rois, name, max_pool=True)
+
+    def _crop_pool(self, bottom, rois, name, max_pool):
+        """RoI pooling.  TEST: one kernel (the 2x2 max fused).  TRAIN: crop and max pool are separate tape records so that the
+        reverse sweep routes the gradient through the arg-max and then through the bilinear taps."""
+        P, C = cfg.POOLING_SIZE, bottom.shape[-1]
+        R = rois.shape[0]
+        fs = float(self._feat_stride[0])
+        if self._mode != "TRAIN":
+            return self._crop_images(bottom, rois, self._sess.buf(self._tag + "/" + name, (R, P, P, C)), max_pool=max_pool)
+        pre = 2 * P if max_pool else P
+        crop = self._sess.buf(self._tag + "/" + name + ("/crop" if max_pool else ""), (R, pre, pre, C))
+        self._sess.mark("op:crop_and_resize", 0, lambda: ops.crop_and_resize(bottom, rois, fs, pre, max_pool=False, out=crop),
+                        nbytes=4 * (bottom.numel() + crop.numel()))
+        self._tape.append(dict(kind="crop", feat=bottom, rois=rois, y=crop, stride=fs))
+        if bottom.data_ptr() in self._requires_grad:
+            self._requires_grad.add(crop.data_ptr())
+        return self._max_pool(crop, 2, 2, name) if max_pool else crop
+
+    def _max_pool(self, x, k, stride, name):
+        """slim.max_pool2d(padding='SAME') for k == stride (pads bottom / right only, out = ceil(n / stride)); recorded in TRAIN mode."""
+        N, H, W, C = x.shape
+        OH, OW = (H + stride - 1) // stride, (W + stride - 1) // stride
+        out = self._sess.buf(self._tag + "/" + name, (N, OH, OW, C))
+        pad = (0, (OH - 1) * stride + k - H, 0, (OW - 1) * stride + k - W)
+        self._sess.mark("op:maxpool", 0, lambda: ops.maxpool(x, k, stride, pad, out=out), nbytes=4 * (x.numel() + out.numel()))
+        if self._mode == "TRAIN":
+            self._tape.append(dict(kind="maxpool", x=x, y=out, k=k, stride=stride, name=name))
+            if x.data_ptr() in self._requires_grad:
+                self._requires_grad.add(out.data_ptr())
+        return out
+
+    def weight_decay_for(self, scope):
+        """L2 coefficient of one layer's weights; None = cfg.TRAIN.WEIGHT_DECAY (network.py:303-311 arg_scope)."""
+        return None
 
     def _region_proposal(self, net_conv, is_training, initializer=None):
         A = self._num_anchors
@@ -438,10 +471,7 @@ class Network(object):
         assert tag is not None
         self._check_supported_cfg(mode)
         if mode == "TRAIN" and not self._trainable_on_device:
-            raise NotImplementedError("%s: TRAIN mode is provided for the ResNet family only (no backward for depthwise conv / "
-                                      "crop + 2x2 max pool / dropout); TEST mode works" % type(self).__name__)
-        if mode == "TRAIN" and cfg.RESNET.MAX_POOL:
-            raise NotImplementedError("RESNET.MAX_POOL in TRAIN mode: the 14x14 crop + 2x2 max has no max-routed backward")
+            raise NotImplementedError("%s: no reverse sweep for this network's TRAIN graph; TEST mode works" % type(self).__name__)
         self._tag = tag
         self._num_classes = num_classes
         self._mode = mode

@@ -96,14 +96,7 @@ class resnetv1(Network):
 
     def _crop_pool_layer(self, bottom, rois, name):
         # resnet_v1.py:55-76: direct 7x7 crop unless RESNET.MAX_POOL
-        P = cfg.POOLING_SIZE
-        out = self._sess.buf(self._tag + "/" + name, (rois.shape[0], P, P, bottom.shape[-1]))
-        res = self._crop_images(bottom, rois, out, max_pool=bool(cfg.RESNET.MAX_POOL))
-        if self._mode == "TRAIN":
-            self._tape.append(dict(kind="crop", feat=bottom, rois=rois, y=res, stride=float(self._feat_stride[0])))
-            if bottom.data_ptr() in self._requires_grad:
-                self._requires_grad.add(res.data_ptr())
-        return res
+        return self._crop_pool(bottom, rois, name, max_pool=bool(cfg.RESNET.MAX_POOL))
 
     def _build_base(self):
         # resnet_v1.py:80-86.  The image buffer is [1,H,W,4]: 7x7x3 stem as a channel-folded GEMM.
