@@ -408,7 +408,7 @@ def main():
                 # launched FLOPs over the TIMED region's clock (all chains, non-conv stages included)
                 "frac_timed_region_launched": round(whole_launched / F32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": traffic, "traffic_source": tsrc,
-                "kernel": "k_conv_igemm (f32 MFMA 32x32x2 implicit GEMM, all tile shapes; Winograd GEMMs included)",
+                "kernel": "k_conv_igemm + k_gemm_stream (f32 MFMA 32x32x2 implicit GEMM / streaming GEMM, all tile shapes; Winograd GEMMs included)",
                 "algorithmic_bytes_per_launch": conv[3] // max(conv[2], 1), "launches_per_step": conv[2] // steps_p,
                 "avg_launch_us": round(1000.0 * conv[0] / conv[2], 2), "conv_ms_per_image": round(conv[0] / steps_p / B, 3)}
             # the bandwidth-bound stages (north_star: achieved HBM GB/s): algorithmic bytes / event time of the stage

@@ -13,6 +13,8 @@ shapes = {
  "b1c1x4": ("conv", 150000, 256, 64, False), "b1c3x4": ("conv", 150000, 64, 256, True),
  "w3x4": ("gemm", 36, 640, 256, 256), "w7x4": ("gemm", 121, 1200, 512, 512), "wrpn": ("gemm", 36, 640, 512, 1024),
  "tail": ("conv", 1000, 96, 192, True),
+ "b3c1x1": ("conv", 2394, 1024, 256, False), "b3c3x1": ("conv", 2394, 256, 1024, True), "w3x1": ("gemm", 36, 160, 256, 256),
+ "b2c1x1": ("conv", 9375, 512, 128, False), "b2c3x1": ("conv", 9375, 128, 512, True),
 }
 cfgs = [int(c) for c in sys.argv[1].split(",")]
 only = sys.argv[2].split(",") if len(sys.argv) > 2 else list(shapes)
