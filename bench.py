@@ -203,9 +203,13 @@ def main():
     ap.add_argument("--reference-order", action="store_true",
                     help="keep the reference op order crop -> 1x1 convs at the block4 entry (default: the 1x1 convs run on the "
                          "feature map and their outputs are cropped; same result up to f32 rounding, 64.5 GFLOP less)")
-    ap.add_argument("--mfma", choices=["f32", "bf16x3"], default="f32",
-                    help="f32: v_mfma_f32_32x32x2_f32 (default, the headline).  bf16x3: EXPERIMENTAL exact 3-way bf16 split of both "
-                         "operands, six bf16 MFMAs per f32 product, f32 accumulate (f32-class error, csrc/conv_igemm_b3.hip)")
+    ap.add_argument("--mfma", choices=["x3", "f32", "bf16x3"], default="x3",
+                    help="x3 (default = cfg.HIP.MFMA_X3): the large plain GEMMs (pointwise convolutions, Winograd products, Cout %% 128 == 0) "
+                         "on the bf16 matrix pipe with exactly split f32 operands (csrc/gemm_x3.hip: six bf16 MFMAs per f32 product, f32 "
+                         "accumulate; measured error vs float64 <= the f32 MFMA kernel's), everything else on v_mfma_f32_32x32x2_f32; the "
+                         "all-f32-MFMA variant is then timed in the same run and reported as `f32_mfma_variant`.  f32: every product on "
+                         "v_mfma_f32_32x32x2_f32.  bf16x3: round-1 experiment, every convolution through csrc/conv_igemm_b3.hip")
+    ap.add_argument("--no-f32-variant", action="store_true", help="with --mfma x3: skip the second timed region (all-f32-MFMA variant)")
     ap.add_argument("--winograd-f2", default=None, help="comma list of scope tokens run as F(2x2,3x3) instead of F(4x4,3x3) (default: cfg.HIP)")
     ap.add_argument("--winograd-direct", default=None, help="comma list of scope tokens that keep the direct kernel (default: cfg.HIP)")
     ap.add_argument("--no-stream-gemm", action="store_true", help="A/B knob: frcnn_set_tuning key 6 = 0 (short-K GEMMs on k_conv_igemm instead of k_gemm_stream)")
@@ -240,6 +244,7 @@ def main():
     from frcnn_hip.runtime import Session
     from model.config import cfg
 
+    cfg.HIP.MFMA_X3 = args.mfma == "x3"
     if args.winograd_f2 is not None:
         cfg.HIP.WINOGRAD_F2_SCOPES = tuple(t for t in args.winograd_f2.split(",") if t)
     if args.winograd_direct is not None:
@@ -260,7 +265,9 @@ def main():
     S = max(1, args.streams or c["streams"])
     common = {"metric": METRIC, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
-              "dtype": "f32" if args.mfma == "f32" else "f32 via exact bf16x3 operand split (6 bf16 MFMAs / product, f32 accumulate)"}
+              "dtype": {"f32": "f32", "bf16x3": "f32 via exact bf16x3 operand split (6 bf16 MFMAs / product, f32 accumulate)",
+                        "x3": "f32 (operands, accumulators, results; the large GEMMs form each f32 product from exact 3-way bf16 "
+                              "operand splits on the bf16 matrix pipe -- 6 MFMAs / product, dropped terms <= 2^-23 -- the rest on the f32 MFMA)"}[args.mfma]}
 
     if args.config == "c5":
         elapsed, sess = train_bench(args, c, dev, world, rank, dist)
@@ -320,26 +327,31 @@ def main():
                 parallel.set_count(recs[i], counts[i])
                 parallel.all_gather_records(recs[i], gathered[i])
 
-    if args.no_graph:
-        sess.profile = []                                # forward_device runs eagerly while profile is not None
-    for k in range(max(args.warmup, S)):
-        step(k)
+    def timed_region():
+        """W untimed warm-up steps (first use of a configuration also builds / captures its graphs), then exactly K steps between
+        barrier + synchronize pairs."""
         if args.no_graph:
-            sess.profile = []
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
-        if args.no_graph:
-            sess.profile = []
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+            sess.profile = []                            # forward_device runs eagerly while profile is not None
+        for k in range(max(args.warmup, S)):
+            step(k)
+            if args.no_graph:
+                sess.profile = []
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(k)
+            if args.no_graph:
+                sess.profile = []
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    elapsed = timed_region()
     n_det = int(count_i32[0].item())
     n_rois = int(net._num_rois[0].item())
     flops_per_image = sess.flops_last_forward / B        # launched MFMA FLOPs (Winograd / commuted crop already taken out)
@@ -367,6 +379,15 @@ def main():
                     f.write("%-70s %3d %9.1f %9.3f %8.1f %8.0f\n" % (tag, n, 1000 * ms / n, fl / n / 1e9, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0,
                                                                      nb / (ms * 1e-3) / 1e9 if ms > 0 else 0))
 
+    f32_variant = None
+    if args.mfma == "x3" and world == 1 and not args.no_f32_variant and not args.no_graph:
+        # the same workload with every product on v_mfma_f32_32x32x2_f32, timed in the same run (rank 0, N = 1 like cpu_baseline)
+        cfg.HIP.MFMA_X3 = False
+        e32 = timed_region()
+        cfg.HIP.MFMA_X3 = True
+        f32_variant = {"value": round(args.steps * B / e32, 3), "unit": "images/sec", "ms_per_step": round(1000.0 * e32 / args.steps, 4),
+                       "what": "identical run with cfg.HIP.MFMA_X3 = False (bench.py --mfma f32): all GEMMs on the f32 MFMA"}
+
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -385,7 +406,13 @@ def main():
                          "graph": "reference op order" if args.reference_order else
                                   "block4/unit_1 1x1 convs commuted past the bilinear crop (exact algebra, same outputs to f32 rounding; "
                                   "--reference-order keeps crop -> conv)",
+                         "mfma": {"x3": "cfg.HIP.MFMA_X3: plain GEMMs with Cout % 128 == 0 and >= 150 tiles on v_mfma_f32_32x32x16_bf16 with "
+                                        "exactly split f32 operands (csrc/gemm_x3.hip); the stem, strided / small-Cout convolutions and heads on "
+                                        "v_mfma_f32_32x32x2_f32", "f32": "v_mfma_f32_32x32x2_f32 everywhere",
+                                  "bf16x3": "round-1 experiment (csrc/conv_igemm_b3.hip)"}[args.mfma],
                          "gflop_per_image_launched": round(flops_per_image / 1e9, 2), "gflop_per_image_reference_graph": c["gflop_ref"]}
+        if f32_variant is not None:
+            out["f32_mfma_variant"] = f32_variant
         if conv[2]:
             steps_p = args.profile_steps
             ach = conv[1] / (conv[0] * 1e-3) / 1e12

@@ -473,3 +473,52 @@ def test_streaming_gemm_configurations_bit_identical_to_igemm(dev, cfg, base):
     assert np.array_equal(res[cfg][1], res[base][1])
     want = torch.einsum("gmk,gnk->gmn", xg.double().cpu(), wg.double().cpu()).numpy()
     assert float(np.abs(res[cfg][1] - want).max()) <= 2e-5 * max(1.0, float(np.abs(want).max()))
+
+
+X3_CASES = [
+    # G, M, N, K, residual, act
+    (1, 128 * 40 + 77, 256, 96, True, 1),        # conv3-like with an M tail (8 x 32x64 waves)
+    (1, 128 * 9 + 1, 128, 2048, False, 1),       # long K
+    (5, 64 * 9 + 13, 128, 64, False, 0),         # batched product (Winograd), M tail
+    (1, 128 * 70, 2048, 64, True, 2),            # >= 1024 tiles: 64x64 wave tiles, ReLU6
+]
+
+
+@pytest.mark.parametrize("case", X3_CASES, ids=[str(i) for i in range(len(X3_CASES))])
+def test_gemm_x3_exact_bf16_split_is_f32_class(dev, case):
+    """frcnn_gemm_x3 (cfg.HIP.MFMA_X3): f32 GEMM on the bf16 matrix pipe with exactly split operands.  Against float64 it must be
+    (a) inside the dense-kernel bound 2e-5 of the (pre-activation) output scale and (b) of the f32-MFMA kernels' class on the same
+    data (<= 3x their error; on the path's shapes it is smaller, profiles/r02_m_x3_sweep.txt) -- with bias + residual + activation,
+    mixed operand magnitudes, M tails, batches; rows past M untouched."""
+    from frcnn_hip import ops
+    G, M, N, K, with_res, act = case
+    rng = np.random.RandomState(M % 997 + N + K)
+    x = rng.randn(G, M, K).astype(np.float32)
+    x[:, :, ::7] *= 1e3                                                         # mixed magnitudes: the split must stay exact
+    w = (rng.randn(G, N, K) / np.sqrt(K)).astype(np.float32)
+    b = rng.randn(N).astype(np.float32) if G == 1 else None
+    r = rng.randn(G, M, N).astype(np.float32) if with_res else None
+    want = np.einsum("gmk,gnk->gmn", x.astype(np.float64), w.astype(np.float64))
+    if b is not None: want += b.astype(np.float64)
+    if r is not None: want += r.astype(np.float64)
+    scale = max(1.0, float(np.abs(want).max()))                                 # before the activation clips it
+    if act == 1: want = np.maximum(want, 0)
+    if act == 2: want = np.clip(want, 0, 6)
+    xd, wd = T(x, dev), T(w, dev)
+    bd, rd = (T(b, dev) if b is not None else None), (T(r, dev) if r is not None else None)
+    planes = ops.gemm_x3_planes(wd)
+    guard = torch.full((G, M + 64, N), 7.25, dtype=torch.float32, device=dev)
+    if G == 1:
+        ops.gemm_x3(xd, planes, 1, M, N, K, bd, rd, act, out=guard[0, :M])
+        got = guard[0, :M].cpu().numpy()[None]
+        assert bool((guard[0, M:] == 7.25).all()), "store past the last row"
+        f32 = ops.conv2d(xd.view(1, 1, M, K), wd.view(N, 1, 1, K), bd, 1, 1, 1, (0, 0, 0, 0), act, None if rd is None else rd.view(1, 1, M, N), 1)
+        f32 = f32.view(1, M, N).cpu().numpy()
+    else:
+        out = torch.full((G, M, N), float("nan"), dtype=torch.float32, device=dev)
+        ops.gemm_x3(xd, planes, G, M, N, K, out=out)
+        got = out.cpu().numpy()
+        f32 = ops.gemm_batched_nt(xd, wd, torch.empty((G, M, N), dtype=torch.float32, device=dev)).cpu().numpy()
+    e_x3, e_f32 = float(np.abs(got - want).max()) / scale, float(np.abs(f32 - want).max()) / scale
+    print("x3 %s: max |err| / scale = %.3e (f32-MFMA kernel %.3e)" % (str(case), e_x3, e_f32))
+    assert e_x3 <= 2e-5 and e_x3 <= 3.0 * e_f32 + 1e-7

@@ -9,7 +9,7 @@ Per case (oracle/fullsize.py::run_harness):
   3. RoI tail on the reference's rois: cls_score / bbox_pred / cls_prob vs float64   <= 1e-4
   4. detections vs the oracle on the device's own tensors            (score, class) bit-exact
      detections vs the reference's, per class                        within eps
-for the direct f32-MFMA path AND the shipped Winograd policy, on the bench's damped synthetic weights and on
+for the direct f32-MFMA path, the shipped policy (Winograd + exact bf16x3 GEMMs) AND the shipped Winograd policy on the f32 MFMA only, on the bench's damped synthetic weights and on
 "calibrated" weights whose activations have a trained network's scale (every BN gamma ~ U(0.5, 1.5)).
 The measured maxima are printed (pytest -s) and written to gpurun_out/fullsize_parity.txt."""
 import os
@@ -23,17 +23,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHIPPED = "shipped"
 
 
+SHIPPED_F32 = "shipped_f32"
+
+
 def _shipped_policy():
-    """the cfg.HIP defaults as a harness policy"""
+    """the cfg.HIP defaults as a harness policy (Winograd policy + the exact bf16x3 GEMMs of cfg.HIP.MFMA_X3), and the same
+    Winograd policy with every product on the f32 MFMA (bench.py's `f32_mfma_variant`)"""
     from model.config import cfg
-    fs.POLICIES[SHIPPED] = {k: cfg.HIP[k] for k in ("WINOGRAD", "WINOGRAD_M", "WINOGRAD_F2_SCOPES", "WINOGRAD_DIRECT_SCOPES", "WINOGRAD_7X7", "WINOGRAD_MIN_CIN")}
+    fs.POLICIES[SHIPPED] = {k: cfg.HIP[k] for k in ("WINOGRAD", "WINOGRAD_M", "WINOGRAD_F2_SCOPES", "WINOGRAD_DIRECT_SCOPES", "WINOGRAD_7X7",
+                                                    "WINOGRAD_MIN_CIN", "MFMA_X3")}
+    fs.POLICIES[SHIPPED_F32] = dict(fs.POLICIES[SHIPPED], MFMA_X3=False)
     return SHIPPED
 
 
 @pytest.mark.parametrize("config,weights", [("c2", "damped"), ("c2", "calibrated"), ("c3", "calibrated")])
-@pytest.mark.parametrize("policy", ["direct", SHIPPED])
+@pytest.mark.parametrize("policy", ["direct", SHIPPED, SHIPPED_F32])
 def test_fullsize_parity(dev, config, weights, policy):
-    if policy == SHIPPED:
+    if policy != "direct":
         _shipped_policy()
     rep = fs.run_harness(config, weights, policy, dev)
     line = fs.format_report(rep)

@@ -104,6 +104,10 @@ SIGNATURES = {
     "frcnn_conv2d_dgrad_strided": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int,
                                            c_int, c_int, _P]),
     "frcnn_relu_bwd": (c_int, [_P, _P, c_longlong, _P]),
+    "frcnn_gemm_x3_pack_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "frcnn_gemm_x3_pack": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
+    "frcnn_gemm_x3": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "frcnn_gemm_x3_set_config": (c_int, [c_int]),
     "frcnn_relu6_bwd": (c_int, [_P, _P, c_longlong, _P]),
     "frcnn_maxpool_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P]),
     "frcnn_dropout": (c_int, [_P, c_longlong, c_ulonglong, c_float, _P, _P]),

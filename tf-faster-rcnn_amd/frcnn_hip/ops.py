@@ -658,6 +658,31 @@ def relu_bwd(grad, y):
     return grad
 
 
+_x3_planes = {}
+
+
+def gemm_x3_planes(w):
+    """bf16 planes [G][3][N][K] of a static filter bank w [G,N,K] or [N,...K] (split once, cached by the filter's device address)."""
+    _chk(w)
+    key = (w.data_ptr(), tuple(w.shape))
+    ent = _x3_planes.get(key)
+    if ent is None:
+        G, N, K = (w.shape[0], w.shape[1], w.shape[2]) if w.dim() == 3 else (1, w.shape[0], w[0].numel())
+        planes = torch.empty(lib().frcnn_gemm_x3_pack_bytes(G, N, K), dtype=torch.uint8, device=w.device)
+        call("frcnn_gemm_x3_pack", _ptr(w), G, N, K, _ptr(planes), _stream())
+        ent = (planes, w)                     # keep the filter alive: the key is its address
+        _x3_planes[key] = ent
+    return ent[0]
+
+
+def gemm_x3(x, planes, G, M, N, K, bias=None, residual=None, act=ACT_NONE, out=None):
+    """out[g] = act(x[g] W[g]^T + bias + residual[g]) through frcnn_gemm_x3 (products on the bf16 pipe as exact 3-way splits)."""
+    _chk(x)
+    out = torch.empty((G, M, N) if G > 1 else (M, N), dtype=torch.float32, device=x.device) if out is None else out
+    call("frcnn_gemm_x3", _ptr(x), _ptr(planes), _ptr(bias), _ptr(residual), _ptr(out), int(G), int(M), int(N), int(K), int(act), _stream())
+    return out
+
+
 def relu6_bwd(grad, y):
     _chk(grad), _chk(y)
     call("frcnn_relu6_bwd", _ptr(grad), _ptr(y), grad.numel(), _stream())

@@ -104,6 +104,12 @@ class Network(object):
             v, mm = sess.buf(self._tag + "/wino_v", (G, T, Cin)), sess.buf(self._tag + "/wino_m", (G, T, Cout))
             sess.mark("conv:" + scope, 2 * G * T * Cout * Cin, lambda: ops.conv3x3_winograd(x, u, b, act, out=out, v_buf=v, m_buf=mm),
                       nbytes=4 * (v.numel() + u.numel() + mm.numel()))
+        elif self._x3_eligible(N * OH * OW, Cout, Cin, 1) and k == 1 and stride == 1 and tuple(pad) == (0, 0, 0, 0) and not fold_w \
+                and (residual is None or res_stride == 1):
+            # a plain GEMM with a static filter: exact bf16x3 operand split on the bf16 matrix pipe (cfg.HIP.MFMA_X3)
+            planes, M = ops.gemm_x3_planes(w), N * OH * OW
+            sess.mark("conv:" + scope, flops, lambda: ops.gemm_x3(x, planes, 1, M, Cout, Cin, b, residual, act, out=out),
+                      nbytes=4 * (x.numel() + out.numel() + (out.numel() if residual is not None else 0)) + 6 * w.numel())
         else:
             sess.mark("conv:" + scope, flops,
                       lambda: ops.conv2d(x, w, b, k, k, stride, pad, act, residual, res_stride, fold_w, out=out),
@@ -116,6 +122,12 @@ class Network(object):
             if residual is not None and residual.data_ptr() in self._requires_grad:
                 self._requires_grad.add(out.data_ptr())
         return out
+
+    def _x3_eligible(self, M, N, K, G):
+        """cfg.HIP.MFMA_X3: TEST mode (static filters), N % 128 == 0, K % 32 == 0 and at least 150 tiles of 128 x 128 -- below that
+        the split-K f32 launches are as fast (profiles/r02_m_x3_sweep.txt, single-image rows)."""
+        return (bool(cfg.HIP.MFMA_X3) and self._mode == "TEST" and N % 128 == 0 and K % 32 == 0
+                and ((M + 127) // 128) * (N // 128) * G >= 150 and M * N < (1 << 31))
 
     @staticmethod
     def _winograd_scheme(scope, H, W):
@@ -140,8 +152,13 @@ class Network(object):
         mm = sess.buf(self._tag + "/wino_m", (G, T, Cout))
         out = sess.buf(self._tag + "/" + scope, (N, H, W, Cout))
         sess.mark("op:wino_in", 0, lambda: ops.winograd_input_transform(x, v, m), nbytes=4 * (x.numel() + v.numel()))
-        sess.mark("conv:" + scope, 2 * G * T * Cout * Cin, lambda: ops.gemm_batched_nt(v, u, mm),
-                  nbytes=4 * (v.numel() + u.numel() + mm.numel()))
+        if self._x3_eligible(T, Cout, Cin, G):
+            planes = ops.gemm_x3_planes(u)
+            sess.mark("conv:" + scope, 2 * G * T * Cout * Cin, lambda: ops.gemm_x3(v, planes, G, T, Cout, Cin, out=mm),
+                      nbytes=4 * (v.numel() + mm.numel()) + 6 * u.numel())
+        else:
+            sess.mark("conv:" + scope, 2 * G * T * Cout * Cin, lambda: ops.gemm_batched_nt(v, u, mm),
+                      nbytes=4 * (v.numel() + u.numel() + mm.numel()))
         sess.mark("op:wino_out", 0, lambda: ops.winograd_output_transform(mm, b, act, out, m), nbytes=4 * (mm.numel() + out.numel()))
         return out
 
@@ -518,7 +535,7 @@ class Network(object):
                bool(cfg.USE_GPU_NMS), tuple(image_d.shape), self._im_info[:2], self._mode, cfg.TEST.MODE, self._fuse_tail_entry,
                c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH, cfg.TEST.RPN_TOP_N, cfg.POOLING_SIZE,
                bool(cfg.HIP.WINOGRAD), int(cfg.HIP.WINOGRAD_MIN_CIN), int(cfg.HIP.WINOGRAD_M), tuple(cfg.HIP.WINOGRAD_F2_SCOPES),
-               tuple(cfg.HIP.WINOGRAD_DIRECT_SCOPES), bool(cfg.HIP.WINOGRAD_7X7), bool(cfg.HIP.FUSE_TAIL_MEAN), bool(cfg.HIP.OVERLAP_TAIL_ENTRY), bool(cfg.USE_E2E_TF))
+               tuple(cfg.HIP.WINOGRAD_DIRECT_SCOPES), bool(cfg.HIP.WINOGRAD_7X7), bool(cfg.HIP.FUSE_TAIL_MEAN), bool(cfg.HIP.OVERLAP_TAIL_ENTRY), bool(cfg.HIP.MFMA_X3), bool(cfg.USE_E2E_TF))
         cur = torch.cuda.current_stream(sess.device)
         if not use_graph or sess.profile is not None:
             sess.flops_last_forward = 0
