@@ -31,6 +31,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 METRIC = "images/sec (600×1000) ResNet-101 Faster R-CNN at 1/2/4/8 MI355X"
+X3_PEAK_TFLOPS = 416.7          # 2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per f32 product block (csrc/gemm_x3.hip)
 F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 HBM_PEAK_GBS = 8000.0                 # same guide: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
@@ -358,7 +359,7 @@ def main():
 
     # ---- HIP-event pass: events around every launch group, on the stream the kernels run on, over `profile_steps` further
     #      steps of the same workload (a hipGraph replay cannot carry events, so this pass launches eagerly on ONE chain)
-    per_layer, conv = {}, [0.0, 0, 0, 0]
+    per_layer, conv, x3 = {}, [0.0, 0, 0, 0], [0.0, 0, 0]
     if rank == 0 and args.profile_steps > 0:
         with torch.cuda.stream(run_stream):
             sess.profile = []
@@ -371,6 +372,8 @@ def main():
                 a[0] += ms; a[1] += fl; a[2] += 1; a[3] += nb
                 if tag.startswith("conv:"):
                     conv[0] += ms; conv[1] += fl; conv[2] += 1; conv[3] += nb
+                    if tag.startswith("conv:x3:"):
+                        x3[0] += ms; x3[1] += fl; x3[2] += 1
             sess.profile = None
         if args.layer_report:
             with open(args.layer_report, "w") as f:
@@ -437,6 +440,16 @@ def main():
                 "traffic": traffic, "traffic_source": tsrc,
                 "kernel": "k_conv_igemm + k_gemm_stream (f32 MFMA 32x32x2 implicit GEMM / streaming GEMM, all tile shapes; Winograd GEMMs included)",
                 "algorithmic_bytes_per_launch": conv[3] // max(conv[2], 1), "launches_per_step": conv[2] // steps_p,
+                # pipe mix of the launches behind `achieved` (f32-equivalent FLOPs): the x3 GEMMs issue 6 bf16 MFMAs (8 passes, 16 k) per
+                # product block, ceiling 2500 / 6 = 416.7 TFLOP/s f32-equivalent; the others run on the f32 MFMA (157.3)
+                "x3": None if not x3[2] else {
+                    "share_of_launched_flops": round(x3[1] / conv[1], 4), "launches_per_step": x3[2] // steps_p,
+                    "achieved_f32_equivalent": round(x3[1] / (x3[0] * 1e-3) / 1e12, 2), "bf16_pipe_ceiling_f32_equivalent": X3_PEAK_TFLOPS,
+                    "f32_mfma_launches_achieved": round((conv[1] - x3[1]) / max((conv[0] - x3[0]) * 1e-3, 1e-9) / 1e12, 2),
+                    # time the issued instruction mix needs at both pipes' peaks / time taken
+                    "frac_of_issued_pipe_peaks": round((x3[1] / X3_PEAK_TFLOPS + (conv[1] - x3[1]) / F32_MFMA_PEAK_TFLOPS) / 1e12 / (conv[0] * 1e-3), 4),
+                    "note": "frac / frac_launched above divide f32-equivalent FLOPs by the f32-MFMA peak of the dtype and can exceed what "
+                            "that pipe alone could do; with x3 the run is power-limited (rocm-smi: ~1.92 GHz at ~1 385 W, profiles/r02_o_clock_power.txt)"},
                 "avg_launch_us": round(1000.0 * conv[0] / conv[2], 2), "conv_ms_per_image": round(conv[0] / steps_p / B, 3)}
             # the bandwidth-bound stages (north_star: achieved HBM GB/s): algorithmic bytes / event time of the stage
             stages = {}

@@ -282,7 +282,7 @@ static int launch_x3(const GemmX3Params& q, hipStream_t st) {
     slots = per_cu * cus;
   });
   HIP_TRY(rc0);
-  if (slots < 8) return FRCNN_E_UNSUPPORTED;
+  if (slots < 8 || q.N % BN) return FRCNN_E_UNSUPPORTED;
   GemmX3Params p = q;
   p.mtiles = cdiv(p.M, BM); p.ntiles = p.N / BN; p.nsteps = p.K / 32;
   const long long T = (long long)p.mtiles * p.ntiles * p.batch;
@@ -315,6 +315,9 @@ extern "C" int frcnn_gemm_x3(const float* x_d, const void* planes_d, const float
     case 0: return launch_x3<128, 128, 64, 64>(p, st);
     case 1: return launch_x3<128, 128, 32, 64>(p, st);
     case 2: return launch_x3<64, 128, 32, 64>(p, st);
+    case 3: return launch_x3<128, 128, 32, 128>(p, st);       // 4 waves, each 32 rows x the whole tile width: every A row is split once
+    case 4: return launch_x3<256, 128, 64, 64>(p, st);        // 8 waves, 112 KB: 1 workgroup / CU, W slab shared by twice the rows
+    case 5: return launch_x3<128, 256, 64, 64>(p, st);        // 8 waves, 128 KB
     case 10: return launch_x3<128, 128, 64, 64, 1>(p, st);      // ablations (wrong results by construction)
     case 11: return launch_x3<128, 128, 64, 64, 2>(p, st);
     case 12: return launch_x3<128, 128, 64, 64, 3>(p, st);
