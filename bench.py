@@ -438,7 +438,7 @@ def main():
                 # launched FLOPs over the TIMED region's clock (all chains, non-conv stages included)
                 "frac_timed_region_launched": round(whole_launched / F32_MFMA_PEAK_TFLOPS, 4),
                 "traffic": traffic, "traffic_source": tsrc,
-                "kernel": "k_conv_igemm + k_gemm_stream (f32 MFMA 32x32x2 implicit GEMM / streaming GEMM, all tile shapes; Winograd GEMMs included)",
+                "kernel": "k_gemm_x3 (f32 GEMM on the bf16 pipe, exact operand split) + k_conv_igemm / k_gemm_stream (f32 MFMA 32x32x2), all tile shapes; Winograd GEMMs included",
                 "algorithmic_bytes_per_launch": conv[3] // max(conv[2], 1), "launches_per_step": conv[2] // steps_p,
                 # pipe mix of the launches behind `achieved` (f32-equivalent FLOPs): the x3 GEMMs issue 6 bf16 MFMAs (8 passes, 16 k) per
                 # product block, ceiling 2500 / 6 = 416.7 TFLOP/s f32-equivalent; the others run on the f32 MFMA (157.3)
@@ -449,7 +449,7 @@ def main():
                     # time the issued instruction mix needs at both pipes' peaks / time taken
                     "frac_of_issued_pipe_peaks": round((x3[1] / X3_PEAK_TFLOPS + (conv[1] - x3[1]) / F32_MFMA_PEAK_TFLOPS) / 1e12 / (conv[0] * 1e-3), 4),
                     "note": "frac / frac_launched above divide f32-equivalent FLOPs by the f32-MFMA peak of the dtype and can exceed what "
-                            "that pipe alone could do; with x3 the run is power-limited (rocm-smi: ~1.92 GHz at ~1 385 W, profiles/r02_o_clock_power.txt)"},
+                            "that pipe alone could do; with x3 the run is power-limited (rocm-smi: ~1.90 GHz at ~1 385 W; all-f32-MFMA: 2.36 GHz at ~1 316 W, profiles/r02_p_clock_power.txt)"},
                 "avg_launch_us": round(1000.0 * conv[0] / conv[2], 2), "conv_ms_per_image": round(conv[0] / steps_p / B, 3)}
             # the bandwidth-bound stages (north_star: achieved HBM GB/s): algorithmic bytes / event time of the stage
             stages = {}
