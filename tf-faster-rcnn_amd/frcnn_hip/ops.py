@@ -675,6 +675,14 @@ def gemm_x3_planes(w):
     return ent[0]
 
 
+def gemm_x3_refresh():
+    """Re-split every cached filter into its EXISTING plane buffer (addresses captured by hipGraphs stay valid).  The solver calls
+    this after it has updated filters in place, so a TEST-mode network sharing the session never multiplies by stale planes."""
+    for (ptr, shape), (planes, w) in _x3_planes.items():
+        G, N, K = (w.shape[0], w.shape[1], w.shape[2]) if w.dim() == 3 else (1, w.shape[0], w[0].numel())
+        call("frcnn_gemm_x3_pack", _ptr(w), G, N, K, _ptr(planes), _stream())
+
+
 def gemm_x3(x, planes, G, M, N, K, bias=None, residual=None, act=ACT_NONE, out=None):
     """out[g] = act(x[g] W[g]^T + bias + residual[g]) through frcnn_gemm_x3 (products on the bf16 pipe as exact 3-way splits)."""
     _chk(x)
