@@ -258,7 +258,7 @@ int frcnn_gemm_batched_nt(const float* x_d, const float* w_d, float* y_d, int G,
  * = h + m + l (three bf16 pieces, exact), a product = the six leading cross terms on v_mfma_f32_32x32x16_bf16 with f32 accumulation
  * (dropped terms <= 2^-23 relative).  Results agree with frcnn_gemm_batched_nt / frcnn_conv2d_nhwc to f32 rounding, NOT bit for bit.
  *   frcnn_gemm_x3_pack: W [G][N][K] f32 (device) -> planes [G][3][N][K] bf16 (frcnn_gemm_x3_pack_bytes bytes), once per filter.
- *   frcnn_gemm_x3:      y[g] = act(x[g] W[g]^T + bias + res[g]);  x [G][M][K], res / y [G][M][N];  K % 32 == 0, N % 128 == 0. */
+ *   frcnn_gemm_x3:      y[g] = act(x[g] W[g]^T + bias + res[g]);  x [G][M][K], res / y [G][M][N];  K % 32 == 0, N % 64 == 0. */
 size_t frcnn_gemm_x3_pack_bytes(int G, int N, int K);
 int frcnn_gemm_x3_pack(const float* w_d, int G, int N, int K, void* planes_d, void* stream);
 int frcnn_gemm_x3(const float* x_d, const void* planes_d, const float* bias_d, const float* res_d, float* y_d, int G, int M, int N,

@@ -9,6 +9,7 @@ shapes = {  # name: (G, M, N, K, residual, act)
  "b4c1x4": (1, 58800, 512, 2048, False, 1), "b4c3x4": (1, 58800, 2048, 512, True, 1), "w7x4": (121, 1200, 512, 512, False, 0),
  "wrpn": (36, 640, 512, 1024, False, 0), "b3c1x4": (1, 9576, 256, 1024, False, 1), "b3c3x4": (1, 9576, 1024, 256, True, 1),
  "w3x4": (36, 640, 256, 256, False, 0), "small": (3, 333, 128, 96, True, 2),
+ "b1c1x4": (1, 150000, 64, 256, False, 1), "w1x4": (16, 37500, 64, 64, False, 0), "b1c3x4": (1, 150000, 256, 64, True, 1),
  "b3c1x1": (1, 2394, 256, 1024, False, 1), "b3c3x1": (1, 2394, 1024, 256, True, 1), "w3x1": (36, 160, 256, 256, False, 0), "b4c1x1": (1, 14700, 512, 2048, False, 1),
  "b4c3x1": (1, 14700, 2048, 512, True, 1), "w7x1": (121, 300, 512, 512, False, 0), "b2c3x4": (1, 37500, 512, 128, True, 1), "b2c1x4": (1, 37500, 128, 512, False, 1),
 }

@@ -481,6 +481,8 @@ X3_CASES = [
     (1, 128 * 9 + 1, 128, 2048, False, 1),       # long K
     (5, 64 * 9 + 13, 128, 64, False, 0),         # batched product (Winograd), M tail
     (1, 128 * 70, 2048, 64, True, 2),            # >= 1024 tiles: 64x64 wave tiles, ReLU6
+    (1, 128 * 33 + 5, 64, 256, True, 1),         # Cout = 64 (block1): 128x64 tiles
+    (4, 128 * 3 + 9, 192, 64, False, 0),         # N % 128 != 0, batched
 ]
 
 

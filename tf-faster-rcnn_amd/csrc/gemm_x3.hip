@@ -300,7 +300,7 @@ extern "C" int frcnn_gemm_x3_set_config(int cfg) { g_x3_cfg = cfg; return FRCNN_
 extern "C" int frcnn_gemm_x3(const float* x_d, const void* planes_d, const float* bias_d, const float* res_d, float* y_d, int G, int M,
                              int N, int K, int act, void* stream) {
   if (!x_d || !planes_d || !y_d || G <= 0 || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 2) return FRCNN_E_ARG;
-  if (K % 32 || N % 128 || (long long)M * N >= (1ll << 31) || (long long)M * K >= (1ll << 29) || (long long)N * K >= (1ll << 27))
+  if (K % 32 || N % 64 || (long long)M * N >= (1ll << 31) || (long long)M * K >= (1ll << 29) || (long long)N * K >= (1ll << 27))
     return FRCNN_E_UNSUPPORTED;
   GemmX3Params p;
   p.x = x_d; p.wp = (const unsigned short*)planes_d; p.bias = bias_d; p.res = res_d; p.y = y_d;
@@ -309,8 +309,8 @@ extern "C" int frcnn_gemm_x3(const float* x_d, const void* planes_d, const float
   p.nsteps = p.mtiles = p.ntiles = 0;
   hipStream_t st = (hipStream_t)stream;
   int cfg = g_x3_cfg;
-  if (cfg < 0)       // measured (profiles/r02_m_x3_sweep.txt): 64x64 wave tiles once the launch has >= 1024 tiles, 8 x (32x64) waves below
-    cfg = ((long long)cdiv(M, 128) * (N / 128) * G >= 1024) ? 0 : 1;
+  if (cfg < 0)       // measured (profiles/r02_p_x3_sweep.txt): 64x64 wave tiles once the launch has >= 1024 tiles, 8 x (32x64) waves below;
+    cfg = (N % 128) ? 6 : ((long long)cdiv(M, 128) * (N / 128) * G >= 1024) ? 0 : 1;          // N = 64 (block1): 128x64 tiles
   switch (cfg) {
     case 0: return launch_x3<128, 128, 64, 64>(p, st);
     case 1: return launch_x3<128, 128, 32, 64>(p, st);
@@ -318,6 +318,7 @@ extern "C" int frcnn_gemm_x3(const float* x_d, const void* planes_d, const float
     case 3: return launch_x3<128, 128, 32, 128>(p, st);       // 4 waves, each 32 rows x the whole tile width: every A row is split once
     case 4: return launch_x3<256, 128, 64, 64>(p, st);        // 8 waves, 112 KB: 1 workgroup / CU, W slab shared by twice the rows
     case 5: return launch_x3<128, 256, 64, 64>(p, st);        // 8 waves, 128 KB
+    case 6: return launch_x3<128, 64, 64, 32>(p, st);         // N % 64 == 0: 4 waves of 64x32, 56 KB
     case 10: return launch_x3<128, 128, 64, 64, 1>(p, st);      // ablations (wrong results by construction)
     case 11: return launch_x3<128, 128, 64, 64, 2>(p, st);
     case 12: return launch_x3<128, 128, 64, 64, 3>(p, st);
