@@ -41,7 +41,7 @@ for name in only:
     if run32 is not None:
         run32(); torch.cuda.synchronize()
         err32 = float((out32[:, rows].double() - ref).abs().max()) / scale
-    planes = ops.gemm_x3_planes(w)
+    planes = ops.gemm_x3_pack(w)
     out = torch.full((G, M + 8, N), 7.25, device=dev)
     outv = out[:, :M] if G == 1 else None
     runs = {}

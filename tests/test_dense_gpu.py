@@ -508,7 +508,7 @@ def test_gemm_x3_exact_bf16_split_is_f32_class(dev, case):
     if act == 2: want = np.clip(want, 0, 6)
     xd, wd = T(x, dev), T(w, dev)
     bd, rd = (T(b, dev) if b is not None else None), (T(r, dev) if r is not None else None)
-    planes = ops.gemm_x3_planes(wd)
+    planes = ops.gemm_x3_pack(wd)
     guard = torch.full((G, M + 64, N), 7.25, dtype=torch.float32, device=dev)
     if G == 1:
         ops.gemm_x3(xd, planes, 1, M, N, K, bd, rd, act, out=guard[0, :M])

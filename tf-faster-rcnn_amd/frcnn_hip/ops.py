@@ -658,29 +658,14 @@ def relu_bwd(grad, y):
     return grad
 
 
-_x3_planes = {}
-
-
-def gemm_x3_planes(w):
-    """bf16 planes [G][3][N][K] of a static filter bank w [G,N,K] or [N,...K] (split once, cached by the filter's device address)."""
+def gemm_x3_pack(w, planes=None):
+    """bf16 planes [G][3][N][K] of a filter bank w [G,N,K] or [N,...K] (frcnn_gemm_x3_pack); `planes`: re-split into an existing buffer."""
     _chk(w)
-    key = (w.data_ptr(), tuple(w.shape))
-    ent = _x3_planes.get(key)
-    if ent is None:
-        G, N, K = (w.shape[0], w.shape[1], w.shape[2]) if w.dim() == 3 else (1, w.shape[0], w[0].numel())
+    G, N, K = (w.shape[0], w.shape[1], w.shape[2]) if w.dim() == 3 else (1, w.shape[0], w[0].numel())
+    if planes is None:
         planes = torch.empty(lib().frcnn_gemm_x3_pack_bytes(G, N, K), dtype=torch.uint8, device=w.device)
-        call("frcnn_gemm_x3_pack", _ptr(w), G, N, K, _ptr(planes), _stream())
-        ent = (planes, w)                     # keep the filter alive: the key is its address
-        _x3_planes[key] = ent
-    return ent[0]
-
-
-def gemm_x3_refresh():
-    """Re-split every cached filter into its EXISTING plane buffer (addresses captured by hipGraphs stay valid).  The solver calls
-    this after it has updated filters in place, so a TEST-mode network sharing the session never multiplies by stale planes."""
-    for (ptr, shape), (planes, w) in _x3_planes.items():
-        G, N, K = (w.shape[0], w.shape[1], w.shape[2]) if w.dim() == 3 else (1, w.shape[0], w[0].numel())
-        call("frcnn_gemm_x3_pack", _ptr(w), G, N, K, _ptr(planes), _stream())
+    call("frcnn_gemm_x3_pack", _ptr(w), G, N, K, _ptr(planes), _stream())
+    return planes
 
 
 def gemm_x3(x, planes, G, M, N, K, bias=None, residual=None, act=ACT_NONE, out=None):

@@ -27,6 +27,7 @@ class VariableStore(object):
     def __init__(self, seed=3):
         self.variables = collections.OrderedDict()     # TF name -> numpy (HWIO conv, [in,out] fc)
         self.packed = {}                                # layer key -> device tensors
+        self.x3 = {}                                    # (filter address, shape) -> (bf16 planes, filter): frcnn_gemm_x3 operands
         self.conv_info = {}                             # scope -> {w (folded, device), b, scale (np or None), bn}
         self.graphs = {}
         self.seed = seed
@@ -180,6 +181,22 @@ class Session(VariableStore):
         return t
 
     # ---- profiling hook: HIP events around selected launches, on the stream they run on ----------
+    def x3_planes(self, w):
+        """Pre-split bf16 planes of a static device filter for frcnn_gemm_x3 (cfg.HIP.MFMA_X3), split once and cached for the
+        life of the session (the entry keeps the filter alive: its address is the key)."""
+        key = (w.data_ptr(), tuple(w.shape))
+        ent = self.x3.get(key)
+        if ent is None:
+            ent = (ops.gemm_x3_pack(w), w)
+            self.x3[key] = ent
+        return ent[0]
+
+    def x3_refresh(self):
+        """Re-split every cached filter into its EXISTING plane buffer (addresses captured by hipGraphs stay valid): the solver
+        calls this after updating filters in place, so a TEST-mode network on the same session never multiplies by stale planes."""
+        for planes, w in self.x3.values():
+            ops.gemm_x3_pack(w, planes)
+
     def mark(self, tag, flops, fn, nbytes=0):
         """nbytes: algorithmic HBM bytes of the launch (operands read once + result written once), for the roofline report."""
         self.flops_last_forward += flops
@@ -199,6 +216,7 @@ class Session(VariableStore):
         self.graphs.clear()
         self.buffers.clear()
         self.packed.clear()
+        self.x3.clear()
 
 
 class Timer(object):

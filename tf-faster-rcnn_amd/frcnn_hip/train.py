@@ -265,8 +265,8 @@ class TrainState(object):
         for p in self.params.values():
             if getattr(p, "dw", False):
                 ops.dwconv3x3_refold(p.w, p.scale, p.wf)
-        if ops._x3_planes:                           # a TEST-mode network on the same session (cfg.HIP.MFMA_X3) reads pre-split filters
-            ops.gemm_x3_refresh()
+        if self.sess.x3:                             # a TEST-mode network on the same session (cfg.HIP.MFMA_X3) reads pre-split filters
+            self.sess.x3_refresh()
 
     def _wd(self, scope):
         wd = self.net.weight_decay_for(scope) if hasattr(self.net, "weight_decay_for") else None

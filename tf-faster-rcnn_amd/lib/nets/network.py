@@ -107,7 +107,7 @@ class Network(object):
         elif self._x3_eligible(N * OH * OW, Cout, Cin, 1) and k == 1 and stride == 1 and tuple(pad) == (0, 0, 0, 0) and not fold_w \
                 and (residual is None or res_stride == 1):
             # a plain GEMM with a static filter: exact bf16x3 operand split on the bf16 matrix pipe (cfg.HIP.MFMA_X3)
-            planes, M = ops.gemm_x3_planes(w), N * OH * OW
+            planes, M = sess.x3_planes(w), N * OH * OW
             sess.mark("conv:x3:" + scope, flops, lambda: ops.gemm_x3(x, planes, 1, M, Cout, Cin, b, residual, act, out=out),
                       nbytes=4 * (x.numel() + out.numel() + (out.numel() if residual is not None else 0)) + 6 * w.numel())
         else:
@@ -153,7 +153,7 @@ class Network(object):
         out = sess.buf(self._tag + "/" + scope, (N, H, W, Cout))
         sess.mark("op:wino_in", 0, lambda: ops.winograd_input_transform(x, v, m), nbytes=4 * (x.numel() + v.numel()))
         if self._x3_eligible(T, Cout, Cin, G):
-            planes = ops.gemm_x3_planes(u)
+            planes = sess.x3_planes(u)
             sess.mark("conv:x3:" + scope, 2 * G * T * Cout * Cin, lambda: ops.gemm_x3(v, planes, G, T, Cout, Cin, out=mm),
                       nbytes=4 * (v.numel() + mm.numel()) + 6 * u.numel())
         else:
