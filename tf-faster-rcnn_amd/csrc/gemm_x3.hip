@@ -300,7 +300,7 @@ extern "C" int frcnn_gemm_x3_set_config(int cfg) { g_x3_cfg = cfg; return FRCNN_
 extern "C" int frcnn_gemm_x3(const float* x_d, const void* planes_d, const float* bias_d, const float* res_d, float* y_d, int G, int M,
                              int N, int K, int act, void* stream) {
   if (!x_d || !planes_d || !y_d || G <= 0 || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 2) return FRCNN_E_ARG;
-  if (K % 32 || N % 64 || (long long)M * N >= (1ll << 31) || (long long)M * K >= (1ll << 29) || (long long)N * K >= (1ll << 27))
+  if (K % 32 || N % 64 || (long long)M * N >= (1ll << 31) || (long long)N * K >= (1ll << 28) || K >= (1 << 22))     // 32-bit per-lane byte offsets
     return FRCNN_E_UNSUPPORTED;
   GemmX3Params p;
   p.x = x_d; p.wp = (const unsigned short*)planes_d; p.bias = bias_d; p.res = res_d; p.y = y_d;

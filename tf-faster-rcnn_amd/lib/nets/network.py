@@ -127,7 +127,7 @@ class Network(object):
         """cfg.HIP.MFMA_X3: TEST mode (static filters), N % 64 == 0, K % 32 == 0 and at least 150 tiles of 128 x 128 -- below that
         the split-K f32 launches are as fast (profiles/r02_m_x3_sweep.txt, single-image rows)."""
         return (bool(cfg.HIP.MFMA_X3) and self._mode == "TEST" and N % 64 == 0 and K % 32 == 0
-                and ((M + 127) // 128) * ((N + 127) // 128) * G >= 150 and M * N < (1 << 31))
+                and ((M + 127) // 128) * ((N + 127) // 128) * G >= 150 and M * N < (1 << 31) and N * K < (1 << 28))
 
     @staticmethod
     def _winograd_scheme(scope, H, W):
