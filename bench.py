@@ -210,6 +210,8 @@ def main():
                          "accumulate; measured error vs float64 <= the f32 MFMA kernel's), everything else on v_mfma_f32_32x32x2_f32; the "
                          "all-f32-MFMA variant is then timed in the same run and reported as `f32_mfma_variant`.  f32: every product on "
                          "v_mfma_f32_32x32x2_f32.  bf16x3: round-1 experiment, every convolution through csrc/conv_igemm_b3.hip")
+    ap.add_argument("--x3-terms", type=int, choices=[6, 9], default=6, help="with --mfma x3: 6 = the three cross terms below 2^-23 are dropped "
+                    "(default), 9 = all nine cross terms, every f32 product exact (frcnn_gemm_x3_set_terms)")
     ap.add_argument("--no-f32-variant", action="store_true", help="with --mfma x3: skip the second timed region (all-f32-MFMA variant)")
     ap.add_argument("--winograd-f2", default=None, help="comma list of scope tokens run as F(2x2,3x3) instead of F(4x4,3x3) (default: cfg.HIP)")
     ap.add_argument("--winograd-direct", default=None, help="comma list of scope tokens that keep the direct kernel (default: cfg.HIP)")
@@ -242,6 +244,7 @@ def main():
     frcnn_hip.lib()
     if args.mfma == "bf16x3":
         frcnn_hip.lib().frcnn_set_tuning(2, 1)
+    frcnn_hip.lib().frcnn_gemm_x3_set_terms(args.x3_terms)
     from frcnn_hip.runtime import Session
     from model.config import cfg
 

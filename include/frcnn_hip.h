@@ -263,6 +263,7 @@ size_t frcnn_gemm_x3_pack_bytes(int G, int N, int K);
 int frcnn_gemm_x3_pack(const float* w_d, int G, int N, int K, void* planes_d, void* stream);
 int frcnn_gemm_x3(const float* x_d, const void* planes_d, const float* bias_d, const float* res_d, float* y_d, int G, int M, int N,
                   int K, int act, void* stream);
+int frcnn_gemm_x3_set_terms(int terms);         /* 6 (default): cross terms am*wl, al*wm, al*wl dropped (<= 2^-23 relative); 9: all nine -> every f32 product exact */
 int frcnn_gemm_x3_set_config(int cfg);          /* A/B runs: -1 = by shape (default), 0 = 128x128 tiles / 64x64 waves, 1 = 128x128 / 32x64, 2 = 64x128 / 32x64 */
 /* Winograd F(m x m, 3x3), m = 2 or 4, for stride-1 pad-1 3x3 convolutions (exact algebra, f32): filter transform on the
  * host (U [(m+2)^2][Cout][Cin], optional folded BN scale), input transform V [(m+2)^2][T][C] with

@@ -64,7 +64,8 @@ __device__ __forceinline__ void x3_split8(const float4 a, const float4 b, bf16x8
   l = __builtin_bit_cast(bf16x8, make_uint4(ll[0], ll[1], ll[2], ll[3]));
 }
 
-template <int BM, int BN, int WM, int WN, int ABL = 0>       // ABL: compile-time ablations for measurements only (1: no operand split, 2: no slab loads after the first)
+template <int BM, int BN, int WM, int WN, int ABL = 0, int TERMS = 6>   // ABL: compile-time ablations for measurements only (1: no operand split, 2: no slab
+                                                                     // loads after the first); TERMS = 9: also am*wl, al*wm, al*wl -> every product exact
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_waves_per_eu(2))) void k_gemm_x3(const GemmX3Params p) {
   constexpr int NW = (BM / WM) * (BN / WN);
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -178,6 +179,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
           acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], acs[i][j], 0, 0, 0);
           acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acs[i][j], 0, 0, 0);
           acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acs[i][j], 0, 0, 0);
+          if (TERMS == 9) {
+            acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bl[j], acs[i][j], 0, 0, 0);
+            acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bm[j], acs[i][j], 0, 0, 0);
+            acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bl[j], acs[i][j], 0, 0, 0);
+          }
         }
     }
     advance_k();
@@ -265,11 +271,11 @@ extern "C" int frcnn_gemm_x3_pack(const float* w_d, int G, int N, int K, void* p
   return FRCNN_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int ABL = 0>
+template <int BM, int BN, int WM, int WN, int ABL = 0, int TERMS = 6>
 static int launch_x3(const GemmX3Params& q, hipStream_t st) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   constexpr size_t lds = 2 * (size_t)(BM * 128 + 3 * BN * 64);
-  auto kern = k_gemm_x3<BM, BN, WM, WN, ABL>;
+  auto kern = k_gemm_x3<BM, BN, WM, WN, ABL, TERMS>;
   static std::once_flag once;
   static hipError_t rc0 = hipSuccess;
   static int slots = 0;
@@ -294,6 +300,12 @@ static int launch_x3(const GemmX3Params& q, hipStream_t st) {
 }
 
 static int g_x3_cfg = -1;                   // -1: by shape
+static int g_x3_terms = 6;                  // 6: dropped cross terms <= 2^-23 relative; 9: every product exact
+extern "C" int frcnn_gemm_x3_set_terms(int terms) {
+  if (terms != 6 && terms != 9) return FRCNN_E_ARG;
+  g_x3_terms = terms;
+  return FRCNN_OK;
+}
 extern "C" int frcnn_gemm_x3_set_config(int cfg) { g_x3_cfg = cfg; return FRCNN_OK; }
 
 // y[g] = act(x[g] W[g]^T + bias + res[g]) for g < G; x [G][M][K] f32, planes = frcnn_gemm_x3_pack(W [G][N][K]); res / y [G][M][N].
@@ -311,6 +323,14 @@ extern "C" int frcnn_gemm_x3(const float* x_d, const void* planes_d, const float
   int cfg = g_x3_cfg;
   if (cfg < 0)       // measured (profiles/r02_p_x3_sweep.txt): 64x64 wave tiles once the launch has >= 1024 tiles, 8 x (32x64) waves below;
     cfg = (N % 128) ? 6 : ((long long)cdiv(M, 128) * (N / 128) * G >= 1024) ? 0 : 1;          // N = 64 (block1): 128x64 tiles
+  if (g_x3_terms == 9) {
+    switch (cfg) {
+      case 0: return launch_x3<128, 128, 64, 64, 0, 9>(p, st);
+      case 1: return launch_x3<128, 128, 32, 64, 0, 9>(p, st);
+      case 6: return launch_x3<128, 64, 64, 32, 0, 9>(p, st);
+      default: return FRCNN_E_ARG;
+    }
+  }
   switch (cfg) {
     case 0: return launch_x3<128, 128, 64, 64>(p, st);
     case 1: return launch_x3<128, 128, 32, 64>(p, st);
