@@ -212,6 +212,7 @@ def main():
                          "v_mfma_f32_32x32x2_f32.  bf16x3: round-1 experiment, every convolution through csrc/conv_igemm_b3.hip")
     ap.add_argument("--x3-terms", type=int, choices=[6, 9], default=6, help="with --mfma x3: 6 = the three cross terms below 2^-23 are dropped "
                     "(default), 9 = all nine cross terms, every f32 product exact (frcnn_gemm_x3_set_terms)")
+    ap.add_argument("--x3-config", type=int, default=-1, help="A/B knob: frcnn_gemm_x3_set_config (-1 = by shape)")
     ap.add_argument("--no-f32-variant", action="store_true", help="with --mfma x3: skip the second timed region (all-f32-MFMA variant)")
     ap.add_argument("--winograd-f2", default=None, help="comma list of scope tokens run as F(2x2,3x3) instead of F(4x4,3x3) (default: cfg.HIP)")
     ap.add_argument("--winograd-direct", default=None, help="comma list of scope tokens that keep the direct kernel (default: cfg.HIP)")
@@ -245,6 +246,7 @@ def main():
     if args.mfma == "bf16x3":
         frcnn_hip.lib().frcnn_set_tuning(2, 1)
     frcnn_hip.lib().frcnn_gemm_x3_set_terms(args.x3_terms)
+    frcnn_hip.lib().frcnn_gemm_x3_set_config(args.x3_config)
     from frcnn_hip.runtime import Session
     from model.config import cfg
 

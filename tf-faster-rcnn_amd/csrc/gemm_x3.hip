@@ -321,8 +321,11 @@ extern "C" int frcnn_gemm_x3(const float* x_d, const void* planes_d, const float
   p.nsteps = p.mtiles = p.ntiles = 0;
   hipStream_t st = (hipStream_t)stream;
   int cfg = g_x3_cfg;
-  if (cfg < 0)       // measured (profiles/r02_p_x3_sweep.txt): 64x64 wave tiles once the launch has >= 1024 tiles, 8 x (32x64) waves below;
-    cfg = (N % 128) ? 6 : ((long long)cdiv(M, 128) * (N / 128) * G >= 1024) ? 0 : 1;          // N = 64 (block1): 128x64 tiles
+  if (cfg >= 0 && cfg < 10 && (N % 128) && cfg != 6) cfg = -1;       // a forced A/B configuration that cannot tile this N: by shape
+  if (cfg < 0)       // 64x64 wave tiles (fewest LDS reads and operand splits per MFMA) from 256 tiles up: alone, a 150..1000-tile launch is
+                     // 5-10 % faster with 8 x (32x64) waves (profiles/r02_p_x3_sweep.txt), but in the power-limited pipeline the 64x64
+                     // tiles win (profiles/r02_t_x3_config_in_pipeline.txt: 427 vs 424 images/s); N = 64 (block1): 128x64 tiles
+    cfg = (N % 128) ? 6 : ((long long)cdiv(M, 128) * (N / 128) * G >= 256) ? 0 : 1;
   if (g_x3_terms == 9) {
     switch (cfg) {
       case 0: return launch_x3<128, 128, 64, 64, 0, 9>(p, st);
