@@ -210,7 +210,7 @@ def main():
                          "accumulate; measured error vs float64 <= the f32 MFMA kernel's), everything else on v_mfma_f32_32x32x2_f32; the "
                          "all-f32-MFMA variant is then timed in the same run and reported as `f32_mfma_variant`.  f32: every product on "
                          "v_mfma_f32_32x32x2_f32.  bf16x3: round-1 experiment, every convolution through csrc/conv_igemm_b3.hip")
-    ap.add_argument("--x3-terms", type=int, choices=[6, 9], default=6, help="with --mfma x3: 6 = the three cross terms below 2^-23 are dropped "
+    ap.add_argument("--x3-terms", type=int, choices=[6, 9], default=6, help="with --mfma x3: 6 = the three cross terms below 2^-24 are dropped "
                     "(default), 9 = all nine cross terms, every f32 product exact (frcnn_gemm_x3_set_terms)")
     ap.add_argument("--x3-config", type=int, default=-1, help="A/B knob: frcnn_gemm_x3_set_config (-1 = by shape)")
     ap.add_argument("--no-f32-variant", action="store_true", help="with --mfma x3: skip the second timed region (all-f32-MFMA variant)")
@@ -273,7 +273,7 @@ def main():
               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
               "dtype": {"f32": "f32", "bf16x3": "f32 via exact bf16x3 operand split (6 bf16 MFMAs / product, f32 accumulate)",
                         "x3": "f32 (operands, accumulators, results; the large GEMMs form each f32 product from exact 3-way bf16 "
-                              "operand splits on the bf16 matrix pipe -- 6 MFMAs / product, dropped terms <= 2^-23 -- the rest on the f32 MFMA)"}[args.mfma]}
+                              "operand splits on the bf16 matrix pipe -- 6 MFMAs / product, dropped terms <= 2^-24 -- the rest on the f32 MFMA)"}[args.mfma]}
 
     if args.config == "c5":
         elapsed, sess = train_bench(args, c, dev, world, rank, dist)

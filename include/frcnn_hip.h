@@ -256,14 +256,14 @@ int frcnn_prep_image(const void* src_d, int src_is_float, int h, int w, const do
 int frcnn_gemm_batched_nt(const float* x_d, const float* w_d, float* y_d, int G, int M, int N, int K, void* stream);
 /* f32 "NT" GEMM on the bf16 matrix pipe with exactly split operands (csrc/gemm_x3.hip; opt-in, cfg.HIP.MFMA_X3): every f32 value
  * = h + m + l (three bf16 pieces, exact), a product = the six leading cross terms on v_mfma_f32_32x32x16_bf16 with f32 accumulation
- * (dropped terms <= 2^-23 relative).  Results agree with frcnn_gemm_batched_nt / frcnn_conv2d_nhwc to f32 rounding, NOT bit for bit.
+ * (dropped terms <= 2^-24 relative).  Results agree with frcnn_gemm_batched_nt / frcnn_conv2d_nhwc to f32 rounding, NOT bit for bit.
  *   frcnn_gemm_x3_pack: W [G][N][K] f32 (device) -> planes [G][3][N][K] bf16 (frcnn_gemm_x3_pack_bytes bytes), once per filter.
  *   frcnn_gemm_x3:      y[g] = act(x[g] W[g]^T + bias + res[g]);  x [G][M][K], res / y [G][M][N];  K % 32 == 0, N % 64 == 0. */
 size_t frcnn_gemm_x3_pack_bytes(int G, int N, int K);
 int frcnn_gemm_x3_pack(const float* w_d, int G, int N, int K, void* planes_d, void* stream);
 int frcnn_gemm_x3(const float* x_d, const void* planes_d, const float* bias_d, const float* res_d, float* y_d, int G, int M, int N,
                   int K, int act, void* stream);
-int frcnn_gemm_x3_set_terms(int terms);         /* 6 (default): cross terms am*wl, al*wm, al*wl dropped (<= 2^-23 relative); 9: all nine -> every f32 product exact */
+int frcnn_gemm_x3_set_terms(int terms);         /* 6 (default): cross terms am*wl, al*wm, al*wl dropped (<= 2^-24 relative); 9: all nine -> every f32 product exact */
 int frcnn_gemm_x3_set_config(int cfg);          /* A/B runs: -1 = by shape (default), 0 = 128x128 tiles / 64x64 waves, 1 = 128x128 / 32x64, 2 = 64x128 / 32x64 */
 /* Winograd F(m x m, 3x3), m = 2 or 4, for stride-1 pad-1 3x3 convolutions (exact algebra, f32): filter transform on the
  * host (U [(m+2)^2][Cout][Cin], optional folded BN scale), input transform V [(m+2)^2][T][C] with

@@ -1,8 +1,8 @@
 // f32 "NT" GEMM on the bf16 matrix pipe with EXACTLY split operands ("x3"):  Y[m][n] = act(sum_k A[m][k] * W[n][k] + bias + res).
 //
-// Every f32 value is split by truncation into three bf16 pieces, x = h + m + l (8 + 8 + 8 significand bits, exact), and a product
-// a*w is evaluated as the six leading cross terms  ah*wh + (ah*wm + am*wh) + (ah*wl + al*wh + am*wm)  on
-// v_mfma_f32_32x32x16_bf16 with f32 accumulation; the three dropped terms are <= 2^-23 |a*w|, the size of an f32 product rounding.
+// Every f32 value is split into three bf16 pieces rounded to nearest, x = h + m + l exactly (|m| <= 2^-8 |x|, |l| <= 2^-17 |x|), and a
+// product a*w is evaluated as the six leading cross terms  ah*wh + (ah*wm + am*wh) + (ah*wl + al*wh + am*wm)  on
+// v_mfma_f32_32x32x16_bf16 with f32 accumulation; the three dropped terms are <= 2^-24 |a*w|, the size of ONE f32 rounding of the product.
 // The leading term and the five small terms go to separate accumulators.  Six bf16 MFMAs (8 passes, 16 k) replace eight f32 MFMAs
 // (16 passes, 2 k each): 192 instead of 512 matrix-pipe cycles per 16 k.  NOT the f32 MFMA: results agree with k_conv_igemm to
 // f32 rounding, not bit for bit -- opt-in (cfg.HIP.MFMA_X3 / bench.py --mfma x3), labelled wherever a number is reported.
@@ -45,23 +45,20 @@ __device__ __forceinline__ void x3_glds16(const void* gsrc, unsigned lds_base) {
       : "memory");
 }
 
-// exact truncation split of 8 consecutive k values (two float4) into three bf16x8 operands
+// exact split of 8 consecutive k values (two float4) into three bf16x8 operands, every piece rounded to nearest-even
+// (v_cvt_pk_bf16_f32): h = bf16(x), m = bf16(x - h), l = x - h - m.  Both subtractions are exact in f32 and l has at most 8
+// significant bits left, so h + m + l == x; |m| <= 2^-8 |x|, |l| <= 2^-17 |x|, errors of either sign (truncation would bias every
+// product towards zero and is 8x looser: tests/test_x3_math_cpu.py).
 __device__ __forceinline__ void x3_split8(const float4 a, const float4 b, bf16x8& h, bf16x8& m, bf16x8& l) {
   const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-  u32 hh[4], mm[4], ll[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const u32 x0 = __float_as_uint(v[2 * q]), x1 = __float_as_uint(v[2 * q + 1]);
-    hh[q] = __builtin_amdgcn_perm(x1, x0, 0x07060302);
-    const float r0 = v[2 * q] - __uint_as_float(x0 & 0xffff0000u), r1 = v[2 * q + 1] - __uint_as_float(x1 & 0xffff0000u);
-    const u32 y0 = __float_as_uint(r0), y1 = __float_as_uint(r1);
-    mm[q] = __builtin_amdgcn_perm(y1, y0, 0x07060302);
-    const float s0 = r0 - __uint_as_float(y0 & 0xffff0000u), s1 = r1 - __uint_as_float(y1 & 0xffff0000u);
-    ll[q] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302);
+  for (int q = 0; q < 8; ++q) {
+    const __bf16 hq = (__bf16)v[q];
+    const float r = v[q] - (float)hq;
+    const __bf16 mq = (__bf16)r;
+    const float s = r - (float)mq;
+    h[q] = hq; m[q] = mq; l[q] = (__bf16)s;
   }
-  h = __builtin_bit_cast(bf16x8, make_uint4(hh[0], hh[1], hh[2], hh[3]));
-  m = __builtin_bit_cast(bf16x8, make_uint4(mm[0], mm[1], mm[2], mm[3]));
-  l = __builtin_bit_cast(bf16x8, make_uint4(ll[0], ll[1], ll[2], ll[3]));
 }
 
 template <int BM, int BN, int WM, int WN, int ABL = 0, int TERMS = 6>   // ABL: compile-time ablations for measurements only (1: no operand split, 2: no slab
@@ -244,18 +241,18 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// W [G][N][K] f32 -> planes [G][3][N][K] bf16 (h, m, l by truncation): once per filter
+// W [G][N][K] f32 -> planes [G][3][N][K] bf16 (h, m, l rounded to nearest): once per filter
 __global__ void k_x3_pack(const float* __restrict__ w, long long nk, int G, unsigned short* __restrict__ out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nk * G) return;
   const long long g = i / nk, e = i - g * nk;
   const float x = w[i];
-  const u32 xb = __float_as_uint(x);
-  const float r = x - __uint_as_float(xb & 0xffff0000u);
-  const u32 rb = __float_as_uint(r);
-  const float s = r - __uint_as_float(rb & 0xffff0000u);
+  const __bf16 h = (__bf16)x;                      // round to nearest-even, like x3_split8
+  const float r = x - (float)h;
+  const __bf16 m = (__bf16)r;
+  const __bf16 l = (__bf16)(r - (float)m);
   unsigned short* o = out + (size_t)g * 3 * nk + e;
-  o[0] = (unsigned short)(xb >> 16); o[nk] = (unsigned short)(rb >> 16); o[2 * nk] = (unsigned short)(__float_as_uint(s) >> 16);
+  o[0] = __builtin_bit_cast(unsigned short, h); o[nk] = __builtin_bit_cast(unsigned short, m); o[2 * nk] = __builtin_bit_cast(unsigned short, l);
 }
 
 extern "C" size_t frcnn_gemm_x3_pack_bytes(int G, int N, int K) {
@@ -300,7 +297,7 @@ static int launch_x3(const GemmX3Params& q, hipStream_t st) {
 }
 
 static int g_x3_cfg = -1;                   // -1: by shape
-static int g_x3_terms = 6;                  // 6: dropped cross terms <= 2^-23 relative; 9: every product exact
+static int g_x3_terms = 6;                  // 6: dropped cross terms <= 2^-24 relative; 9: every product exact
 extern "C" int frcnn_gemm_x3_set_terms(int terms) {
   if (terms != 6 && terms != 9) return FRCNN_E_ARG;
   g_x3_terms = terms;
