@@ -469,3 +469,56 @@ def test_maxpool_and_depthwise_gradients_vs_torch(dev):
         dw = ops.dwconv3x3_wgrad(gd, xd, stride, (1, 1, 1, 1), torch.from_numpy(scale).to(dev), torch.empty((3, 3, C), device=dev))
         want = wt.grad.numpy()
         assert np.abs(dw.cpu().numpy() - want).max() <= 1e-5 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("arch", ["mobile", "vgg16"])
+def test_snapshot_restore_is_bit_identical_for_mobilenet_and_vgg16(dev, tmp_path, arch):
+    """The solver state of the other two backbone families survives a snapshot: depthwise master filters
+    (`.../depthwise_weights` [3,3,C,1]) and their Momentum slots for MobileNet, fc6 / fc7 matrices and biases for VGG16."""
+    from frcnn_hip.runtime import Session
+    from frcnn_hip.tensor_bundle import BundleReader
+    from model.config import cfg
+    from model.train_val import SolverWrapper
+    from nets.mobilenet_v1 import mobilenetv1
+    from nets.vgg16 import vgg16
+    old = (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.SNAPSHOT_ITERS, cfg.TRAIN.DISPLAY)
+    cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.SNAPSHOT_ITERS, cfg.TRAIN.DISPLAY = 64, 0.0, 2e-4, 2, 1000
+    rng = np.random.RandomState(2)
+    image = ((rng.rand(1, 128, 160, 3) * 255.0).astype(np.float32) - cfg.PIXEL_MEANS.astype(np.float32)) * np.float32(1 / 256.0)
+    gt = np.array([[16, 16, 79, 79, 3], [60, 30, 150, 110, 7], [5, 70, 60, 120, 12]], dtype=np.float32)
+
+    def layer():
+        while True:
+            yield dict(data=image, im_info=np.array([128, 160, 1.0], dtype=np.float32), gt_boxes=gt)
+
+    def solver(tag):
+        sess = Session(device=dev, seed=5)
+        net = mobilenetv1() if arch == "mobile" else vgg16()
+        net.create_architecture("TRAIN", 21, tag=tag, anchor_scales=(4, 8, 16), anchor_ratios=(0.5, 1, 2))
+        sess.init_variables(net.variable_specs())
+        return sess, net, SolverWrapper(sess, net, layer())
+
+    try:
+        _, net, sw = solver(arch + "_snapA")
+        losses = sw.train_model(2, verbose=False, snapshot_dir=str(tmp_path))
+        assert len(losses) == 2 and np.all(np.isfinite(losses))
+        at_snapshot = sw.state.export_variables(slots=True)
+        import glob
+        ck = sorted(glob.glob(str(tmp_path / "*_iter_2.ckpt*")))[0].split(".ckpt")[0] + ".ckpt"
+        pk = ck[:-5] + ".pkl"
+        shapes = BundleReader(ck).get_variable_to_shape_map()
+        probe = (net._scope + "/Conv2d_6_depthwise/depthwise_weights") if arch == "mobile" else (net._scope + "/fc6/weights")
+        assert probe in shapes and probe + "/Momentum" in shapes
+        assert shapes[probe] == ([3, 3, 256, 1] if arch == "mobile" else [7 * 7 * 512, 4096])
+        sess, net2, sw2 = solver(arch + "_snapB")
+        assert sw2.restore(ck, pk) == 2
+        net2.train_forward(sess, next(layer()))
+        sw2.state.build()
+        sw2.state.import_slots(sw2.state.pending_slots)
+        sw2.state.pending_slots = None
+        restored = sw2.state.export_variables(slots=True)
+        assert sorted(restored) == sorted(at_snapshot)
+        for k in at_snapshot:
+            assert np.array_equal(restored[k], at_snapshot[k]), k
+    finally:
+        cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.TRAIN.LEARNING_RATE, cfg.TRAIN.SNAPSHOT_ITERS, cfg.TRAIN.DISPLAY = old
