@@ -68,6 +68,7 @@ class VariableStore(object):
         for k, v in values.items():
             self.variables[k] = np.asarray(v, dtype=np.float32)
         self.packed.clear()
+        self.x3.clear()                                 # planes of the filters just dropped (no graph is left that reads them)
         self.graphs.clear()
 
     def restore(self, ckpt_prefix, names=None, verify=True):
