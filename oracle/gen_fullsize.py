@@ -24,25 +24,49 @@ import torch  # noqa: E402
 
 import frcnn_oracle as ora  # noqa: E402
 import fullsize as fs  # noqa: E402
-from dense_ref import DenseRef  # noqa: E402
 
 
-class CalibRef(DenseRef):
-    """DenseRef whose bn() can (re)define the frozen statistics from the tensor it normalises: moving_mean / moving_variance :=
-    per-channel mean / variance of the convolution output, rounded to float32 BEFORE use (the GPU loads the f32 values)."""
-    calibrate = False
+def calib_class(Base):
+    """Base (a dense_ref restatement class) whose bn() can (re)define the frozen statistics from the tensor it normalises:
+    moving_mean / moving_variance := per-channel mean / variance of the convolution output, rounded to float32 BEFORE use (the GPU
+    loads the f32 values)."""
+    class CalibRef(Base):
+        calibrate = False
 
-    def bn(self, x, scope, eps=1e-5):
-        if self.calibrate:
-            mean = x.mean(dim=(0, 2, 3)).numpy().astype(np.float32)
-            var = x.var(dim=(0, 2, 3), unbiased=False).numpy().astype(np.float32)
-            var = np.maximum(var, np.float32(1e-6))
-            self.v[scope + "/BatchNorm/moving_mean"] = mean
-            self.v[scope + "/BatchNorm/moving_variance"] = var
-            self._cache.pop(scope + "/BatchNorm/moving_mean", None)
-            self._cache.pop(scope + "/BatchNorm/moving_variance", None)
-            self.bn_order.append(scope)
-        return DenseRef.bn(self, x, scope, eps)
+        def bn(self, x, scope, eps=1e-5):
+            if self.calibrate:
+                mean = x.mean(dim=(0, 2, 3)).numpy().astype(np.float32)
+                var = x.var(dim=(0, 2, 3), unbiased=False).numpy().astype(np.float32)
+                var = np.maximum(var, np.float32(1e-6))
+                self.v[scope + "/BatchNorm/moving_mean"] = mean
+                self.v[scope + "/BatchNorm/moving_variance"] = var
+                self._cache.pop(scope + "/BatchNorm/moving_mean", None)
+                self._cache.pop(scope + "/BatchNorm/moving_variance", None)
+                self.bn_order.append(scope)
+            return Base.bn(self, x, scope, eps)
+    return CalibRef
+
+
+def control_pass(c, v, image, rois, ref64=None):
+    """The float32 control: the same restatement run by plain torch-CPU float32 on the same weights; the tail sees the f32 head
+    (as on the device), cropped at the reference's rois.  Returns (tensors for full_*_ctrl.npz, scalar errors vs float64 or {})."""
+    c32 = fs.make_ref(c, v, torch.float32)
+    with torch.no_grad():
+        feat32 = c32.head(image)
+        s32, p32, b32 = c32.rpn(feat32)
+        h32 = feat32.permute(0, 2, 3, 1).contiguous().numpy()
+        fc32 = c32.tail(ora.crop_and_resize(h32[0], rois.astype(np.float32), 16.0, 7, max_pool=c32.max_pool_crop))
+        cs32, cp32, bp32 = c32.classify(fc32)
+    f = lambda a: np.asarray(a).astype(np.float32)
+    tensors = dict(head_sub=f(h32[0, ::4, ::4, :]), rpn_cls_score=f(s32), rpn_cls_prob=f(p32), rpn_bbox_pred=f(b32),
+                   fc7_sub=f(fc32.numpy()[::8]), cls_score=f(cs32), cls_prob=f(cp32), bbox_pred=f(bp32))
+    errs = {}
+    if ref64 is not None:
+        errs = dict(ctrl_head=fs.rel_err(h32, ref64["head"]), ctrl_rpn_cls_score=fs.rel_err(s32, ref64["score"]),
+                    ctrl_rpn_cls_prob=fs.rel_err(p32, ref64["prob"]), ctrl_rpn_bbox_pred=fs.rel_err(b32, ref64["bbox"]),
+                    ctrl_cls_score=fs.rel_err(cs32, ref64["cls_score"]), ctrl_cls_prob_abs=float(np.abs(cp32 - ref64["cls_prob"]).max()),
+                    ctrl_bbox_pred=fs.rel_err(bp32, ref64["bbox_pred"]))
+    return tensors, errs
 
 
 def main():
@@ -50,16 +74,27 @@ def main():
     ap.add_argument("--config", choices=sorted(fs.CONFIGS), default="c2")
     ap.add_argument("--weights", choices=["damped", "calibrated"], default="damped")
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--ctrl-only", action="store_true", help="only (re)write full_<config>_<weights>_ctrl.npz: the float32 control's "
+                    "tensors, from the committed fixture's weights and rois (seconds; no float64 pass)")
     args = ap.parse_args()
     if args.threads:
         torch.set_num_threads(args.threads)
     c = fs.CONFIGS[args.config]
     t0 = time.time()
+    if args.ctrl_only:
+        fx = np.load(fs.fixture_path(args.config, args.weights))
+        net, v = fs.base_variables(args.config, args.weights)
+        fs.apply_fixture(v, net._scope, fx)
+        tensors, _ = control_pass(c, v, fs.synth_image(c), fx["rois"])
+        np.savez_compressed(fs.ctrl_path(args.config, args.weights), **tensors)
+        print("wrote %s (%.2f MB) in %.1fs" % (fs.ctrl_path(args.config, args.weights), os.path.getsize(fs.ctrl_path(args.config, args.weights)) / 1e6,
+                                               time.time() - t0))
+        return
     net, v = fs.base_variables(args.config, args.weights)
     scope = net._scope
     image = fs.synth_image(c)
     im_info = np.array([c["H"], c["W"], c["scale"]], dtype=np.float32)
-    ref = CalibRef(v, c["layers"], c["classes"], c["scales"], c["ratios"], dtype=torch.float64)
+    ref = fs.make_ref(c, v, torch.float64, cls=calib_class(fs.ref_class(c)))
     ref.bn_order = []
     ref.calibrate = args.weights == "calibrated"
     A = ref.A
@@ -83,9 +118,18 @@ def main():
                                               pre_nms_topN=c["pre"], post_nms_topN=c["post"], nms_thresh=0.7)
         print("proposals: %d" % rois.shape[0], flush=True)
         feat_nhwc = feat.permute(0, 2, 3, 1).contiguous().numpy()
-        pool5 = ora.crop_and_resize(feat_nhwc[0].astype(np.float32), rois.astype(np.float32), 16.0, 7)
+        pool5 = ora.crop_and_resize(feat_nhwc[0].astype(np.float32), rois.astype(np.float32), 16.0, 7, max_pool=ref.max_pool_crop)
         fc7 = ref.tail(pool5)
         print("tail %.1fs  fc7 |x|max %.3g" % (time.time() - t0, float(fc7.abs().max())), flush=True)
+        cls_score, cls_prob, bbox_pred = ref.classify(fc7)
+        # class-head scales (SURVEY 8d "per-class stage": logits ~N(0, 2^2), de-normalised deltas ~N(0, 0.1^2)): random-init heads
+        # give near-uniform probabilities, i.e. a per-class stage full of ties; f32 constants, then recompute
+        s_c = np.float32(2.0 / max(float(np.std(cls_score)), 1e-12))
+        s_b = np.float32(0.1 / max(float(np.std(bbox_pred)), 1e-12))
+        fx.update(cls_scale=s_c, bbox_scale=s_b)
+        for name, sc in (("/cls_score/weights", s_c), ("/bbox_pred/weights", s_b)):
+            v[scope + name] = (v[scope + name] * sc).astype(np.float32)
+            ref._cache.pop(scope + name, None)
         cls_score, cls_prob, bbox_pred = ref.classify(fc7)
     orig = (int(c["H"] / c["scale"]), int(c["W"] / c["scale"]), 3)
     sc, boxes = ora.im_detect_post(cls_prob.astype(np.float32), bbox_pred.astype(np.float32), rois.astype(np.float32), float(c["scale"]), orig)
@@ -100,17 +144,10 @@ def main():
     # control: what plain float32 arithmetic (torch-CPU, the same restatement) loses against float64 on THIS network --
     # the yardstick for "as exact as f32 gets" when the 1e-4 budget is smaller than f32's own noise on a graph
     ref.calibrate = False
-    c32 = DenseRef(v, c["layers"], c["classes"], c["scales"], c["ratios"], dtype=torch.float32)
-    with torch.no_grad():
-        feat32 = c32.head(image)
-        s32, p32, b32 = c32.rpn(feat32)
-        h32_nhwc = feat32.permute(0, 2, 3, 1).contiguous().numpy()
-        # the f32 tail sees the f32 head (as on the device), cropped at the reference's rois
-        fc32 = c32.tail(ora.crop_and_resize(h32_nhwc[0], rois.astype(np.float32), 16.0, 7))
-        cs32, cp32, bp32 = c32.classify(fc32)
-    fx.update(ctrl_head=fs.rel_err(h32_nhwc, feat_nhwc), ctrl_rpn_cls_score=fs.rel_err(s32, score), ctrl_rpn_cls_prob=fs.rel_err(p32, prob),
-              ctrl_rpn_bbox_pred=fs.rel_err(b32, bbox), ctrl_cls_score=fs.rel_err(cs32, cls_score),
-              ctrl_cls_prob_abs=float(np.abs(cp32 - cls_prob).max()), ctrl_bbox_pred=fs.rel_err(bp32, bbox_pred))
+    tensors, errs = control_pass(c, v, image, rois, dict(head=feat_nhwc, score=score, prob=prob, bbox=bbox, cls_score=cls_score, cls_prob=cls_prob,
+                                                           bbox_pred=bbox_pred))
+    fx.update(errs)
+    np.savez_compressed(fs.ctrl_path(args.config, args.weights), **tensors)
     print("f32 control vs f64: " + "  ".join("%s %.2e" % (k[5:], float(fx[k])) for k in sorted(fx) if k.startswith("ctrl_")), flush=True)
     if args.weights == "calibrated":
         names = ref.bn_order

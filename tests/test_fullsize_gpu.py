@@ -1,6 +1,10 @@
-"""GPU: full-size end-to-end parity (VERDICT r1 "next round" item 1): BASELINE.json configs[1] (ResNet-101, 600x1000,
-A = 9, 300 proposals) and configs[2] (800x1333, A = 15, 1000 proposals, 81 classes) through the whole HIP chain, against
-the committed float64 reference (oracle/gen_fullsize.py -> tests/golden/full_*.npz) and the pinned detection oracle.
+"""GPU: full-size end-to-end parity for EVERY BASELINE.json config under the shipped configuration: configs[1] (ResNet-101,
+600x1000, A = 9, 300 proposals), configs[2] (800x1333, A = 15, 1000 proposals, 81 classes), configs[0]'s network (VGG16 600x1000 incl.
+fc6 / fc7 at 300 RoIs, lib/nets/vgg16.py:26-60), configs[3] (MobileNet-v1 600x1000, A = 12, 81 classes, mobilenet_v1.py:214-250) through
+the whole HIP chain, and configs[4] (ResNet-152 600x1000 TRAIN step: four losses + gradients, network.py:264-321,
+train_val.py:116-153), against the committed float64 references (oracle/gen_fullsize*.py -> tests/golden/full_*.npz) and the pinned
+detection oracle.  Every report prints |device - float64| AND |device - float32 control| (the same graph in torch-CPU float32:
+another f32 implementation, which is what the reference -- an f32 TensorFlow graph -- is).
 
 Per case (oracle/fullsize.py::run_harness):
   1. RPN tensors vs float64                                          <= 1e-4 (relative to the tensor's scale)
@@ -36,7 +40,7 @@ def _shipped_policy():
     return SHIPPED
 
 
-@pytest.mark.parametrize("config,weights", [("c2", "damped"), ("c2", "calibrated"), ("c3", "calibrated")])
+@pytest.mark.parametrize("config,weights", [("c2", "damped"), ("c2", "calibrated"), ("c3", "calibrated"), ("c1", "damped"), ("c4", "calibrated")])
 @pytest.mark.parametrize("policy", ["direct", SHIPPED, SHIPPED_F32])
 def test_fullsize_parity(dev, config, weights, policy):
     if policy != "direct":
@@ -49,3 +53,17 @@ def test_fullsize_parity(dev, config, weights, policy):
     with open(os.path.join(out, "fullsize_parity.txt"), "a") as f:
         f.write(line + "\n")
     assert rep["ok"], line
+
+
+@pytest.mark.parametrize("policy", ["direct", "shipped"])
+def test_fullsize_train_step_parity(dev, policy):
+    """configs[4]: ResNet-152, 600x1000, A = 12, 81 classes, 256 RoIs -- the four losses and the gradients of 16 parameter tensors
+    (RPN, class / box heads, block2 / block3 / block4 filters incl. a stride-2 3x3 and the Winograd 3x3 layers) vs float64 autograd."""
+    rep = fs.run_train_harness("c5", policy, dev)
+    text = fs.format_train_report(rep)
+    print("\n" + text)
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "fullsize_parity.txt"), "a") as f:
+        f.write(text + "\n")
+    assert rep["ok"], text

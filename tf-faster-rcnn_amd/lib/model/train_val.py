@@ -38,7 +38,9 @@ def find_previous(output_dir):
 def remove_snapshot(np_paths, ss_paths):
     """train_val.py:235-256: keep the newest cfg.TRAIN.SNAPSHOT_KEPT snapshots, delete older ones (both files of the bundle)."""
     for _ in range(max(0, len(np_paths) - cfg.TRAIN.SNAPSHOT_KEPT)):
-        os.remove(str(np_paths.pop(0)))
+        nfile = str(np_paths.pop(0))
+        if os.path.exists(nfile):                                 # another rank (or an earlier run) may have pruned it already
+            os.remove(nfile)
     for _ in range(max(0, len(ss_paths) - cfg.TRAIN.SNAPSHOT_KEPT)):
         sfile = ss_paths.pop(0)
         for suffix in ('.data-00000-of-00001', '.index'):
@@ -81,6 +83,8 @@ class SolverWrapper(object):
     def snapshot(self, it, output_dir):
         """train_val.py:58-100: `<prefix>_iter_<it>.ckpt` (variables + Momentum slots + global_step) and a .pkl with the
         iteration (the reference also pickles numpy RNG / data-layer cursors; the sampling here is seeded per step)."""
+        if not self.write_snapshots:                             # data-parallel: rank 0 writes, the others only read
+            return None, None
         os.makedirs(output_dir, exist_ok=True)
         base = os.path.join(output_dir, cfg.TRAIN.SNAPSHOT_PREFIX + '_iter_{:d}'.format(it))
         extra = self.state.export_variables(slots=True) if self.state.params else {}
@@ -175,7 +179,11 @@ def train_net(network, sess, data_layer, max_iters=40000, all_reduce=None, world
         sw.initialize(pretrained_model)
     print('Solving...')
     hist = sw.train_model(max_iters, start_iter=start, snapshot_dir=output_dir)
-    if output_dir is not None and max_iters % cfg.TRAIN.SNAPSHOT_ITERS:
+    if output_dir is not None and write_snapshots and max_iters % cfg.TRAIN.SNAPSHOT_ITERS:
         sw.snapshot(max_iters, output_dir)                        # the reference snapshots the last iteration too (:338-340)
+    if world_size > 1 and output_dir is not None:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()                                        # nobody returns (and resumes / evaluates) before rank 0's files are complete
     print('done solving')
     return hist
