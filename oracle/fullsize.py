@@ -213,7 +213,9 @@ TRAIN_POLICIES = {
     "direct": dict(WINOGRAD=False, WINOGRAD_TRAIN=False),           # every convolution and gradient on the direct f32-MFMA kernels
     "shipped": dict(),                                               # cfg.HIP defaults (Winograd forward + data gradient for 3x3 stride 1)
 }
-GRAD_TOL = 2e-4
+GRAD_TOL = 2e-4              # of the tensor's largest entry; or GRAD_CTRL_FACTOR x the float32 control's own distance to float64
+GRAD_CTRL_FACTOR = 4.0
+GATE_EPS = 2e-5              # relative to the layer's largest pre-activation: what a Winograd F(4x4,3x3) forward may move a gate by
 EPS_SCORE, EPS_IOU, TOL = 1e-4, 1e-3, 1e-4        # BASELINE.json north_star: 1e-4 on scores / box coordinates
 CTRL_FACTOR = {"direct": 1.5, "shipped": 1.5, "shipped_f32": 1.5}     # allowed multiple of the float32 control's own loss (exploratory policies: 2.5)
 
@@ -357,17 +359,20 @@ def run_harness(config, weights, policy, dev, fuse_tail=True):
         got2 = d2[:n2].cpu().numpy()
         s_ref, b_ref = perclass_candidates(fx["cls_prob"], fx["bbox_pred"], fx["rois"], c["scale"], orig + (3,))
         floor = float(got2[:, 4].min()) if n2 >= c["max_per_image"] else None
+        # scores may move by what float32 itself moves them on this graph (the control's own cls_prob distance to float64)
+        eps_det = max(EPS_SCORE, CTRL_FACTOR.get(policy, 2.5) * float(fx["ctrl_cls_prob_abs"]))
+        rep["dets_eps_score"] = eps_det
         worst_s = worst_i = 0.0
         frag = 0
         ok = n2 >= min(c["max_per_image"], fx["dets"].shape[0])
         for j in range(1, c["classes"]):
             rows = got2[got2[:, 5] == j]
-            mm = mg.match_to_candidates(rows[:, :4], rows[:, 4], b_ref[:, 4 * j:4 * j + 4], s_ref[:, j], TOL * max(orig) * 4, EPS_SCORE)
+            mm = mg.match_to_candidates(rows[:, :4], rows[:, 4], b_ref[:, 4 * j:4 * j + 4], s_ref[:, j], TOL * max(orig) * 4, eps_det)
             if rows.shape[0] == 0:
-                unexplained = (s_ref[:, j] > (floor if floor is not None else -np.inf) + EPS_SCORE) & (s_ref[:, j] > 0)
+                unexplained = (s_ref[:, j] > (floor if floor is not None else -np.inf) + eps_det) & (s_ref[:, j] > 0)
                 r = dict(ok=bool(not unexplained.any()), slack_score=0.0, slack_iou=0.0, fragile=0)
             else:
-                r = mg.check_greedy_nms(b_ref[:, 4 * j:4 * j + 4], s_ref[:, j], mm, 0.3, EPS_SCORE, EPS_IOU, score_floor=floor)
+                r = mg.check_greedy_nms(b_ref[:, 4 * j:4 * j + 4], s_ref[:, j], mm, 0.3, eps_det, EPS_IOU, score_floor=floor)
             ok = ok and r["ok"]
             worst_s, worst_i, frag = max(worst_s, r["slack_score"]), max(worst_i, r["slack_iou"]), frag + r["fragile"]
         rep["dets_slack_score"], rep["dets_slack_iou"], rep["dets_fragile"] = worst_s, worst_i, frag
@@ -459,14 +464,28 @@ def run_train_harness(config, policy, dev):
                 got = g.cpu().numpy().ravel()
             got = got[::stride]
             amax = max(float(fx["gabs_" + key]), 1e-300)
-            e64 = float(np.abs(got - fx["grad_" + key].astype(np.float64)).max()) / amax
-            e32 = float(np.abs(got - fx["ctrl_grad_" + key].astype(np.float64)).max()) / amax
+            d64 = np.abs(got - fx["grad_" + key].astype(np.float64))
+            d32 = np.abs(got - fx["ctrl_grad_" + key].astype(np.float64))
+            if key in ("rpn_conv", "rpn_conv_b"):
+                # sparse upstream gradient (<= 256 sampled anchors): output channels with a ReLU gate within GATE_EPS of zero at an
+                # active pixel may legitimately flip between two float32 implementations (a 1/300 step of that channel's gradient);
+                # they are counted, not compared (decision margin, like the proposal / NMS decisions of the inference harness)
+                fragile = fx["rpn_gate_margin"] < GATE_EPS * float(fx["rpn_pre_absmax"])
+                per = got.size * stride // fragile.size if key == "rpn_conv" else 1           # elements of the master layout per Cout
+                ch = (np.arange(got.size) * stride) // max(per, 1)
+                keep = ~fragile[np.minimum(ch, fragile.size - 1)]
+                rep["gates_fragile"] = int(fragile.sum())
+                check("rpn gates: fragile channels <= 5 %", fragile.sum() <= 0.05 * fragile.size)
+                tol_k = max(GRAD_TOL, GRAD_CTRL_FACTOR * float(fx["ctrl_gerr_" + key])) * amax
+                rep["gates_flipped_" + key] = int(np.unique(ch[(d64 > tol_k) & ~keep]).size)     # fragile channels that did move
+                d64, d32 = d64[keep], d32[keep]
+            e64, e32 = float(d64.max()) / amax, float(d32.max()) / amax
             rep["g_" + key], rep["dc_g_" + key], rep["ctrl_g_" + key] = e64, e32, float(fx["ctrl_gerr_" + key])
             worst = max(worst, e64)
             # a gradient is a sum over ~1e4 ... 1e6 products of activations and back-propagated errors through up to 150 layers:
             # 2e-3 of the tensor's largest entry is the bound of the toy-size autograd tests; at full size the float32 control's own
             # distance to float64 is the yardstick
-            check("grad " + key, e64 <= max(GRAD_TOL, 2.5 * rep["ctrl_g_" + key]))
+            check("grad " + key, e64 <= max(GRAD_TOL, GRAD_CTRL_FACTOR * rep["ctrl_g_" + key]))
         rep["grad_worst"] = worst
         sess.close()
     finally:
@@ -481,6 +500,8 @@ def format_train_report(rep):
     lines = ["%s TRAIN %-8s %s%s" % (rep["config"], rep["policy"], "OK" if rep["ok"] else "FAIL", ("  <- " + "; ".join(rep["notes"])) if rep["notes"] else "")]
     lines.append("   losses  |dev-f64| (|dev-f32ctl|, f32ctl-vs-f64): " + "  ".join(
         "%s %s (%s, %s)" % (k, e(rep["loss_" + k]), e(rep["dc_loss_" + k]), e(rep["ctrl_loss_" + k])) for k in LOSS_KEYS))
+    lines.append("   rpn_conv channels not compared (a ReLU gate within %.0e x |pre|max of zero at a sampled anchor's pixel): %s of 512; of those, moved by more than the tolerance: %s (filter), %s (bias)"
+                 % (GATE_EPS, rep.get("gates_fragile"), rep.get("gates_flipped_rpn_conv"), rep.get("gates_flipped_rpn_conv_b")))
     lines.append("   grads   |dev-f64|/|g|max (|dev-f32ctl|, f32ctl-vs-f64): " + "  ".join(
         "%s %s (%s, %s)" % (k, e(rep["g_" + k]), e(rep["dc_g_" + k]), e(rep["ctrl_g_" + k])) for k in TRAIN_GRAD_SCOPES))
     return "\n".join(lines)

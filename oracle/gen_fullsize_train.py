@@ -131,6 +131,20 @@ def main():
         results[tag] = (dict((k, float(x.item())) for k, x in losses.items()), collect(tr, scope, fs.TRAIN_GRAD_SCOPES))
         print("%s: %s  (%.1fs)" % (tag, "  ".join("%s %.6f" % kv for kv in results[tag][0].items()), time.time() - t1), flush=True)
         del tr, losses, total
+    # ReLU gate margins of the RPN 3x3 layer.  Its upstream gradient is SPARSE: only the <= 256 sampled anchors' pixels carry any
+    # (network.py:282-297), so one gate of relu(conv + b) that flips at an active pixel -- a pre-activation within rounding of zero
+    # -- moves that output channel's bias / filter gradient by ~1/300 of its size.  Stored: per output channel, the smallest
+    # |pre-activation| over the active pixels (float64), so the test can tell a flipped gate from an arithmetic error.
+    with torch.no_grad():
+        r64 = DenseRef(v, c["layers"], c["classes"], c["scales"], c["ratios"], dtype=torch.float64)
+        feat = r64.head(image)
+        pre = torch.nn.functional.conv2d(feat, r64.w(scope + "/rpn_conv/3x3/weights"), r64.w(scope + "/rpn_conv/3x3/biases"), padding=1)[0].numpy()
+    lab = np.asarray(at[0]).reshape(A, pre.shape[1], pre.shape[2])
+    active = (lab >= 0).any(axis=0)                                        # [H, W]
+    fx["rpn_gate_margin"] = np.abs(pre[:, active]).min(axis=1).astype(np.float32)
+    fx["rpn_pre_absmax"] = np.float64(np.abs(pre).max())
+    print("rpn gates: %d active pixels, pre |max| %.3g, channels with a gate within 2e-4 of zero: %d" % (
+        int(active.sum()), float(fx["rpn_pre_absmax"]), int((fx["rpn_gate_margin"] < 2e-4 * float(fx["rpn_pre_absmax"])).sum())), flush=True)
     l64, g64 = results["f64"]
     l32, g32 = results["f32"]
     for k in fs.LOSS_KEYS:
