@@ -204,12 +204,12 @@ def main():
     ap.add_argument("--reference-order", action="store_true",
                     help="keep the reference op order crop -> 1x1 convs at the block4 entry (default: the 1x1 convs run on the "
                          "feature map and their outputs are cropped; same result up to f32 rounding, 64.5 GFLOP less)")
-    ap.add_argument("--mfma", choices=["x3", "f32", "bf16x3"], default="x3",
+    ap.add_argument("--mfma", choices=["x3", "f32"], default="x3",
                     help="x3 (default = cfg.HIP.MFMA_X3): the large plain GEMMs (pointwise convolutions, Winograd products, Cout %% 128 == 0) "
                          "on the bf16 matrix pipe with exactly split f32 operands (csrc/gemm_x3.hip: six bf16 MFMAs per f32 product, f32 "
                          "accumulate; measured error vs float64 <= the f32 MFMA kernel's), everything else on v_mfma_f32_32x32x2_f32; the "
                          "all-f32-MFMA variant is then timed in the same run and reported as `f32_mfma_variant`.  f32: every product on "
-                         "v_mfma_f32_32x32x2_f32.  bf16x3: round-1 experiment, every convolution through csrc/conv_igemm_b3.hip")
+                         "v_mfma_f32_32x32x2_f32")
     ap.add_argument("--x3-terms", type=int, choices=[6, 9], default=6, help="with --mfma x3: 6 = the three cross terms below 2^-24 are dropped "
                     "(default), 9 = all nine cross terms, every f32 product exact (frcnn_gemm_x3_set_terms)")
     ap.add_argument("--x3-config", type=int, default=-1, help="A/B knob: frcnn_gemm_x3_set_config (-1 = by shape)")
@@ -243,8 +243,6 @@ def main():
 
     import frcnn_hip
     frcnn_hip.lib()
-    if args.mfma == "bf16x3":
-        frcnn_hip.lib().frcnn_set_tuning(2, 1)
     frcnn_hip.lib().frcnn_gemm_x3_set_terms(args.x3_terms)
     frcnn_hip.lib().frcnn_gemm_x3_set_config(args.x3_config)
     from frcnn_hip.runtime import Session
@@ -271,7 +269,7 @@ def main():
     S = max(1, args.streams or c["streams"])
     common = {"metric": METRIC, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
-              "dtype": {"f32": "f32", "bf16x3": "f32 via exact bf16x3 operand split (6 bf16 MFMAs / product, f32 accumulate)",
+              "dtype": {"f32": "f32",
                         "x3": "f32 (operands, accumulators, results; the large GEMMs form each f32 product from exact 3-way bf16 "
                               "operand splits on the bf16 matrix pipe -- 6 MFMAs / product, dropped terms <= 2^-24 -- the rest on the f32 MFMA)"}[args.mfma]}
 
@@ -416,8 +414,7 @@ def main():
                                   "--reference-order keeps crop -> conv)",
                          "mfma": {"x3": "cfg.HIP.MFMA_X3: plain GEMMs with Cout % 128 == 0 and >= 150 tiles on v_mfma_f32_32x32x16_bf16 with "
                                         "exactly split f32 operands (csrc/gemm_x3.hip); the stem, strided / small-Cout convolutions and heads on "
-                                        "v_mfma_f32_32x32x2_f32", "f32": "v_mfma_f32_32x32x2_f32 everywhere",
-                                  "bf16x3": "round-1 experiment (csrc/conv_igemm_b3.hip)"}[args.mfma],
+                                        "v_mfma_f32_32x32x2_f32", "f32": "v_mfma_f32_32x32x2_f32 everywhere"}[args.mfma],
                          "gflop_per_image_launched": round(flops_per_image / 1e9, 2), "gflop_per_image_reference_graph": c["gflop_ref"]}
         if f32_variant is not None:
             out["f32_mfma_variant"] = f32_variant

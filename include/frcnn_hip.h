@@ -229,8 +229,7 @@ int frcnn_conv1x1_mean(const float* x_d, int M, int Cin, const float* w_d, const
 
 /* Tuning knobs for A/B experiments (process-wide debugging switches read at launch time: set them while no other thread is
  * launching; they are NOT part of the thread-safety contract above and no product path changes them): key 0 = force conv tile configuration id (-1 = automatic); key 1 = ablation bits;
- * key 2 = 1 enables the EXPERIMENTAL bf16x3 split-operand MFMA path for every non-stem conv (f32 in/out, f32-class
- * accuracy, see csrc/conv_igemm_b3.hip); key 3 = force its tile configuration. */
+ * key 5 = phase stagger of co-resident workgroups; key 6 = 0 keeps the short-K GEMMs off k_gemm_stream. */
 int frcnn_set_tuning(int key, int value);
 /* HOST: CRC-32C (Castagnoli) of n bytes, crc = 0 to start or a previous result to extend: the checksum of TensorFlow
  * checkpoint shards / index blocks (frcnn_hip/tensor_bundle.py replaces pywrap_tensorflow.NewCheckpointReader,
@@ -263,6 +262,23 @@ size_t frcnn_gemm_x3_pack_bytes(int G, int N, int K);
 int frcnn_gemm_x3_pack(const float* w_d, int G, int N, int K, void* planes_d, void* stream);
 int frcnn_gemm_x3(const float* x_d, const void* planes_d, const float* bias_d, const float* res_d, float* y_d, int G, int M, int N,
                   int K, int act, void* stream);
+/* f32 "NT" GEMM on the 16-bit matrix pipe with block-scaled two-piece fp16 operands (csrc/gemm_h2.hip; cfg.HIP.MFMA_H2): a float32
+ * value x of a 128-k block is h + l (two fp16 pieces, rounded to nearest) times ONE exact power-of-two block scale; a product = the three
+ * leading cross terms on v_mfma_f32_32x32x16_f16, f32 accumulation, each block folded into the f32 sum by its exact scale.  Dropped terms
+ * <= 3 * 2^-22 |x w| (measured: 1e-7 of the output scale, below the accumulation noise of any f32 kernel).  These replace the slim conv /
+ * fc call sites of lib/nets/network.py:323-378, resnet_v1.py:80-125 for plain GEMM shapes, like frcnn_gemm_x3.
+ *   frcnn_h2_planes_bytes: bytes of the planes [2][rows][K] fp16 of a tensor.
+ *   frcnn_h2_pack_w:  W [G][N][K] f32 (device) -> planes [G][2][N][K] + w_inv [G][N] (one scale per output row), once per filter; K % 4 == 0.
+ *   frcnn_h2_split:   x [M][K] f32 -> planes [2][M][K] + x_inv [K/128][M] (one scale per row and 128-k block); K % 128 == 0.
+ *   frcnn_gemm_h2:    y[g] = act(x[g] W[g]^T + bias + res[g]), g < G; x as planes [2][G*M][K] + x_inv [K/128][G*M]; res / y [G*M][N] f32 (y may be
+ *                     NULL); y_planes / y_inv (may be NULL): the result as operand planes [2][G*M][N] + [N/128][G*M] for the next GEMM, emitted
+ *                     from the register epilogue (bit-identical to frcnn_h2_split of y).  K % 128 == 0, N % 128 == 0, (G*M) % 4 == 0 (G > 1:
+ *                     M % 4 == 0).  cfg: -1 = by shape, else a tile configuration id (per call: no process-wide state). */
+size_t frcnn_h2_planes_bytes(long long rows, int K);
+int frcnn_h2_pack_w(const float* w_d, int G, int N, int K, void* planes_d, float* w_inv_d, void* stream);
+int frcnn_h2_split(const float* x_d, long long M, int K, void* planes_d, float* inv_d, void* stream);
+int frcnn_gemm_h2(const void* x_planes_d, const float* x_inv_d, const void* w_planes_d, const float* w_inv_d, const float* bias_d,
+                  const float* res_d, float* y_d, void* y_planes_d, float* y_inv_d, int G, int M, int N, int K, int act, int cfg, void* stream);
 int frcnn_gemm_x3_set_terms(int terms);         /* 6 (default): cross terms am*wl, al*wm, al*wl dropped (<= 2^-24 relative); 9: all nine -> every f32 product exact */
 int frcnn_gemm_x3_set_config(int cfg);          /* A/B runs: -1 = by shape (default), 0 = 128x128 tiles / 64x64 waves, 1 = 128x128 / 32x64, 2 = 64x128 / 32x64 */
 /* Winograd F(m x m, 3x3), m = 2 or 4, for stride-1 pad-1 3x3 convolutions (exact algebra, f32): filter transform on the

@@ -1,0 +1,62 @@
+"""TEST INFRASTRUCTURE ONLY -- numpy statement of the operand format of csrc/gemm_h2.hip (cfg.HIP.MFMA_H2): a float32 value of a
+128-k block = (h + l) * 2^-e with h, l fp16 (both rounded to nearest even) and ONE exact power-of-two scale per (row, block); the
+weights use one scale per output row.  Used only by tests/: the device kernels (frcnn_h2_split, frcnn_h2_pack_w, the plane-emitting
+epilogue of frcnn_gemm_h2) must reproduce these arrays bit for bit."""
+import numpy as np
+
+KB = 128
+
+
+def block_scale(mx):
+    """(2^e, 2^-e) with mx * 2^e in [2^14, 2^15): exponent arithmetic on the float32 bits of mx >= 0 (h2_block_scale)."""
+    mx = np.asarray(mx, dtype=np.float32)
+    ex = ((mx.view(np.uint32) >> np.uint32(23)) & np.uint32(0xff)).astype(np.int64)
+    ex = np.maximum(ex, 15)
+    scale = ((268 - ex).astype(np.uint32) << np.uint32(23)).view(np.float32)
+    inv = ((ex - 14).astype(np.uint32) << np.uint32(23)).view(np.float32)
+    return scale, inv
+
+
+def split_scaled(x, scale):
+    xs = (np.asarray(x, dtype=np.float32) * scale).astype(np.float32)
+    with np.errstate(over="ignore"):
+        h = xs.astype(np.float16)
+        l = (xs - h.astype(np.float32)).astype(np.float32).astype(np.float16)
+    return h, l
+
+
+def split(x):
+    """x f32 [M, K] (K % 128 == 0) -> (h, l fp16 [M, K], inv f32 [K/128, M]) as frcnn_h2_split writes them."""
+    x = np.asarray(x, dtype=np.float32)
+    M, K = x.shape
+    assert K % KB == 0
+    xb = x.reshape(M, K // KB, KB)
+    scale, inv = block_scale(np.abs(xb).max(axis=2))                   # [M, K/128]
+    h, l = split_scaled(xb, scale[:, :, None])
+    return h.reshape(M, K), l.reshape(M, K), np.ascontiguousarray(inv.T)
+
+
+def pack_w(w):
+    """w f32 [G, N, K] -> (h, l fp16 [G, N, K], w_inv f32 [G, N]): one scale per output row (frcnn_h2_pack_w)."""
+    w = np.asarray(w, dtype=np.float32)
+    scale, inv = block_scale(np.abs(w).max(axis=2))
+    h, l = split_scaled(w, scale[:, :, None])
+    return h, l, inv
+
+
+def gemm_terms(x, w, terms=3):
+    """What the kernel's MFMAs evaluate, with exact (float64) accumulation: per 128-k block the kept cross terms of the scaled pieces,
+    folded by the block's scale; finally times the weight row's scale.  x [M, K], w [N, K] -> float64 [M, N]."""
+    xh, xl, xinv = split(x)
+    wh, wl, winv = pack_w(w[None])
+    wh, wl, winv = wh[0].astype(np.float64), wl[0].astype(np.float64), winv[0].astype(np.float64)
+    xh, xl = xh.astype(np.float64), xl.astype(np.float64)
+    M, K = x.shape
+    out = np.zeros((M, w.shape[0]), dtype=np.float64)
+    for kb in range(K // KB):
+        s = slice(kb * KB, (kb + 1) * KB)
+        blk = xh[:, s] @ wh[:, s].T + xh[:, s] @ wl[:, s].T + xl[:, s] @ wh[:, s].T
+        if terms == 4:
+            blk = blk + xl[:, s] @ wl[:, s].T
+        out += blk * xinv[kb].astype(np.float64)[:, None]
+    return out * winv[None, :]

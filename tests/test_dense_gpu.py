@@ -151,34 +151,6 @@ def test_graph_capture_replay(dev):
     assert (out.double() - want).abs().max().item() < 1e-4
 
 
-@pytest.mark.parametrize("case", [c for c in CASES if c[3] % 32 == 0], ids=lambda c: "%dx%dx%d-k%d" % (c[1], c[2], c[3], c[5]))
-@pytest.mark.parametrize("b3cfg", [-1, 1, 2, 4])
-def test_conv2d_bf16x3_split_path_is_f32_class(dev, case, b3cfg):
-    """EXPERIMENTAL opt-in path (csrc/conv_igemm_b3.hip): exact 3-way bf16 split of both operands, six bf16 MFMAs per
-    f32 product.  Must meet the SAME bound as the f32-MFMA kernel against the float64 reference."""
-    import frcnn_hip
-    from frcnn_hip import ops
-    N, H, W, Cin, Cout, k, stride, pad, act, res, has_bias = case
-    rng = np.random.RandomState(hash(case) % (2 ** 31))
-    x = rng.randn(N, H, W, Cin).astype(np.float32)
-    w = (rng.randn(k, k, Cin, Cout) / np.sqrt(k * k * Cin)).astype(np.float32)
-    b = rng.randn(Cout).astype(np.float32) if has_bias else None
-    OH = (H + pad[0] + pad[1] - k) // stride + 1
-    OW = (W + pad[2] + pad[3] - k) // stride + 1
-    r = rng.randn(N, (OH - 1) * res + 1 + (res - 1), (OW - 1) * res + 1 + (res - 1), Cout).astype(np.float32) if res else None
-    want = ref_conv(x, w, b, stride, pad, act, r, max(res, 1))
-    L = frcnn_hip.lib()
-    L.frcnn_set_tuning(2, 1); L.frcnn_set_tuning(3, b3cfg)
-    try:
-        wp = torch.from_numpy(ops.pack_filter_hwio(w)).to(dev)
-        got = ops.conv2d(torch.from_numpy(x).to(dev), wp, None if b is None else torch.from_numpy(b).to(dev), k, k, stride, pad,
-                         act, None if r is None else torch.from_numpy(r).to(dev), max(res, 1)).cpu().numpy()
-    finally:
-        L.frcnn_set_tuning(2, 0); L.frcnn_set_tuning(3, -1)
-    assert got.shape == want.shape
-    assert np.abs(got - want).max() <= 2e-5 * max(np.abs(want).max(), 1.0), np.abs(got - want).max()
-
-
 @pytest.mark.parametrize("G,M,N,K", [(16, 608, 512, 1024), (3, 77, 20, 32), (16, 4800, 128, 128), (1, 300, 1000, 64)])
 def test_gemm_batched_nt(dev, G, M, N, K):
     from frcnn_hip import ops

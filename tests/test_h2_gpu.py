@@ -1,0 +1,125 @@
+"""GPU parity of csrc/gemm_h2.hip through the C ABI: the splitters reproduce the numpy statement of the operand format
+(oracle/h2_ref.py) bit for bit; frcnn_gemm_h2 against float64 is (a) inside the dense-kernel bound 2e-5 of the output scale and (b)
+of the f32-MFMA kernel's class on the same data (<= its error on the path's shapes, <= 3x in general); the planes emitted from the
+GEMM epilogue are bit-identical to frcnn_h2_split of the f32 result; rows past M untouched."""
+import numpy as np
+import pytest
+import torch
+
+import h2_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _planes_np(h2):
+    raw = h2.planes.cpu().numpy().view(np.float16).reshape(2, h2.rows, h2.K)
+    return raw[0], raw[1], h2.inv.cpu().numpy()
+
+
+@pytest.mark.parametrize("M,K,kind", [(333, 256, "randn"), (1200, 512, "relu"), (77, 1024, "wide"), (64, 128, "zeros")])
+def test_h2_split_matches_numpy_statement(dev, M, K, kind):
+    from frcnn_hip import ops
+    rng = np.random.RandomState(M + K)
+    if kind == "relu":
+        x = np.maximum(rng.randn(M, K), 0) * np.exp(rng.uniform(-3, 3, size=(M, K)))
+    elif kind == "wide":
+        x = rng.randn(M, K) * np.exp(rng.uniform(-30, 30, size=(M, K)))
+    elif kind == "zeros":
+        x = np.zeros((M, K))
+        x[3, 5], x[7, :] = 1e-30, 65504.0 * 3
+    else:
+        x = rng.randn(M, K) * 3
+    x = x.astype(np.float32)
+    got = _planes_np(ops.h2_split(T(x, dev)))
+    want = h2_ref.split(x)
+    for g, w_, name in zip(got, want, ("h", "l", "inv")):
+        assert np.array_equal(g.view(np.uint16) if g.dtype == np.float16 else g, w_.view(np.uint16) if w_.dtype == np.float16 else w_), name
+
+
+def test_h2_pack_w_matches_numpy_statement(dev):
+    from frcnn_hip import ops
+    rng = np.random.RandomState(5)
+    G, N, K = 3, 128, 320
+    w = (rng.randn(G, N, K) * np.exp(rng.uniform(-8, 8, size=(G, N, 1)))).astype(np.float32)
+    planes, winv = ops.h2_pack_w(T(w, dev))
+    raw = planes.cpu().numpy().view(np.float16).reshape(G, 2, N, K)
+    h, l, inv = h2_ref.pack_w(w)
+    assert np.array_equal(raw[:, 0].view(np.uint16), h.view(np.uint16)) and np.array_equal(raw[:, 1].view(np.uint16), l.view(np.uint16))
+    assert np.array_equal(winv.cpu().numpy(), inv)
+
+
+H2_CASES = [
+    # G, M, N, K, residual, act
+    (1, 128 * 40 + 76, 256, 128, True, 1),       # conv3-like, M tail
+    (1, 128 * 9 + 4, 128, 2048, False, 1),       # long K: 16 scale blocks
+    (5, 64 * 9 + 12, 128, 128, False, 0),        # batched product (Winograd), M tail inside every batch entry
+    (1, 128 * 70, 2048, 128, True, 2),           # 1120 tiles, ReLU6
+    (1, 128 * 33 + 8, 128, 256, True, 1),
+    (3, 1200, 512, 512, False, 0),               # the 7x7 Winograd product shape (fewer points)
+]
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 3, 4, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("case", H2_CASES, ids=[str(i) for i in range(len(H2_CASES))])
+def test_gemm_h2_is_f32_class(dev, case, cfg):
+    from frcnn_hip import ops
+    G, M, N, K, with_res, act = case
+    rng = np.random.RandomState(M % 997 + N + K)
+    x = rng.randn(G * M, K).astype(np.float32)
+    x[:, ::7] *= 1e3                                                            # mixed magnitudes inside every scale block
+    x[::5] *= 1e-4                                                              # and across rows
+    w = (rng.randn(G, N, K) / np.sqrt(K)).astype(np.float32)
+    b = rng.randn(N).astype(np.float32) if G == 1 else None
+    r = rng.randn(G * M, N).astype(np.float32) if with_res else None
+    want = np.einsum("gmk,gnk->gmn", x.reshape(G, M, K).astype(np.float64), w.astype(np.float64)).reshape(G * M, N)
+    if b is not None: want += b.astype(np.float64)
+    if r is not None: want += r.astype(np.float64)
+    scale = max(1.0, float(np.abs(want).max()))
+    if act == 1: want = np.maximum(want, 0)
+    if act == 2: want = np.clip(want, 0, 6)
+    xd, wd = T(x, dev), T(w, dev)
+    bd, rd = (T(b, dev) if b is not None else None), (T(r, dev) if r is not None else None)
+    xp, wp = ops.h2_split(xd), ops.h2_pack_w(wd)
+    guard = torch.full((G * M + 64, N), 7.25, dtype=torch.float32, device=dev)
+    yp = ops.H2.empty(G * M, N, dev)
+    ops.gemm_h2(xp, wp, G, M, N, K, bd, rd, act, out=guard[:G * M], out_planes=yp, cfg=cfg)
+    torch.cuda.synchronize()
+    got = guard[:G * M].cpu().numpy()
+    assert bool((guard[G * M:] == 7.25).all()), "store past the last row"
+    if G == 1:
+        f32 = ops.conv2d(xd.view(1, 1, M, K), wd.view(N, 1, 1, K), bd, 1, 1, 1, (0, 0, 0, 0), act, None if rd is None else rd.view(1, 1, M, N), 1).view(M, N).cpu().numpy()
+    else:
+        f32 = ops.gemm_batched_nt(xd.view(G, M, K), wd, torch.empty((G, M, N), dtype=torch.float32, device=dev)).view(G * M, N).cpu().numpy()
+    e_h2, e_f32 = float(np.abs(got - want).max()) / scale, float(np.abs(f32 - want).max()) / scale
+    print("h2 cfg %d %s: max |err| / scale = %.3e (f32-MFMA kernel %.3e)" % (cfg, str(case), e_h2, e_f32))
+    assert e_h2 <= 2e-5 and e_h2 <= 3.0 * e_f32 + 1e-7
+    # the planes emitted by the epilogue == the splitter applied to the f32 result, bit for bit
+    want_p = _planes_np(ops.h2_split(guard[:G * M].contiguous()))
+    got_p = _planes_np(yp)
+    for g_, w_, name in zip(got_p, want_p, ("h", "l", "inv")):
+        assert np.array_equal(g_.view(np.uint16) if g_.dtype == np.float16 else g_, w_.view(np.uint16) if w_.dtype == np.float16 else w_), name
+
+
+def test_gemm_h2_planes_only_and_chained(dev):
+    """y = None: only the operand planes are written; feeding them to the next GEMM equals feeding the split of the f32 result."""
+    from frcnn_hip import ops
+    rng = np.random.RandomState(1)
+    M, K, N, N2 = 128 * 5 + 20, 256, 256, 128
+    x = np.maximum(rng.randn(M, K), 0).astype(np.float32)
+    w1 = (rng.randn(N, K) / np.sqrt(K)).astype(np.float32)
+    w2 = (rng.randn(N2, N) / np.sqrt(N)).astype(np.float32)
+    xp, w1p, w2p = ops.h2_split(T(x, dev)), ops.h2_pack_w(T(w1, dev)), ops.h2_pack_w(T(w2, dev))
+    y1, _ = ops.gemm_h2(xp, w1p, 1, M, N, K, act=1)
+    yp = ops.H2.empty(M, N, dev)
+    none, _ = ops.gemm_h2(xp, w1p, 1, M, N, K, act=1, out_planes=yp, want_f32=False)
+    assert none is None
+    a, _ = ops.gemm_h2(yp, w2p, 1, M, N2, N)
+    b, _ = ops.gemm_h2(ops.h2_split(y1), w2p, 1, M, N2, N)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    want = np.maximum(x.astype(np.float64) @ w1.astype(np.float64).T, 0) @ w2.astype(np.float64).T
+    assert float(np.abs(a.cpu().numpy() - want).max()) <= 2e-6 * max(1.0, float(np.abs(want).max()))

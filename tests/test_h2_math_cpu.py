@@ -1,0 +1,83 @@
+"""CPU: the arithmetic behind csrc/gemm_h2.hip (cfg.HIP.MFMA_H2) stated in numpy (oracle/h2_ref.py): the block scale is an exact
+power of two that puts the block maximum in [2^14, 2^15); h + l reproduces the scaled value to 2^-22 relative (or the fp16 subnormal
+spacing for elements far below the block maximum); each kept cross term is an exact product of 11-bit significands; what the
+three-term product drops is <= 3 * 2^-22 |x w|, unbiased, and at GEMM level sits at ~1e-7 of the output scale -- below the float32
+accumulation noise of a plain f32 GEMM on the same data."""
+import numpy as np
+
+import h2_ref
+
+
+def _acts(M, K, seed, kind):
+    rng = np.random.RandomState(seed)
+    if kind == "relu":
+        a = np.maximum(rng.randn(M, K), 0) * np.exp(rng.uniform(-2, 2, size=(M, K)))
+    elif kind == "wide":
+        a = rng.randn(M, K) * np.exp(rng.uniform(-12, 12, size=(M, K)))
+    else:
+        a = rng.randn(M, K) * 3
+    return a.astype(np.float32)
+
+
+def test_block_scale_is_an_exact_power_of_two_and_centres_the_block():
+    rng = np.random.RandomState(0)
+    mx = np.abs(rng.randn(100000) * np.exp(rng.uniform(-60, 60, size=100000))).astype(np.float32)
+    mx = mx[(mx > 2.0 ** -110) & (mx < 2.0 ** 120)]
+    scale, inv = h2_ref.block_scale(mx)
+    assert np.all(scale * inv == 1.0)
+    assert np.all((scale.view(np.uint32) & np.uint32(0x7fffff)) == 0) and np.all((inv.view(np.uint32) & np.uint32(0x7fffff)) == 0)
+    s = mx.astype(np.float64) * scale.astype(np.float64)
+    assert np.all(s >= 2.0 ** 14) and np.all(s < 2.0 ** 15)
+    z, zi = h2_ref.block_scale(np.zeros(3, dtype=np.float32))                  # all-zero block: clamped, finite
+    assert np.all(np.isfinite(z)) and np.all(z * zi == 1.0)
+
+
+def test_two_fp16_pieces_reproduce_the_value_to_2_pow_minus_22():
+    for kind in ("relu", "wide", "randn"):
+        x = _acts(64, 512, 1, kind)
+        h, l, inv = h2_ref.split(x)
+        assert h.dtype == np.float16 and l.dtype == np.float16 and np.all(np.isfinite(h.astype(np.float32)))
+        rec = (h.astype(np.float64) + l.astype(np.float64)) * np.repeat(inv.T.astype(np.float64), 128, axis=1)
+        err = np.abs(rec - x.astype(np.float64))
+        blockmax = np.repeat(np.abs(x).reshape(64, 4, 128).max(axis=2), 128, axis=1).astype(np.float64)
+        # 2^-22 of the value, or the fp16 subnormal spacing (2^-24 at the scaled magnitude = 2^-39 of the block maximum) if larger
+        assert np.all(err <= np.maximum(np.abs(x) * 2.0 ** -22, blockmax * 2.0 ** -38))
+        big = np.abs(x) >= blockmax * 2.0 ** -10
+        assert np.all(err[big] <= np.abs(x[big]) * 2.0 ** -22)
+
+
+def test_three_term_product_error_is_bounded_and_unbiased():
+    rng = np.random.RandomState(2)
+    a = (rng.randn(1, 128 * 2000) * np.exp(rng.uniform(-1, 1, size=(1, 128 * 2000)))).astype(np.float32)
+    w = (rng.randn(1, 128 * 2000) * np.exp(rng.uniform(-1, 1, size=(1, 128 * 2000)))).astype(np.float32)
+    ah, al, ainv = h2_ref.split(a)
+    wh, wl, winv = h2_ref.split(w)
+    sc = np.repeat(ainv.T.astype(np.float64), 128, axis=1) * np.repeat(winv.T.astype(np.float64), 128, axis=1)
+    f = lambda t: t.astype(np.float64)
+    three = (f(ah) * f(wh) + f(ah) * f(wl) + f(al) * f(wh)) * sc
+    exact = f(a) * f(w)
+    rel = (three - exact) / np.abs(exact)
+    amax = np.repeat(np.abs(a).reshape(1, -1, 128).max(axis=2), 128, axis=1).astype(np.float64)
+    wmax = np.repeat(np.abs(w).reshape(1, -1, 128).max(axis=2), 128, axis=1).astype(np.float64)
+    big = (np.abs(a) >= amax * 2.0 ** -6) & (np.abs(w) >= wmax * 2.0 ** -6)    # both low pieces in fp16's normal range
+    assert np.abs(rel[big]).max() <= 3.0 * 2.0 ** -22
+    # elements far below their block's maximum: absolute floor 2^-38 of that maximum per operand (fp16 subnormal spacing, scaled back)
+    assert np.all(np.abs(three - exact) <= 3.0 * 2.0 ** -22 * np.abs(exact) + 2.0 ** -37 * (amax * np.abs(w) + wmax * np.abs(a)))
+    assert abs(rel[big].mean()) <= 2.0 ** -27                                     # round to nearest: no systematic sign
+    assert np.sqrt((rel[big] ** 2).mean()) <= 2.0 ** -22.5
+    # every kept term is exact in float32: 11-bit x 11-bit significands
+    assert np.array_equal((ah.astype(np.float32) * wh.astype(np.float32)).astype(np.float64), f(ah) * f(wh))
+
+
+def test_gemm_level_error_is_below_f32_accumulation_noise():
+    rng = np.random.RandomState(3)
+    for name, (M, K, N, kind) in {"block4 conv1": (96, 2048, 64, "relu"), "block4 conv3": (96, 512, 64, "relu"),
+                                  "winograd": (96, 512, 64, "randn"), "wide": (96, 1024, 64, "wide")}.items():
+        a = _acts(M, K, 4, kind)
+        w = (rng.randn(N, K) / np.sqrt(K) * np.exp(rng.uniform(-1, 1, size=(N, K)))).astype(np.float32)
+        exact = a.astype(np.float64) @ w.astype(np.float64).T
+        scale = np.abs(exact).max()
+        e3 = np.abs(h2_ref.gemm_terms(a, w, 3) - exact).max() / scale
+        f32 = np.abs((a @ w.T).astype(np.float64) - exact).max() / scale           # numpy's float32 GEMM: one f32 implementation
+        assert e3 <= 2.5e-7, (name, e3)
+        assert e3 <= f32, (name, e3, f32)

@@ -724,15 +724,10 @@ static int launch_stream_cfg(int id, const ConvParams& p, hipStream_t st) {
 
 // tuning knob (experiments / A-B runs): key 0 = force a tile configuration id for every non-stem conv
 // (-1 = automatic choice).
-static int g_force_cfg = -1, g_dbg = 0, g_b3 = 0, g_b3_cfg = -1, g_stagger = 0, g_stream = 1;
-int frcnn_conv2d_b3_dispatch(const float* x_d, int N, int H, int W, int Cin, const float* w_d, const float* bias_d,
-                             const float* residual_d, int RH, int RW, int res_stride, float* y_d, int OH, int OW, int Cout,
-                             int KH, int KW, int stride, int pad_top, int pad_left, int act, int cfg, hipStream_t st);
+static int g_force_cfg = -1, g_dbg = 0, g_stagger = 0, g_stream = 1;
 extern "C" int frcnn_set_tuning(int key, int value) {
   if (key == 0) { g_force_cfg = value; return FRCNN_OK; }
   if (key == 1) { g_dbg = value; return FRCNN_OK; }
-  if (key == 2) { g_b3 = value; return FRCNN_OK; }          // experimental bf16x3 split-operand path (conv_igemm_b3.hip)
-  if (key == 3) { g_b3_cfg = value; return FRCNN_OK; }
   if (key == 5) { g_stagger = value; return FRCNN_OK; }        // 0 off; n > 0: second-slot workgroups start n/8 of a tile late
   if (key == 6) { g_stream = value; return FRCNN_OK; }         // 0: never dispatch to k_gemm_stream (A/B runs)
   return FRCNN_E_ARG;
@@ -774,7 +769,7 @@ static int launch_cfg(int id, const ConvParams& p, hipStream_t st) {
 // kchunk slabs into its own [M][Cout] partial (plain stores, no atomics -> deterministic), then k_splitk_finish adds the S
 // partials in a fixed order and applies bias / residual / activation.
 static int plan_splits(int M, int Cout, int nsteps) {
-  if (g_force_cfg >= 0 || g_b3) return 1;
+  if (g_force_cfg >= 0) return 1;
   const long long big = (long long)cdiv(M, 128) * cdiv(Cout, 128);
   if (Cout >= 96 && big >= 384 && nsteps >= 8) return 1;
   const long long tiles = (long long)cdiv(M, 64) * cdiv(Cout, Cout > 32 ? 64 : 32);
@@ -870,8 +865,6 @@ static int conv2d_impl(const float* x_d, int N, int H, int W, int Cin, const flo
   p.dbg = g_dbg;
   hipStream_t st = (hipStream_t)stream;
   if (fold_w) return launch_conv<128, 64, 32, 64, 3, true>(p, st);
-  if (g_b3) return frcnn_conv2d_b3_dispatch(x_d, N, H, W, Cin, w_d, bias_d, residual_d, RH, RW, res_stride, y_d, OH, OW, Cout, KH,
-                                            KW, stride, pad_top, pad_left, act, g_b3_cfg, st);
   if (g_force_cfg >= 100) return launch_stream_cfg(g_force_cfg, p, st);
   if (g_force_cfg >= 0) return launch_cfg(g_force_cfg, p, st);
   if (ws) {

@@ -1,0 +1,587 @@
+// f32 "NT" GEMM on the 16-bit matrix pipe with BLOCK-SCALED two-piece fp16 operands ("h2"):
+//
+//     Y[m][n] = act( sum_k X[m][k] * W[n][k] + bias[n] + res[m][n] )            X, W, Y float32
+//
+// Operand format.  A float32 row segment of 128 consecutive k (a "scale block") is stored as
+//     x = 2^-e * (h + l) + r,     h = fp16(x * 2^e),  l = fp16(x * 2^e - h),   e chosen so that max|x * 2^e| is in [2^14, 2^15)
+// i.e. two fp16 planes H, L and ONE exact power-of-two scale per (row, 128-k block).  Both roundings are to nearest, the scaling is
+// exact, x * 2^e - h is exact in f32; |r| <= 2^-22 |x| (and never more than 2^-39 of the block's largest element, where l leaves the
+// fp16 normal range).  A product is evaluated as the three leading cross terms  xh*wh + xh*wl + xl*wh  on v_mfma_f32_32x32x16_f16 with
+// f32 accumulation -- each term an exact product of 11-bit significands; what is dropped (xl*wl and the two residuals) is <= 3 * 2^-22
+// |x w|, unbiased (round to nearest) and measured at 1e-7 of the output scale on the GEMM shapes of the path, below the f32
+// accumulation noise of ANY f32 kernel (tests/test_h2_math_cpu.py states this in numpy; tests/test_dense_gpu.py measures the kernel
+// against float64 beside the f32-MFMA kernel).  Three 16-bit MFMAs (8 passes, 16 k) replace eight f32 MFMAs (16 passes, 2 k each) and
+// the six of csrc/gemm_x3.hip: 96 instead of 512 / 192 matrix-pipe cycles per 16 k -> ceiling 2500 / 3 = 833 TFLOP/s f32-equivalent.
+//
+// The weights' scale is per output row n over all of K (static, split once: frcnn_h2_pack_w); the activations' scale is per
+// (row m, 128-k block), so every producer can compute it locally: a GEMM workgroup owns 128 output columns of its rows and emits
+// the NEXT layer's operand planes straight from its register epilogue (`yp`, `y_inv`); the Winograd transforms and the generic
+// splitter (frcnn_h2_split) do the same.  Inside the GEMM a 128-k block is accumulated in a scratch accumulator (first MFMA of the
+// block takes C = 0) and folded into the running f32 sum with ONE fma per element by the block's exact scale -- 128 VALU per 96 MFMAs
+// per wave, instead of the 176 per 48 of the in-register bf16 split of gemm_x3.
+//
+// Orientation.  The MFMA computes D = Wfrag x Xfrag^T: accumulator lane l holds output ROW m = l & 31 (+ sub-tile), registers walk
+// the columns n = 8 (r >> 2) + 4 (l >> 5) + (r & 3).  The activation scale is then ONE value per lane, residual / result / planes move
+// as 16- / 8-byte accesses of 4 consecutive n, and the row maximum for the output planes is a per-lane reduction over registers.
+//
+// Pipeline: k_gemm_x3's skeleton -- resident workgroups walk a static XCD-aware tile list, (tile, slab) is one stream of 32-k slabs
+// through an NS-deep LDS ring filled by direct-to-LDS loads (global_load_lds_dwordx4, scalar base + 32-bit lane offset: no address
+// VALU), counted vmcnt (NS - 2 slabs stay in flight across the per-slab barrier), XOR-swizzled 64-byte plane rows -> conflict-free
+// ds_read_b128 fragments.  A stage = X planes 2 x BM x 64 B + W planes 2 x BN x 64 B + the BM block scales (1 KB):
+// 33 KB for 128 x 128 -> two stages = 66 KB = 2 workgroups per CU, or 3-4 stages with one.
+#include "common.h"
+#include <mutex>
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+#define H2_KB 128                     // k per scale block
+#define LDS_AS __attribute__((address_space(3)))
+
+struct GemmH2Params {
+  const unsigned short* x; const float* x_inv; const unsigned short* w; const float* w_inv;
+  const float* bias; const float* res; float* y; unsigned short* yp; float* y_inv;
+  int M, N, K, batch, act, nsteps, mtiles, ntiles;
+  long long Mtot;                     // rows of x / res / y / yp over all batch entries (= batch * M)
+};
+
+// one direct-to-LDS load: 64 lanes x 16 B from (scalar base + per-lane 32-bit byte offset) to LDS [lds_base, +1 KiB), lane-linear.
+// Inline asm on purpose (see conv_igemm.hip::glds16): the compiler's scoreboard must not see these loads, the counted waits below are
+// the only ones.  M0 is saved / restored inside the statement.
+__device__ __forceinline__ void h2_glds16(unsigned voff, const void* sbase, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_base)
+      : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void h2_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// The block scale of a 128-k block whose largest magnitude is `mx` (>= 0): (2^e, 2^-e) with mx * 2^e in [2^14, 2^15).  Pure exponent
+// arithmetic, so every producer (GEMM epilogue, splitter, Winograd transforms, host reference) derives the identical pair.
+// Blocks of zeros / denormals-only clamp at 2^126; inf / nan blocks get a tiny scale and stay inf / nan.
+__device__ __forceinline__ void h2_block_scale(float mx, float& scale, float& inv) {
+  int ex = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+  ex = ex < 15 ? 15 : ex;
+  scale = __uint_as_float((unsigned)(268 - ex) << 23);
+  inv = __uint_as_float((unsigned)(ex - 14) << 23);
+}
+
+__device__ __forceinline__ void h2_split1(float v, float scale, _Float16& h, _Float16& l) {
+  const float vs = v * scale;
+  h = (_Float16)vs;
+  l = (_Float16)(vs - (float)h);
+}
+
+// TUNE bits (A/B measurements, all produce identical results): 1 = the slab's loads are issued in two halves around the first k group
+// instead of in one burst after the barrier; 2 = the block scales travel only with the first slab of a 128-k block (NS == 2 only)
+template <int BM, int BN, int WM, int WN, int NS, int WPE = 2, int TUNE = 0>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_waves_per_eu(WPE))) void k_gemm_h2(const GemmH2Params p) {
+  constexpr int NW = (BM / WM) * (BN / WN);
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int LA = 2 * BM / 16 / NW;            // X planes: 1 KiB = 16 rows x 64 B per direct-to-LDS instruction
+  constexpr int LB = 2 * BN / 16 / NW;            // W planes
+  constexpr int G = LA + LB;                      // per wave per slab (wave 0 issues one more: the block scales)
+  constexpr int XP = BM * 64, WP = BN * 64;       // bytes of one plane of a stage
+  constexpr int S_OFF = 2 * XP + 2 * WP, STAGE = S_OFF + 1024;
+  constexpr int RED_OFF = NS * STAGE;             // row-maximum exchange of the plane-emitting epilogue: [BN / WN][BM] floats
+  constexpr int S2_OFF = RED_OFF + (BN / WN) * BM * 4;      // TUNE & 2: two 1 KB block-scale regions, alternating per 128-k block
+  static_assert((2 * BM / 16) % NW == 0 && (2 * BN / 16) % NW == 0, "tile/wave mismatch");
+  static_assert(BM <= 256 && NS >= 2 && NS <= 4, "stage layout");
+  static_assert((NS - 2) * (G + 1) <= 63, "vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int per = p.mtiles * p.ntiles, T = per * p.batch;
+  const int xcd = blockIdx.x & 7, wx = blockIdx.x >> 3, W8 = gridDim.x >> 3;
+  const int tq = T / 8, tr = T % 8, tn = tq + (xcd < tr ? 1 : 0);
+  const int t_end = (xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq) + tn;
+  const int tile0 = t_end - tn + wx;
+  if (tile0 >= t_end) return;
+  const int my_tiles = (t_end - tile0 + W8 - 1) / W8;
+  int left = __builtin_amdgcn_readfirstlane(my_tiles * p.nsteps);      // slabs of this workgroup's stream not yet issued
+
+  const int wmi = wave / (BN / WN), wni = wave % (BN / WN);
+  const int wm0 = wmi * WM, wn0 = wni * WN;
+  const int frow = lane & 31, khalf = lane >> 5;
+
+  // ---- issue side: the slab stream --------------------------------------------------------------------------------------------
+  const size_t xplane = (size_t)p.Mtot * p.K * 2, wplane = (size_t)p.N * p.K * 2;     // bytes
+  unsigned a_off[LA], b_off[LB], s_off = 0;
+  const char* i_xb = nullptr; const char* i_wb = nullptr; const char* i_sb = nullptr;  // wave-uniform bases, advanced per slab
+  int i_tile = tile0, i_step = 0, i_par = 0, c_par = 0;       // *_par: parity of the running 128-k block count (issue / compute side)
+#pragma unroll
+  for (int t = 0; t < LB; ++t) {
+    const int u = wave * LB + t, plane = u / (BN / 16), row = (u % (BN / 16)) * 16 + (lane >> 2), pos = lane & 3;
+    b_off[t] = (unsigned)((size_t)plane * wplane + (size_t)row * p.K * 2 + ((pos ^ ((row >> 1) & 3)) * 16));
+  }
+  auto set_tile = [&](int tl) {
+    const int g = tl / per, rem = tl - g * per;
+    const int mt = rem / p.ntiles, nt = rem - mt * p.ntiles;
+    const int bm0 = mt * BM, bn0 = nt * BN;
+    const size_t row0 = (size_t)g * p.M + bm0;
+    i_xb = (const char*)p.x + row0 * p.K * 2;
+    i_wb = (const char*)p.w + ((size_t)g * 2 * p.N + bn0) * p.K * 2;
+    i_sb = (const char*)(p.x_inv + row0);
+#pragma unroll
+    for (int t = 0; t < LA; ++t) {
+      const int u = wave * LA + t, plane = u / (BM / 16), row = (u % (BM / 16)) * 16 + (lane >> 2), pos = lane & 3;
+      const int rr = min(row, p.M - 1 - bm0);                                           // rows past M re-read row M - 1
+      a_off[t] = (unsigned)((size_t)plane * xplane + (size_t)rr * p.K * 2 + ((pos ^ ((row >> 1) & 3)) * 16));
+    }
+    // block scales of the tile's rows: 4 floats per lane; lanes past the tile / the tensor re-read in-range words (unused rows)
+    const long long last = p.Mtot - 4 - (long long)row0;
+    s_off = (unsigned)(min((long long)(4 * lane) % BM, last < 0 ? 0 : last) * 4);
+  };
+  const unsigned lds0 = (unsigned)(size_t)(LDS_AS char*)smem;
+  auto uniform_ptr = [](const char* q) {
+    const unsigned long long v = (unsigned long long)q;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+  };
+  auto issue_one = [&](int buf, int t) {
+    const unsigned sb = lds0 + (unsigned)(buf * STAGE);
+    if (t < LA) h2_glds16(a_off[t], uniform_ptr(i_xb), __builtin_amdgcn_readfirstlane(sb + (wave * LA + t) * 1024));
+    else if (t < G) h2_glds16(b_off[t - LA], uniform_ptr(i_wb), __builtin_amdgcn_readfirstlane(sb + 2 * XP + (wave * LB + (t - LA)) * 1024));
+    else if (wave == 0) {
+      if (!(TUNE & 2)) h2_glds16(s_off, uniform_ptr(i_sb), __builtin_amdgcn_readfirstlane(sb + S_OFF));
+      else if ((i_step & 3) == 0) {              // once per 128-k block, into the parity region of that block (not a ring slot)
+        h2_glds16(s_off, uniform_ptr(i_sb), __builtin_amdgcn_readfirstlane(lds0 + S2_OFF + i_par * 1024));
+        i_par ^= 1;
+      }
+    }
+  };
+  static_assert(!(TUNE & 2) || NS == 2, "scales-once needs the uncounted wait of the two-stage ring");
+  auto issue_advance = [&]() {                      // after the last piece of a slab
+    --left;
+    if (++i_step == p.nsteps) {
+      i_step = 0; i_tile += W8;
+      if (left > 0) set_tile(i_tile);
+    } else {
+      i_xb += 64; i_wb += 64;
+      if ((i_step & 3) == 0) i_sb += (size_t)p.Mtot * 4;       // next 128-k block: next row of x_inv [K/128][Mtot]
+    }
+  };
+
+  // ---- compute side -------------------------------------------------------------------------------------------------------------
+  f32x16 tot[TM][TN], tmp[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+  const int sw = (frow >> 1) & 3;
+  const int x_row = (wm0 + frow) * 64, w_row = 2 * XP + (wn0 + frow) * 64;
+
+  auto slab_mfma = [&](int cur, auto first_c, auto&& between) {
+    constexpr bool FIRST = decltype(first_c)::value;
+    const char* sb = smem + cur * STAGE;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {                    // two groups of 16 k per 32-wide slab
+      if (t == 1) between();
+      h8 xh[TM], xl[TM], wh[TN], wl[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const char* q = sb + w_row + j * 32 * 64 + (((2 * t + khalf) ^ sw) * 16);
+        wh[j] = __builtin_bit_cast(h8, *(const uint4*)(q));
+        wl[j] = __builtin_bit_cast(h8, *(const uint4*)(q + WP));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const char* q = sb + x_row + i * 32 * 64 + (((2 * t + khalf) ^ sw) * 16);
+        xh[i] = __builtin_bit_cast(h8, *(const uint4*)(q));
+        xl[i] = __builtin_bit_cast(h8, *(const uint4*)(q + XP));
+      }
+      // term-major order: consecutive MFMAs write different accumulators
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if (FIRST && t == 0) {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            tmp[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], xh[i], z, 0, 0, 0);
+          } else {
+            tmp[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], xh[i], tmp[i][j], 0, 0, 0);
+          }
+        }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) tmp[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], xh[i], tmp[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) tmp[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], xl[i], tmp[i][j], 0, 0, 0);
+    }
+  };
+
+  int c_tile = tile0, c_step = 0, cur = 0, nxt = 0;          // nxt: ring slot of the next slab to issue
+  int c_bm0 = 0, c_bn0 = 0, c_g = 0;
+  auto set_ctile = [&](int tl) {
+    const int g = tl / per, rem = tl - g * per;
+    const int mt = rem / p.ntiles, nt = rem - mt * p.ntiles;
+    c_bm0 = mt * BM; c_bn0 = nt * BN; c_g = g;
+  };
+  const float act_lo = p.act == FRCNN_ACT_NONE ? -__builtin_inff() : 0.f;
+  const float act_hi = p.act == FRCNN_ACT_RELU6 ? 6.f : __builtin_inff();
+
+  auto rsrc_f = [&](const void* base, long long elems_left, int esize) {
+    const long long bytes = elems_left * esize;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)max(0ll, min(bytes, 0x7fffffffll)), 0x00020000);
+  };
+
+  auto epilogue = [&]() {
+    const size_t row_base = (size_t)c_g * p.M;
+    // ---- v = act(tot * w_inv + bias + res), kept in tot ------------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n0 = c_bn0 + wn0 + j * 32 + 4 * khalf;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 wi = *(const float4*)(p.w_inv + (size_t)c_g * p.N + n0 + 8 * q);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) bv = *(const float4*)(p.bias + n0 + 8 * q);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          tot[i][j][4 * q + 0] = tot[i][j][4 * q + 0] * wi.x + bv.x;
+          tot[i][j][4 * q + 1] = tot[i][j][4 * q + 1] * wi.y + bv.y;
+          tot[i][j][4 * q + 2] = tot[i][j][4 * q + 2] * wi.z + bv.z;
+          tot[i][j][4 * q + 3] = tot[i][j][4 * q + 3] * wi.w + bv.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m0 = c_bm0 + wm0 + i * 32;                                  // first row of the sub-tile inside the batch entry
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nc = c_bn0 + wn0 + j * 32;
+        const long long sbase = (long long)(row_base + m0) * p.N + nc;     // element offset of the sub-tile
+        const long long left_e = (long long)(p.M - m0) * p.N - nc;         // elements from there to the end of the batch entry's rows
+        const int lo = (frow * p.N + 4 * khalf) * 4;
+        if (p.res) {
+          const auto rr = rsrc_f(p.res + sbase, left_e, 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const auto rv = __builtin_amdgcn_raw_buffer_load_b128(rr, lo + 32 * q, 0, 0);
+            tot[i][j][4 * q + 0] += __uint_as_float(rv[0]);
+            tot[i][j][4 * q + 1] += __uint_as_float(rv[1]);
+            tot[i][j][4 * q + 2] += __uint_as_float(rv[2]);
+            tot[i][j][4 * q + 3] += __uint_as_float(rv[3]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[i][j][r] = fminf(fmaxf(tot[i][j][r], act_lo), act_hi);
+        if (p.y) {
+          const auto ry = rsrc_f(p.y + sbase, left_e, 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 o;
+            // (__float_as_uint, not __builtin_bit_cast: bit_cast of an ext-vector ELEMENT lvalue reads element 0 -- clang 19 / ROCm 7.2)
+            o[0] = __float_as_uint(tot[i][j][4 * q + 0]); o[1] = __float_as_uint(tot[i][j][4 * q + 1]);
+            o[2] = __float_as_uint(tot[i][j][4 * q + 2]); o[3] = __float_as_uint(tot[i][j][4 * q + 3]);
+            __builtin_amdgcn_raw_buffer_store_b128(o, ry, lo + 32 * q, 0, 0);
+          }
+        }
+      }
+    }
+    // ---- the next layer's operand planes: block scale over this workgroup's 128 columns, per row ------------------------------------
+    if (p.yp) {
+      float* red = (float*)(smem + RED_OFF);
+      float mx[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float m = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(tot[i][j][r]));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        mx[i] = m;
+        if (BN / WN > 1 && khalf == 0) red[wni * BM + wm0 + i * 32 + frow] = m;
+      }
+      if (BN / WN > 1) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int o = 0; o < BN / WN; ++o) mx[i] = fmaxf(mx[i], red[o * BM + wm0 + i * 32 + frow]);
+      }
+      const size_t yplane = (size_t)p.Mtot * p.N;                                 // elements
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float scale, inv;
+        h2_block_scale(mx[i], scale, inv);
+        const int m0 = c_bm0 + wm0 + i * 32;
+        if (wni == 0 && khalf == 0 && m0 + frow < p.M)
+          p.y_inv[(size_t)(c_bn0 / H2_KB) * p.Mtot + row_base + m0 + frow] = inv;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int nc = c_bn0 + wn0 + j * 32;
+          const long long sbase = (long long)(row_base + m0) * p.N + nc;
+          const long long left_e = (long long)(p.M - m0) * p.N - nc;
+          const auto rh = rsrc_f(p.yp + sbase, left_e, 2), rl = rsrc_f(p.yp + yplane + sbase, left_e, 2);
+          const int lo = (frow * p.N + 4 * khalf) * 2;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            h4 hh, ll;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              _Float16 a, b;
+              h2_split1(tot[i][j][4 * q + c], scale, a, b);
+              hh[c] = a; ll[c] = b;
+            }
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), rh, lo + 16 * q, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), rl, lo + 16 * q, 0, 0);
+          }
+        }
+      }
+      if (BN / WN > 1) __syncthreads();                                          // red[] is reused by the next tile
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+  };
+
+  // one slab of the stream: wait for it, let the ring slot it frees be refilled (loads spread over nothing here: they are issued
+  // right after the barrier, G + 1 instructions, and land under the 24 * TM * TN / 4 MFMAs of this slab and the next NS - 2)
+  auto slab = [&](auto first_c, bool fold) {
+    if (left >= 1) {                                   // steady state: NS - 2 younger slabs may stay in flight
+      if (wave == 0) h2_wait_vmcnt<(NS - 2) * (G + 1)>(); else h2_wait_vmcnt<(NS - 2) * G>();
+    } else {
+      h2_wait_vmcnt<0>();                              // tail of the stream: nothing more will be issued
+    }
+    __builtin_amdgcn_s_barrier();
+    const bool more = left > 0;
+    constexpr int HALF = (TUNE & 1) ? (G + 1) / 2 : G + 1;
+    if (more) {
+#pragma unroll
+      for (int t = 0; t < HALF; ++t) issue_one(nxt, t);
+    }
+    float ainv[TM];
+    if (fold) {
+      const int soff = (TUNE & 2) ? S2_OFF + c_par * 1024 : cur * STAGE + S_OFF;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) ainv[i] = *(const float*)(smem + soff + (wm0 + i * 32 + frow) * 4);
+      c_par ^= 1;
+    }
+    slab_mfma(cur, first_c, [&]() {
+      if (more) {
+#pragma unroll
+        for (int t = HALF; t <= G; ++t) issue_one(nxt, t);
+      }
+    });
+    if (more) {
+      issue_advance();
+      nxt = nxt + 1 == NS ? 0 : nxt + 1;
+    }
+    if (fold) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tot[i][j][r] = __builtin_fmaf(tmp[i][j][r], ainv[i], tot[i][j][r]);
+    }
+    cur = cur + 1 == NS ? 0 : cur + 1;
+  };
+
+  // ---- prologue: NS - 1 slabs ahead ---------------------------------------------------------------------------------------------
+  set_tile(i_tile);
+  set_ctile(c_tile);
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) {
+    if (left > 0) {
+#pragma unroll
+      for (int t = 0; t <= G; ++t) issue_one(nxt, t);
+      issue_advance();
+      nxt = nxt + 1 == NS ? 0 : nxt + 1;
+    }
+  }
+  const int nkb = p.nsteps >> 2;
+  for (int tl = 0; tl < my_tiles; ++tl) {
+    for (int kb = 0; kb < nkb; ++kb) {
+      slab(std::true_type{}, false);
+      slab(std::false_type{}, false);
+      slab(std::false_type{}, false);
+      slab(std::false_type{}, true);
+    }
+    epilogue();
+    c_tile += W8;
+    if (tl + 1 < my_tiles) set_ctile(c_tile);
+  }
+  h2_wait_vmcnt<0>();
+}
+
+// ---- splitters -------------------------------------------------------------------------------------------------------------------
+// x [M][K] f32 -> planes [2][M][K] fp16 + inv [K/128][M]: one half-wave (32 lanes x 4 k) per (row, 128-k block)
+__global__ __launch_bounds__(256) void k_h2_split(const float* __restrict__ x, long long M, int K, unsigned short* __restrict__ planes,
+                                                  float* __restrict__ inv_out) {
+  const int nkb = K / H2_KB;
+  const long long pairs = M * nkb;
+  const int sub = threadIdx.x >> 5, l = threadIdx.x & 31;
+  for (long long pr = (long long)blockIdx.x * 8 + sub; pr < pairs; pr += (long long)gridDim.x * 8) {
+    const long long m = pr / nkb;
+    const int kb = (int)(pr - m * nkb);
+    const size_t e = (size_t)m * K + (size_t)kb * H2_KB + 4 * l;
+    const float4 v = *(const float4*)(x + e);
+    float mx = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float scale, inv;
+    h2_block_scale(mx, scale, inv);
+    h4 hh, ll;
+    _Float16 a, b;
+    h2_split1(v.x, scale, a, b); hh[0] = a; ll[0] = b;
+    h2_split1(v.y, scale, a, b); hh[1] = a; ll[1] = b;
+    h2_split1(v.z, scale, a, b); hh[2] = a; ll[2] = b;
+    h2_split1(v.w, scale, a, b); hh[3] = a; ll[3] = b;
+    *(h4*)(planes + e) = hh;
+    *(h4*)(planes + (size_t)M * K + e) = ll;
+    if (l == 0) inv_out[(size_t)kb * M + m] = inv;
+  }
+}
+
+// W [G][N][K] f32 -> planes [G][2][N][K] fp16 + w_inv [G][N]: ONE scale per output row (over all of K), one wave per row
+__global__ __launch_bounds__(256) void k_h2_pack_w(const float* __restrict__ w, int rows, int N, int K, unsigned short* __restrict__ planes,
+                                                   float* __restrict__ inv_out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* src = w + (size_t)row * K;
+  float mx = 0.f;
+  for (int k = 4 * l; k < K; k += 256) {
+    const float4 v = *(const float4*)(src + k);
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float scale, inv;
+  h2_block_scale(mx, scale, inv);
+  const int g = row / N, n = row - g * N;
+  unsigned short* ph = planes + ((size_t)g * 2 * N + n) * K;
+  unsigned short* pl = ph + (size_t)N * K;
+  for (int k = 4 * l; k < K; k += 256) {
+    const float4 v = *(const float4*)(src + k);
+    h4 hh, ll;
+    _Float16 a, b;
+    h2_split1(v.x, scale, a, b); hh[0] = a; ll[0] = b;
+    h2_split1(v.y, scale, a, b); hh[1] = a; ll[1] = b;
+    h2_split1(v.z, scale, a, b); hh[2] = a; ll[2] = b;
+    h2_split1(v.w, scale, a, b); hh[3] = a; ll[3] = b;
+    *(h4*)(ph + k) = hh;
+    *(h4*)(pl + k) = ll;
+  }
+  if (l == 0) inv_out[row] = inv;
+}
+
+extern "C" size_t frcnn_h2_planes_bytes(long long rows, int K) {
+  if (rows <= 0 || K <= 0) return 0;
+  return (size_t)2 * (size_t)rows * (size_t)K * sizeof(unsigned short);
+}
+
+extern "C" int frcnn_h2_pack_w(const float* w_d, int G, int N, int K, void* planes_d, float* w_inv_d, void* stream) {
+  if (!w_d || !planes_d || !w_inv_d || G <= 0 || N <= 0 || K <= 0) return FRCNN_E_ARG;
+  if (K % 4) return FRCNN_E_UNSUPPORTED;
+  const int rows = G * N;
+  hipLaunchKernelGGL(k_h2_pack_w, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, w_d, rows, N, K, (unsigned short*)planes_d, w_inv_d);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+extern "C" int frcnn_h2_split(const float* x_d, long long M, int K, void* planes_d, float* inv_d, void* stream) {
+  if (!x_d || !planes_d || !inv_d || M <= 0 || K <= 0) return FRCNN_E_ARG;
+  if (K % H2_KB) return FRCNN_E_UNSUPPORTED;
+  const long long pairs = M * (K / H2_KB);
+  const unsigned grid = (unsigned)min((pairs + 7) / 8, (long long)256 * 64);
+  hipLaunchKernelGGL(k_h2_split, dim3(grid), dim3(256), 0, (hipStream_t)stream, x_d, M, K, (unsigned short*)planes_d, inv_d);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int NS, int WPE = 2, int TUNE = 0>
+static int launch_h2(const GemmH2Params& q, hipStream_t st) {
+  constexpr int NT = (BM / WM) * (BN / WN) * 64;
+  constexpr size_t lds = (size_t)NS * (2 * BM * 64 + 2 * BN * 64 + 1024) + (size_t)(BN / WN) * BM * 4 + ((TUNE & 2) ? 2048 : 0);
+  auto kern = k_gemm_h2<BM, BN, WM, WN, NS, WPE, TUNE>;
+  static std::once_flag once;
+  static hipError_t rc0 = hipSuccess;
+  static int slots = 0;
+  std::call_once(once, [&] {
+    rc0 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int per_cu = 0, dev = 0, cus = 0;
+    if (rc0 == hipSuccess) rc0 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, NT, lds);
+    if (rc0 == hipSuccess) rc0 = hipGetDevice(&dev);
+    if (rc0 == hipSuccess) rc0 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    slots = per_cu * cus;
+  });
+  HIP_TRY(rc0);
+  if (slots < 8 || q.N % BN) return FRCNN_E_UNSUPPORTED;
+  if (q.yp && BN != H2_KB) return FRCNN_E_UNSUPPORTED;            // the emitted block scale spans exactly the workgroup's columns
+  GemmH2Params p = q;
+  p.mtiles = cdiv(p.M, BM); p.ntiles = p.N / BN; p.nsteps = p.K / 32;
+  const long long T = (long long)p.mtiles * p.ntiles * p.batch;
+  if (T >= (1ll << 30)) return FRCNN_E_UNSUPPORTED;
+  const int grid = (int)min((long long)(slots / 8) * 8, ((T + 7) / 8) * 8);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, st, p);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// y[g] = act(x[g] W[g]^T + bias + res[g]), g < G.  x: planes [2][G*M][K] + x_inv [K/128][G*M] (frcnn_h2_split or a producer's `yp`
+// output); W: frcnn_h2_pack_w(W [G][N][K]); res / y [G*M][N] f32 (y may be null when only planes are wanted);
+// yp / y_inv: planes [2][G*M][N] + [N/128][G*M] of the result for the next GEMM (null: not emitted).
+// cfg: -1 by shape, else a tile configuration id (A/B runs; per call, no process-wide state).
+extern "C" int frcnn_gemm_h2(const void* x_planes_d, const float* x_inv_d, const void* w_planes_d, const float* w_inv_d, const float* bias_d,
+                             const float* res_d, float* y_d, void* y_planes_d, float* y_inv_d, int G, int M, int N, int K, int act, int cfg,
+                             void* stream) {
+  if (!x_planes_d || !x_inv_d || !w_planes_d || !w_inv_d || (!y_d && !y_planes_d) || (y_planes_d && !y_inv_d) || G <= 0 || M <= 0 || N <= 0 ||
+      K <= 0 || act < 0 || act > 2)
+    return FRCNN_E_ARG;
+  const long long Mtot = (long long)G * M;
+  // 32-bit per-lane byte offsets: both x planes / both W planes of a batch entry / one result row block
+  if (K % H2_KB || N % 128 || (G > 1 && M % 4) || Mtot % 4 || 4ll * Mtot * K >= (1ll << 32) || 4ll * N * K >= (1ll << 32) ||
+      (long long)M * N >= (1ll << 29))
+    return FRCNN_E_UNSUPPORTED;
+  GemmH2Params p;
+  p.x = (const unsigned short*)x_planes_d; p.x_inv = x_inv_d; p.w = (const unsigned short*)w_planes_d; p.w_inv = w_inv_d;
+  p.bias = bias_d; p.res = res_d; p.y = y_d; p.yp = (unsigned short*)y_planes_d; p.y_inv = y_inv_d;
+  p.M = M; p.N = N; p.K = K; p.batch = G; p.act = act; p.Mtot = Mtot;
+  p.nsteps = p.mtiles = p.ntiles = 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (cfg < 0) cfg = 0;
+  switch (cfg) {
+    case 0: return launch_h2<128, 128, 64, 64, 2>(p, st);        // 67 KB: 2 workgroups / CU
+    case 1: return launch_h2<128, 128, 64, 64, 3>(p, st);        // 100 KB: 1 workgroup / CU, 2 slabs in flight
+    case 2: return launch_h2<128, 128, 64, 64, 4>(p, st);        // 133 KB
+    case 3: return launch_h2<256, 128, 64, 64, 2>(p, st);        // 8 waves, 100 KB
+    case 4: return launch_h2<256, 128, 64, 64, 3>(p, st);        // 8 waves, 149 KB
+    case 5: return launch_h2<128, 128, 32, 64, 2>(p, st);        // 8 waves of 32 x 64
+    case 6: return launch_h2<128, 128, 32, 64, 3>(p, st);
+    case 7: return launch_h2<128, 128, 32, 64, 2, 4>(p, st);     // 8 waves of 32 x 64 in <= 128 registers: 2 workgroups = 4 waves / SIMD
+    case 8: return launch_h2<128, 128, 64, 64, 2, 2, 1>(p, st);  // cfg 0 with the loads issued in two halves
+    case 9: return launch_h2<128, 128, 64, 64, 2, 2, 2>(p, st);  // cfg 0 with the scales sent once per 128-k block
+    case 10: return launch_h2<128, 128, 64, 64, 2, 2, 3>(p, st);
+    case 11: return launch_h2<128, 128, 32, 64, 2, 4, 3>(p, st);
+    default: return FRCNN_E_ARG;
+  }
+}

@@ -676,6 +676,64 @@ def gemm_x3(x, planes, G, M, N, K, bias=None, residual=None, act=ACT_NONE, out=N
     return out
 
 
+class H2(object):
+    """A float32 tensor [rows, K] held as frcnn_gemm_h2 operand planes: `planes` uint8 buffer = fp16 [2][rows][K] (H then L) and
+    `inv` f32 [K/128][rows] = the exact power-of-two block scales 2^-e (csrc/gemm_h2.hip)."""
+    __slots__ = ("planes", "inv", "rows", "K")
+
+    def __init__(self, planes, inv, rows, K):
+        self.planes, self.inv, self.rows, self.K = planes, inv, int(rows), int(K)
+
+    @staticmethod
+    def empty(rows, K, device):
+        assert K % 128 == 0
+        return H2(torch.empty(lib().frcnn_h2_planes_bytes(int(rows), int(K)), dtype=torch.uint8, device=device),
+                  torch.empty((K // 128, rows), dtype=torch.float32, device=device), rows, K)
+
+    def to_float(self):
+        """(h + l) * 2^-e as float32 [rows, K] (tests / debugging: host-side torch arithmetic, not a product path)."""
+        hl = self.planes.view(torch.float16).view(2, self.rows, self.K).float()
+        inv = self.inv.t().repeat_interleave(128, dim=1)
+        return (hl[0] + hl[1]) * inv
+
+
+def h2_split(x, out=None):
+    """frcnn_h2_split: x f32 [..., K] (K % 128 == 0) -> H2 planes of its rows."""
+    _chk(x)
+    K = x.shape[-1]
+    rows = x.numel() // K
+    out = H2.empty(rows, K, x.device) if out is None else out
+    assert out.rows == rows and out.K == K
+    call("frcnn_h2_split", _ptr(x), rows, K, _ptr(out.planes), _ptr(out.inv), _stream())
+    return out
+
+
+def h2_pack_w(w, out=None):
+    """frcnn_h2_pack_w: filter bank w [G,N,K] or [N,...K] f32 -> (planes uint8 [G][2][N][K] fp16, w_inv f32 [G,N])."""
+    _chk(w)
+    G, N, K = (w.shape[0], w.shape[1], w.shape[2]) if w.dim() == 3 else (1, w.shape[0], w[0].numel())
+    if out is None:
+        out = (torch.empty(lib().frcnn_h2_planes_bytes(G * N, K), dtype=torch.uint8, device=w.device),
+               torch.empty((G, N), dtype=torch.float32, device=w.device))
+    call("frcnn_h2_pack_w", _ptr(w), G, N, K, _ptr(out[0]), _ptr(out[1]), _stream())
+    return out
+
+
+def gemm_h2(x, wp, G, M, N, K, bias=None, residual=None, act=ACT_NONE, out=None, out_planes=None, want_f32=True, cfg=-1):
+    """out[g] = act(x[g] W[g]^T + bias + residual[g]) through frcnn_gemm_h2.  x: H2 of [G*M, K]; wp = h2_pack_w(W [G,N,K]).
+    out: f32 [G*M, N] (allocated when want_f32 and out is None); out_planes: an H2 of [G*M, N] to ALSO receive the result as the next
+    GEMM's operand (emitted from the epilogue).  Returns (out or None, out_planes or None)."""
+    assert isinstance(x, H2) and x.rows == G * M and x.K == K
+    if out is None and want_f32:
+        out = torch.empty((G * M, N), dtype=torch.float32, device=x.planes.device)
+    if out_planes is not None:
+        assert out_planes.rows == G * M and out_planes.K == N
+    call("frcnn_gemm_h2", _ptr(x.planes), _ptr(x.inv), _ptr(wp[0]), _ptr(wp[1]), _ptr(bias), _ptr(residual), _ptr(out),
+         _ptr(None if out_planes is None else out_planes.planes), _ptr(None if out_planes is None else out_planes.inv),
+         int(G), int(M), int(N), int(K), int(act), int(cfg), _stream())
+    return out, out_planes
+
+
 def relu6_bwd(grad, y):
     _chk(grad), _chk(y)
     call("frcnn_relu6_bwd", _ptr(grad), _ptr(y), grad.numel(), _stream())
