@@ -32,6 +32,7 @@ import torch  # noqa: E402
 
 METRIC = "images/sec (600×1000) ResNet-101 Faster R-CNN at 1/2/4/8 MI355X"
 X3_PEAK_TFLOPS = 416.7          # 2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per f32 product block (csrc/gemm_x3.hip)
+H2_PEAK_TFLOPS = 833.3          # 2500 TFLOP/s dense fp16 MFMA / 3 MFMAs per f32 product block (csrc/gemm_h2.hip)
 F32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 HBM_PEAK_GBS = 8000.0                 # same guide: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
@@ -88,6 +89,61 @@ def calibrate_rpn(sess, net, img_d, im_info):
     sess.variables[scope + "/rpn_bbox_pred/weights"] *= np.float32(0.2 / max(s_box, 1e-12))
     sess.packed.clear()
     sess.graphs.clear()
+
+
+class Telemetry(object):
+    """Shader clock / socket power sampled from the amdgpu sysfs nodes of the GPU in use while a region runs (a thread reading two
+    small files every 100 ms: no subprocess, nothing on the device).  None when the nodes are not there."""
+
+    def __init__(self, index=0):
+        import glob
+        self.sclk, self.power = None, None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        if index < len(cards):
+            self.sclk = cards[index]
+            hw = sorted(glob.glob(os.path.join(os.path.dirname(cards[index]), "hwmon", "hwmon*", "power1_average")) +
+                        glob.glob(os.path.join(os.path.dirname(cards[index]), "hwmon", "hwmon*", "power1_input")))
+            self.power = hw[0] if hw else None
+        self.samples = []
+        self._stop = False
+
+    def _read(self):
+        mhz, watt = None, None
+        try:
+            for line in open(self.sclk):
+                if "*" in line:
+                    mhz = float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except Exception:
+            pass
+        try:
+            watt = float(open(self.power).read().strip()) / 1e6
+        except Exception:
+            pass
+        return mhz, watt
+
+    def run(self, fn):
+        import threading
+        if self.sclk is None:
+            fn()
+            return None
+        self.samples, self._stop = [], False
+
+        def loop():
+            while not self._stop:
+                self.samples.append(self._read())
+                time.sleep(0.1)
+        t = threading.Thread(target=loop, daemon=True)
+        t.start()
+        try:
+            fn()
+        finally:
+            self._stop = True
+            t.join()
+        tail = self.samples[len(self.samples) // 3:]                 # the clock settles after the first third
+        mhz = sorted(v[0] for v in tail if v[0])
+        watt = sorted(v[1] for v in tail if v[1])
+        return {"sclk_mhz": mhz[len(mhz) // 2] if mhz else None, "socket_w": round(watt[len(watt) // 2], 1) if watt else None,
+                "samples": len(tail)}
 
 
 def physical_cores():
@@ -204,16 +260,18 @@ def main():
     ap.add_argument("--reference-order", action="store_true",
                     help="keep the reference op order crop -> 1x1 convs at the block4 entry (default: the 1x1 convs run on the "
                          "feature map and their outputs are cropped; same result up to f32 rounding, 64.5 GFLOP less)")
-    ap.add_argument("--mfma", choices=["x3", "f32"], default="x3",
-                    help="x3 (default = cfg.HIP.MFMA_X3): the large plain GEMMs (pointwise convolutions, Winograd products, Cout %% 128 == 0) "
-                         "on the bf16 matrix pipe with exactly split f32 operands (csrc/gemm_x3.hip: six bf16 MFMAs per f32 product, f32 "
-                         "accumulate; measured error vs float64 <= the f32 MFMA kernel's), everything else on v_mfma_f32_32x32x2_f32; the "
-                         "all-f32-MFMA variant is then timed in the same run and reported as `f32_mfma_variant`.  f32: every product on "
-                         "v_mfma_f32_32x32x2_f32")
+    ap.add_argument("--mfma", choices=["h2", "x3", "f32"], default="h2",
+                    help="h2 (default = cfg.HIP.MFMA_H2 + MFMA_X3): plain GEMMs with Cin, Cout %% 128 == 0 on the fp16 matrix pipe with "
+                         "block-scaled two-piece f32 operands (csrc/gemm_h2.hip: three fp16 MFMAs per f32 product, f32 accumulate), the "
+                         "other large plain GEMMs on the bf16 pipe with exact 3-way splits (csrc/gemm_x3.hip: six MFMAs), everything else on "
+                         "v_mfma_f32_32x32x2_f32; the x3-only and all-f32-MFMA variants are then timed in the same run (`x3_variant`, "
+                         "`f32_mfma_variant`).  x3: MFMA_H2 off.  f32: every product on v_mfma_f32_32x32x2_f32")
+    ap.add_argument("--h2-lazy-split", type=int, default=-1, help="cfg.HIP.H2_LAZY_SPLIT (A/B): 1 = split un-planed inputs of eligible layers, 0 = such layers stay on x3 / f32")
+    ap.add_argument("--h2-min-tiles", type=int, default=-1, help="cfg.HIP.H2_MIN_TILES (A/B)")
     ap.add_argument("--x3-terms", type=int, choices=[6, 9], default=6, help="with --mfma x3: 6 = the three cross terms below 2^-24 are dropped "
                     "(default), 9 = all nine cross terms, every f32 product exact (frcnn_gemm_x3_set_terms)")
     ap.add_argument("--x3-config", type=int, default=-1, help="A/B knob: frcnn_gemm_x3_set_config (-1 = by shape)")
-    ap.add_argument("--no-f32-variant", action="store_true", help="with --mfma x3: skip the second timed region (all-f32-MFMA variant)")
+    ap.add_argument("--no-f32-variant", action="store_true", help="skip the extra timed regions (x3-only / all-f32-MFMA variants)")
     ap.add_argument("--winograd-f2", default=None, help="comma list of scope tokens run as F(2x2,3x3) instead of F(4x4,3x3) (default: cfg.HIP)")
     ap.add_argument("--winograd-direct", default=None, help="comma list of scope tokens that keep the direct kernel (default: cfg.HIP)")
     ap.add_argument("--no-stream-gemm", action="store_true", help="A/B knob: frcnn_set_tuning key 6 = 0 (short-K GEMMs on k_conv_igemm instead of k_gemm_stream)")
@@ -248,7 +306,12 @@ def main():
     from frcnn_hip.runtime import Session
     from model.config import cfg
 
-    cfg.HIP.MFMA_X3 = args.mfma == "x3"
+    cfg.HIP.MFMA_H2 = args.mfma == "h2"
+    cfg.HIP.MFMA_X3 = args.mfma in ("h2", "x3")
+    if args.h2_lazy_split >= 0:
+        cfg.HIP.H2_LAZY_SPLIT = bool(args.h2_lazy_split)
+    if args.h2_min_tiles >= 0:
+        cfg.HIP.H2_MIN_TILES = args.h2_min_tiles
     if args.winograd_f2 is not None:
         cfg.HIP.WINOGRAD_F2_SCOPES = tuple(t for t in args.winograd_f2.split(",") if t)
     if args.winograd_direct is not None:
@@ -270,6 +333,10 @@ def main():
     common = {"metric": METRIC, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
               "dtype": {"f32": "f32",
+                        "h2": "f32 (operands, accumulators, results; GEMMs with Cin, Cout % 128 == 0 form each f32 product from two-piece "
+                              "fp16 operands with an exact power-of-two scale per 128-k block on the fp16 matrix pipe -- 3 MFMAs / product, "
+                              "dropped terms <= 3 * 2^-22, measured error vs float64 below the f32-MFMA kernel's; other large GEMMs: exact "
+                              "3-way bf16 splits, 6 MFMAs / product; the rest on the f32 MFMA)",
                         "x3": "f32 (operands, accumulators, results; the large GEMMs form each f32 product from exact 3-way bf16 "
                               "operand splits on the bf16 matrix pipe -- 6 MFMAs / product, dropped terms <= 2^-24 -- the rest on the f32 MFMA)"}[args.mfma]}
 
@@ -362,7 +429,8 @@ def main():
 
     # ---- HIP-event pass: events around every launch group, on the stream the kernels run on, over `profile_steps` further
     #      steps of the same workload (a hipGraph replay cannot carry events, so this pass launches eagerly on ONE chain)
-    per_layer, conv, x3 = {}, [0.0, 0, 0, 0], [0.0, 0, 0]
+    per_layer, conv = {}, [0.0, 0, 0, 0]
+    pipes = {"h2": [0.0, 0, 0], "x3": [0.0, 0, 0], "f32": [0.0, 0, 0]}          # ms, f32-equivalent FLOPs, launches per matrix pipe
     if rank == 0 and args.profile_steps > 0:
         with torch.cuda.stream(run_stream):
             sess.profile = []
@@ -375,8 +443,8 @@ def main():
                 a[0] += ms; a[1] += fl; a[2] += 1; a[3] += nb
                 if tag.startswith("conv:"):
                     conv[0] += ms; conv[1] += fl; conv[2] += 1; conv[3] += nb
-                    if tag.startswith("conv:x3:"):
-                        x3[0] += ms; x3[1] += fl; x3[2] += 1
+                    pp = pipes["h2" if tag.startswith("conv:h2:") else "x3" if tag.startswith("conv:x3:") else "f32"]
+                    pp[0] += ms; pp[1] += fl; pp[2] += 1
             sess.profile = None
         if args.layer_report:
             with open(args.layer_report, "w") as f:
@@ -385,14 +453,22 @@ def main():
                     f.write("%-70s %3d %9.1f %9.3f %8.1f %8.0f\n" % (tag, n, 1000 * ms / n, fl / n / 1e9, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0,
                                                                      nb / (ms * 1e-3) / 1e9 if ms > 0 else 0))
 
-    f32_variant = None
-    if args.mfma == "x3" and world == 1 and not args.no_f32_variant and not args.no_graph:
-        # the same workload with every product on v_mfma_f32_32x32x2_f32, timed in the same run (rank 0, N = 1 like cpu_baseline)
-        cfg.HIP.MFMA_X3 = False
+    f32_variant, x3_variant, telemetry = None, None, None
+    if world == 1 and not args.no_graph:
+        telemetry = Telemetry(local_rank).run(lambda: [timed_region() for _ in range(3)])      # clock / power of the shipped configuration
+    if args.mfma in ("h2", "x3") and world == 1 and not args.no_f32_variant and not args.no_graph:
+        # the same workload on the other pipe choices, timed in the same run (rank 0, N = 1 like cpu_baseline)
+        keep = (cfg.HIP.MFMA_H2, cfg.HIP.MFMA_X3)
+        if args.mfma == "h2":
+            cfg.HIP.MFMA_H2 = False
+            e3 = timed_region()
+            x3_variant = {"value": round(args.steps * B / e3, 3), "unit": "images/sec", "ms_per_step": round(1000.0 * e3 / args.steps, 4),
+                          "what": "identical run with cfg.HIP.MFMA_H2 = False (bench.py --mfma x3): round 2's configuration"}
+        cfg.HIP.MFMA_H2 = cfg.HIP.MFMA_X3 = False
         e32 = timed_region()
-        cfg.HIP.MFMA_X3 = True
+        cfg.HIP.MFMA_H2, cfg.HIP.MFMA_X3 = keep
         f32_variant = {"value": round(args.steps * B / e32, 3), "unit": "images/sec", "ms_per_step": round(1000.0 * e32 / args.steps, 4),
-                       "what": "identical run with cfg.HIP.MFMA_X3 = False (bench.py --mfma f32): all GEMMs on the f32 MFMA"}
+                       "what": "identical run with cfg.HIP.MFMA_H2 = MFMA_X3 = False (bench.py --mfma f32): all GEMMs on the f32 MFMA"}
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -412,52 +488,65 @@ def main():
                          "graph": "reference op order" if args.reference_order else
                                   "block4/unit_1 1x1 convs commuted past the bilinear crop (exact algebra, same outputs to f32 rounding; "
                                   "--reference-order keeps crop -> conv)",
-                         "mfma": {"x3": "cfg.HIP.MFMA_X3: plain GEMMs with Cout % 128 == 0 and >= 150 tiles on v_mfma_f32_32x32x16_bf16 with "
+                         "mfma": {"h2": "cfg.HIP.MFMA_H2: plain GEMMs with Cin, Cout % 128 == 0 and >= %d tiles on v_mfma_f32_32x32x16_f16 with "
+                                        "block-scaled two-piece f32 operands (csrc/gemm_h2.hip), operand planes emitted by the producers; "
+                                        "remaining large plain GEMMs: cfg.HIP.MFMA_X3 (bf16 pipe, exact 3-way splits); the stem, strided / "
+                                        "small-Cout convolutions and heads on v_mfma_f32_32x32x2_f32" % int(cfg.HIP.H2_MIN_TILES),
+                                  "x3": "cfg.HIP.MFMA_X3: plain GEMMs with Cout % 128 == 0 and >= 150 tiles on v_mfma_f32_32x32x16_bf16 with "
                                         "exactly split f32 operands (csrc/gemm_x3.hip); the stem, strided / small-Cout convolutions and heads on "
                                         "v_mfma_f32_32x32x2_f32", "f32": "v_mfma_f32_32x32x2_f32 everywhere"}[args.mfma],
                          "gflop_per_image_launched": round(flops_per_image / 1e9, 2), "gflop_per_image_reference_graph": c["gflop_ref"]}
+        if x3_variant is not None:
+            out["x3_variant"] = x3_variant
         if f32_variant is not None:
             out["f32_mfma_variant"] = f32_variant
         if conv[2]:
             steps_p = args.profile_steps
             ach = conv[1] / (conv[0] * 1e-3) / 1e12
-            traffic, tsrc = None, None      # HBM bytes per conv launch from the committed rocprofv3 PMC passes of this command
-            for name in ("r02_pmc_traffic.json",):
+            # HBM bytes per GEMM launch and matrix-pipe busy fraction from the committed rocprofv3 PMC passes of THIS command
+            # (scratch/pmc_traffic.py; regenerated per round, the file names the commit it was taken at)
+            traffic, tsrc, busy = None, None, None
+            for name in ("r03_pmc_traffic.json",):
                 tpath = os.path.join(ROOT, "profiles", name)
-                if os.path.exists(tpath) and args.config == "c2" and B == 4 and not args.reference_order:
+                if os.path.exists(tpath) and args.config == "c2" and B == 4 and not args.reference_order and args.mfma == "h2":
                     try:
-                        traffic, tsrc = round(json.load(open(tpath))["hbm_bytes_per_launch"]), "profiles/" + name
+                        pj = json.load(open(tpath))
+                        traffic, tsrc, busy = round(pj["hbm_bytes_per_launch"]), "profiles/" + name, round(pj["mfma_util_conv_launches"], 4)
                     except Exception:
                         traffic = None
             whole_launched = flops_per_image * value / world / 1e12
+            peaks = {"h2": H2_PEAK_TFLOPS, "x3": X3_PEAK_TFLOPS, "f32": F32_MFMA_PEAK_TFLOPS}
+            t_at_peak = sum(pp[1] / (peaks[k] * 1e12) for k, pp in pipes.items())       # seconds the issued MFMA mix needs at its pipes' peaks
+            ceiling = conv[1] / t_at_peak / 1e12                                         # f32-equivalent TFLOP/s of that mix at peak
             out["roofline"] = {
-                "bound": "mfma", "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                # frac == frac_launched: FLOPs the conv kernels actually execute / their launch time (event pass, one chain)
-                "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "frac_launched": round(ach / F32_MFMA_PEAK_TFLOPS, 4),
-                # the same kernels credited with the reference graph's direct-convolution FLOPs (SURVEY 8d / BASELINE.md formula):
-                # > 1 is what Winograd and the commuted crop buy, not a kernel-efficiency claim
+                "bound": "mfma", "achieved": round(ach, 2), "peak": round(ceiling, 1), "unit": "TFLOP/s",
+                # frac = sum_launch (FLOPs_i / peak of the pipe launch i issues on) / sum_launch time_i  (event pass, one chain):
+                # the fraction of the matrix pipes' dense peak the issued instruction mix achieves.  `achieved` / `peak` are the same
+                # ratio in f32-equivalent TFLOP/s (peak = what this mix of 3-MFMA / 6-MFMA / f32-MFMA products could reach)
+                "frac": round(t_at_peak / (conv[0] * 1e-3), 4),
+                "achieved_f32_equivalent": round(ach, 2),
+                "pipe_peaks_f32_equivalent": {"h2 (3 x v_mfma_f32_32x32x16_f16 per product, 2500 / 3)": H2_PEAK_TFLOPS,
+                                              "x3 (6 x v_mfma_f32_32x32x16_bf16, 2500 / 6)": X3_PEAK_TFLOPS,
+                                              "f32 (v_mfma_f32_32x32x2_f32)": F32_MFMA_PEAK_TFLOPS},
+                # the same kernels credited with the reference graph's direct-convolution FLOPs over the f32-MFMA peak of the dtype
+                # (SURVEY 8d / BASELINE.md formula): > 1 is what Winograd, the commuted crop and the 16-bit pipes buy
                 "frac_algorithmic": round(c["gflop_ref"] * value / world / 1e3 / F32_MFMA_PEAK_TFLOPS, 4),
-                # launched FLOPs over the TIMED region's clock (all chains, non-conv stages included)
-                "frac_timed_region_launched": round(whole_launched / F32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": traffic, "traffic_source": tsrc,
-                "kernel": "k_gemm_x3 (f32 GEMM on the bf16 pipe, exact operand split) + k_conv_igemm / k_gemm_stream (f32 MFMA 32x32x2), all tile shapes; Winograd GEMMs included",
+                # launched FLOPs over the TIMED region's clock (all chains, non-conv stages included), same per-pipe peaks
+                "frac_timed_region": round(whole_launched / ceiling, 4),
+                "mfma_busy": busy, "traffic": traffic, "traffic_source": tsrc,
+                "sclk_mhz": None if telemetry is None else telemetry["sclk_mhz"], "socket_w": None if telemetry is None else telemetry["socket_w"],
+                "kernel": "k_gemm_h2 (fp16 pipe, block-scaled two-piece operands) + k_gemm_x3 (bf16 pipe, exact 3-way split) + k_conv_igemm / "
+                          "k_gemm_stream (f32 MFMA 32x32x2), all tile shapes; Winograd GEMMs included",
                 "algorithmic_bytes_per_launch": conv[3] // max(conv[2], 1), "launches_per_step": conv[2] // steps_p,
-                # pipe mix of the launches behind `achieved` (f32-equivalent FLOPs): the x3 GEMMs issue 6 bf16 MFMAs (8 passes, 16 k) per
-                # product block, ceiling 2500 / 6 = 416.7 TFLOP/s f32-equivalent; the others run on the f32 MFMA (157.3)
-                "x3": None if not x3[2] else {
-                    "share_of_launched_flops": round(x3[1] / conv[1], 4), "launches_per_step": x3[2] // steps_p,
-                    "achieved_f32_equivalent": round(x3[1] / (x3[0] * 1e-3) / 1e12, 2), "bf16_pipe_ceiling_f32_equivalent": X3_PEAK_TFLOPS,
-                    "f32_mfma_launches_achieved": round((conv[1] - x3[1]) / max((conv[0] - x3[0]) * 1e-3, 1e-9) / 1e12, 2),
-                    # time the issued instruction mix needs at both pipes' peaks / time taken
-                    "frac_of_issued_pipe_peaks": round((x3[1] / X3_PEAK_TFLOPS + (conv[1] - x3[1]) / F32_MFMA_PEAK_TFLOPS) / 1e12 / (conv[0] * 1e-3), 4),
-                    "note": "frac / frac_launched above divide f32-equivalent FLOPs by the f32-MFMA peak of the dtype and can exceed what "
-                            "that pipe alone could do; with x3 the run is power-limited (rocm-smi: ~1.90 GHz at ~1 385 W; all-f32-MFMA: 2.36 GHz at ~1 316 W, profiles/r02_p_clock_power.txt)"},
+                "pipes": {k: {"share_of_launched_flops": round(pp[1] / conv[1], 4), "launches_per_step": pp[2] // steps_p,
+                              "achieved_f32_equivalent": round(pp[1] / (pp[0] * 1e-3) / 1e12, 2),
+                              "frac_of_pipe_peak": round(pp[1] / (pp[0] * 1e-3) / 1e12 / peaks[k], 4)} for k, pp in pipes.items() if pp[2]},
                 "avg_launch_us": round(1000.0 * conv[0] / conv[2], 2), "conv_ms_per_image": round(conv[0] / steps_p / B, 3)}
             # the bandwidth-bound stages (north_star: achieved HBM GB/s): algorithmic bytes / event time of the stage
             stages = {}
             for tag, key in (("op:proposal_layer", "proposal_layer"), ("op:proposal_layer_tf", "proposal_layer"),
                              ("op:crop_and_resize", "crop_and_resize"), ("op:detect_post", "detect_post"), ("op:wino_in", "winograd_input_transform"),
-                             ("op:wino_out", "winograd_output_transform"), ("op:maxpool", "maxpool"), ("op:spatial_mean", "spatial_mean"),
+                             ("op:wino_out", "winograd_output_transform"), ("op:h2_split", "h2_split"), ("op:maxpool", "maxpool"), ("op:spatial_mean", "spatial_mean"),
                              ("op:dwconv3x3", "depthwise_conv")):
                 if tag in per_layer:
                     ms, _, n, nb = per_layer[tag]

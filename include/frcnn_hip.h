@@ -302,6 +302,17 @@ int frcnn_winograd7_filter_transform(const float* w_hwio, int Cin, int Cout, con
 int frcnn_winograd7_filter_transform_device(const float* w_packed_d, int Cout, int Cin, int transpose_flip, float* u_d, void* stream);
 int frcnn_winograd7_input_transform(const float* x_d, int R, int C, float* v_d, void* stream);
 int frcnn_winograd7_output_transform(const float* m_d, int R, int C, const float* bias_d, int act, float* y_d, void* stream);
+/* The Winograd transforms as PRODUCERS of frcnn_gemm_h2 operand planes (csrc/gemm_h2.hip): the input transforms emit V as fp16 pieces
+ * [2][G*T][C] + v_inv [C/128][G*T] (G = (m+2)^2 or 121 points, T tiles / RoIs) instead of float32; the output transforms emit
+ * act(A^T M A + bias) as planes [2][pixels][C] + y_inv [C/128][pixels] for the bottleneck's next 1x1 convolution (resnet_v1.py:80-125:
+ * conv2 -> conv3) and, when y_d is not NULL, the float32 tensor as well.  Bit-identical to frcnn_h2_split of the float32 transform.
+ * C % 128 == 0. */
+int frcnn_winograd_input_transform_h2(const float* x_d, int N, int H, int W, int C, int m, void* v_planes_d, float* v_inv_d, void* stream);
+int frcnn_winograd_output_transform_h2(const float* m_d, int N, int H, int W, int C, int m, const float* bias_d, int act, float* y_d,
+                                       void* y_planes_d, float* y_inv_d, void* stream);
+int frcnn_winograd7_input_transform_h2(const float* x_d, int R, int C, void* v_planes_d, float* v_inv_d, void* stream);
+int frcnn_winograd7_output_transform_h2(const float* m_d, int R, int C, const float* bias_d, int act, float* y_d, void* y_planes_d,
+                                        float* y_inv_d, void* stream);
 /* HOST helper: HWIO (TF layout, [KH][KW][Cin][Cout]) -> packed [Cout][KH][KW][Cin], optionally
  * multiplying output channel o by scale[o] (folded frozen batch-norm gamma/sqrt(var+eps)). */
 int frcnn_pack_filter_hwio(const float* w_hwio, int KH, int KW, int Cin, int Cout, const float* scale, float* out);

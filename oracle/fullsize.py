@@ -199,7 +199,7 @@ def perclass_candidates(cls_prob, bbox_pred, rois, im_scale, orig_shape):
 # ------------------------------------------------------------------------------------------------------------------
 POLICIES = {
     # name -> cfg.HIP overrides
-    "direct": dict(WINOGRAD=False, MFMA_X3=False),                # every product on the f32 MFMA, direct convolutions
+    "direct": dict(WINOGRAD=False, MFMA_X3=False, MFMA_H2=False),  # every product on the f32 MFMA, direct convolutions
     "f2": dict(WINOGRAD=True, WINOGRAD_M=2, WINOGRAD_F2_SCOPES=(), WINOGRAD_7X7=False),
     "f4": dict(WINOGRAD=True, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=(), WINOGRAD_7X7=True),
     "f4_rpn_f2": dict(WINOGRAD=True, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=("rpn_conv",), WINOGRAD_7X7=True),
@@ -217,7 +217,7 @@ GRAD_TOL = 2e-4              # of the tensor's largest entry; or GRAD_CTRL_FACTO
 GRAD_CTRL_FACTOR = 4.0
 GATE_EPS = 2e-5              # relative to the layer's largest pre-activation: what a Winograd F(4x4,3x3) forward may move a gate by
 EPS_SCORE, EPS_IOU, TOL = 1e-4, 1e-3, 1e-4        # BASELINE.json north_star: 1e-4 on scores / box coordinates
-CTRL_FACTOR = {"direct": 1.5, "shipped": 1.5, "shipped_f32": 1.5}     # allowed multiple of the float32 control's own loss (exploratory policies: 2.5)
+CTRL_FACTOR = {"direct": 1.5, "shipped": 1.5, "shipped_x3": 1.5, "shipped_f32": 1.5}     # allowed multiple of the float32 control's own loss (exploratory policies: 2.5)
 
 
 def tolerance(fx, key, policy):

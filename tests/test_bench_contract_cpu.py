@@ -29,12 +29,13 @@ def test_metric_configs_and_peaks_match_baseline():
     c3 = b.CONFIGS["c3"]
     assert (c3["H"], c3["W"], c3["post"], c3["classes"]) == (800, 1333, 1000, 81) and len(c3["scales"]) == 5
     assert b.F32_MFMA_PEAK_TFLOPS == 157.3 and abs(b.X3_PEAK_TFLOPS - 2500.0 / 6.0) < 0.1 and b.HBM_PEAK_GBS == 8000.0
+    assert abs(b.H2_PEAK_TFLOPS - 2500.0 / 3.0) < 0.1
 
 
 def test_driver_flags_and_variants_parse():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for flag in ("--gpus", "--steps", "--warmup", "--config", "--mfma", "--x3-terms", "--no-f32-variant", "--no-cpu-baseline", "--layer-report"):
         assert '"%s"' % flag in src, flag
-    # the shipped configuration and its all-f32-MFMA twin are both reported by the default invocation
-    assert 'default="x3"' in src and '"f32_mfma_variant"' in src and '"cpu_baseline"' in src and '"roofline"' in src
+    # the shipped configuration and its x3-only / all-f32-MFMA twins are all reported by the default invocation
+    assert 'default="h2"' in src and '"x3_variant"' in src and '"f32_mfma_variant"' in src and '"cpu_baseline"' in src and '"roofline"' in src
     assert "RANK" in src and "WORLD_SIZE" in src and "dist.barrier()" in src and "torch.cuda.synchronize()" in src

@@ -13,7 +13,7 @@ Per case (oracle/fullsize.py::run_harness):
   3. RoI tail on the reference's rois: cls_score / bbox_pred / cls_prob vs float64   <= 1e-4
   4. detections vs the oracle on the device's own tensors            (score, class) bit-exact
      detections vs the reference's, per class                        within eps
-for the direct f32-MFMA path, the shipped policy (Winograd + exact bf16x3 GEMMs) AND the shipped Winograd policy on the f32 MFMA only, on the bench's damped synthetic weights and on
+for the direct f32-MFMA path, the shipped policy (Winograd + block-scaled fp16x2 GEMMs of cfg.HIP.MFMA_H2 + exact bf16x3 GEMMs), the same without MFMA_H2 AND the shipped Winograd policy on the f32 MFMA only, on the bench's damped synthetic weights and on
 "calibrated" weights whose activations have a trained network's scale (every BN gamma ~ U(0.5, 1.5)).
 The measured maxima are printed (pytest -s) and written to gpurun_out/fullsize_parity.txt."""
 import os
@@ -28,20 +28,22 @@ SHIPPED = "shipped"
 
 
 SHIPPED_F32 = "shipped_f32"
+SHIPPED_X3 = "shipped_x3"
 
 
 def _shipped_policy():
-    """the cfg.HIP defaults as a harness policy (Winograd policy + the exact bf16x3 GEMMs of cfg.HIP.MFMA_X3), and the same
+    """the cfg.HIP defaults as a harness policy (Winograd policy + cfg.HIP.MFMA_H2 + cfg.HIP.MFMA_X3), and the same
     Winograd policy with every product on the f32 MFMA (bench.py's `f32_mfma_variant`)"""
     from model.config import cfg
     fs.POLICIES[SHIPPED] = {k: cfg.HIP[k] for k in ("WINOGRAD", "WINOGRAD_M", "WINOGRAD_F2_SCOPES", "WINOGRAD_DIRECT_SCOPES", "WINOGRAD_7X7",
-                                                    "WINOGRAD_MIN_CIN", "MFMA_X3")}
-    fs.POLICIES[SHIPPED_F32] = dict(fs.POLICIES[SHIPPED], MFMA_X3=False)
+                                                    "WINOGRAD_MIN_CIN", "MFMA_X3", "MFMA_H2", "H2_LAZY_SPLIT", "H2_MIN_TILES")}
+    fs.POLICIES[SHIPPED_X3] = dict(fs.POLICIES[SHIPPED], MFMA_H2=False)               # round 2's configuration (bench.py `x3_variant`)
+    fs.POLICIES[SHIPPED_F32] = dict(fs.POLICIES[SHIPPED], MFMA_X3=False, MFMA_H2=False)
     return SHIPPED
 
 
 @pytest.mark.parametrize("config,weights", [("c2", "damped"), ("c2", "calibrated"), ("c3", "calibrated"), ("c1", "damped"), ("c4", "calibrated")])
-@pytest.mark.parametrize("policy", ["direct", SHIPPED, SHIPPED_F32])
+@pytest.mark.parametrize("policy", ["direct", SHIPPED, SHIPPED_X3, SHIPPED_F32])
 def test_fullsize_parity(dev, config, weights, policy):
     if policy != "direct":
         _shipped_policy()

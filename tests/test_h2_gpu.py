@@ -123,3 +123,40 @@ def test_gemm_h2_planes_only_and_chained(dev):
     assert torch.equal(a, b)
     want = np.maximum(x.astype(np.float64) @ w1.astype(np.float64).T, 0) @ w2.astype(np.float64).T
     assert float(np.abs(a.cpu().numpy() - want).max()) <= 2e-6 * max(1.0, float(np.abs(want).max()))
+
+
+def _same_planes(a, b):
+    for g_, w_, name in zip(_planes_np(a), _planes_np(b), ("h", "l", "inv")):
+        assert np.array_equal(g_.view(np.uint16) if g_.dtype == np.float16 else g_, w_.view(np.uint16) if w_.dtype == np.float16 else w_), name
+
+
+@pytest.mark.parametrize("m,N,H,W,C", [(2, 2, 19, 25, 128), (4, 3, 38, 63, 256), (4, 1, 10, 13, 384), (7, 37, 7, 7, 512), (7, 4, 7, 7, 128)])
+def test_winograd_transforms_emit_the_planes_of_their_f32_results(dev, m, N, H, W, C):
+    """frcnn_winograd[7]_input/output_transform_h2: V / y as operand planes == frcnn_h2_split of the float32 transform (bit for bit),
+    the optional float32 output of the output transform == the plain transform's."""
+    from frcnn_hip import ops
+    rng = np.random.RandomState(m * 100 + C)
+    x = (np.maximum(rng.randn(N, H, W, C), 0) * np.exp(rng.uniform(-3, 3, size=(N, H, W, C)))).astype(np.float32)
+    x[:, :, :, 5] = 0.0                                                  # a dead channel
+    x[0, 0, 0, :] = 0.0                                                  # an all-zero pixel: whole scale blocks of zeros
+    G, Tl = ops.winograd_points(m), ops.winograd_tiles(N, H, W, m)
+    xd = T(x, dev)
+    v = torch.empty((G, Tl, C), dtype=torch.float32, device=dev)
+    ops.winograd_input_transform(xd, v, m)
+    vp = ops.H2.empty(G * Tl, C, dev)
+    vp.planes.fill_(0x5a); vp.inv.fill_(-1.0)
+    ops.winograd_input_transform_h2(xd, vp, m)
+    _same_planes(vp, ops.h2_split(v.view(G * Tl, C)))
+    mm = torch.from_numpy((rng.randn(G, Tl, C) * 3).astype(np.float32)).to(dev)
+    bias = T(rng.randn(C).astype(np.float32), dev)
+    for act in (0, 1):
+        y = torch.empty((N, H, W, C), dtype=torch.float32, device=dev)
+        ops.winograd_output_transform(mm, bias, act, y, m)
+        yp, y2 = ops.H2.empty(N * H * W, C, dev), torch.full((N, H, W, C), 7.0, dtype=torch.float32, device=dev)
+        yp.planes.fill_(0x5a); yp.inv.fill_(-1.0)
+        ops.winograd_output_transform_h2(mm, bias, act, (N, H, W, C), m, yp, y2)
+        assert torch.equal(y, y2)
+        _same_planes(yp, ops.h2_split(y.view(N * H * W, C)))
+        yp2 = ops.H2.empty(N * H * W, C, dev)
+        ops.winograd_output_transform_h2(mm, bias, act, (N, H, W, C), m, yp2, None)          # planes only
+        _same_planes(yp2, yp)

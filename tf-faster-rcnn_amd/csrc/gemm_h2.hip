@@ -29,15 +29,13 @@
 // VALU), counted vmcnt (NS - 2 slabs stay in flight across the per-slab barrier), XOR-swizzled 64-byte plane rows -> conflict-free
 // ds_read_b128 fragments.  A stage = X planes 2 x BM x 64 B + W planes 2 x BN x 64 B + the BM block scales (1 KB):
 // 33 KB for 128 x 128 -> two stages = 66 KB = 2 workgroups per CU, or 3-4 stages with one.
-#include "common.h"
+#include "h2_common.h"
 #include <mutex>
 #include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
-#define H2_KB 128                     // k per scale block
 #define LDS_AS __attribute__((address_space(3)))
 
 struct GemmH2Params {
@@ -66,22 +64,6 @@ __device__ __forceinline__ void h2_glds16(unsigned voff, const void* sbase, unsi
 template <int N>
 __device__ __forceinline__ void h2_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// The block scale of a 128-k block whose largest magnitude is `mx` (>= 0): (2^e, 2^-e) with mx * 2^e in [2^14, 2^15).  Pure exponent
-// arithmetic, so every producer (GEMM epilogue, splitter, Winograd transforms, host reference) derives the identical pair.
-// Blocks of zeros / denormals-only clamp at 2^126; inf / nan blocks get a tiny scale and stay inf / nan.
-__device__ __forceinline__ void h2_block_scale(float mx, float& scale, float& inv) {
-  int ex = (int)((__float_as_uint(mx) >> 23) & 0xffu);
-  ex = ex < 15 ? 15 : ex;
-  scale = __uint_as_float((unsigned)(268 - ex) << 23);
-  inv = __uint_as_float((unsigned)(ex - 14) << 23);
-}
-
-__device__ __forceinline__ void h2_split1(float v, float scale, _Float16& h, _Float16& l) {
-  const float vs = v * scale;
-  h = (_Float16)vs;
-  l = (_Float16)(vs - (float)h);
 }
 
 // TUNE bits (A/B measurements, all produce identical results): 1 = the slab's loads are issued in two halves around the first k group

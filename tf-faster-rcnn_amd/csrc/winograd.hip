@@ -6,7 +6,7 @@
 //   Y = A^T M A (2x2 outputs per tile), + bias, activation
 // The 16 element-wise products are 16 independent [T x Cin] x [Cin x Cout] GEMMs -> frcnn_gemm_batched_nt
 // (the same f32-MFMA kernel, grid.y = 16).  The two transforms below are bandwidth-bound float4 kernels.
-#include "common.h"
+#include "h2_common.h"
 
 //
 // m = 2: F(2x2,3x3), 4x4 input tiles, 16 GEMMs.   m = 4: F(4x4,3x3) (Lavin & Gray points 0,+-1,+-2,inf), 6x6 input tiles,
@@ -42,8 +42,22 @@ extern "C" int frcnn_winograd_filter_transform(const float* w_hwio, int Cin, int
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
+// Where a transform's result goes.  H2 = false: float32 tensor `f` (rows x C, float4 words).  H2 = true: operand planes of
+// frcnn_gemm_h2 (csrc/gemm_h2.hip) -- fp16 pieces [2][rows][C] + one power-of-two scale per (row, 128 channels), inv [C/128][rows];
+// the 32 consecutive threads that hold a row's 128 channels (C4 % 32 == 0, so they are one half-wave) reduce the block maximum with
+// DPP / permlane-swap moves.  Bit-identical to frcnn_h2_split of the float32 result.  `f` may be given as well (both are written).
+template <bool H2>
+struct WinoSink {
+  float4* f; unsigned short* planes; float* inv; size_t rows;      // rows: total rows of the result (plane stride = rows * C)
+  __device__ __forceinline__ void put(size_t row, int c4, int C4, float4 v) const {
+    if (!H2 || f) f[row * C4 + c4] = v;
+    if (H2) h2_emit_block32(v, planes, rows * (size_t)C4 * 4, (row * C4 + c4) * 4, inv + (size_t)(c4 >> 5) * rows + row, c4 & 31);
+  }
+};
+
 // V[xn][t][c] = (B^T d B)[xi][nu], tile t = (img, ty, tx), d[i][j] = x[img, 2ty-1+i, 2tx-1+j, c]
-__global__ void k_wino_input(const float4* __restrict__ x, int N, int H, int W, int C4, int TH, int TW, float4* __restrict__ V) {
+template <bool H2>
+__global__ void k_wino_input(const float4* __restrict__ x, int N, int H, int W, int C4, int TH, int TW, const WinoSink<H2> V) {
   const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long T = (long long)N * TH * TW;
   if (id >= T * C4) return;
@@ -69,14 +83,12 @@ __global__ void k_wino_input(const float4* __restrict__ x, int N, int H, int W, 
     b[2][j] = f4sub(d[2][j], d[1][j]);
     b[3][j] = f4sub(d[1][j], d[3][j]);
   }
-  const size_t plane = (size_t)T * C4;
-  float4* out = V + (size_t)t * C4 + c4;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {     // (.. B): columns (b0-b2, b1+b2, b2-b1, b1-b3)
-    out[(size_t)(i * 4 + 0) * plane] = f4sub(b[i][0], b[i][2]);
-    out[(size_t)(i * 4 + 1) * plane] = f4add(b[i][1], b[i][2]);
-    out[(size_t)(i * 4 + 2) * plane] = f4sub(b[i][2], b[i][1]);
-    out[(size_t)(i * 4 + 3) * plane] = f4sub(b[i][1], b[i][3]);
+    V.put((size_t)(i * 4 + 0) * T + t, c4, C4, f4sub(b[i][0], b[i][2]));
+    V.put((size_t)(i * 4 + 1) * T + t, c4, C4, f4add(b[i][1], b[i][2]));
+    V.put((size_t)(i * 4 + 2) * T + t, c4, C4, f4sub(b[i][2], b[i][1]));
+    V.put((size_t)(i * 4 + 3) * T + t, c4, C4, f4sub(b[i][1], b[i][3]));
   }
 }
 
@@ -99,8 +111,9 @@ __device__ __forceinline__ float4 f4mul(float a, float4 x) { return make_float4(
     o5 = r5;                                                                           \
   }
 
+template <bool H2>
 __global__ void __launch_bounds__(256) k_wino4_input(const float4* __restrict__ x, int N, int H, int W, int C4, int TH, int TW,
-                                                      float4* __restrict__ V) {
+                                                      const WinoSink<H2> V) {
   const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long T = (long long)N * TH * TW;
   if (id >= T * C4) return;
@@ -120,18 +133,16 @@ __global__ void __launch_bounds__(256) k_wino4_input(const float4* __restrict__ 
   }
 #pragma unroll
   for (int j = 0; j < 6; ++j) WINO4_BT(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);
-  const size_t plane = (size_t)T * C4;
-  float4* out = V + (size_t)t * C4 + c4;
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     float4 o0, o1, o2, o3, o4, o5;
     WINO4_BT(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], o0, o1, o2, o3, o4, o5);
-    out[(size_t)(i * 6 + 0) * plane] = o0;
-    out[(size_t)(i * 6 + 1) * plane] = o1;
-    out[(size_t)(i * 6 + 2) * plane] = o2;
-    out[(size_t)(i * 6 + 3) * plane] = o3;
-    out[(size_t)(i * 6 + 4) * plane] = o4;
-    out[(size_t)(i * 6 + 5) * plane] = o5;
+    V.put((size_t)(i * 6 + 0) * T + t, c4, C4, o0);
+    V.put((size_t)(i * 6 + 1) * T + t, c4, C4, o1);
+    V.put((size_t)(i * 6 + 2) * T + t, c4, C4, o2);
+    V.put((size_t)(i * 6 + 3) * T + t, c4, C4, o3);
+    V.put((size_t)(i * 6 + 4) * T + t, c4, C4, o4);
+    V.put((size_t)(i * 6 + 5) * T + t, c4, C4, o5);
   }
 }
 
@@ -145,8 +156,9 @@ __global__ void __launch_bounds__(256) k_wino4_input(const float4* __restrict__ 
     o3 = f4add(f4mad(8.f, u, q), v5);                                                  \
   }
 
+template <bool H2>
 __global__ void __launch_bounds__(256) k_wino4_output(const float4* __restrict__ Mx, int N, int H, int W, int C4, int TH, int TW,
-                                                       const float4* __restrict__ bias, int act, float4* __restrict__ y) {
+                                                       const float4* __restrict__ bias, int act, const WinoSink<H2> y) {
   const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long T = (long long)N * TH * TW;
   if (id >= T * C4) return;
@@ -169,38 +181,51 @@ __global__ void __launch_bounds__(256) k_wino4_output(const float4* __restrict__
     if (oh >= H) continue;
     float4 o[4];
     WINO4_AT(s[a][0], s[a][1], s[a][2], s[a][3], s[a][4], s[a][5], o[0], o[1], o[2], o[3]);
-    float4* row = y + ((size_t)(img * H + oh) * W) * C4 + c4;
+    const size_t row = (size_t)(img * H + oh) * W;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const int ow = 4 * tx + b;
       if (ow >= W) continue;
       float4 v = f4add(o[b], bv);
       if (act == FRCNN_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-      row[(size_t)ow * C4] = v;
+      y.put(row + ow, c4, C4, v);
     }
   }
+}
+
+template <bool H2>
+static int wino_input_launch(const float* x_d, int N, int H, int W, int C, int m, const WinoSink<H2>& sink, hipStream_t st) {
+  const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
+  const long long tot = (long long)N * TH * TW * (C / 4);
+  if (m == 4)
+    hipLaunchKernelGGL(k_wino4_input<H2>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float4*)x_d, N, H, W, C / 4, TH, TW, sink);
+  else
+    hipLaunchKernelGGL(k_wino_input<H2>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float4*)x_d, N, H, W, C / 4, TH, TW, sink);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
 }
 
 extern "C" int frcnn_winograd_input_transform(const float* x_d, int N, int H, int W, int C, int m, float* v_d, void* stream) {
   if (!x_d || !v_d || N <= 0 || H <= 0 || W <= 0 || C <= 0) return FRCNN_E_ARG;
   if (C % 4 || (m != 2 && m != 4)) return FRCNN_E_UNSUPPORTED;
+  const WinoSink<false> sink{(float4*)v_d, nullptr, nullptr, 0};
+  return wino_input_launch<false>(x_d, N, H, W, C, m, sink, (hipStream_t)stream);
+}
+
+// The same transform with V emitted as frcnn_gemm_h2 operand planes [2][(m+2)^2 * T][C] + v_inv [C/128][(m+2)^2 * T]; C % 128 == 0
+extern "C" int frcnn_winograd_input_transform_h2(const float* x_d, int N, int H, int W, int C, int m, void* v_planes_d, float* v_inv_d,
+                                                 void* stream) {
+  if (!x_d || !v_planes_d || !v_inv_d || N <= 0 || H <= 0 || W <= 0 || C <= 0) return FRCNN_E_ARG;
+  if (C % H2_KB || (m != 2 && m != 4)) return FRCNN_E_UNSUPPORTED;
   const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
-  const long long tot = (long long)N * TH * TW * (C / 4);
-  if (m == 4) {
-    hipLaunchKernelGGL(k_wino4_input, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x_d, N, H, W,
-                       C / 4, TH, TW, (float4*)v_d);
-    LAUNCH_CHECK();
-    return FRCNN_OK;
-  }
-  hipLaunchKernelGGL(k_wino_input, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x_d, N, H, W,
-                     C / 4, TH, TW, (float4*)v_d);
-  LAUNCH_CHECK();
-  return FRCNN_OK;
+  const WinoSink<true> sink{nullptr, (unsigned short*)v_planes_d, v_inv_d, (size_t)(m + 2) * (m + 2) * N * TH * TW};
+  return wino_input_launch<true>(x_d, N, H, W, C, m, sink, (hipStream_t)stream);
 }
 
 // y[img, 2ty+a, 2tx+b, o] = act( (A^T M A)[a][b] + bias[o] ),  M[xn][t][o]
+template <bool H2>
 __global__ void k_wino_output(const float4* __restrict__ Mx, int N, int H, int W, int C4, int TH, int TW,
-                              const float4* __restrict__ bias, int act, float4* __restrict__ y) {
+                              const float4* __restrict__ bias, int act, const WinoSink<H2> y) {
   const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long T = (long long)N * TH * TW;
   if (id >= T * C4) return;
@@ -231,28 +256,43 @@ __global__ void k_wino_output(const float4* __restrict__ Mx, int N, int H, int W
       o0 = make_float4(fmaxf(o0.x, 0.f), fmaxf(o0.y, 0.f), fmaxf(o0.z, 0.f), fmaxf(o0.w, 0.f));
       o1 = make_float4(fmaxf(o1.x, 0.f), fmaxf(o1.y, 0.f), fmaxf(o1.z, 0.f), fmaxf(o1.w, 0.f));
     }
-    float4* row = y + ((size_t)(img * H + oh) * W) * C4 + c4;
-    if (2 * tx < W) row[(size_t)(2 * tx) * C4] = o0;
-    if (2 * tx + 1 < W) row[(size_t)(2 * tx + 1) * C4] = o1;
+    const size_t row = (size_t)(img * H + oh) * W;
+    if (2 * tx < W) y.put(row + 2 * tx, c4, C4, o0);
+    if (2 * tx + 1 < W) y.put(row + 2 * tx + 1, c4, C4, o1);
   }
+}
+
+template <bool H2>
+static int wino_output_launch(const float* m_d, int N, int H, int W, int C, int m, const float* bias_d, int act, const WinoSink<H2>& sink,
+                              hipStream_t st) {
+  const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
+  const long long tot = (long long)N * TH * TW * (C / 4);
+  if (m == 4)
+    hipLaunchKernelGGL(k_wino4_output<H2>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float4*)m_d, N, H, W, C / 4, TH, TW,
+                       (const float4*)bias_d, act, sink);
+  else
+    hipLaunchKernelGGL(k_wino_output<H2>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float4*)m_d, N, H, W, C / 4, TH, TW,
+                       (const float4*)bias_d, act, sink);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
 }
 
 extern "C" int frcnn_winograd_output_transform(const float* m_d, int N, int H, int W, int C, int m, const float* bias_d, int act,
                                                float* y_d, void* stream) {
   if (!m_d || !y_d || N <= 0 || H <= 0 || W <= 0 || C <= 0) return FRCNN_E_ARG;
   if (C % 4 || (m != 2 && m != 4) || (act != FRCNN_ACT_NONE && act != FRCNN_ACT_RELU)) return FRCNN_E_UNSUPPORTED;
-  const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
-  const long long tot = (long long)N * TH * TW * (C / 4);
-  if (m == 4) {
-    hipLaunchKernelGGL(k_wino4_output, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)m_d, N, H, W,
-                       C / 4, TH, TW, (const float4*)bias_d, act, (float4*)y_d);
-    LAUNCH_CHECK();
-    return FRCNN_OK;
-  }
-  hipLaunchKernelGGL(k_wino_output, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)m_d, N, H, W,
-                     C / 4, TH, TW, (const float4*)bias_d, act, (float4*)y_d);
-  LAUNCH_CHECK();
-  return FRCNN_OK;
+  const WinoSink<false> sink{(float4*)y_d, nullptr, nullptr, 0};
+  return wino_output_launch<false>(m_d, N, H, W, C, m, bias_d, act, sink, (hipStream_t)stream);
+}
+
+// The same transform with the result emitted as operand planes [2][N*H*W][C] + y_inv [C/128][N*H*W] for a following frcnn_gemm_h2
+// (the bottleneck's conv3); y_d may be NULL (planes only) or receives the float32 result as well.  C % 128 == 0.
+extern "C" int frcnn_winograd_output_transform_h2(const float* m_d, int N, int H, int W, int C, int m, const float* bias_d, int act,
+                                                  float* y_d, void* y_planes_d, float* y_inv_d, void* stream) {
+  if (!m_d || !y_planes_d || !y_inv_d || N <= 0 || H <= 0 || W <= 0 || C <= 0) return FRCNN_E_ARG;
+  if (C % H2_KB || (m != 2 && m != 4) || (act != FRCNN_ACT_NONE && act != FRCNN_ACT_RELU)) return FRCNN_E_UNSUPPORTED;
+  const WinoSink<true> sink{(float4*)y_d, (unsigned short*)y_planes_d, y_inv_d, (size_t)N * H * W};
+  return wino_output_launch<true>(m_d, N, H, W, C, m, bias_d, act, sink, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------------- filter transform on device

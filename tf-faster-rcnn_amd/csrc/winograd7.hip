@@ -8,7 +8,7 @@
 // exact rationals and checked by scratch/wino_matrices.py; block-structured 1-D forms B^T (11 x 9 padded inputs),
 // A^T (7 x 11), G (11 x 3).  The unrolled loops skip zero coefficients at compile time (the tables are constexpr), so the
 // transforms are add/multiply chains like the hand-written F(4,3) ones; both are HBM-bound.
-#include "common.h"
+#include "h2_common.h"
 
 namespace w7 {
 constexpr float BT[11][9] = {
@@ -43,8 +43,21 @@ __device__ __forceinline__ void acc_term(float2& acc, bool& first, float coef, c
   }
 }
 
+// Where a transform's result goes (float2 words: a thread owns two channels).  H2 = false: float32 tensor `f`.  H2 = true: operand
+// planes of frcnn_gemm_h2 -- fp16 pieces [2][rows][C] + inv [C/128][rows]; the 64 consecutive threads that hold a row's 128 channels
+// are one wave (C2 % 64 == 0) and reduce the block maximum with DPP / permlane-swap moves.  `f` may be given as well.
+template <bool H2>
+struct Wino7Sink {
+  float2* f; unsigned short* planes; float* inv; size_t rows;
+  __device__ __forceinline__ void put(size_t row, int c2, int C2, float2 v) const {
+    if (!H2 || f) f[row * C2 + c2] = v;
+    if (H2) h2_emit_block64(v, planes, rows * (size_t)C2 * 2, (row * C2 + c2) * 2, inv + (size_t)(c2 >> 6) * rows + row, c2 & 63);
+  }
+};
+
 // V[(xi*11+nu)][r][c] = (B^T d B)[xi][nu], d = the 7x7 map of RoI r, channel c, zero padded by one pixel
-__global__ void __launch_bounds__(256) k_wino7_input(const float2* __restrict__ x, int R, int C2, float2* __restrict__ V) {
+template <bool H2>
+__global__ void __launch_bounds__(256) k_wino7_input(const float2* __restrict__ x, int R, int C2, const Wino7Sink<H2> V) {
   const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= (long long)R * C2) return;
   const int c2 = (int)(id % C2);
@@ -55,8 +68,6 @@ __global__ void __launch_bounds__(256) k_wino7_input(const float2* __restrict__ 
   for (int i = 0; i < 7; ++i)
 #pragma unroll
     for (int j = 0; j < 7; ++j) d[i][j] = src[(size_t)(i * 7 + j) * C2];
-  const size_t plane = (size_t)R * C2;
-  float2* out = V + (size_t)r * C2 + c2;
 #pragma unroll
   for (int xi = 0; xi < 11; ++xi) {
     float2 t[7];
@@ -73,16 +84,16 @@ __global__ void __launch_bounds__(256) k_wino7_input(const float2* __restrict__ 
       float2 v = make_float2(0.f, 0.f);
 #pragma unroll
       for (int j = 0; j < 7; ++j) acc_term(v, first, w7::BT[nu][j + 1], t[j]);
-      out[(size_t)(xi * 11 + nu) * plane] = v;
+      V.put((size_t)(xi * 11 + nu) * R + r, c2, C2, v);
     }
   }
 }
 
 // y[r][i][j][o] = act( (A^T M A)[i][j] + bias[o] ), M[(xi*11+nu)][r][o]; the two row segments (xi 0..5 -> rows 0..3, xi 6..10 ->
 // rows 4..6) are processed one after the other to bound the register footprint
-template <int XI0, int NXI, int I0, int NI>
-__device__ __forceinline__ void wino7_out_segment(const float2* __restrict__ in, size_t plane, float2 bv, int act, float2* __restrict__ dst,
-                                                  int C2) {
+template <int XI0, int NXI, int I0, int NI, bool H2>
+__device__ __forceinline__ void wino7_out_segment(const float2* __restrict__ in, size_t plane, float2 bv, int act, const Wino7Sink<H2>& y,
+                                                  size_t row0, int c2, int C2) {
   float2 m[NXI][11];
 #pragma unroll
   for (int a = 0; a < NXI; ++a)
@@ -106,13 +117,14 @@ __device__ __forceinline__ void wino7_out_segment(const float2* __restrict__ in,
       for (int nu = 0; nu < 11; ++nu) acc_term(v, first, w7::AT[j][nu], s[nu]);
       v = make_float2(v.x + bv.x, v.y + bv.y);
       if (act == FRCNN_ACT_RELU) v = make_float2(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f));
-      dst[(size_t)((I0 + i) * 7 + j) * C2] = v;
+      y.put(row0 + (I0 + i) * 7 + j, c2, C2, v);
     }
   }
 }
 
+template <bool H2>
 __global__ void __launch_bounds__(256) k_wino7_output(const float2* __restrict__ Mx, int R, int C2, const float2* __restrict__ bias, int act,
-                                                       float2* __restrict__ y) {
+                                                       const Wino7Sink<H2> y) {
   const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= (long long)R * C2) return;
   const int c2 = (int)(id % C2);
@@ -120,9 +132,8 @@ __global__ void __launch_bounds__(256) k_wino7_output(const float2* __restrict__
   const size_t plane = (size_t)R * C2;
   const float2* in = Mx + (size_t)r * C2 + c2;
   const float2 bv = bias ? bias[c2] : make_float2(0.f, 0.f);
-  float2* dst = y + (size_t)r * 49 * C2 + c2;
-  wino7_out_segment<0, 6, 0, 4>(in, plane, bv, act, dst, C2);
-  wino7_out_segment<6, 5, 4, 3>(in, plane, bv, act, dst, C2);
+  wino7_out_segment<0, 6, 0, 4, H2>(in, plane, bv, act, y, (size_t)r * 49, c2, C2);
+  wino7_out_segment<6, 5, 4, 3, H2>(in, plane, bv, act, y, (size_t)r * 49, c2, C2);
 }
 
 // U[(xi*11+nu)][o][c] = (G g G^T)[xi][nu] on the device from the packed filter [Cout][3][3][Cin] (training); transpose_flip as in
@@ -188,8 +199,19 @@ extern "C" int frcnn_winograd7_input_transform(const float* x_d, int R, int C, f
   if (!x_d || !v_d || R <= 0 || C <= 0) return FRCNN_E_ARG;
   if (C % 2) return FRCNN_E_UNSUPPORTED;
   const long long tot = (long long)R * (C / 2);
-  hipLaunchKernelGGL(k_wino7_input, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float2*)x_d, R, C / 2,
-                     (float2*)v_d);
+  const Wino7Sink<false> sink{(float2*)v_d, nullptr, nullptr, 0};
+  hipLaunchKernelGGL(k_wino7_input<false>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float2*)x_d, R, C / 2, sink);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// ... -> operand planes [2][121 * R][C] + v_inv [C/128][121 * R] of frcnn_gemm_h2; C % 128 == 0
+extern "C" int frcnn_winograd7_input_transform_h2(const float* x_d, int R, int C, void* v_planes_d, float* v_inv_d, void* stream) {
+  if (!x_d || !v_planes_d || !v_inv_d || R <= 0 || C <= 0) return FRCNN_E_ARG;
+  if (C % H2_KB) return FRCNN_E_UNSUPPORTED;
+  const long long tot = (long long)R * (C / 2);
+  const Wino7Sink<true> sink{nullptr, (unsigned short*)v_planes_d, v_inv_d, (size_t)121 * R};
+  hipLaunchKernelGGL(k_wino7_input<true>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float2*)x_d, R, C / 2, sink);
   LAUNCH_CHECK();
   return FRCNN_OK;
 }
@@ -199,8 +221,22 @@ extern "C" int frcnn_winograd7_output_transform(const float* m_d, int R, int C, 
   if (!m_d || !y_d || R <= 0 || C <= 0) return FRCNN_E_ARG;
   if (C % 2 || (act != FRCNN_ACT_NONE && act != FRCNN_ACT_RELU)) return FRCNN_E_UNSUPPORTED;
   const long long tot = (long long)R * (C / 2);
-  hipLaunchKernelGGL(k_wino7_output, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float2*)m_d, R, C / 2,
-                     (const float2*)bias_d, act, (float2*)y_d);
+  const Wino7Sink<false> sink{(float2*)y_d, nullptr, nullptr, 0};
+  hipLaunchKernelGGL(k_wino7_output<false>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float2*)m_d, R, C / 2,
+                     (const float2*)bias_d, act, sink);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// ... -> operand planes [2][R * 49][C] + y_inv [C/128][R * 49] (y_d: NULL or the float32 result as well); C % 128 == 0
+extern "C" int frcnn_winograd7_output_transform_h2(const float* m_d, int R, int C, const float* bias_d, int act, float* y_d, void* y_planes_d,
+                                                   float* y_inv_d, void* stream) {
+  if (!m_d || !y_planes_d || !y_inv_d || R <= 0 || C <= 0) return FRCNN_E_ARG;
+  if (C % H2_KB || (act != FRCNN_ACT_NONE && act != FRCNN_ACT_RELU)) return FRCNN_E_UNSUPPORTED;
+  const long long tot = (long long)R * (C / 2);
+  const Wino7Sink<true> sink{(float2*)y_d, (unsigned short*)y_planes_d, y_inv_d, (size_t)R * 49};
+  hipLaunchKernelGGL(k_wino7_output<true>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float2*)m_d, R, C / 2,
+                     (const float2*)bias_d, act, sink);
   LAUNCH_CHECK();
   return FRCNN_OK;
 }

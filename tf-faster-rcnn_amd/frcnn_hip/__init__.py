@@ -77,6 +77,10 @@ SIGNATURES = {
     "frcnn_winograd7_filter_transform_device": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "frcnn_winograd7_input_transform": (c_int, [_P, c_int, c_int, _P, _P]),
     "frcnn_winograd7_output_transform": (c_int, [_P, c_int, c_int, _P, c_int, _P, _P]),
+    "frcnn_winograd_input_transform_h2": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "frcnn_winograd_output_transform_h2": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
+    "frcnn_winograd7_input_transform_h2": (c_int, [_P, c_int, c_int, _P, _P, _P]),
+    "frcnn_winograd7_output_transform_h2": (c_int, [_P, c_int, c_int, _P, c_int, _P, _P, _P, _P]),
     "frcnn_set_tuning": (c_int, [c_int, c_int]),
     "frcnn_pack_filter_hwio": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "frcnn_maxpool_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),

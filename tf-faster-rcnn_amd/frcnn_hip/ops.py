@@ -734,6 +734,37 @@ def gemm_h2(x, wp, G, M, N, K, bias=None, residual=None, act=ACT_NONE, out=None,
     return out, out_planes
 
 
+def winograd_input_transform_h2(x, v, m):
+    """x [N,H,W,C] f32 -> V as H2 planes of [points * tiles, C] (frcnn_winograd[7]_input_transform_h2)."""
+    _chk(x)
+    N, H, W, C = x.shape
+    assert isinstance(v, H2) and v.K == C and v.rows == winograd_points(m) * winograd_tiles(N, H, W, m)
+    if m == 7:
+        call("frcnn_winograd7_input_transform_h2", _ptr(x), N, C, _ptr(v.planes), _ptr(v.inv), _stream())
+    else:
+        call("frcnn_winograd_input_transform_h2", _ptr(x), N, H, W, C, int(m), _ptr(v.planes), _ptr(v.inv), _stream())
+    return v
+
+
+def winograd_output_transform_h2(mm, bias, act, shape, m, out_planes, out=None):
+    """mm [(points), tiles, C] f32 -> act(A^T M A + bias) of shape [N,H,W,C] as H2 planes (`out_planes`, rows = N*H*W) and, when `out`
+    is given, as the float32 tensor too."""
+    _chk(mm)
+    N, H, W, C = shape
+    assert isinstance(out_planes, H2) and out_planes.rows == N * H * W and out_planes.K == C
+    assert mm.numel() == winograd_points(m) * winograd_tiles(N, H, W, m) * C
+    if out is not None:
+        _chk(out)
+        assert tuple(out.shape) == tuple(shape)
+    if m == 7:
+        call("frcnn_winograd7_output_transform_h2", _ptr(mm), N, C, _ptr(bias), int(act), _ptr(out), _ptr(out_planes.planes),
+             _ptr(out_planes.inv), _stream())
+    else:
+        call("frcnn_winograd_output_transform_h2", _ptr(mm), N, H, W, C, int(m), _ptr(bias), int(act), _ptr(out), _ptr(out_planes.planes),
+             _ptr(out_planes.inv), _stream())
+    return out_planes
+
+
 def relu6_bwd(grad, y):
     _chk(grad), _chk(y)
     call("frcnn_relu6_bwd", _ptr(grad), _ptr(y), grad.numel(), _stream())

@@ -28,6 +28,7 @@ class VariableStore(object):
         self.variables = collections.OrderedDict()     # TF name -> numpy (HWIO conv, [in,out] fc)
         self.packed = {}                                # layer key -> device tensors
         self.x3 = {}                                    # (filter address, shape) -> (bf16 planes, filter): frcnn_gemm_x3 operands
+        self.h2 = {}                                    # (filter address, shape) -> ((fp16 planes, w_inv), filter): frcnn_gemm_h2 operands
         self.conv_info = {}                             # scope -> {w (folded, device), b, scale (np or None), bn}
         self.graphs = {}
         self.seed = seed
@@ -69,6 +70,7 @@ class VariableStore(object):
             self.variables[k] = np.asarray(v, dtype=np.float32)
         self.packed.clear()
         self.x3.clear()                                 # planes of the filters just dropped (no graph is left that reads them)
+        self.h2.clear()
         self.graphs.clear()
 
     def restore(self, ckpt_prefix, names=None, verify=True):
@@ -198,6 +200,29 @@ class Session(VariableStore):
         for planes, w in self.x3.values():
             ops.gemm_x3_pack(w, planes)
 
+    def h2_planes(self, w):
+        """Pre-split fp16 planes + per-row scales of a static device filter [N, ...K] / [G, N, K] for frcnn_gemm_h2 (cfg.HIP.MFMA_H2),
+        split once and cached like x3_planes."""
+        key = (w.data_ptr(), tuple(w.shape))
+        ent = self.h2.get(key)
+        if ent is None:
+            ent = (ops.h2_pack_w(w), w)
+            self.h2[key] = ent
+        return ent[0]
+
+    def h2_refresh(self):
+        """Re-split every cached filter into its existing buffers (see x3_refresh)."""
+        for packed, w in self.h2.values():
+            ops.h2_pack_w(w, packed)
+
+    def h2_buf(self, name, rows, K):
+        """Static operand-plane buffer (ops.H2) for an activation tensor of [rows, K]."""
+        key = ("h2", name, int(rows), int(K))
+        t = self.buffers.get(key)
+        if t is None:
+            t = self.buffers[key] = ops.H2.empty(rows, K, self.device)
+        return t
+
     def mark(self, tag, flops, fn, nbytes=0):
         """nbytes: algorithmic HBM bytes of the launch (operands read once + result written once), for the roofline report."""
         self.flops_last_forward += flops
@@ -218,6 +243,7 @@ class Session(VariableStore):
         self.buffers.clear()
         self.packed.clear()
         self.x3.clear()
+        self.h2.clear()
 
 
 class Timer(object):

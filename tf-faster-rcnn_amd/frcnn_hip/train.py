@@ -267,6 +267,8 @@ class TrainState(object):
                 ops.dwconv3x3_refold(p.w, p.scale, p.wf)
         if self.sess.x3:                             # a TEST-mode network on the same session (cfg.HIP.MFMA_X3) reads pre-split filters
             self.sess.x3_refresh()
+        if self.sess.h2:                             # the same for cfg.HIP.MFMA_H2
+            self.sess.h2_refresh()
 
     def _wd(self, scope):
         wd = self.net.weight_decay_for(scope) if hasattr(self.net, "weight_decay_for") else None

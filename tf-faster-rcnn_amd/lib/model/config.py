@@ -85,9 +85,15 @@ __C = AttrDict(
     # matrix pipe with EXACTLY split f32 operands (csrc/gemm_x3.hip: x = h + m + l, six bf16 MFMAs per f32 product, f32 accumulation,
     # dropped terms <= 2^-24 relative): 1.3-1.6x faster than the f32 MFMA and, measured against float64, slightly MORE accurate than
     # it (profiles/r02_m_x3_sweep.txt).  False = every product on v_mfma_f32_32x32x2_f32 (bench.py --mfma f32).
+    # MFMA_H2: TEST mode, plain GEMMs with Cin % 128 == 0 and Cout % 128 == 0 run on the fp16 matrix pipe with BLOCK-SCALED two-piece
+    # operands (csrc/gemm_h2.hip: x = 2^-e (h + l) per 128-k block, three fp16 MFMAs per f32 product, f32 accumulation, dropped terms
+    # <= 3 * 2^-22 relative, measured 1e-7 of the output scale -- below the f32 MFMA kernel's own error): 1.3-1.7x faster than MFMA_X3.
+    # The producers (GEMM epilogue, Winograd transforms) emit the next layer's operand planes; H2_LAZY_SPLIT: an eligible layer
+    # whose input has no planes yet splits it with a separate pass (False: such a layer takes the X3 / f32 path instead).
     HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=64, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=("block1", "block2"), WINOGRAD_DIRECT_SCOPES=(),
              WINOGRAD_TRAIN=True,
-             WINOGRAD_7X7=True, FUSE_TAIL_MEAN=False, OVERLAP_TAIL_ENTRY=False, MFMA_X3=True))
+             WINOGRAD_7X7=True, FUSE_TAIL_MEAN=False, OVERLAP_TAIL_ENTRY=False, MFMA_X3=True,
+             MFMA_H2=True, H2_LAZY_SPLIT=True, H2_MIN_TILES=150))
 __C.DATA_DIR = osp.abspath(osp.join(__C.ROOT_DIR, 'data'))
 cfg = __C
 

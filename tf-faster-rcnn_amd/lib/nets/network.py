@@ -45,6 +45,8 @@ class Network(object):
         self._sample_seed = 0
         self._train_state = None
         self._fuse_tail_entry = False          # TEST-only graph restructuring, see resnetv1._fused_tail_entry
+        self._h2_of = {}                       # activation address -> ops.H2 operand planes of that tensor (cfg.HIP.MFMA_H2)
+        self._f32_missing = set()              # addresses of activations that exist ONLY as operand planes (never read as f32)
 
     # ------------------------------------------------------------------ variable declaration
     def _var(self, name, shape, init, arg=None):
@@ -75,7 +77,10 @@ class Network(object):
 
     # ------------------------------------------------------------------ building blocks
     def _conv(self, x, scope, k, stride=1, pad=(0, 0, 0, 0), act=ACT_RELU, bn_eps=None, residual=None,
-              res_stride=1, fold_w=False, out_affine=None, real_cin=None, no_bias=False):
+              res_stride=1, fold_w=False, out_affine=None, real_cin=None, no_bias=False, emit_h2=False, want_f32=True):
+        """emit_h2 / want_f32 (cfg.HIP.MFMA_H2, TEST mode): the caller knows the consumers of the result -- emit_h2: a frcnn_gemm_h2
+        launch will read it, so the producer writes its operand planes from its epilogue; want_f32 = False: nothing reads the
+        float32 tensor (honoured only where the planes are emitted)."""
         sess = self._sess
         N, H, W, Cin = x.shape
         wino = (cfg.HIP.WINOGRAD and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1)
@@ -83,7 +88,7 @@ class Network(object):
                 and Cin % 32 == 0 and Cin >= cfg.HIP.WINOGRAD_MIN_CIN and act in (ACT_NONE, ACT_RELU)
                 and not any(tok in scope for tok in cfg.HIP.WINOGRAD_DIRECT_SCOPES))
         if wino and self._mode == "TEST":
-            return self._conv_winograd(x, scope, act, bn_eps)
+            return self._conv_winograd(x, scope, act, bn_eps, emit_h2, want_f32)
         wino = wino and cfg.HIP.WINOGRAD_TRAIN
         w, b = sess.conv_params(scope, bn_eps=bn_eps, fold_w=fold_w,
                                 out_scale=None if out_affine is None else out_affine[0],
@@ -96,6 +101,8 @@ class Network(object):
         Cout = w.shape[0]
         out = sess.buf(self._tag + "/" + scope, (N, OH, OW, Cout))
         flops = 2 * N * OH * OW * Cout * k * k * (Cin if real_cin is None else real_cin)
+        plain = k == 1 and stride == 1 and tuple(pad) == (0, 0, 0, 0) and not fold_w and (residual is None or res_stride == 1)
+        M = N * OH * OW
         if wino:
             # TRAIN: the filter changes every step -> transform the live (folded) device filter, then the same Winograd chain
             m = self._winograd_scheme(scope, H, W)
@@ -104,13 +111,27 @@ class Network(object):
             v, mm = sess.buf(self._tag + "/wino_v", (G, T, Cin)), sess.buf(self._tag + "/wino_m", (G, T, Cout))
             sess.mark("conv:" + scope, 2 * G * T * Cout * Cin, lambda: ops.conv3x3_winograd(x, u, b, act, out=out, v_buf=v, m_buf=mm),
                       nbytes=4 * (v.numel() + u.numel() + mm.numel()))
-        elif self._x3_eligible(N * OH * OW, Cout, Cin, 1) and k == 1 and stride == 1 and tuple(pad) == (0, 0, 0, 0) and not fold_w \
-                and (residual is None or res_stride == 1):
-            # a plain GEMM with a static filter: exact bf16x3 operand split on the bf16 matrix pipe (cfg.HIP.MFMA_X3)
-            planes, M = sess.x3_planes(w), N * OH * OW
+        elif plain and self._h2_eligible(M, Cout, Cin, 1) and self._h2_input(x) is not None:
+            # a plain GEMM with a static filter on the fp16 matrix pipe, block-scaled two-piece operands (cfg.HIP.MFMA_H2)
+            xp, wp = self._h2_input(x), sess.h2_planes(w)
+            yp = sess.h2_buf(self._tag + "/" + scope, M, Cout) if emit_h2 else None
+            y = out if (want_f32 or yp is None) else None
+            sess.mark("conv:h2:" + scope, flops, lambda: ops.gemm_h2(xp, wp, 1, M, Cout, Cin, b, residual, act, out=y, out_planes=yp,
+                                                                      want_f32=False),
+                      nbytes=4 * M * Cin + 4 * w.numel() + (4 * out.numel() if y is not None else 0)
+                      + (4 * out.numel() if yp is not None else 0) + (4 * out.numel() if residual is not None else 0))
+            if yp is not None:
+                self._h2_of[out.data_ptr()] = yp
+            if y is None:
+                self._f32_missing.add(out.data_ptr())
+        elif plain and self._x3_eligible(M, Cout, Cin, 1):
+            # ... on the bf16 matrix pipe with exact bf16x3 operand splits (cfg.HIP.MFMA_X3)
+            self._need_f32(x)
+            planes = sess.x3_planes(w)
             sess.mark("conv:x3:" + scope, flops, lambda: ops.gemm_x3(x, planes, 1, M, Cout, Cin, b, residual, act, out=out),
                       nbytes=4 * (x.numel() + out.numel() + (out.numel() if residual is not None else 0)) + 6 * w.numel())
         else:
+            self._need_f32(x)
             sess.mark("conv:" + scope, flops,
                       lambda: ops.conv2d(x, w, b, k, k, stride, pad, act, residual, res_stride, fold_w, out=out),
                       nbytes=4 * (x.numel() + w.numel() + out.numel() + (out.numel() if residual is not None else 0)))
@@ -122,6 +143,30 @@ class Network(object):
             if residual is not None and residual.data_ptr() in self._requires_grad:
                 self._requires_grad.add(out.data_ptr())
         return out
+
+    # ---- cfg.HIP.MFMA_H2 plumbing -------------------------------------------------------------------------------------------------
+    def _h2_eligible(self, M, N, K, G):
+        """TEST mode (static filters), K % 128 == 0 (scale blocks), N % 128 == 0 (tiles), enough tiles to fill the chip, and the
+        32-bit offset limits of frcnn_gemm_h2."""
+        rows = G * M
+        return (bool(cfg.HIP.MFMA_H2) and self._mode == "TEST" and K % 128 == 0 and N % 128 == 0 and rows % 4 == 0 and (G == 1 or M % 4 == 0)
+                and ((M + 127) // 128) * (N // 128) * G >= int(cfg.HIP.H2_MIN_TILES)
+                and 4 * rows * K < (1 << 32) and 4 * N * K < (1 << 32) and M * N < (1 << 29))
+
+    def _h2_input(self, x):
+        """Operand planes of activation x: those its producer emitted, else (cfg.HIP.H2_LAZY_SPLIT) a frcnn_h2_split pass, else None."""
+        xp = self._h2_of.get(x.data_ptr())
+        if xp is None and cfg.HIP.H2_LAZY_SPLIT:
+            self._need_f32(x)
+            K = x.shape[-1]
+            xp = self._sess.h2_buf(self._tag + "/split@%x" % x.data_ptr(), x.numel() // K, K)
+            self._sess.mark("op:h2_split", 0, lambda: ops.h2_split(x, out=xp), nbytes=8 * x.numel())
+            self._h2_of[x.data_ptr()] = xp
+        return xp
+
+    def _need_f32(self, x):
+        if x.data_ptr() in self._f32_missing:
+            raise RuntimeError("graph construction error: a float32 consumer reads a tensor that was emitted as operand planes only")
 
     def _x3_eligible(self, M, N, K, G):
         """cfg.HIP.MFMA_X3: TEST mode (static filters), N % 64 == 0, K % 32 == 0 and at least 150 tiles of 128 x 128 -- below that
@@ -137,29 +182,47 @@ class Network(object):
         m = int(cfg.HIP.WINOGRAD_M)
         return 7 if (m == 4 and H == 7 and W == 7 and cfg.HIP.WINOGRAD_7X7) else m
 
-    def _conv_winograd(self, x, scope, act, bn_eps):
+    def _conv_winograd(self, x, scope, act, bn_eps, emit_h2=False, want_f32=True):
         """3x3 / stride 1 / SAME convolution as Winograd F(m x m,3x3): input transform -> (m+2)^2 GEMMs in ONE launch of
         the f32-MFMA kernel -> output transform with bias + ReLU.  Exact algebra in f32; m = 2 (2.25x fewer
         multiplications, rounding like the direct kernel) or m = 4 (4x fewer; a single layer rounds ~10x worse than
-        direct, but through the full ResNet-101 the outputs move by ~1e-6 relative, profiles/r01_e_winograd_error.txt)."""
+        direct, but through the full ResNet-101 the outputs move by ~1e-6 relative, profiles/r01_e_winograd_error.txt).
+        cfg.HIP.MFMA_H2: the input transform emits V as operand planes, the products run in frcnn_gemm_h2, and (emit_h2) the
+        output transform emits the result as the next 1x1 convolution's operand planes."""
         sess = self._sess
+        self._need_f32(x)
         N, H, W, Cin = x.shape
         m = self._winograd_scheme(scope, H, W)
         u, b = sess.winograd_params(scope, bn_eps=bn_eps, m=m)
         G, Cout = u.shape[0], u.shape[1]
         T = ops.winograd_tiles(N, H, W, m)
-        v = sess.buf(self._tag + "/wino_v", (G, T, Cin))
         mm = sess.buf(self._tag + "/wino_m", (G, T, Cout))
         out = sess.buf(self._tag + "/" + scope, (N, H, W, Cout))
-        sess.mark("op:wino_in", 0, lambda: ops.winograd_input_transform(x, v, m), nbytes=4 * (x.numel() + v.numel()))
-        if self._x3_eligible(T, Cout, Cin, G):
-            planes = sess.x3_planes(u)
-            sess.mark("conv:x3:" + scope, 2 * G * T * Cout * Cin, lambda: ops.gemm_x3(v, planes, G, T, Cout, Cin, out=mm),
-                      nbytes=4 * (v.numel() + mm.numel()) + 6 * u.numel())
+        flops = 2 * G * T * Cout * Cin
+        if self._h2_eligible(T, Cout, Cin, G):
+            vp, wp = sess.h2_buf(self._tag + "/wino_v", G * T, Cin), sess.h2_planes(u)
+            sess.mark("op:wino_in", 0, lambda: ops.winograd_input_transform_h2(x, vp, m), nbytes=4 * (x.numel() + G * T * Cin))
+            sess.mark("conv:h2:" + scope, flops, lambda: ops.gemm_h2(vp, wp, G, T, Cout, Cin, out=mm),
+                      nbytes=4 * (G * T * Cin + mm.numel()) + 4 * u.numel())
         else:
-            sess.mark("conv:" + scope, 2 * G * T * Cout * Cin, lambda: ops.gemm_batched_nt(v, u, mm),
-                      nbytes=4 * (v.numel() + u.numel() + mm.numel()))
-        sess.mark("op:wino_out", 0, lambda: ops.winograd_output_transform(mm, b, act, out, m), nbytes=4 * (mm.numel() + out.numel()))
+            v = sess.buf(self._tag + "/wino_v", (G, T, Cin))
+            sess.mark("op:wino_in", 0, lambda: ops.winograd_input_transform(x, v, m), nbytes=4 * (x.numel() + v.numel()))
+            if self._x3_eligible(T, Cout, Cin, G):
+                planes = sess.x3_planes(u)
+                sess.mark("conv:x3:" + scope, flops, lambda: ops.gemm_x3(v, planes, G, T, Cout, Cin, out=mm),
+                          nbytes=4 * (v.numel() + mm.numel()) + 6 * u.numel())
+            else:
+                sess.mark("conv:" + scope, flops, lambda: ops.gemm_batched_nt(v, u, mm), nbytes=4 * (v.numel() + u.numel() + mm.numel()))
+        if emit_h2 and cfg.HIP.MFMA_H2 and Cout % 128 == 0:
+            yp = sess.h2_buf(self._tag + "/" + scope, N * H * W, Cout)
+            y = out if want_f32 else None
+            sess.mark("op:wino_out", 0, lambda: ops.winograd_output_transform_h2(mm, b, act, (N, H, W, Cout), m, yp, y),
+                      nbytes=4 * (mm.numel() + out.numel() * (2 if want_f32 else 1)))
+            self._h2_of[out.data_ptr()] = yp
+            if y is None:
+                self._f32_missing.add(out.data_ptr())
+        else:
+            sess.mark("op:wino_out", 0, lambda: ops.winograd_output_transform(mm, b, act, out, m), nbytes=4 * (mm.numel() + out.numel()))
         return out
 
     def _conv1x1_mean(self, x, scope, group_rows, act=ACT_RELU, bn_eps=None, residual=None, name="fc7"):
@@ -447,6 +510,7 @@ class Network(object):
     def _build_network(self, is_training=True):
         self._tape = []
         self._requires_grad = set()
+        self._h2_of, self._f32_missing = {}, set()      # planes are facts about THIS build's launches (buffers are reused across builds)
         net_conv = self._image_to_head(is_training)
         self._anchor_component()
         fused = self._fuse_tail_entry and not is_training and hasattr(self, "_fused_tail_entry")
@@ -535,7 +599,8 @@ class Network(object):
                bool(cfg.USE_GPU_NMS), tuple(image_d.shape), self._im_info[:2], self._mode, cfg.TEST.MODE, self._fuse_tail_entry,
                c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH, cfg.TEST.RPN_TOP_N, cfg.POOLING_SIZE,
                bool(cfg.HIP.WINOGRAD), int(cfg.HIP.WINOGRAD_MIN_CIN), int(cfg.HIP.WINOGRAD_M), tuple(cfg.HIP.WINOGRAD_F2_SCOPES),
-               tuple(cfg.HIP.WINOGRAD_DIRECT_SCOPES), bool(cfg.HIP.WINOGRAD_7X7), bool(cfg.HIP.FUSE_TAIL_MEAN), bool(cfg.HIP.OVERLAP_TAIL_ENTRY), bool(cfg.HIP.MFMA_X3), bool(cfg.USE_E2E_TF))
+               tuple(cfg.HIP.WINOGRAD_DIRECT_SCOPES), bool(cfg.HIP.WINOGRAD_7X7), bool(cfg.HIP.FUSE_TAIL_MEAN), bool(cfg.HIP.OVERLAP_TAIL_ENTRY), bool(cfg.HIP.MFMA_X3), bool(cfg.USE_E2E_TF),
+               bool(cfg.HIP.MFMA_H2), bool(cfg.HIP.H2_LAZY_SPLIT), int(cfg.HIP.H2_MIN_TILES))
         cur = torch.cuda.current_stream(sess.device)
         if not use_graph or sess.profile is not None:
             sess.flops_last_forward = 0
@@ -560,6 +625,7 @@ class Network(object):
     def extract_head(self, sess, image):
         self._sess = sess
         self._image = self._stage_image(sess, image)
+        self._h2_of, self._f32_missing = {}, set()
         feat = self._image_to_head(False)
         return feat.cpu().numpy()
 

@@ -70,9 +70,12 @@ class resnetv1(Network):
         return self._blocks[3][1] * 4
 
     # ---- graph -----------------------------------------------------------------------------------
-    def _bottleneck(self, x, prefix, base, stride, mean_rows=0):
+    def _bottleneck(self, x, prefix, base, stride, mean_rows=0, emit_out=True):
         """mean_rows > 0 (TEST mode, last unit of the tail): returns mean over every `mean_rows` consecutive pixels of the unit's
-        output instead of the output itself (conv3 + residual + ReLU + reduce_mean in one kernel)."""
+        output instead of the output itself (conv3 + residual + ReLU + reduce_mean in one kernel).
+        cfg.HIP.MFMA_H2 (TEST mode): conv2 hands conv3 its operand planes only (nothing else reads conv2's float32 result); conv3
+        emits float32 (the next residual) AND the planes the next unit's conv1 / shortcut read (emit_out = False: a consumer that
+        is not a GEMM follows, e.g. the spatial mean)."""
         depth = base * 4
         cin = x.shape[-1]
         if cin != depth:
@@ -82,16 +85,21 @@ class resnetv1(Network):
             shortcut, res_stride = x, stride                # slim `subsample`: fused into conv3's epilogue
         r = self._conv(x, prefix + "/conv1", 1, 1, act=ACT_RELU, bn_eps=BN_EPS)
         pad = (1, 1, 1, 1) if stride == 1 else _same_pad(3, stride)
-        r = self._conv(r, prefix + "/conv2", 3, stride, pad, act=ACT_RELU, bn_eps=BN_EPS)
         if mean_rows and res_stride == 1 and cfg.HIP.FUSE_TAIL_MEAN:
+            r = self._conv(r, prefix + "/conv2", 3, stride, pad, act=ACT_RELU, bn_eps=BN_EPS)
             return self._conv1x1_mean(r, prefix + "/conv3", mean_rows, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut)
-        return self._conv(r, prefix + "/conv3", 1, 1, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut, res_stride=res_stride)
+        N, H, W, _ = r.shape
+        M3 = N * ops.conv_out_size(H, 3, stride, pad[0], pad[1]) * ops.conv_out_size(W, 3, stride, pad[2], pad[3])
+        c3_h2 = res_stride == 1 and self._h2_eligible(M3, depth, base, 1)
+        r = self._conv(r, prefix + "/conv2", 3, stride, pad, act=ACT_RELU, bn_eps=BN_EPS, emit_h2=c3_h2, want_f32=not c3_h2)
+        return self._conv(r, prefix + "/conv3", 1, 1, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut, res_stride=res_stride,
+                          emit_h2=emit_out)
 
-    def _run_blocks(self, x, blocks):
-        for name, base, n_units, stride in blocks:
+    def _run_blocks(self, x, blocks, emit_last=True):
+        for bi, (name, base, n_units, stride) in enumerate(blocks):
             for u in range(1, n_units + 1):
                 x = self._bottleneck(x, "%s/%s/unit_%d/bottleneck_v1" % (self._scope, name, u), base,
-                                     stride if u == n_units else 1)
+                                     stride if u == n_units else 1, emit_out=emit_last or u < n_units or bi + 1 < len(blocks))
         return x
 
     def _crop_pool_layer(self, bottom, rois, name):
@@ -140,12 +148,13 @@ class resnetv1(Network):
         c1_out = sess.buf(self._tag + "/" + prefix + "/conv1_crop", (R, P, P, c1_map.shape[-1]))
         shortcut = self._crop_images(sc_map, rois, sc_out, bias=b_sc, act=ACT_NONE)
         r = self._crop_images(c1_map, rois, c1_out, bias=b_c1, act=ACT_RELU)
-        r = self._conv(r, prefix + "/conv2", 3, 1, (1, 1, 1, 1), act=ACT_RELU, bn_eps=BN_EPS)
-        x = self._conv(r, prefix + "/conv3", 1, 1, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut, res_stride=1)
+        c3_h2 = self._h2_eligible(R * P * P, 4 * base, base, 1)
+        r = self._conv(r, prefix + "/conv2", 3, 1, (1, 1, 1, 1), act=ACT_RELU, bn_eps=BN_EPS, emit_h2=c3_h2, want_f32=not c3_h2)
+        x = self._conv(r, prefix + "/conv3", 1, 1, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut, res_stride=1, emit_h2=n_units >= 2)
         fused = bool(cfg.HIP.FUSE_TAIL_MEAN) and stride == 1 and n_units >= 2
         for u in range(2, n_units + 1):
             x = self._bottleneck(x, "%s/%s/unit_%d/bottleneck_v1" % (self._scope, name, u), base, stride if u == n_units else 1,
-                                 mean_rows=P * P if (fused and u == n_units) else 0)
+                                 mean_rows=P * P if (fused and u == n_units) else 0, emit_out=u < n_units)
         if fused:
             return x                                          # [R, 2048]: the mean came out of the last conv3's epilogue
         out = sess.buf(self._tag + "/fc7", (x.shape[0], x.shape[-1]))
@@ -159,7 +168,7 @@ class resnetv1(Network):
             for u in range(1, n_units + 1):
                 x = self._bottleneck(x, "%s/%s/unit_%d/bottleneck_v1" % (self._scope, name, u), base, 1, mean_rows=hw if u == n_units else 0)
             return x
-        fc7 = self._run_blocks(pool5, self._blocks[-1:])
+        fc7 = self._run_blocks(pool5, self._blocks[-1:], emit_last=False)
         # average pooling done by reduce_mean (resnet_v1.py:124)
         out = self._sess.buf(self._tag + "/fc7", (fc7.shape[0], fc7.shape[-1]))
         res = self._sess.mark("op:spatial_mean", 0, lambda: ops.spatial_mean(fc7, out=out), nbytes=4 * (fc7.numel() + out.numel()))
