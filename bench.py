@@ -488,7 +488,7 @@ def main():
                          "graph": "reference op order" if args.reference_order else
                                   "block4/unit_1 1x1 convs commuted past the bilinear crop (exact algebra, same outputs to f32 rounding; "
                                   "--reference-order keeps crop -> conv)",
-                         "mfma": {"h2": "cfg.HIP.MFMA_H2: plain GEMMs with Cin, Cout % 128 == 0 and >= %d tiles on v_mfma_f32_32x32x16_f16 with "
+                         "mfma": {"h2": "cfg.HIP.MFMA_H2: plain GEMMs with Cin, Cout %% 128 == 0 and >= %d tiles on v_mfma_f32_32x32x16_f16 with "
                                         "block-scaled two-piece f32 operands (csrc/gemm_h2.hip), operand planes emitted by the producers; "
                                         "remaining large plain GEMMs: cfg.HIP.MFMA_X3 (bf16 pipe, exact 3-way splits); the stem, strided / "
                                         "small-Cout convolutions and heads on v_mfma_f32_32x32x2_f32" % int(cfg.HIP.H2_MIN_TILES),

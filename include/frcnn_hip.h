@@ -272,8 +272,7 @@ int frcnn_gemm_x3(const float* x_d, const void* planes_d, const float* bias_d, c
  *   frcnn_h2_split:   x [M][K] f32 -> planes [2][M][K] + x_inv [K/128][M] (one scale per row and 128-k block); K % 128 == 0.
  *   frcnn_gemm_h2:    y[g] = act(x[g] W[g]^T + bias + res[g]), g < G; x as planes [2][G*M][K] + x_inv [K/128][G*M]; res / y [G*M][N] f32 (y may be
  *                     NULL); y_planes / y_inv (may be NULL): the result as operand planes [2][G*M][N] + [N/128][G*M] for the next GEMM, emitted
- *                     from the register epilogue (bit-identical to frcnn_h2_split of y).  K % 128 == 0, N % 128 == 0, (G*M) % 4 == 0 (G > 1:
- *                     M % 4 == 0).  cfg: -1 = by shape, else a tile configuration id (per call: no process-wide state). */
+ *                     from the register epilogue (bit-identical to frcnn_h2_split of y).  K % 128 == 0, N % 128 == 0, any M.  cfg: -1 = by shape, else a tile configuration id (per call: no process-wide state). */
 size_t frcnn_h2_planes_bytes(long long rows, int K);
 int frcnn_h2_pack_w(const float* w_d, int G, int N, int K, void* planes_d, float* w_inv_d, void* stream);
 int frcnn_h2_split(const float* x_d, long long M, int K, void* planes_d, float* inv_d, void* stream);
@@ -305,8 +304,10 @@ int frcnn_winograd7_output_transform(const float* m_d, int R, int C, const float
 /* The Winograd transforms as PRODUCERS of frcnn_gemm_h2 operand planes (csrc/gemm_h2.hip): the input transforms emit V as fp16 pieces
  * [2][G*T][C] + v_inv [C/128][G*T] (G = (m+2)^2 or 121 points, T tiles / RoIs) instead of float32; the output transforms emit
  * act(A^T M A + bias) as planes [2][pixels][C] + y_inv [C/128][pixels] for the bottleneck's next 1x1 convolution (resnet_v1.py:80-125:
- * conv2 -> conv3) and, when y_d is not NULL, the float32 tensor as well.  Bit-identical to frcnn_h2_split of the float32 transform.
- * C % 128 == 0. */
+ * conv2 -> conv3) and, when y_d is not NULL, the float32 tensor as well.  The rows one thread writes together (the points of one
+ * transform row of a tile / the pixels of one output row of a tile) SHARE the scale of their common maximum -- one cross-lane
+ * reduction per group; any power of two that keeps the block maximum below 2^15 is a valid scale for frcnn_gemm_h2 (numpy statement:
+ * oracle/h2_ref.py split_grouped).  C % 128 == 0. */
 int frcnn_winograd_input_transform_h2(const float* x_d, int N, int H, int W, int C, int m, void* v_planes_d, float* v_inv_d, void* stream);
 int frcnn_winograd_output_transform_h2(const float* m_d, int N, int H, int W, int C, int m, const float* bias_d, int act, float* y_d,
                                        void* y_planes_d, float* y_inv_d, void* stream);

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY -- numpy statement of the operand format of csrc/gemm_h2.hip (cfg.HIP.MFMA_H2): a float32 value of a
 128-k block = (h + l) * 2^-e with h, l fp16 (both rounded to nearest even) and ONE exact power-of-two scale per (row, block); the
 weights use one scale per output row.  Used only by tests/: the device kernels (frcnn_h2_split, frcnn_h2_pack_w, the plane-emitting
-epilogue of frcnn_gemm_h2) must reproduce these arrays bit for bit."""
+epilogue of frcnn_gemm_h2, the plane-emitting Winograd transforms with their row-group scales) must reproduce these arrays bit for bit."""
 import numpy as np
 
 KB = 128
@@ -33,6 +33,25 @@ def split(x):
     xb = x.reshape(M, K // KB, KB)
     scale, inv = block_scale(np.abs(xb).max(axis=2))                   # [M, K/128]
     h, l = split_scaled(xb, scale[:, :, None])
+    return h.reshape(M, K), l.reshape(M, K), np.ascontiguousarray(inv.T)
+
+
+def split_grouped(x, group):
+    """Producers that write several rows together may give them ONE scale per 128-k block, from the group's common maximum (the
+    Winograd transforms: csrc/h2_common.h h2_emit_rows32 / 64).  x f32 [M, K], group int [M] (rows with equal id share) ->
+    (h, l, inv) like split()."""
+    x = np.asarray(x, dtype=np.float32)
+    M, K = x.shape
+    assert K % KB == 0
+    xb = np.abs(x).reshape(M, K // KB, KB).max(axis=2)                 # [M, K/128]
+    group = np.asarray(group)
+    order = np.argsort(group, kind="stable")
+    uniq, start = np.unique(group[order], return_index=True)
+    gmax = np.maximum.reduceat(xb[order], start, axis=0)               # [groups, K/128]
+    mx = np.empty_like(xb)
+    mx[order] = np.repeat(gmax, np.diff(np.append(start, M)), axis=0)
+    scale, inv = block_scale(mx)
+    h, l = split_scaled(x.reshape(M, K // KB, KB), scale[:, :, None])
     return h.reshape(M, K), l.reshape(M, K), np.ascontiguousarray(inv.T)
 
 

@@ -60,6 +60,9 @@ H2_CASES = [
     (1, 128 * 70, 2048, 128, True, 2),           # 1120 tiles, ReLU6
     (1, 128 * 33 + 8, 128, 256, True, 1),
     (3, 1200, 512, 512, False, 0),               # the 7x7 Winograd product shape (fewer points)
+    (1, 2394, 256, 1024, False, 1),              # one 38 x 63 image: M % 4 == 2
+    (7, 131, 128, 256, False, 0),                # batched, M odd: every batch entry starts at an unaligned scale row
+    (1, 61, 128, 128, True, 1),                  # less than one tile
 ]
 
 
@@ -125,28 +128,50 @@ def test_gemm_h2_planes_only_and_chained(dev):
     assert float(np.abs(a.cpu().numpy() - want).max()) <= 2e-6 * max(1.0, float(np.abs(want).max()))
 
 
-def _same_planes(a, b):
-    for g_, w_, name in zip(_planes_np(a), _planes_np(b), ("h", "l", "inv")):
+def _same_planes(got, want):
+    """got: ops.H2 on the device; want: an ops.H2 or the (h, l, inv) arrays of the numpy statement"""
+    want = _planes_np(want) if hasattr(want, "planes") else want
+    for g_, w_, name in zip(_planes_np(got), want, ("h", "l", "inv")):
         assert np.array_equal(g_.view(np.uint16) if g_.dtype == np.float16 else g_, w_.view(np.uint16) if w_.dtype == np.float16 else w_), name
+
+
+def _wino_groups(m, N, H, W):
+    """row -> scale-group id of the plane-emitting transforms: the rows ONE thread writes together share a scale (csrc/winograd*.hip):
+    input side = the (m+2) / 11 points of one transform row of one tile; output side = the pixels of one output row of one tile."""
+    from frcnn_hip import ops
+    G, Tl = ops.winograd_points(m), ops.winograd_tiles(N, H, W, m)
+    a = 11 if m == 7 else m + 2
+    xn, t = np.divmod(np.arange(G * Tl), Tl)
+    gin = (xn // a) * Tl + t
+    if m == 7:
+        gout = np.arange(N * 49) // 7
+    else:
+        TW = (W + m - 1) // m
+        img, rem = np.divmod(np.arange(N * H * W), H * W)
+        oh, ow = np.divmod(rem, W)
+        gout = (img * H + oh) * TW + ow // m
+    return gin, gout
 
 
 @pytest.mark.parametrize("m,N,H,W,C", [(2, 2, 19, 25, 128), (4, 3, 38, 63, 256), (4, 1, 10, 13, 384), (7, 37, 7, 7, 512), (7, 4, 7, 7, 128)])
 def test_winograd_transforms_emit_the_planes_of_their_f32_results(dev, m, N, H, W, C):
-    """frcnn_winograd[7]_input/output_transform_h2: V / y as operand planes == frcnn_h2_split of the float32 transform (bit for bit),
-    the optional float32 output of the output transform == the plain transform's."""
+    """frcnn_winograd[7]_input/output_transform_h2: V / y as operand planes == the numpy statement of the format applied to the float32
+    transform (row-group scales, bit for bit); the optional float32 output of the output transform == the plain transform's."""
     from frcnn_hip import ops
     rng = np.random.RandomState(m * 100 + C)
     x = (np.maximum(rng.randn(N, H, W, C), 0) * np.exp(rng.uniform(-3, 3, size=(N, H, W, C)))).astype(np.float32)
     x[:, :, :, 5] = 0.0                                                  # a dead channel
-    x[0, 0, 0, :] = 0.0                                                  # an all-zero pixel: whole scale blocks of zeros
+    x[0, 0:6, 0:6, :] = 0.0                                              # all-zero tiles: whole scale groups of zeros
     G, Tl = ops.winograd_points(m), ops.winograd_tiles(N, H, W, m)
+    gin, gout = _wino_groups(m, N, H, W)
     xd = T(x, dev)
     v = torch.empty((G, Tl, C), dtype=torch.float32, device=dev)
     ops.winograd_input_transform(xd, v, m)
     vp = ops.H2.empty(G * Tl, C, dev)
     vp.planes.fill_(0x5a); vp.inv.fill_(-1.0)
     ops.winograd_input_transform_h2(xd, vp, m)
-    _same_planes(vp, ops.h2_split(v.view(G * Tl, C)))
+    torch.cuda.synchronize()
+    _same_planes(vp, h2_ref.split_grouped(v.view(G * Tl, C).cpu().numpy(), gin))
     mm = torch.from_numpy((rng.randn(G, Tl, C) * 3).astype(np.float32)).to(dev)
     bias = T(rng.randn(C).astype(np.float32), dev)
     for act in (0, 1):
@@ -156,7 +181,11 @@ def test_winograd_transforms_emit_the_planes_of_their_f32_results(dev, m, N, H, 
         yp.planes.fill_(0x5a); yp.inv.fill_(-1.0)
         ops.winograd_output_transform_h2(mm, bias, act, (N, H, W, C), m, yp, y2)
         assert torch.equal(y, y2)
-        _same_planes(yp, ops.h2_split(y.view(N * H * W, C)))
+        _same_planes(yp, h2_ref.split_grouped(y.view(N * H * W, C).cpu().numpy(), gout))
         yp2 = ops.H2.empty(N * H * W, C, dev)
         ops.winograd_output_transform_h2(mm, bias, act, (N, H, W, C), m, yp2, None)          # planes only
         _same_planes(yp2, yp)
+        # and the planes are a faithful image of the float32 tensor: 2^-22 of the value or 2^-38 of the group's block maximum
+        rec = yp.to_float().double().cpu().numpy()
+        want = y.view(N * H * W, C).double().cpu().numpy()
+        assert np.all(np.abs(rec - want) <= np.maximum(np.abs(want) * 2.0 ** -22, np.abs(want).max() * 2.0 ** -30))

@@ -81,3 +81,32 @@ def test_gemm_level_error_is_below_f32_accumulation_noise():
         f32 = np.abs((a @ w.T).astype(np.float64) - exact).max() / scale           # numpy's float32 GEMM: one f32 implementation
         assert e3 <= 2.5e-7, (name, e3)
         assert e3 <= f32, (name, e3, f32)
+
+
+def test_row_groups_sharing_a_scale_keep_the_representation_bounds():
+    """The Winograd transforms give the rows one thread writes together ONE scale per 128-k block (their common maximum): every
+    element is still h + l to 2^-22 of its value, or 2^-38 of the GROUP's block maximum where l leaves the fp16 normal range; a
+    GEMM on such planes stays at the 1e-7 level."""
+    rng = np.random.RandomState(7)
+    M, K, N = 96, 512, 64
+    x = (rng.randn(M, K) * np.exp(rng.uniform(-2, 2, size=(M, 1)))).astype(np.float32)          # rows of different magnitude
+    group = np.arange(M) // 6                                                                  # six rows share (F(4x4,3x3) input rows)
+    h, l, inv = h2_ref.split_grouped(x, group)
+    assert np.all(np.isfinite(h.astype(np.float32)))
+    for g in range(M // 6):
+        assert np.all(inv[:, 6 * g:6 * g + 6] == inv[:, 6 * g:6 * g + 1])
+    scaled_max = np.abs(x).reshape(M // 6, 6, K // 128, 128).max(axis=(1, 3)) / inv.T[::6].astype(np.float64)
+    assert np.all(scaled_max >= 2.0 ** 14) and np.all(scaled_max < 2.0 ** 15)
+    rec = (h.astype(np.float64) + l.astype(np.float64)) * np.repeat(inv.T.astype(np.float64), 128, axis=1)
+    gmax = np.repeat(np.repeat(np.abs(x).reshape(M // 6, 6, K // 128, 128).max(axis=(1, 3)), 6, axis=0), 128, axis=1)
+    assert np.all(np.abs(rec - x) <= np.maximum(np.abs(x) * 2.0 ** -22, gmax * 2.0 ** -38))
+    w = (rng.randn(N, K) / np.sqrt(K)).astype(np.float32)
+    wh, wl, winv = h2_ref.pack_w(w[None])
+    f = lambda t: t.astype(np.float64)
+    out = np.zeros((M, N))
+    for kb in range(K // 128):
+        s_ = slice(kb * 128, (kb + 1) * 128)
+        out += (f(h[:, s_]) @ f(wh[0][:, s_]).T + f(h[:, s_]) @ f(wl[0][:, s_]).T + f(l[:, s_]) @ f(wh[0][:, s_]).T) * f(inv[kb])[:, None]
+    out *= f(winv[0])[None, :]
+    exact = f(x) @ f(w).T
+    assert np.abs(out - exact).max() / np.abs(exact).max() <= 2.5e-7

@@ -61,6 +61,21 @@ __device__ __forceinline__ void h2_glds16(unsigned voff, const void* sbase, unsi
       : "memory");
 }
 
+// the 4-byte form: 64 lanes x 4 B -> LDS [lds_base, +256 B), lane-linear.  Fetches the block scales one row per lane, so a tile's
+// last rows never read past the tensor (any M; the 16-byte form would fetch four rows per lane)
+__device__ __forceinline__ void h2_glds4(unsigned voff, const void* sbase, unsigned lds_base) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dword %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_base)
+      : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void h2_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -74,14 +89,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int LA = 2 * BM / 16 / NW;            // X planes: 1 KiB = 16 rows x 64 B per direct-to-LDS instruction
   constexpr int LB = 2 * BN / 16 / NW;            // W planes
-  constexpr int G = LA + LB;                      // per wave per slab (wave 0 issues one more: the block scales)
+  constexpr int G = LA + LB;                      // per wave per slab (wave 0 issues SL more: the block scales, 64 rows each)
+  constexpr int SL = BM / 64;
   constexpr int XP = BM * 64, WP = BN * 64;       // bytes of one plane of a stage
   constexpr int S_OFF = 2 * XP + 2 * WP, STAGE = S_OFF + 1024;
   constexpr int RED_OFF = NS * STAGE;             // row-maximum exchange of the plane-emitting epilogue: [BN / WN][BM] floats
   constexpr int S2_OFF = RED_OFF + (BN / WN) * BM * 4;      // TUNE & 2: two 1 KB block-scale regions, alternating per 128-k block
   static_assert((2 * BM / 16) % NW == 0 && (2 * BN / 16) % NW == 0, "tile/wave mismatch");
   static_assert(BM <= 256 && NS >= 2 && NS <= 4, "stage layout");
-  static_assert((NS - 2) * (G + 1) <= 63, "vmcnt range");
+  static_assert((NS - 2) * (G + SL) <= 63, "vmcnt range");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -101,7 +117,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
 
   // ---- issue side: the slab stream --------------------------------------------------------------------------------------------
   const size_t xplane = (size_t)p.Mtot * p.K * 2, wplane = (size_t)p.N * p.K * 2;     // bytes
-  unsigned a_off[LA], b_off[LB], s_off = 0;
+  unsigned a_off[LA], b_off[LB], s_off[SL];
   const char* i_xb = nullptr; const char* i_wb = nullptr; const char* i_sb = nullptr;  // wave-uniform bases, advanced per slab
   int i_tile = tile0, i_step = 0, i_par = 0, c_par = 0;       // *_par: parity of the running 128-k block count (issue / compute side)
 #pragma unroll
@@ -123,9 +139,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
       const int rr = min(row, p.M - 1 - bm0);                                           // rows past M re-read row M - 1
       a_off[t] = (unsigned)((size_t)plane * xplane + (size_t)rr * p.K * 2 + ((pos ^ ((row >> 1) & 3)) * 16));
     }
-    // block scales of the tile's rows: 4 floats per lane; lanes past the tile / the tensor re-read in-range words (unused rows)
-    const long long last = p.Mtot - 4 - (long long)row0;
-    s_off = (unsigned)(min((long long)(4 * lane) % BM, last < 0 ? 0 : last) * 4);
+    // block scales of the tile's rows: one float per lane and 64-row group; rows past the tensor re-read its last row (unused)
+    const long long last = p.Mtot - 1 - (long long)row0;
+#pragma unroll
+    for (int j = 0; j < SL; ++j) s_off[j] = (unsigned)(min((long long)(j * 64 + lane), last) * 4);
   };
   const unsigned lds0 = (unsigned)(size_t)(LDS_AS char*)smem;
   auto uniform_ptr = [](const char* q) {
@@ -138,10 +155,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
     if (t < LA) h2_glds16(a_off[t], uniform_ptr(i_xb), __builtin_amdgcn_readfirstlane(sb + (wave * LA + t) * 1024));
     else if (t < G) h2_glds16(b_off[t - LA], uniform_ptr(i_wb), __builtin_amdgcn_readfirstlane(sb + 2 * XP + (wave * LB + (t - LA)) * 1024));
     else if (wave == 0) {
-      if (!(TUNE & 2)) h2_glds16(s_off, uniform_ptr(i_sb), __builtin_amdgcn_readfirstlane(sb + S_OFF));
+      const int j = t - G;
+      if (!(TUNE & 2)) h2_glds4(s_off[j], uniform_ptr(i_sb), __builtin_amdgcn_readfirstlane(sb + S_OFF + j * 256));
       else if ((i_step & 3) == 0) {              // once per 128-k block, into the parity region of that block (not a ring slot)
-        h2_glds16(s_off, uniform_ptr(i_sb), __builtin_amdgcn_readfirstlane(lds0 + S2_OFF + i_par * 1024));
-        i_par ^= 1;
+        h2_glds4(s_off[j], uniform_ptr(i_sb), __builtin_amdgcn_readfirstlane(lds0 + S2_OFF + i_par * 1024 + j * 256));
+        if (j == SL - 1) i_par ^= 1;
       }
     }
   };
@@ -323,12 +341,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             h4 hh, ll;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              _Float16 a, b;
-              h2_split1(tot[i][j][4 * q + c], scale, a, b);
-              hh[c] = a; ll[c] = b;
-            }
+            h2_split4(make_float4(tot[i][j][4 * q + 0], tot[i][j][4 * q + 1], tot[i][j][4 * q + 2], tot[i][j][4 * q + 3]), scale, hh, ll);
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), rh, lo + 16 * q, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), rl, lo + 16 * q, 0, 0);
@@ -346,16 +359,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
   };
 
   // one slab of the stream: wait for it, let the ring slot it frees be refilled (loads spread over nothing here: they are issued
-  // right after the barrier, G + 1 instructions, and land under the 24 * TM * TN / 4 MFMAs of this slab and the next NS - 2)
+  // right after the barrier, G + SL instructions, and land under the 24 * TM * TN / 4 MFMAs of this slab and the next NS - 2)
   auto slab = [&](auto first_c, bool fold) {
     if (left >= 1) {                                   // steady state: NS - 2 younger slabs may stay in flight
-      if (wave == 0) h2_wait_vmcnt<(NS - 2) * (G + 1)>(); else h2_wait_vmcnt<(NS - 2) * G>();
+      if (wave == 0) h2_wait_vmcnt<(NS - 2) * (G + SL)>(); else h2_wait_vmcnt<(NS - 2) * G>();
     } else {
       h2_wait_vmcnt<0>();                              // tail of the stream: nothing more will be issued
     }
     __builtin_amdgcn_s_barrier();
     const bool more = left > 0;
-    constexpr int HALF = (TUNE & 1) ? (G + 1) / 2 : G + 1;
+    constexpr int HALF = (TUNE & 1) ? (G + SL) / 2 : G + SL;
     if (more) {
 #pragma unroll
       for (int t = 0; t < HALF; ++t) issue_one(nxt, t);
@@ -370,7 +383,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
     slab_mfma(cur, first_c, [&]() {
       if (more) {
 #pragma unroll
-        for (int t = HALF; t <= G; ++t) issue_one(nxt, t);
+        for (int t = HALF; t < G + SL; ++t) issue_one(nxt, t);
       }
     });
     if (more) {
@@ -395,7 +408,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
   for (int s = 0; s < NS - 1; ++s) {
     if (left > 0) {
 #pragma unroll
-      for (int t = 0; t <= G; ++t) issue_one(nxt, t);
+      for (int t = 0; t < G + SL; ++t) issue_one(nxt, t);
       issue_advance();
       nxt = nxt + 1 == NS ? 0 : nxt + 1;
     }
@@ -433,11 +446,7 @@ __global__ __launch_bounds__(256) void k_h2_split(const float* __restrict__ x, l
     float scale, inv;
     h2_block_scale(mx, scale, inv);
     h4 hh, ll;
-    _Float16 a, b;
-    h2_split1(v.x, scale, a, b); hh[0] = a; ll[0] = b;
-    h2_split1(v.y, scale, a, b); hh[1] = a; ll[1] = b;
-    h2_split1(v.z, scale, a, b); hh[2] = a; ll[2] = b;
-    h2_split1(v.w, scale, a, b); hh[3] = a; ll[3] = b;
+    h2_split4(v, scale, hh, ll);
     *(h4*)(planes + e) = hh;
     *(h4*)(planes + (size_t)M * K + e) = ll;
     if (l == 0) inv_out[(size_t)kb * M + m] = inv;
@@ -541,7 +550,7 @@ extern "C" int frcnn_gemm_h2(const void* x_planes_d, const float* x_inv_d, const
     return FRCNN_E_ARG;
   const long long Mtot = (long long)G * M;
   // 32-bit per-lane byte offsets: both x planes / both W planes of a batch entry / one result row block
-  if (K % H2_KB || N % 128 || (G > 1 && M % 4) || Mtot % 4 || 4ll * Mtot * K >= (1ll << 32) || 4ll * N * K >= (1ll << 32) ||
+  if (K % H2_KB || N % 128 || 4ll * Mtot * K >= (1ll << 32) || 4ll * N * K >= (1ll << 32) ||
       (long long)M * N >= (1ll << 29))
     return FRCNN_E_UNSUPPORTED;
   GemmH2Params p;

@@ -56,39 +56,66 @@ __device__ __forceinline__ unsigned h2_max64(unsigned v) {
   return max(r[0], r[1]);
 }
 
-// 4 consecutive k of one row -> the two fp16 pieces, as 8-byte words
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+// 4 consecutive k of one row -> the two fp16 pieces, as 8-byte words.  Vector form so that the compiler issues the packed
+// instructions (v_pk_mul_f32, v_cvt_pk_f16_f32: round to nearest even like the scalar conversions of h2_split1 -- same bits)
 __device__ __forceinline__ void h2_split4(float4 v, float scale, h4& hh, h4& ll) {
-  _Float16 a, b;
-  h2_split1(v.x, scale, a, b); hh[0] = a; ll[0] = b;
-  h2_split1(v.y, scale, a, b); hh[1] = a; ll[1] = b;
-  h2_split1(v.z, scale, a, b); hh[2] = a; ll[2] = b;
-  h2_split1(v.w, scale, a, b); hh[3] = a; ll[3] = b;
+  const f32x4v vs = f32x4v{v.x, v.y, v.z, v.w} * scale;
+  hh = __builtin_convertvector(vs, h4);
+  ll = __builtin_convertvector(vs - __builtin_convertvector(hh, f32x4v), h4);
+}
+__device__ __forceinline__ void h2_split2(float2 v, float scale, h2v& hh, h2v& ll) {
+  const f32x2v vs = f32x2v{v.x, v.y} * scale;
+  hh = __builtin_convertvector(vs, h2v);
+  ll = __builtin_convertvector(vs - __builtin_convertvector(hh, f32x2v), h2v);
 }
 
-// One (row, 128-k block) of an operand written by one half-wave: lane `l32` (0..31) holds the 4 consecutive k  4*l32 .. 4*l32+3  of the
-// block.  `e` = element offset of (row, block start + 4*l32) inside a plane, `plane` = elements per plane, `inv_slot` = where the block's
-// 2^-e goes.  All 32 lanes of the half-wave must call (the maximum is a cross-lane reduction).
-__device__ __forceinline__ void h2_emit_block32(float4 v, unsigned short* __restrict__ planes, size_t plane, size_t e, float* inv_slot, int l32) {
-  const unsigned mx = h2_max32(h2_abs_bits4(v));
+// NR rows of an operand written together by one half-wave with ONE shared scale per 128-k block: lane `l32` (0..31) holds the 4
+// consecutive k  4*l32 .. 4*l32+3  of the block for each of the rows; the scale comes from the largest magnitude over all valid rows
+// (one cross-lane reduction instead of NR; a producer may choose any power of two that keeps max |x| 2^e below 2^15 -- sharing it
+// between a few rows of similar magnitude costs nothing until elements drop below 2^-38 of the group maximum).  `valid`: bit n set =
+// row n is written (wave-uniform).  e = row * K + block start + 4*l32 per row.  All 32 lanes must call.
+template <int NR>
+__device__ __forceinline__ void h2_emit_rows32(const float4* v, const size_t* e, float* const* inv_slot, unsigned valid,
+                                               unsigned short* __restrict__ planes, size_t plane, int l32) {
+  unsigned mx = 0;
+#pragma unroll
+  for (int n = 0; n < NR; ++n)
+    if ((valid >> n) & 1u) mx = max(mx, h2_abs_bits4(v[n]));
+  mx = h2_max32(mx);
   float scale, inv;
   h2_block_scale_bits(mx, scale, inv);
-  h4 hh, ll;
-  h2_split4(v, scale, hh, ll);
-  *(h4*)(planes + e) = hh;
-  *(h4*)(planes + plane + e) = ll;
-  if (l32 == 0) *inv_slot = inv;
+#pragma unroll
+  for (int n = 0; n < NR; ++n) {
+    if (!((valid >> n) & 1u)) continue;
+    h4 hh, ll;
+    h2_split4(v[n], scale, hh, ll);
+    *(h4*)(planes + e[n]) = hh;
+    *(h4*)(planes + plane + e[n]) = ll;
+    if (l32 == 0) *inv_slot[n] = inv;
+  }
 }
 
 // The same for a whole wave holding 2 consecutive k per lane (lane l: k 2l, 2l+1 of the block)
-__device__ __forceinline__ void h2_emit_block64(float2 v, unsigned short* __restrict__ planes, size_t plane, size_t e, float* inv_slot, int l64) {
-  const unsigned mx = h2_max64(max(h2_abs_bits(v.x), h2_abs_bits(v.y)));
+template <int NR>
+__device__ __forceinline__ void h2_emit_rows64(const float2* v, const size_t* e, float* const* inv_slot, unsigned valid,
+                                               unsigned short* __restrict__ planes, size_t plane, int l64) {
+  unsigned mx = 0;
+#pragma unroll
+  for (int n = 0; n < NR; ++n)
+    if ((valid >> n) & 1u) mx = max(mx, max(h2_abs_bits(v[n].x), h2_abs_bits(v[n].y)));
+  mx = h2_max64(mx);
   float scale, inv;
   h2_block_scale_bits(mx, scale, inv);
-  _Float16 a, b;
-  h2v hh, ll;
-  h2_split1(v.x, scale, a, b); hh[0] = a; ll[0] = b;
-  h2_split1(v.y, scale, a, b); hh[1] = a; ll[1] = b;
-  *(h2v*)(planes + e) = hh;
-  *(h2v*)(planes + plane + e) = ll;
-  if (l64 == 0) *inv_slot = inv;
+#pragma unroll
+  for (int n = 0; n < NR; ++n) {
+    if (!((valid >> n) & 1u)) continue;
+    h2v hh, ll;
+    h2_split2(v[n], scale, hh, ll);
+    *(h2v*)(planes + e[n]) = hh;
+    *(h2v*)(planes + plane + e[n]) = ll;
+    if (l64 == 0) *inv_slot[n] = inv;
+  }
 }

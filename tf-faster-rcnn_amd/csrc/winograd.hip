@@ -43,15 +43,30 @@ __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
 // Where a transform's result goes.  H2 = false: float32 tensor `f` (rows x C, float4 words).  H2 = true: operand planes of
-// frcnn_gemm_h2 (csrc/gemm_h2.hip) -- fp16 pieces [2][rows][C] + one power-of-two scale per (row, 128 channels), inv [C/128][rows];
-// the 32 consecutive threads that hold a row's 128 channels (C4 % 32 == 0, so they are one half-wave) reduce the block maximum with
-// DPP / permlane-swap moves.  Bit-identical to frcnn_h2_split of the float32 result.  `f` may be given as well (both are written).
+// frcnn_gemm_h2 (csrc/gemm_h2.hip) -- fp16 pieces [2][rows][C] + one power-of-two scale per (row, 128 channels), inv [C/128][rows].
+// A thread writes the NR rows of one transform row together and they SHARE the scale of their common maximum (h2_emit_rows32): the
+// 32 consecutive threads that hold the rows' 128 channels (C4 % 32 == 0, so they are one half-wave) reduce it with DPP /
+// permlane-swap moves, once per group.  `f` may be given as well (both are written).
 template <bool H2>
 struct WinoSink {
   float4* f; unsigned short* planes; float* inv; size_t rows;      // rows: total rows of the result (plane stride = rows * C)
-  __device__ __forceinline__ void put(size_t row, int c4, int C4, float4 v) const {
-    if (!H2 || f) f[row * C4 + c4] = v;
-    if (H2) h2_emit_block32(v, planes, rows * (size_t)C4 * 4, (row * C4 + c4) * 4, inv + (size_t)(c4 >> 5) * rows + row, c4 & 31);
+  template <int NR>
+  __device__ __forceinline__ void putn(const size_t* row, const float4* v, unsigned valid, int c4, int C4) const {
+    if (!H2 || f) {
+#pragma unroll
+      for (int n = 0; n < NR; ++n)
+        if ((valid >> n) & 1u) f[row[n] * C4 + c4] = v[n];
+    }
+    if (H2) {
+      size_t e[NR];
+      float* slot[NR];
+#pragma unroll
+      for (int n = 0; n < NR; ++n) {
+        e[n] = (row[n] * C4 + c4) * 4;
+        slot[n] = inv + (size_t)(c4 >> 5) * rows + row[n];
+      }
+      h2_emit_rows32<NR>(v, e, slot, valid, planes, rows * (size_t)C4 * 4, c4 & 31);
+    }
   }
 };
 
@@ -85,10 +100,9 @@ __global__ void k_wino_input(const float4* __restrict__ x, int N, int H, int W, 
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {     // (.. B): columns (b0-b2, b1+b2, b2-b1, b1-b3)
-    V.put((size_t)(i * 4 + 0) * T + t, c4, C4, f4sub(b[i][0], b[i][2]));
-    V.put((size_t)(i * 4 + 1) * T + t, c4, C4, f4add(b[i][1], b[i][2]));
-    V.put((size_t)(i * 4 + 2) * T + t, c4, C4, f4sub(b[i][2], b[i][1]));
-    V.put((size_t)(i * 4 + 3) * T + t, c4, C4, f4sub(b[i][1], b[i][3]));
+    const float4 o[4] = {f4sub(b[i][0], b[i][2]), f4add(b[i][1], b[i][2]), f4sub(b[i][2], b[i][1]), f4sub(b[i][1], b[i][3])};
+    const size_t r[4] = {(size_t)(i * 4 + 0) * T + t, (size_t)(i * 4 + 1) * T + t, (size_t)(i * 4 + 2) * T + t, (size_t)(i * 4 + 3) * T + t};
+    V.template putn<4>(r, o, 0xfu, c4, C4);
   }
 }
 
@@ -135,14 +149,12 @@ __global__ void __launch_bounds__(256) k_wino4_input(const float4* __restrict__ 
   for (int j = 0; j < 6; ++j) WINO4_BT(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    float4 o0, o1, o2, o3, o4, o5;
-    WINO4_BT(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], o0, o1, o2, o3, o4, o5);
-    V.put((size_t)(i * 6 + 0) * T + t, c4, C4, o0);
-    V.put((size_t)(i * 6 + 1) * T + t, c4, C4, o1);
-    V.put((size_t)(i * 6 + 2) * T + t, c4, C4, o2);
-    V.put((size_t)(i * 6 + 3) * T + t, c4, C4, o3);
-    V.put((size_t)(i * 6 + 4) * T + t, c4, C4, o4);
-    V.put((size_t)(i * 6 + 5) * T + t, c4, C4, o5);
+    float4 o[6];
+    WINO4_BT(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5], o[0], o[1], o[2], o[3], o[4], o[5]);
+    size_t r[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) r[j] = (size_t)(i * 6 + j) * T + t;
+    V.template putn<6>(r, o, 0x3fu, c4, C4);
   }
 }
 
@@ -182,14 +194,18 @@ __global__ void __launch_bounds__(256) k_wino4_output(const float4* __restrict__
     float4 o[4];
     WINO4_AT(s[a][0], s[a][1], s[a][2], s[a][3], s[a][4], s[a][5], o[0], o[1], o[2], o[3]);
     const size_t row = (size_t)(img * H + oh) * W;
+    size_t r[4];
+    unsigned valid = 0;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const int ow = 4 * tx + b;
-      if (ow >= W) continue;
+      r[b] = row + ow;
+      valid |= (ow < W ? 1u : 0u) << b;
       float4 v = f4add(o[b], bv);
       if (act == FRCNN_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-      y.put(row + ow, c4, C4, v);
+      o[b] = v;
     }
+    y.template putn<4>(r, o, valid, c4, C4);
   }
 }
 
@@ -257,8 +273,9 @@ __global__ void k_wino_output(const float4* __restrict__ Mx, int N, int H, int W
       o1 = make_float4(fmaxf(o1.x, 0.f), fmaxf(o1.y, 0.f), fmaxf(o1.z, 0.f), fmaxf(o1.w, 0.f));
     }
     const size_t row = (size_t)(img * H + oh) * W;
-    if (2 * tx < W) y.put(row + 2 * tx, c4, C4, o0);
-    if (2 * tx + 1 < W) y.put(row + 2 * tx + 1, c4, C4, o1);
+    const float4 o[2] = {o0, o1};
+    const size_t r[2] = {row + 2 * tx, row + 2 * tx + 1};
+    y.template putn<2>(r, o, (2 * tx < W ? 1u : 0u) | (2 * tx + 1 < W ? 2u : 0u), c4, C4);
   }
 }
 

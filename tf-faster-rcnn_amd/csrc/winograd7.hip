@@ -44,14 +44,28 @@ __device__ __forceinline__ void acc_term(float2& acc, bool& first, float coef, c
 }
 
 // Where a transform's result goes (float2 words: a thread owns two channels).  H2 = false: float32 tensor `f`.  H2 = true: operand
-// planes of frcnn_gemm_h2 -- fp16 pieces [2][rows][C] + inv [C/128][rows]; the 64 consecutive threads that hold a row's 128 channels
-// are one wave (C2 % 64 == 0) and reduce the block maximum with DPP / permlane-swap moves.  `f` may be given as well.
+// planes of frcnn_gemm_h2 -- fp16 pieces [2][rows][C] + inv [C/128][rows]; the NR rows a thread writes together share the scale of
+// their common maximum (h2_emit_rows64); the 64 consecutive threads that hold the rows' 128 channels are one wave (C2 % 64 == 0) and
+// reduce it with DPP / permlane-swap moves, once per group.  `f` may be given as well.
 template <bool H2>
 struct Wino7Sink {
   float2* f; unsigned short* planes; float* inv; size_t rows;
-  __device__ __forceinline__ void put(size_t row, int c2, int C2, float2 v) const {
-    if (!H2 || f) f[row * C2 + c2] = v;
-    if (H2) h2_emit_block64(v, planes, rows * (size_t)C2 * 2, (row * C2 + c2) * 2, inv + (size_t)(c2 >> 6) * rows + row, c2 & 63);
+  template <int NR>
+  __device__ __forceinline__ void putn(const size_t* row, const float2* v, int c2, int C2) const {
+    if (!H2 || f) {
+#pragma unroll
+      for (int n = 0; n < NR; ++n) f[row[n] * C2 + c2] = v[n];
+    }
+    if (H2) {
+      size_t e[NR];
+      float* slot[NR];
+#pragma unroll
+      for (int n = 0; n < NR; ++n) {
+        e[n] = (row[n] * C2 + c2) * 2;
+        slot[n] = inv + (size_t)(c2 >> 6) * rows + row[n];
+      }
+      h2_emit_rows64<NR>(v, e, slot, (1u << NR) - 1u, planes, rows * (size_t)C2 * 2, c2 & 63);
+    }
   }
 };
 
@@ -78,14 +92,18 @@ __global__ void __launch_bounds__(256) k_wino7_input(const float2* __restrict__ 
 #pragma unroll
       for (int i = 0; i < 7; ++i) acc_term(t[j], first, w7::BT[xi][i + 1], d[i][j]);      // padded row index = i + 1
     }
+    float2 o[11];
+    size_t rw[11];
 #pragma unroll
     for (int nu = 0; nu < 11; ++nu) {
       bool first = true;
       float2 v = make_float2(0.f, 0.f);
 #pragma unroll
       for (int j = 0; j < 7; ++j) acc_term(v, first, w7::BT[nu][j + 1], t[j]);
-      V.put((size_t)(xi * 11 + nu) * R + r, c2, C2, v);
+      o[nu] = v;
+      rw[nu] = (size_t)(xi * 11 + nu) * R + r;
     }
+    V.template putn<11>(rw, o, c2, C2);
   }
 }
 
@@ -109,6 +127,8 @@ __device__ __forceinline__ void wino7_out_segment(const float2* __restrict__ in,
 #pragma unroll
       for (int a = 0; a < NXI; ++a) acc_term(s[nu], first, w7::AT[I0 + i][XI0 + a], m[a][nu]);
     }
+    float2 o[7];
+    size_t rw[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       bool first = true;
@@ -117,8 +137,10 @@ __device__ __forceinline__ void wino7_out_segment(const float2* __restrict__ in,
       for (int nu = 0; nu < 11; ++nu) acc_term(v, first, w7::AT[j][nu], s[nu]);
       v = make_float2(v.x + bv.x, v.y + bv.y);
       if (act == FRCNN_ACT_RELU) v = make_float2(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f));
-      y.put(row0 + (I0 + i) * 7 + j, c2, C2, v);
+      o[j] = v;
+      rw[j] = row0 + (I0 + i) * 7 + j;
     }
+    y.template putn<7>(rw, o, c2, C2);
   }
 }
 

@@ -70,6 +70,7 @@ class mobilenetv1(Network):
         OH, OW = ops.conv_out_size(H, 3, stride, 1, 1), ops.conv_out_size(W, 3, stride, 1, 1)
         out = self._sess.buf(self._tag + "/" + dw_scope, (N, OH, OW, C))
         y = self._sess.mark("op:dwconv3x3", 0, lambda: ops.dwconv3x3(x, w, b, stride, pad, ACT_RELU6, out=out), nbytes=4 * (x.numel() + out.numel()))
+        self._wrote(out)
         if self._mode == "TRAIN":
             self._tape.append(dict(kind="dwconv", scope=dw_scope, x=x, y=out, stride=stride, pad=pad, act=ACT_RELU6))
             if self.trainable_scope(dw_scope) or x.data_ptr() in self._requires_grad:

@@ -111,6 +111,7 @@ class Network(object):
             v, mm = sess.buf(self._tag + "/wino_v", (G, T, Cin)), sess.buf(self._tag + "/wino_m", (G, T, Cout))
             sess.mark("conv:" + scope, 2 * G * T * Cout * Cin, lambda: ops.conv3x3_winograd(x, u, b, act, out=out, v_buf=v, m_buf=mm),
                       nbytes=4 * (v.numel() + u.numel() + mm.numel()))
+            self._wrote(out)
         elif plain and self._h2_eligible(M, Cout, Cin, 1) and self._h2_input(x) is not None:
             # a plain GEMM with a static filter on the fp16 matrix pipe, block-scaled two-piece operands (cfg.HIP.MFMA_H2)
             xp, wp = self._h2_input(x), sess.h2_planes(w)
@@ -120,21 +121,20 @@ class Network(object):
                                                                       want_f32=False),
                       nbytes=4 * M * Cin + 4 * w.numel() + (4 * out.numel() if y is not None else 0)
                       + (4 * out.numel() if yp is not None else 0) + (4 * out.numel() if residual is not None else 0))
-            if yp is not None:
-                self._h2_of[out.data_ptr()] = yp
-            if y is None:
-                self._f32_missing.add(out.data_ptr())
+            self._wrote(out, yp, y is not None)
         elif plain and self._x3_eligible(M, Cout, Cin, 1):
             # ... on the bf16 matrix pipe with exact bf16x3 operand splits (cfg.HIP.MFMA_X3)
             self._need_f32(x)
             planes = sess.x3_planes(w)
             sess.mark("conv:x3:" + scope, flops, lambda: ops.gemm_x3(x, planes, 1, M, Cout, Cin, b, residual, act, out=out),
                       nbytes=4 * (x.numel() + out.numel() + (out.numel() if residual is not None else 0)) + 6 * w.numel())
+            self._wrote(out)
         else:
             self._need_f32(x)
             sess.mark("conv:" + scope, flops,
                       lambda: ops.conv2d(x, w, b, k, k, stride, pad, act, residual, res_stride, fold_w, out=out),
                       nbytes=4 * (x.numel() + w.numel() + out.numel() + (out.numel() if residual is not None else 0)))
+            self._wrote(out)
         if self._mode == "TRAIN":
             self._tape.append(dict(kind="conv", scope=scope, x=x, y=out, k=k, stride=stride, pad=tuple(pad), act=act,
                                    residual=residual, res_stride=res_stride))
@@ -149,7 +149,7 @@ class Network(object):
         """TEST mode (static filters), K % 128 == 0 (scale blocks), N % 128 == 0 (tiles), enough tiles to fill the chip, and the
         32-bit offset limits of frcnn_gemm_h2."""
         rows = G * M
-        return (bool(cfg.HIP.MFMA_H2) and self._mode == "TEST" and K % 128 == 0 and N % 128 == 0 and rows % 4 == 0 and (G == 1 or M % 4 == 0)
+        return (bool(cfg.HIP.MFMA_H2) and self._mode == "TEST" and K % 128 == 0 and N % 128 == 0
                 and ((M + 127) // 128) * (N // 128) * G >= int(cfg.HIP.H2_MIN_TILES)
                 and 4 * rows * K < (1 << 32) and 4 * N * K < (1 << 32) and M * N < (1 << 29))
 
@@ -163,6 +163,17 @@ class Network(object):
             self._sess.mark("op:h2_split", 0, lambda: ops.h2_split(x, out=xp), nbytes=8 * x.numel())
             self._h2_of[x.data_ptr()] = xp
         return xp
+
+    def _wrote(self, t, planes=None, f32=True):
+        """Every launch that writes activation t reports it: planes derived from an earlier write are dropped (buffers are static
+        and sub-graphs may be re-run on new inputs), planes this launch emitted are registered."""
+        k = t.data_ptr()
+        if planes is None:
+            self._h2_of.pop(k, None)
+        else:
+            self._h2_of[k] = planes
+        (self._f32_missing.discard if f32 else self._f32_missing.add)(k)
+        return t
 
     def _need_f32(self, x):
         if x.data_ptr() in self._f32_missing:
@@ -218,11 +229,10 @@ class Network(object):
             y = out if want_f32 else None
             sess.mark("op:wino_out", 0, lambda: ops.winograd_output_transform_h2(mm, b, act, (N, H, W, Cout), m, yp, y),
                       nbytes=4 * (mm.numel() + out.numel() * (2 if want_f32 else 1)))
-            self._h2_of[out.data_ptr()] = yp
-            if y is None:
-                self._f32_missing.add(out.data_ptr())
+            self._wrote(out, yp, y is not None)
         else:
             sess.mark("op:wino_out", 0, lambda: ops.winograd_output_transform(mm, b, act, out, m), nbytes=4 * (mm.numel() + out.numel()))
+            self._wrote(out)
         return out
 
     def _conv1x1_mean(self, x, scope, group_rows, act=ACT_RELU, bn_eps=None, residual=None, name="fc7"):
@@ -233,9 +243,10 @@ class Network(object):
         Cin, Cout = x.shape[-1], w.shape[0]
         M = x.numel() // Cin
         out = sess.buf(self._tag + "/" + name, (M // group_rows, Cout))
+        self._need_f32(x)
         sess.mark("conv:" + scope, 2 * M * Cout * Cin, lambda: ops.conv1x1_mean(x, w, b, group_rows, act, residual, out=out),
                   nbytes=4 * (x.numel() + w.numel() + out.numel() + (M * Cout if residual is not None else 0)))
-        return out
+        return self._wrote(out)
 
     # ------------------------------------------------------------------ ImageNet-pretrained weights (train_val.py:177-202)
     _rgb_first_conv = None                   # scope tail of the stem conv whose input channels are RGB in the released weights
@@ -398,7 +409,7 @@ class Network(object):
             self._sess.mark("op:crop_and_resize", 0, lambda: ops.crop_and_resize(bottom, rois, fs, P, max_pool=max_pool, out=out), nbytes=nbytes)
         else:
             self._sess.mark("op:crop_and_resize", 0, lambda: ops.crop_and_resize_bias_act(bottom, rois, fs, P, bias, act, out=out), nbytes=nbytes)
-        return out
+        return self._wrote(out)
 
     def _crop_pool_layer(self, bottom, rois, name):
         # network.py:141-157: 14x14 crop + 2x2 max pool (TEST: fused in one kernel)
@@ -416,6 +427,7 @@ class Network(object):
         crop = self._sess.buf(self._tag + "/" + name + ("/crop" if max_pool else ""), (R, pre, pre, C))
         self._sess.mark("op:crop_and_resize", 0, lambda: ops.crop_and_resize(bottom, rois, fs, pre, max_pool=False, out=crop),
                         nbytes=4 * (bottom.numel() + crop.numel()))
+        self._wrote(crop)
         self._tape.append(dict(kind="crop", feat=bottom, rois=rois, y=crop, stride=fs))
         if bottom.data_ptr() in self._requires_grad:
             self._requires_grad.add(crop.data_ptr())
@@ -428,6 +440,7 @@ class Network(object):
         out = self._sess.buf(self._tag + "/" + name, (N, OH, OW, C))
         pad = (0, (OH - 1) * stride + k - H, 0, (OW - 1) * stride + k - W)
         self._sess.mark("op:maxpool", 0, lambda: ops.maxpool(x, k, stride, pad, out=out), nbytes=4 * (x.numel() + out.numel()))
+        self._wrote(out)
         if self._mode == "TRAIN":
             self._tape.append(dict(kind="maxpool", x=x, y=out, k=k, stride=stride, name=name))
             if x.data_ptr() in self._requires_grad:

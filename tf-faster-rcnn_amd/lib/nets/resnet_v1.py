@@ -112,7 +112,8 @@ class resnetv1(Network):
                          fold_w=True, real_cin=3)
         N, H, W, C = net.shape
         out = self._sess.buf(self._tag + "/pool1", (N, ops.conv_out_size(H, 3, 2, 1, 1), ops.conv_out_size(W, 3, 2, 1, 1), C))
-        return self._sess.mark("op:maxpool", 0, lambda: ops.maxpool(net, 3, 2, (1, 1, 1, 1), out=out), nbytes=4 * (net.numel() + out.numel()))
+        self._sess.mark("op:maxpool", 0, lambda: ops.maxpool(net, 3, 2, (1, 1, 1, 1), out=out), nbytes=4 * (net.numel() + out.numel()))
+        return self._wrote(out)
 
     def _image_to_head(self, is_training, reuse=None):
         assert (0 <= cfg.RESNET.FIXED_BLOCKS <= 3)
