@@ -58,7 +58,7 @@ def split_grouped(x, group):
 def pack_w(w):
     """w f32 [G, N, K] -> (h, l fp16 [G, N, K], w_inv f32 [G, N]): one scale per output row (frcnn_h2_pack_w)."""
     w = np.asarray(w, dtype=np.float32)
-    scale, inv = block_scale(np.abs(w).max(axis=2))
+    scale, inv = block_scale(np.maximum(np.abs(w).max(axis=2), np.float32(2.0 ** -40)))      # e_w <= 54: (bias + res) * 2^e_w stays finite
     h, l = split_scaled(w, scale[:, :, None])
     return h, l, inv
 

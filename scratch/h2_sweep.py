@@ -48,15 +48,19 @@ for name in only:
     outs["x3"] = out3
     xp, wp = ops.h2_split(x), ops.h2_pack_w(w)
     yp = ops.H2.empty(G * M, N, dev) if planes_out else None
+    ypp = ops.H2.empty(G * M, N, dev)
     for c in cfgs:
         o = torch.empty(G * M, N, device=dev)
         outs["h2/%d" % c] = o
         runs["h2/%d" % c] = (lambda c, o: (lambda: ops.gemm_h2(xp, wp, G, M, N, K, b, res, act, out=o, out_planes=yp, cfg=c)))(c, o)
+        if c in (0, 12) and not planes_out:          # A/B: the same launch also emitting the result's operand planes / planes only
+            runs["h2/%d+p" % c] = (lambda c, o: (lambda: ops.gemm_h2(xp, wp, G, M, N, K, b, res, act, out=o, out_planes=ypp, cfg=c)))(c, o)
+            runs["h2/%d=p" % c] = (lambda c: (lambda: ops.gemm_h2(xp, wp, G, M, N, K, b, res, act, out=None, out_planes=ypp, want_f32=False, cfg=c)))(c)
     xs = ops.H2.empty(G * M, K, dev)
     runs["split"] = lambda: ops.h2_split(x, out=xs)
     errs = {}
     for k_, f in runs.items():
-        if k_ == "split": continue
+        if k_ == "split" or k_ not in outs: continue
         outs[k_].fill_(float("nan")); f(); torch.cuda.synchronize()
         errs[k_] = "%.2e nan %d" % (err_of(outs[k_]), int(torch.isnan(outs[k_]).sum()))
     times = {k_: [] for k_ in runs}

@@ -45,6 +45,8 @@ def test_h2_pack_w_matches_numpy_statement(dev):
     rng = np.random.RandomState(5)
     G, N, K = 3, 128, 320
     w = (rng.randn(G, N, K) * np.exp(rng.uniform(-8, 8, size=(G, N, 1)))).astype(np.float32)
+    w[0, 3, :] = 0.0                                                            # an all-zero filter row: the scale stops at 2^54
+    w[1, 7, :] *= np.float32(1e-20)
     planes, winv = ops.h2_pack_w(T(w, dev))
     raw = planes.cpu().numpy().view(np.float16).reshape(G, 2, N, K)
     h, l, inv = h2_ref.pack_w(w)
@@ -66,7 +68,7 @@ H2_CASES = [
 ]
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 3, 4, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("cfg", [0, 1, 3, 4, 7, 8, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize("case", H2_CASES, ids=[str(i) for i in range(len(H2_CASES))])
 def test_gemm_h2_is_f32_class(dev, case, cfg):
     from frcnn_hip import ops

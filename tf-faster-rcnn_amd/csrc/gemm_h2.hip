@@ -177,12 +177,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
 
   // ---- compute side -------------------------------------------------------------------------------------------------------------
   f32x16 tot[TM][TN], tmp[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
   const int sw = (frow >> 1) & 3;
   const int x_row = (wm0 + frow) * 64, w_row = 2 * XP + (wn0 + frow) * 64;
 
@@ -245,23 +239,58 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)max(0ll, min(bytes, 0x7fffffffll)), 0x00020000);
   };
 
+  // The accumulators of a tile START at (bias + res) * 2^e_w: the filter row's scale w_inv = 2^-e_w is an exact power of two, so the
+  // final  tot * w_inv  = products + bias + res  is one f32 sum evaluated in the scaled domain -- and the residual is fetched when the
+  // tile starts (its latency hides under the first 128-k block; it is first touched by that block's fold) instead of after the last MFMA.
+  auto init_tot = [&]() {
+    const size_t row_base = (size_t)c_g * p.M;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n0 = c_bn0 + wn0 + j * 32 + 4 * khalf;
+      const int nc = c_bn0 + wn0 + j * 32;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 wi = *(const float4*)(p.w_inv + (size_t)c_g * p.N + n0 + 8 * q);
+        // 1 / w_inv, exact: both are powers of two (frcnn_h2_pack_w keeps e_w <= 54, so (bias + res) * 2^e_w cannot overflow)
+        const float s0 = __uint_as_float(0x7f000000u - __float_as_uint(wi.x)), s1 = __uint_as_float(0x7f000000u - __float_as_uint(wi.y));
+        const float s2 = __uint_as_float(0x7f000000u - __float_as_uint(wi.z)), s3 = __uint_as_float(0x7f000000u - __float_as_uint(wi.w));
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) bv = *(const float4*)(p.bias + n0 + 8 * q);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (p.res) {
+            const int m0 = c_bm0 + wm0 + i * 32;
+            const long long sbase = (long long)(row_base + m0) * p.N + nc;
+            const long long left_e = (long long)(p.M - m0) * p.N - nc;
+            const auto rr = rsrc_f(p.res + sbase, left_e, 4);
+            const auto ld = __builtin_amdgcn_raw_buffer_load_b128(rr, (frow * p.N + 4 * khalf) * 4 + 32 * q, 0, 0);
+            rv = make_float4(__uint_as_float(ld[0]), __uint_as_float(ld[1]), __uint_as_float(ld[2]), __uint_as_float(ld[3]));
+          }
+          tot[i][j][4 * q + 0] = (rv.x + bv.x) * s0;
+          tot[i][j][4 * q + 1] = (rv.y + bv.y) * s1;
+          tot[i][j][4 * q + 2] = (rv.z + bv.z) * s2;
+          tot[i][j][4 * q + 3] = (rv.w + bv.w) * s3;
+        }
+      }
+    }
+  };
+
   auto epilogue = [&]() {
     const size_t row_base = (size_t)c_g * p.M;
-    // ---- v = act(tot * w_inv + bias + res), kept in tot ------------------------------------------------------------------------
+    // ---- v = act(tot * w_inv), kept in tot (bias and residual went in with init_tot) ----------------------------------------------
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n0 = c_bn0 + wn0 + j * 32 + 4 * khalf;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 wi = *(const float4*)(p.w_inv + (size_t)c_g * p.N + n0 + 8 * q);
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) bv = *(const float4*)(p.bias + n0 + 8 * q);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          tot[i][j][4 * q + 0] = tot[i][j][4 * q + 0] * wi.x + bv.x;
-          tot[i][j][4 * q + 1] = tot[i][j][4 * q + 1] * wi.y + bv.y;
-          tot[i][j][4 * q + 2] = tot[i][j][4 * q + 2] * wi.z + bv.z;
-          tot[i][j][4 * q + 3] = tot[i][j][4 * q + 3] * wi.w + bv.w;
+          tot[i][j][4 * q + 0] = fminf(fmaxf(tot[i][j][4 * q + 0] * wi.x, act_lo), act_hi);
+          tot[i][j][4 * q + 1] = fminf(fmaxf(tot[i][j][4 * q + 1] * wi.y, act_lo), act_hi);
+          tot[i][j][4 * q + 2] = fminf(fmaxf(tot[i][j][4 * q + 2] * wi.z, act_lo), act_hi);
+          tot[i][j][4 * q + 3] = fminf(fmaxf(tot[i][j][4 * q + 3] * wi.w, act_lo), act_hi);
         }
       }
     }
@@ -274,19 +303,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
         const long long sbase = (long long)(row_base + m0) * p.N + nc;     // element offset of the sub-tile
         const long long left_e = (long long)(p.M - m0) * p.N - nc;         // elements from there to the end of the batch entry's rows
         const int lo = (frow * p.N + 4 * khalf) * 4;
-        if (p.res) {
-          const auto rr = rsrc_f(p.res + sbase, left_e, 4);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const auto rv = __builtin_amdgcn_raw_buffer_load_b128(rr, lo + 32 * q, 0, 0);
-            tot[i][j][4 * q + 0] += __uint_as_float(rv[0]);
-            tot[i][j][4 * q + 1] += __uint_as_float(rv[1]);
-            tot[i][j][4 * q + 2] += __uint_as_float(rv[2]);
-            tot[i][j][4 * q + 3] += __uint_as_float(rv[3]);
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) tot[i][j][r] = fminf(fmaxf(tot[i][j][r], act_lo), act_hi);
         if (p.y) {
           const auto ry = rsrc_f(p.y + sbase, left_e, 4);
 #pragma unroll
@@ -350,12 +366,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
       }
       if (BN / WN > 1) __syncthreads();                                          // red[] is reused by the next tile
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
   };
 
   // one slab of the stream: wait for it, let the ring slot it frees be refilled (loads spread over nothing here: they are issued
@@ -415,6 +425,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
   }
   const int nkb = p.nsteps >> 2;
   for (int tl = 0; tl < my_tiles; ++tl) {
+    init_tot();
     for (int kb = 0; kb < nkb; ++kb) {
       slab(std::true_type{}, false);
       slab(std::false_type{}, false);
@@ -467,7 +478,9 @@ __global__ __launch_bounds__(256) void k_h2_pack_w(const float* __restrict__ w, 
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
   float scale, inv;
-  h2_block_scale(mx, scale, inv);
+  // filter rows: the scale stops at 2^54 (rows whose largest weight is below 2^-40 are zero for every purpose): the GEMM starts its
+  // accumulators at (bias + residual) * 2^e_w, which must stay finite
+  h2_block_scale(fmaxf(mx, 0x1p-40f), scale, inv);
   const int g = row / N, n = row - g * N;
   unsigned short* ph = planes + ((size_t)g * 2 * N + n) * K;
   unsigned short* pl = ph + (size_t)N * K;
@@ -573,6 +586,8 @@ extern "C" int frcnn_gemm_h2(const void* x_planes_d, const float* x_inv_d, const
     case 9: return launch_h2<128, 128, 64, 64, 2, 2, 2>(p, st);  // cfg 0 with the scales sent once per 128-k block
     case 10: return launch_h2<128, 128, 64, 64, 2, 2, 3>(p, st);
     case 11: return launch_h2<128, 128, 32, 64, 2, 4, 3>(p, st);
+    case 12: return launch_h2<64, 128, 32, 64, 2>(p, st);        // 64-row tiles, 4 waves of 32 x 64, 51 KB: 3 workgroups / CU (under-filled launches)
+    case 13: return launch_h2<64, 128, 32, 64, 3>(p, st);
     default: return FRCNN_E_ARG;
   }
 }
