@@ -92,45 +92,49 @@ def calibrate_rpn(sess, net, img_d, im_info):
 
 
 class Telemetry(object):
-    """Shader clock / socket power sampled from the amdgpu sysfs nodes of the GPU in use while a region runs (a thread reading two
-    small files every 100 ms: no subprocess, nothing on the device).  None when the nodes are not there."""
+    """Shader clock / socket power sampled from the amdgpu sysfs nodes while a region runs (a thread reading a few small files every
+    100 ms: no subprocess, nothing on the device).  The node may show more cards than this process sees, so every card is sampled
+    and the one drawing the most power during the region -- the one doing the work -- is reported.  None when the nodes are not there."""
 
-    def __init__(self, index=0):
+    def __init__(self):
         import glob
-        self.sclk, self.power = None, None
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
-        if index < len(cards):
-            self.sclk = cards[index]
-            hw = sorted(glob.glob(os.path.join(os.path.dirname(cards[index]), "hwmon", "hwmon*", "power1_average")) +
-                        glob.glob(os.path.join(os.path.dirname(cards[index]), "hwmon", "hwmon*", "power1_input")))
-            self.power = hw[0] if hw else None
-        self.samples = []
+        self.cards = []
+        for sclk in sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk")):
+            d = os.path.dirname(sclk)
+            hw = sorted(glob.glob(os.path.join(d, "hwmon", "hwmon*", "power1_average")) + glob.glob(os.path.join(d, "hwmon", "hwmon*", "power1_input")))
+            fq = sorted(glob.glob(os.path.join(d, "hwmon", "hwmon*", "freq1_input")))
+            self.cards.append((sclk, hw[0] if hw else None, fq[0] if fq else None))
         self._stop = False
 
-    def _read(self):
+    @staticmethod
+    def _read(card):
+        sclk, power, freq = card
         mhz, watt = None, None
         try:
-            for line in open(self.sclk):
-                if "*" in line:
-                    mhz = float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+            if freq is not None:
+                mhz = float(open(freq).read().strip()) / 1e6
+            else:
+                for line in open(sclk):
+                    if "*" in line:
+                        mhz = float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
         except Exception:
             pass
         try:
-            watt = float(open(self.power).read().strip()) / 1e6
+            watt = float(open(power).read().strip()) / 1e6
         except Exception:
             pass
         return mhz, watt
 
     def run(self, fn):
         import threading
-        if self.sclk is None:
+        if not self.cards:
             fn()
             return None
-        self.samples, self._stop = [], False
+        samples, self._stop = [], False
 
         def loop():
             while not self._stop:
-                self.samples.append(self._read())
+                samples.append([self._read(c) for c in self.cards])
                 time.sleep(0.1)
         t = threading.Thread(target=loop, daemon=True)
         t.start()
@@ -139,11 +143,17 @@ class Telemetry(object):
         finally:
             self._stop = True
             t.join()
-        tail = self.samples[len(self.samples) // 3:]                 # the clock settles after the first third
-        mhz = sorted(v[0] for v in tail if v[0])
-        watt = sorted(v[1] for v in tail if v[1])
-        return {"sclk_mhz": mhz[len(mhz) // 2] if mhz else None, "socket_w": round(watt[len(watt) // 2], 1) if watt else None,
-                "samples": len(tail)}
+        tail = samples[len(samples) // 3:] or samples              # the clock settles after the first third
+        med = lambda v: sorted(v)[len(v) // 2] if v else None
+        best = None
+        for ci in range(len(self.cards)):
+            w = med([s[ci][1] for s in tail if s[ci][1]])
+            if w is not None and (best is None or w > best[1]):
+                best = (ci, w)
+        ci = best[0] if best else 0
+        mhz = med([s[ci][0] for s in tail if s[ci][0]])
+        return {"sclk_mhz": None if mhz is None else round(mhz), "socket_w": None if best is None else round(best[1], 1), "samples": len(tail),
+                "cards_seen": len(self.cards)}
 
 
 def physical_cores():
@@ -268,6 +278,7 @@ def main():
                          "`f32_mfma_variant`).  x3: MFMA_H2 off.  f32: every product on v_mfma_f32_32x32x2_f32")
     ap.add_argument("--h2-lazy-split", type=int, default=-1, help="cfg.HIP.H2_LAZY_SPLIT (A/B): 1 = split un-planed inputs of eligible layers, 0 = such layers stay on x3 / f32")
     ap.add_argument("--h2-min-tiles", type=int, default=-1, help="cfg.HIP.H2_MIN_TILES (A/B)")
+    ap.add_argument("--h2-trunk-planes", type=int, default=-1, help="cfg.HIP.H2_TRUNK_PLANES (A/B): 0 keeps the residual trunk in float32")
     ap.add_argument("--x3-terms", type=int, choices=[6, 9], default=6, help="with --mfma x3: 6 = the three cross terms below 2^-24 are dropped "
                     "(default), 9 = all nine cross terms, every f32 product exact (frcnn_gemm_x3_set_terms)")
     ap.add_argument("--x3-config", type=int, default=-1, help="A/B knob: frcnn_gemm_x3_set_config (-1 = by shape)")
@@ -312,6 +323,8 @@ def main():
         cfg.HIP.H2_LAZY_SPLIT = bool(args.h2_lazy_split)
     if args.h2_min_tiles >= 0:
         cfg.HIP.H2_MIN_TILES = args.h2_min_tiles
+    if args.h2_trunk_planes >= 0:
+        cfg.HIP.H2_TRUNK_PLANES = bool(args.h2_trunk_planes)
     if args.winograd_f2 is not None:
         cfg.HIP.WINOGRAD_F2_SCOPES = tuple(t for t in args.winograd_f2.split(",") if t)
     if args.winograd_direct is not None:
@@ -455,7 +468,7 @@ def main():
 
     f32_variant, x3_variant, telemetry = None, None, None
     if world == 1 and not args.no_graph:
-        telemetry = Telemetry(local_rank).run(lambda: [timed_region() for _ in range(3)])      # clock / power of the shipped configuration
+        telemetry = Telemetry().run(lambda: [timed_region() for _ in range(3)])      # clock / power of the shipped configuration
     if args.mfma in ("h2", "x3") and world == 1 and not args.no_f32_variant and not args.no_graph:
         # the same workload on the other pipe choices, timed in the same run (rank 0, N = 1 like cpu_baseline)
         keep = (cfg.HIP.MFMA_H2, cfg.HIP.MFMA_X3)

@@ -271,13 +271,15 @@ int frcnn_gemm_x3(const float* x_d, const void* planes_d, const float* bias_d, c
  *   frcnn_h2_pack_w:  W [G][N][K] f32 (device) -> planes [G][2][N][K] + w_inv [G][N] (one scale per output row), once per filter; K % 4 == 0.
  *   frcnn_h2_split:   x [M][K] f32 -> planes [2][M][K] + x_inv [K/128][M] (one scale per row and 128-k block); K % 128 == 0.
  *   frcnn_gemm_h2:    y[g] = act(x[g] W[g]^T + bias + res[g]), g < G; x as planes [2][G*M][K] + x_inv [K/128][G*M]; res / y [G*M][N] f32 (y may be
- *                     NULL); y_planes / y_inv (may be NULL): the result as operand planes [2][G*M][N] + [N/128][G*M] for the next GEMM, emitted
+ *                     NULL); res_planes / res_inv (instead of res, may be NULL): the residual as operand planes [2][G*M][N] + [N/128][G*M],
+ *                     read as (h + l) * 2^-e -- the trunk of a bottleneck chain kept as planes only (cfg.HIP.H2_TRUNK_PLANES); y_planes / y_inv (may be NULL): the result as operand planes [2][G*M][N] + [N/128][G*M] for the next GEMM, emitted
  *                     from the register epilogue (bit-identical to frcnn_h2_split of y).  K % 128 == 0, N % 128 == 0, any M.  cfg: -1 = by shape, else a tile configuration id (per call: no process-wide state). */
 size_t frcnn_h2_planes_bytes(long long rows, int K);
 int frcnn_h2_pack_w(const float* w_d, int G, int N, int K, void* planes_d, float* w_inv_d, void* stream);
 int frcnn_h2_split(const float* x_d, long long M, int K, void* planes_d, float* inv_d, void* stream);
 int frcnn_gemm_h2(const void* x_planes_d, const float* x_inv_d, const void* w_planes_d, const float* w_inv_d, const float* bias_d,
-                  const float* res_d, float* y_d, void* y_planes_d, float* y_inv_d, int G, int M, int N, int K, int act, int cfg, void* stream);
+                  const float* res_d, const void* res_planes_d, const float* res_inv_d, float* y_d, void* y_planes_d, float* y_inv_d,
+                  int G, int M, int N, int K, int act, int cfg, void* stream);
 int frcnn_gemm_x3_set_terms(int terms);         /* 6 (default): cross terms am*wl, al*wm, al*wl dropped (<= 2^-24 relative); 9: all nine -> every f32 product exact */
 int frcnn_gemm_x3_set_config(int cfg);          /* A/B runs: -1 = by shape (default), 0 = 128x128 tiles / 64x64 waves, 1 = 128x128 / 32x64, 2 = 64x128 / 32x64 */
 /* Winograd F(m x m, 3x3), m = 2 or 4, for stride-1 pad-1 3x3 convolutions (exact algebra, f32): filter transform on the

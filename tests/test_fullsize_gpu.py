@@ -29,6 +29,7 @@ SHIPPED = "shipped"
 
 SHIPPED_F32 = "shipped_f32"
 SHIPPED_X3 = "shipped_x3"
+SHIPPED_H2F = "shipped_h2_f32trunk"
 
 
 def _shipped_policy():
@@ -36,14 +37,15 @@ def _shipped_policy():
     Winograd policy with every product on the f32 MFMA (bench.py's `f32_mfma_variant`)"""
     from model.config import cfg
     fs.POLICIES[SHIPPED] = {k: cfg.HIP[k] for k in ("WINOGRAD", "WINOGRAD_M", "WINOGRAD_F2_SCOPES", "WINOGRAD_DIRECT_SCOPES", "WINOGRAD_7X7",
-                                                    "WINOGRAD_MIN_CIN", "MFMA_X3", "MFMA_H2", "H2_LAZY_SPLIT", "H2_MIN_TILES")}
+                                                    "WINOGRAD_MIN_CIN", "MFMA_X3", "MFMA_H2", "H2_LAZY_SPLIT", "H2_MIN_TILES", "H2_TRUNK_PLANES")}
+    fs.POLICIES[SHIPPED_H2F] = dict(fs.POLICIES[SHIPPED], H2_TRUNK_PLANES=False)      # MFMA_H2 with the residual trunk kept in float32
     fs.POLICIES[SHIPPED_X3] = dict(fs.POLICIES[SHIPPED], MFMA_H2=False)               # round 2's configuration (bench.py `x3_variant`)
     fs.POLICIES[SHIPPED_F32] = dict(fs.POLICIES[SHIPPED], MFMA_X3=False, MFMA_H2=False)
     return SHIPPED
 
 
 @pytest.mark.parametrize("config,weights", [("c2", "damped"), ("c2", "calibrated"), ("c3", "calibrated"), ("c1", "damped"), ("c4", "calibrated")])
-@pytest.mark.parametrize("policy", ["direct", SHIPPED, SHIPPED_X3, SHIPPED_F32])
+@pytest.mark.parametrize("policy", ["direct", SHIPPED, SHIPPED_H2F, SHIPPED_X3, SHIPPED_F32])
 def test_fullsize_parity(dev, config, weights, policy):
     if policy != "direct":
         _shipped_policy()

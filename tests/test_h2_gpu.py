@@ -130,6 +130,27 @@ def test_gemm_h2_planes_only_and_chained(dev):
     assert float(np.abs(a.cpu().numpy() - want).max()) <= 2e-6 * max(1.0, float(np.abs(want).max()))
 
 
+def test_gemm_h2_residual_as_planes(dev):
+    """The residual given as operand planes (cfg.HIP.H2_TRUNK_PLANES) is read as (h + l) * 2^-e: identical to passing that float32
+    tensor, for tiles with an M tail, batched entries and both tile shapes."""
+    from frcnn_hip import ops
+    rng = np.random.RandomState(8)
+    for G, M, N, K, cfg_ in ((1, 128 * 5 + 37, 256, 128, 0), (1, 9576, 1024, 256, 12), (3, 211, 128, 256, 0), (1, 2394, 1024, 256, -1)):
+        x = np.maximum(rng.randn(G * M, K), 0).astype(np.float32)
+        w = (rng.randn(G, N, K) / np.sqrt(K)).astype(np.float32)
+        r = (np.maximum(rng.randn(G * M, N), 0) * np.exp(rng.uniform(-2, 2, size=(G * M, 1)))).astype(np.float32)
+        b = T(rng.randn(N).astype(np.float32), dev) if G == 1 else None
+        xp, wp, rp = ops.h2_split(T(x, dev)), ops.h2_pack_w(T(w, dev)), ops.h2_split(T(r, dev))
+        y1, _ = ops.gemm_h2(xp, wp, G, M, N, K, b, rp, 1, cfg=cfg_)
+        y2, _ = ops.gemm_h2(xp, wp, G, M, N, K, b, rp.to_float().contiguous(), 1, cfg=cfg_)
+        torch.cuda.synchronize()
+        assert torch.equal(y1, y2), (G, M, N, K)
+        want = np.einsum("gmk,gnk->gmn", x.reshape(G, M, K).astype(np.float64), w.astype(np.float64)).reshape(G * M, N) + r
+        if b is not None: want = want + b.cpu().numpy().astype(np.float64)
+        want = np.maximum(want, 0)
+        assert float(np.abs(y1.cpu().numpy() - want).max()) <= 1e-6 * max(1.0, float(np.abs(want).max()))
+
+
 def _same_planes(got, want):
     """got: ops.H2 on the device; want: an ops.H2 or the (h, l, inv) arrays of the numpy statement"""
     want = _planes_np(want) if hasattr(want, "planes") else want

@@ -40,7 +40,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 struct GemmH2Params {
   const unsigned short* x; const float* x_inv; const unsigned short* w; const float* w_inv;
-  const float* bias; const float* res; float* y; unsigned short* yp; float* y_inv;
+  const float* bias; const float* res; const unsigned short* resp; const float* resp_inv; float* y; unsigned short* yp; float* y_inv;
   int M, N, K, batch, act, nsteps, mtiles, ntiles;
   long long Mtot;                     // rows of x / res / y / yp over all batch entries (= batch * M)
 };
@@ -266,6 +266,19 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
             const auto rr = rsrc_f(p.res + sbase, left_e, 4);
             const auto ld = __builtin_amdgcn_raw_buffer_load_b128(rr, (frow * p.N + 4 * khalf) * 4 + 32 * q, 0, 0);
             rv = make_float4(__uint_as_float(ld[0]), __uint_as_float(ld[1]), __uint_as_float(ld[2]), __uint_as_float(ld[3]));
+          } else if (p.resp) {
+            // the residual as operand planes (the trunk of a bottleneck chain kept as planes only): (h + l) is exact in f32 (<= 23
+            // significant bits), times the block's power-of-two scale; the tile's 128 columns are one scale block (BN == 128)
+            const int m0 = c_bm0 + wm0 + i * 32;
+            const long long sbase = (long long)(row_base + m0) * p.N + nc;
+            const long long left_e = (long long)(p.M - m0) * p.N - nc;
+            const auto rh = rsrc_f(p.resp + sbase, left_e, 2), rl = rsrc_f(p.resp + (size_t)p.Mtot * p.N + sbase, left_e, 2);
+            const int lo2 = (frow * p.N + 4 * khalf) * 2 + 16 * q;
+            const auto hv = __builtin_bit_cast(h4, __builtin_amdgcn_raw_buffer_load_b64(rh, lo2, 0, 0));
+            const auto lv = __builtin_bit_cast(h4, __builtin_amdgcn_raw_buffer_load_b64(rl, lo2, 0, 0));
+            const float ri = p.resp_inv[(size_t)(c_bn0 / H2_KB) * p.Mtot + row_base + min(m0 + frow, p.M - 1)];
+            rv = make_float4(((float)hv[0] + (float)lv[0]) * ri, ((float)hv[1] + (float)lv[1]) * ri, ((float)hv[2] + (float)lv[2]) * ri,
+                             ((float)hv[3] + (float)lv[3]) * ri);
           }
           tot[i][j][4 * q + 0] = (rv.x + bv.x) * s0;
           tot[i][j][4 * q + 1] = (rv.y + bv.y) * s1;
@@ -552,14 +565,15 @@ static int launch_h2(const GemmH2Params& q, hipStream_t st) {
 }
 
 // y[g] = act(x[g] W[g]^T + bias + res[g]), g < G.  x: planes [2][G*M][K] + x_inv [K/128][G*M] (frcnn_h2_split or a producer's `yp`
-// output); W: frcnn_h2_pack_w(W [G][N][K]); res / y [G*M][N] f32 (y may be null when only planes are wanted);
+// output); W: frcnn_h2_pack_w(W [G][N][K]); res / y [G*M][N] f32 (y may be null when only planes are wanted); the residual may be
+// given as operand planes instead (res_planes [2][G*M][N] + res_inv [N/128][G*M], e.g. an earlier launch's `yp`);
 // yp / y_inv: planes [2][G*M][N] + [N/128][G*M] of the result for the next GEMM (null: not emitted).
 // cfg: -1 by shape, else a tile configuration id (A/B runs; per call, no process-wide state).
 extern "C" int frcnn_gemm_h2(const void* x_planes_d, const float* x_inv_d, const void* w_planes_d, const float* w_inv_d, const float* bias_d,
-                             const float* res_d, float* y_d, void* y_planes_d, float* y_inv_d, int G, int M, int N, int K, int act, int cfg,
-                             void* stream) {
+                             const float* res_d, const void* res_planes_d, const float* res_inv_d, float* y_d, void* y_planes_d, float* y_inv_d,
+                             int G, int M, int N, int K, int act, int cfg, void* stream) {
   if (!x_planes_d || !x_inv_d || !w_planes_d || !w_inv_d || (!y_d && !y_planes_d) || (y_planes_d && !y_inv_d) || G <= 0 || M <= 0 || N <= 0 ||
-      K <= 0 || act < 0 || act > 2)
+      K <= 0 || act < 0 || act > 2 || (res_d && res_planes_d) || (res_planes_d && !res_inv_d))
     return FRCNN_E_ARG;
   const long long Mtot = (long long)G * M;
   // 32-bit per-lane byte offsets: both x planes / both W planes of a batch entry / one result row block
@@ -568,11 +582,16 @@ extern "C" int frcnn_gemm_h2(const void* x_planes_d, const float* x_inv_d, const
     return FRCNN_E_UNSUPPORTED;
   GemmH2Params p;
   p.x = (const unsigned short*)x_planes_d; p.x_inv = x_inv_d; p.w = (const unsigned short*)w_planes_d; p.w_inv = w_inv_d;
-  p.bias = bias_d; p.res = res_d; p.y = y_d; p.yp = (unsigned short*)y_planes_d; p.y_inv = y_inv_d;
+  p.bias = bias_d; p.res = res_d; p.resp = (const unsigned short*)res_planes_d; p.resp_inv = res_inv_d; p.y = y_d; p.yp = (unsigned short*)y_planes_d; p.y_inv = y_inv_d;
   p.M = M; p.N = N; p.K = K; p.batch = G; p.act = act; p.Mtot = Mtot;
   p.nsteps = p.mtiles = p.ntiles = 0;
   hipStream_t st = (hipStream_t)stream;
-  if (cfg < 0) cfg = 0;
+  if (cfg < 0) {
+    // by shape (profiles/r03_g_h2_sweep.txt): launches of up to ~600 tiles of 128 x 128 (the 38 x 63 layers, single images) fill the
+    // chip better with 64-row tiles at three workgroups per CU; everything larger runs on the 128 x 128 tiles
+    const long long t128 = (long long)cdiv(M, 128) * (N / 128) * G;
+    cfg = t128 <= 640 ? 12 : 0;
+  }
   switch (cfg) {
     case 0: return launch_h2<128, 128, 64, 64, 2>(p, st);        // 67 KB: 2 workgroups / CU
     case 1: return launch_h2<128, 128, 64, 64, 3>(p, st);        // 100 KB: 1 workgroup / CU, 2 slabs in flight

@@ -115,7 +115,7 @@ SIGNATURES = {
     "frcnn_h2_planes_bytes": (c_size_t, [c_longlong, c_int]),
     "frcnn_h2_pack_w": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     "frcnn_h2_split": (c_int, [_P, c_longlong, c_int, _P, _P, _P]),
-    "frcnn_gemm_h2": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "frcnn_gemm_h2": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "frcnn_gemm_x3_set_terms": (c_int, [c_int]),
     "frcnn_relu6_bwd": (c_int, [_P, _P, c_longlong, _P]),
     "frcnn_maxpool_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P]),

@@ -721,14 +721,19 @@ def h2_pack_w(w, out=None):
 
 def gemm_h2(x, wp, G, M, N, K, bias=None, residual=None, act=ACT_NONE, out=None, out_planes=None, want_f32=True, cfg=-1):
     """out[g] = act(x[g] W[g]^T + bias + residual[g]) through frcnn_gemm_h2.  x: H2 of [G*M, K]; wp = h2_pack_w(W [G,N,K]).
-    out: f32 [G*M, N] (allocated when want_f32 and out is None); out_planes: an H2 of [G*M, N] to ALSO receive the result as the next
-    GEMM's operand (emitted from the epilogue).  Returns (out or None, out_planes or None)."""
+    residual: f32 [G*M, N] or an H2 of [G*M, N] (read as (h + l) * 2^-e).  out: f32 [G*M, N] (allocated when want_f32 and out is None);
+    out_planes: an H2 of [G*M, N] to ALSO receive the result as the next GEMM's operand (emitted from the epilogue).
+    Returns (out or None, out_planes or None)."""
     assert isinstance(x, H2) and x.rows == G * M and x.K == K
     if out is None and want_f32:
         out = torch.empty((G * M, N), dtype=torch.float32, device=x.planes.device)
     if out_planes is not None:
         assert out_planes.rows == G * M and out_planes.K == N
-    call("frcnn_gemm_h2", _ptr(x.planes), _ptr(x.inv), _ptr(wp[0]), _ptr(wp[1]), _ptr(bias), _ptr(residual), _ptr(out),
+    rp = residual if isinstance(residual, H2) else None
+    if rp is not None:
+        assert rp.rows == G * M and rp.K == N
+    call("frcnn_gemm_h2", _ptr(x.planes), _ptr(x.inv), _ptr(wp[0]), _ptr(wp[1]), _ptr(bias), _ptr(None if rp is not None else residual),
+         _ptr(None if rp is None else rp.planes), _ptr(None if rp is None else rp.inv), _ptr(out),
          _ptr(None if out_planes is None else out_planes.planes), _ptr(None if out_planes is None else out_planes.inv),
          int(G), int(M), int(N), int(K), int(act), int(cfg), _stream())
     return out, out_planes

@@ -90,10 +90,14 @@ __C = AttrDict(
     # <= 3 * 2^-22 relative, measured 1e-7 of the output scale -- below the f32 MFMA kernel's own error): 1.3-1.7x faster than MFMA_X3.
     # The producers (GEMM epilogue, Winograd transforms) emit the next layer's operand planes; H2_LAZY_SPLIT: an eligible layer
     # whose input has no planes yet splits it with a separate pass (False: such a layer takes the X3 / f32 path instead).
+    # H2_TRUNK_PLANES: inside a run of h2 bottleneck units with identity shortcuts the unit output (the residual trunk) is kept as operand
+    # planes ONLY -- the next unit's conv1 reads them as its input and its conv3 reads them as the residual ((h + l) * 2^-e, >= 22
+    # significant bits: the stored trunk rounds at 2^-23 relative instead of 2^-24); the float32 tensor is written only where a
+    # non-GEMM consumer follows (block ends, RPN / crop, the spatial mean).  Saves a third of conv3's HBM traffic.
     HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=64, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=("block1", "block2"), WINOGRAD_DIRECT_SCOPES=(),
              WINOGRAD_TRAIN=True,
              WINOGRAD_7X7=True, FUSE_TAIL_MEAN=False, OVERLAP_TAIL_ENTRY=False, MFMA_X3=True,
-             MFMA_H2=True, H2_LAZY_SPLIT=True, H2_MIN_TILES=150))
+             MFMA_H2=True, H2_LAZY_SPLIT=True, H2_MIN_TILES=150, H2_TRUNK_PLANES=True))
 __C.DATA_DIR = osp.abspath(osp.join(__C.ROOT_DIR, 'data'))
 cfg = __C
 

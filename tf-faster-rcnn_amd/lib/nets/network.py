@@ -117,20 +117,23 @@ class Network(object):
             xp, wp = self._h2_input(x), sess.h2_planes(w)
             yp = sess.h2_buf(self._tag + "/" + scope, M, Cout) if emit_h2 else None
             y = out if (want_f32 or yp is None) else None
-            sess.mark("conv:h2:" + scope, flops, lambda: ops.gemm_h2(xp, wp, 1, M, Cout, Cin, b, residual, act, out=y, out_planes=yp,
+            res = residual
+            if residual is not None and residual.data_ptr() in self._f32_missing:
+                res = self._h2_of[residual.data_ptr()]              # the trunk exists as operand planes only (cfg.HIP.H2_TRUNK_PLANES)
+            sess.mark("conv:h2:" + scope, flops, lambda: ops.gemm_h2(xp, wp, 1, M, Cout, Cin, b, res, act, out=y, out_planes=yp,
                                                                       want_f32=False),
                       nbytes=4 * M * Cin + 4 * w.numel() + (4 * out.numel() if y is not None else 0)
                       + (4 * out.numel() if yp is not None else 0) + (4 * out.numel() if residual is not None else 0))
             self._wrote(out, yp, y is not None)
         elif plain and self._x3_eligible(M, Cout, Cin, 1):
             # ... on the bf16 matrix pipe with exact bf16x3 operand splits (cfg.HIP.MFMA_X3)
-            self._need_f32(x)
+            self._need_f32(x), self._need_f32(residual)
             planes = sess.x3_planes(w)
             sess.mark("conv:x3:" + scope, flops, lambda: ops.gemm_x3(x, planes, 1, M, Cout, Cin, b, residual, act, out=out),
                       nbytes=4 * (x.numel() + out.numel() + (out.numel() if residual is not None else 0)) + 6 * w.numel())
             self._wrote(out)
         else:
-            self._need_f32(x)
+            self._need_f32(x), self._need_f32(residual)
             sess.mark("conv:" + scope, flops,
                       lambda: ops.conv2d(x, w, b, k, k, stride, pad, act, residual, res_stride, fold_w, out=out),
                       nbytes=4 * (x.numel() + w.numel() + out.numel() + (out.numel() if residual is not None else 0)))
@@ -176,7 +179,7 @@ class Network(object):
         return t
 
     def _need_f32(self, x):
-        if x.data_ptr() in self._f32_missing:
+        if x is not None and x.data_ptr() in self._f32_missing:
             raise RuntimeError("graph construction error: a float32 consumer reads a tensor that was emitted as operand planes only")
 
     def _x3_eligible(self, M, N, K, G):
@@ -243,7 +246,7 @@ class Network(object):
         Cin, Cout = x.shape[-1], w.shape[0]
         M = x.numel() // Cin
         out = sess.buf(self._tag + "/" + name, (M // group_rows, Cout))
-        self._need_f32(x)
+        self._need_f32(x), self._need_f32(residual)
         sess.mark("conv:" + scope, 2 * M * Cout * Cin, lambda: ops.conv1x1_mean(x, w, b, group_rows, act, residual, out=out),
                   nbytes=4 * (x.numel() + w.numel() + out.numel() + (M * Cout if residual is not None else 0)))
         return self._wrote(out)
@@ -404,6 +407,7 @@ class Network(object):
     def _crop_images(self, bottom, rois, out, max_pool=False, bias=None, act=ACT_NONE):
         """tf.image.crop_and_resize(bottom, boxes, box_ind = rois[:,0]) (network.py:141-157) for the whole batch in one launch."""
         fs, P = float(self._feat_stride[0]), cfg.POOLING_SIZE
+        self._need_f32(bottom)
         nbytes = 4 * (bottom.numel() + out.numel())
         if bias is None and act == ACT_NONE:
             self._sess.mark("op:crop_and_resize", 0, lambda: ops.crop_and_resize(bottom, rois, fs, P, max_pool=max_pool, out=out), nbytes=nbytes)
@@ -613,7 +617,7 @@ class Network(object):
                c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH, cfg.TEST.RPN_TOP_N, cfg.POOLING_SIZE,
                bool(cfg.HIP.WINOGRAD), int(cfg.HIP.WINOGRAD_MIN_CIN), int(cfg.HIP.WINOGRAD_M), tuple(cfg.HIP.WINOGRAD_F2_SCOPES),
                tuple(cfg.HIP.WINOGRAD_DIRECT_SCOPES), bool(cfg.HIP.WINOGRAD_7X7), bool(cfg.HIP.FUSE_TAIL_MEAN), bool(cfg.HIP.OVERLAP_TAIL_ENTRY), bool(cfg.HIP.MFMA_X3), bool(cfg.USE_E2E_TF),
-               bool(cfg.HIP.MFMA_H2), bool(cfg.HIP.H2_LAZY_SPLIT), int(cfg.HIP.H2_MIN_TILES))
+               bool(cfg.HIP.MFMA_H2), bool(cfg.HIP.H2_LAZY_SPLIT), int(cfg.HIP.H2_MIN_TILES), bool(cfg.HIP.H2_TRUNK_PLANES))
         cur = torch.cuda.current_stream(sess.device)
         if not use_graph or sess.profile is not None:
             sess.flops_last_forward = 0

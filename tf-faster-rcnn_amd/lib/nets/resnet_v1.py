@@ -70,12 +70,13 @@ class resnetv1(Network):
         return self._blocks[3][1] * 4
 
     # ---- graph -----------------------------------------------------------------------------------
-    def _bottleneck(self, x, prefix, base, stride, mean_rows=0, emit_out=True):
+    def _bottleneck(self, x, prefix, base, stride, mean_rows=0, emit_out=True, f32_out=True):
         """mean_rows > 0 (TEST mode, last unit of the tail): returns mean over every `mean_rows` consecutive pixels of the unit's
         output instead of the output itself (conv3 + residual + ReLU + reduce_mean in one kernel).
         cfg.HIP.MFMA_H2 (TEST mode): conv2 hands conv3 its operand planes only (nothing else reads conv2's float32 result); conv3
         emits float32 (the next residual) AND the planes the next unit's conv1 / shortcut read (emit_out = False: a consumer that
-        is not a GEMM follows, e.g. the spatial mean)."""
+        is not a GEMM follows, e.g. the spatial mean); f32_out = False (cfg.HIP.H2_TRUNK_PLANES): the next unit reads its input AND its
+        residual from those planes, so conv3 does not write the float32 tensor at all."""
         depth = base * 4
         cin = x.shape[-1]
         if cin != depth:
@@ -93,13 +94,25 @@ class resnetv1(Network):
         c3_h2 = res_stride == 1 and self._h2_eligible(M3, depth, base, 1)
         r = self._conv(r, prefix + "/conv2", 3, stride, pad, act=ACT_RELU, bn_eps=BN_EPS, emit_h2=c3_h2, want_f32=not c3_h2)
         return self._conv(r, prefix + "/conv3", 1, 1, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut, res_stride=res_stride,
-                          emit_h2=emit_out)
+                          emit_h2=emit_out, want_f32=f32_out)
+
+    def _trunk_planes_only(self, rows, base, next_stride):
+        """cfg.HIP.H2_TRUNK_PLANES: may a unit hand its output to the NEXT unit of the same block (identity shortcut) as operand
+        planes only?  Yes when that unit's conv1 reads planes (h2-eligible), its conv3 takes the residual from planes (h2-eligible,
+        stride 1) -- then nothing reads the float32 tensor.  The planes carry >= 22 significant bits (csrc/gemm_h2.hip)."""
+        depth = 4 * base
+        return (bool(cfg.HIP.H2_TRUNK_PLANES) and not cfg.HIP.FUSE_TAIL_MEAN and next_stride == 1 and self._h2_eligible(rows, base, depth, 1)
+                and self._h2_eligible(rows, depth, base, 1))
 
     def _run_blocks(self, x, blocks, emit_last=True):
         for bi, (name, base, n_units, stride) in enumerate(blocks):
             for u in range(1, n_units + 1):
-                x = self._bottleneck(x, "%s/%s/unit_%d/bottleneck_v1" % (self._scope, name, u), base,
-                                     stride if u == n_units else 1, emit_out=emit_last or u < n_units or bi + 1 < len(blocks))
+                s_u = stride if u == n_units else 1
+                N, H, W, _ = x.shape
+                rows = N * ops.conv_out_size(H, 3, s_u, 1, 1) * ops.conv_out_size(W, 3, s_u, 1, 1) if s_u > 1 else N * H * W
+                planes_only = u < n_units and self._trunk_planes_only(rows, base, stride if u + 1 == n_units else 1)
+                x = self._bottleneck(x, "%s/%s/unit_%d/bottleneck_v1" % (self._scope, name, u), base, s_u,
+                                     emit_out=emit_last or u < n_units or bi + 1 < len(blocks), f32_out=not planes_only)
         return x
 
     def _crop_pool_layer(self, bottom, rois, name):
@@ -151,11 +164,13 @@ class resnetv1(Network):
         r = self._crop_images(c1_map, rois, c1_out, bias=b_c1, act=ACT_RELU)
         c3_h2 = self._h2_eligible(R * P * P, 4 * base, base, 1)
         r = self._conv(r, prefix + "/conv2", 3, 1, (1, 1, 1, 1), act=ACT_RELU, bn_eps=BN_EPS, emit_h2=c3_h2, want_f32=not c3_h2)
-        x = self._conv(r, prefix + "/conv3", 1, 1, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut, res_stride=1, emit_h2=n_units >= 2)
+        x = self._conv(r, prefix + "/conv3", 1, 1, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut, res_stride=1, emit_h2=n_units >= 2,
+                       want_f32=not (n_units >= 2 and self._trunk_planes_only(R * P * P, base, stride if n_units == 2 else 1)))
         fused = bool(cfg.HIP.FUSE_TAIL_MEAN) and stride == 1 and n_units >= 2
         for u in range(2, n_units + 1):
             x = self._bottleneck(x, "%s/%s/unit_%d/bottleneck_v1" % (self._scope, name, u), base, stride if u == n_units else 1,
-                                 mean_rows=P * P if (fused and u == n_units) else 0, emit_out=u < n_units)
+                                 mean_rows=P * P if (fused and u == n_units) else 0, emit_out=u < n_units,
+                                 f32_out=not (u < n_units and self._trunk_planes_only(R * P * P, base, stride if u + 1 == n_units else 1)))
         if fused:
             return x                                          # [R, 2048]: the mean came out of the last conv3's epilogue
         out = sess.buf(self._tag + "/fc7", (x.shape[0], x.shape[-1]))
