@@ -278,6 +278,7 @@ def main():
                          "`f32_mfma_variant`).  x3: MFMA_H2 off.  f32: every product on v_mfma_f32_32x32x2_f32")
     ap.add_argument("--h2-lazy-split", type=int, default=-1, help="cfg.HIP.H2_LAZY_SPLIT (A/B): 1 = split un-planed inputs of eligible layers, 0 = such layers stay on x3 / f32")
     ap.add_argument("--h2-min-tiles", type=int, default=-1, help="cfg.HIP.H2_MIN_TILES (A/B)")
+    ap.add_argument("--h2-cfg", type=int, default=-1, help="cfg.HIP.H2_TILE_CFG (A/B): -1 = tile shape by launch size, else one frcnn_gemm_h2 configuration id")
     ap.add_argument("--h2-trunk-planes", type=int, default=-1, help="cfg.HIP.H2_TRUNK_PLANES (A/B): 0 keeps the residual trunk in float32")
     ap.add_argument("--x3-terms", type=int, choices=[6, 9], default=6, help="with --mfma x3: 6 = the three cross terms below 2^-24 are dropped "
                     "(default), 9 = all nine cross terms, every f32 product exact (frcnn_gemm_x3_set_terms)")
@@ -323,6 +324,7 @@ def main():
         cfg.HIP.H2_LAZY_SPLIT = bool(args.h2_lazy_split)
     if args.h2_min_tiles >= 0:
         cfg.HIP.H2_MIN_TILES = args.h2_min_tiles
+    cfg.HIP.H2_TILE_CFG = args.h2_cfg
     if args.h2_trunk_planes >= 0:
         cfg.HIP.H2_TRUNK_PLANES = bool(args.h2_trunk_planes)
     if args.winograd_f2 is not None:
@@ -509,6 +511,7 @@ def main():
                                         "exactly split f32 operands (csrc/gemm_x3.hip); the stem, strided / small-Cout convolutions and heads on "
                                         "v_mfma_f32_32x32x2_f32", "f32": "v_mfma_f32_32x32x2_f32 everywhere"}[args.mfma],
                          "gflop_per_image_launched": round(flops_per_image / 1e9, 2), "gflop_per_image_reference_graph": c["gflop_ref"]}
+        out["telemetry"] = telemetry
         if x3_variant is not None:
             out["x3_variant"] = x3_variant
         if f32_variant is not None:

@@ -26,8 +26,9 @@
 //
 // Pipeline: k_gemm_x3's skeleton -- resident workgroups walk a static XCD-aware tile list, (tile, slab) is one stream of 32-k slabs
 // through an NS-deep LDS ring filled by direct-to-LDS loads (global_load_lds_dwordx4, scalar base + 32-bit lane offset: no address
-// VALU), counted vmcnt (NS - 2 slabs stay in flight across the per-slab barrier), XOR-swizzled 64-byte plane rows -> conflict-free
-// ds_read_b128 fragments.  A stage = X planes 2 x BM x 64 B + W planes 2 x BN x 64 B + the BM block scales (1 KB):
+// VALU), counted vmcnt (NS - 2 slabs stay in flight across the per-slab barrier), 64-byte plane rows with chunk c of row r at position c ^ ((r >> 2) & 3) -> conflict-free
+// ds_read_b128 fragments (a ds_read_b128 is served in the 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): four 64-byte
+// rows share a 256-byte bank row, and the four rows of a group with the same r mod 4 differ in (r >> 2) & 3).  A stage = X planes 2 x BM x 64 B + W planes 2 x BN x 64 B + the BM block scales (1 KB):
 // 33 KB for 128 x 128 -> two stages = 66 KB = 2 workgroups per CU, or 3-4 stages with one.
 #include "h2_common.h"
 #include <mutex>
@@ -123,7 +124,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
 #pragma unroll
   for (int t = 0; t < LB; ++t) {
     const int u = wave * LB + t, plane = u / (BN / 16), row = (u % (BN / 16)) * 16 + (lane >> 2), pos = lane & 3;
-    b_off[t] = (unsigned)((size_t)plane * wplane + (size_t)row * p.K * 2 + ((pos ^ ((row >> 1) & 3)) * 16));
+    b_off[t] = (unsigned)((size_t)plane * wplane + (size_t)row * p.K * 2 + ((pos ^ ((row >> ((TUNE & 8) ? 1 : 2)) & 3)) * 16));
   }
   auto set_tile = [&](int tl) {
     const int g = tl / per, rem = tl - g * per;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
     for (int t = 0; t < LA; ++t) {
       const int u = wave * LA + t, plane = u / (BM / 16), row = (u % (BM / 16)) * 16 + (lane >> 2), pos = lane & 3;
       const int rr = min(row, p.M - 1 - bm0);                                           // rows past M re-read row M - 1
-      a_off[t] = (unsigned)((size_t)plane * xplane + (size_t)rr * p.K * 2 + ((pos ^ ((row >> 1) & 3)) * 16));
+      a_off[t] = (unsigned)((size_t)plane * xplane + (size_t)rr * p.K * 2 + ((pos ^ ((row >> ((TUNE & 8) ? 1 : 2)) & 3)) * 16));
     }
     // block scales of the tile's rows: one float per lane and 64-row group; rows past the tensor re-read its last row (unused)
     const long long last = p.Mtot - 1 - (long long)row0;
@@ -177,10 +178,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
 
   // ---- compute side -------------------------------------------------------------------------------------------------------------
   f32x16 tot[TM][TN], tmp[TM][TN];
-  const int sw = (frow >> 1) & 3;
+  const int sw = (frow >> ((TUNE & 8) ? 1 : 2)) & 3;        // TUNE & 8: round-2 swizzle (two-way bank conflicts), kept for A/B runs
   const int x_row = (wm0 + frow) * 64, w_row = 2 * XP + (wn0 + frow) * 64;
 
-  auto slab_mfma = [&](int cur, auto first_c, auto&& between) {
+  // TUNE & 4: the next slab's G + SL direct-to-LDS loads are issued ONE AT A TIME between the MFMAs of the current slab (evenly spread
+  // over its NM MFMAs, the first after MFMA 1) instead of in a burst after the barrier: a load's issue stall (~60-150 cycles) then falls
+  // under the matrix-pipe time of the MFMAs already issued, not in front of the slab's first fragment reads.
+  constexpr int NM = 2 * 3 * TM * TN, ND = G + SL;
+  auto slab_mfma = [&](int cur, auto first_c, auto&& between, auto&& after) {
     constexpr bool FIRST = decltype(first_c)::value;
     const char* sb = smem + cur * STAGE;
 #pragma unroll
@@ -212,15 +217,22 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
           } else {
             tmp[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], xh[i], tmp[i][j], 0, 0, 0);
           }
+          after(t * 3 * TM * TN + i * TN + j);
         }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) tmp[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], xh[i], tmp[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) {
+          tmp[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], xh[i], tmp[i][j], 0, 0, 0);
+          after(t * 3 * TM * TN + TM * TN + i * TN + j);
+        }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) tmp[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], xl[i], tmp[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) {
+          tmp[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], xl[i], tmp[i][j], 0, 0, 0);
+          after(t * 3 * TM * TN + 2 * TM * TN + i * TN + j);
+        }
     }
   };
 
@@ -391,7 +403,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
     }
     __builtin_amdgcn_s_barrier();
     const bool more = left > 0;
-    constexpr int HALF = (TUNE & 1) ? (G + SL) / 2 : G + SL;
+    constexpr int HALF = (TUNE & 4) ? 0 : (TUNE & 1) ? (G + SL) / 2 : G + SL;
     if (more) {
 #pragma unroll
       for (int t = 0; t < HALF; ++t) issue_one(nxt, t);
@@ -403,12 +415,22 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
       for (int i = 0; i < TM; ++i) ainv[i] = *(const float*)(smem + soff + (wm0 + i * 32 + frow) * 4);
       c_par ^= 1;
     }
-    slab_mfma(cur, first_c, [&]() {
-      if (more) {
+    if (!(TUNE & 4)) {
+      slab_mfma(cur, first_c, [&]() {
+        if (more) {
 #pragma unroll
-        for (int t = HALF; t < G + SL; ++t) issue_one(nxt, t);
-      }
-    });
+          for (int t = HALF; t < G + SL; ++t) issue_one(nxt, t);
+        }
+      }, [](int) {});
+    } else if (more) {                                 // two code instances: the loads sit between the MFMAs without a branch each
+      slab_mfma(cur, first_c, []() {}, [&](int m) {
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+          if (1 + (d * (NM - 1)) / ND == m) issue_one(nxt, d);
+      });
+    } else {
+      slab_mfma(cur, first_c, []() {}, [](int) {});
+    }
     if (more) {
       issue_advance();
       nxt = nxt + 1 == NS ? 0 : nxt + 1;
@@ -586,12 +608,7 @@ extern "C" int frcnn_gemm_h2(const void* x_planes_d, const float* x_inv_d, const
   p.M = M; p.N = N; p.K = K; p.batch = G; p.act = act; p.Mtot = Mtot;
   p.nsteps = p.mtiles = p.ntiles = 0;
   hipStream_t st = (hipStream_t)stream;
-  if (cfg < 0) {
-    // by shape (profiles/r03_g_h2_sweep.txt): launches of up to ~600 tiles of 128 x 128 (the 38 x 63 layers, single images) fill the
-    // chip better with 64-row tiles at three workgroups per CU; everything larger runs on the 128 x 128 tiles
-    const long long t128 = (long long)cdiv(M, 128) * (N / 128) * G;
-    cfg = t128 <= 640 ? 12 : 0;
-  }
+  if (cfg < 0) cfg = 9;      // by measurement in the pipeline (profiles/r03_l_ab.txt): 128 x 128 tiles, scales once per 128-k block, for every launch
   switch (cfg) {
     case 0: return launch_h2<128, 128, 64, 64, 2>(p, st);        // 67 KB: 2 workgroups / CU
     case 1: return launch_h2<128, 128, 64, 64, 3>(p, st);        // 100 KB: 1 workgroup / CU, 2 slabs in flight
@@ -605,6 +622,11 @@ extern "C" int frcnn_gemm_h2(const void* x_planes_d, const float* x_inv_d, const
     case 9: return launch_h2<128, 128, 64, 64, 2, 2, 2>(p, st);  // cfg 0 with the scales sent once per 128-k block
     case 10: return launch_h2<128, 128, 64, 64, 2, 2, 3>(p, st);
     case 11: return launch_h2<128, 128, 32, 64, 2, 4, 3>(p, st);
+    case 14: return launch_h2<128, 128, 64, 64, 2, 2, 4>(p, st);  // cfg 0 with the loads spread between the MFMAs
+    case 15: return launch_h2<128, 128, 64, 64, 2, 2, 6>(p, st);  // ... and the scales sent once per 128-k block
+    case 16: return launch_h2<256, 128, 64, 64, 2, 2, 4>(p, st);  // 8 waves, loads spread
+    case 17: return launch_h2<64, 128, 32, 64, 2, 2, 4>(p, st);
+    case 18: return launch_h2<128, 128, 64, 64, 2, 2, 10>(p, st); // cfg 9 with the (r >> 1) & 3 swizzle
     case 12: return launch_h2<64, 128, 32, 64, 2>(p, st);        // 64-row tiles, 4 waves of 32 x 64, 51 KB: 3 workgroups / CU (under-filled launches)
     case 13: return launch_h2<64, 128, 32, 64, 3>(p, st);
     default: return FRCNN_E_ARG;

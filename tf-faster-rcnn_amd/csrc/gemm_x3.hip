@@ -16,8 +16,10 @@
 //     per element, 176 per slab for a 64x64 wave tile against 48 MFMAs x 32 cycles -- hidden under the matrix pipe;
 //   * resident workgroups, (tile, slab) stream, register epilogue through range-checked buffer stores: k_gemm_stream's skeleton.
 // LDS per stage: 128 A rows x 128 B + 3 planes x 128 W rows x 64 B = 40 KB; two stages = 80 KB -> 2 workgroups per CU.
-// W plane rows are 64 B (4 chunks of 8 bf16); chunk c of row n sits at position c ^ ((n >> 1) & 3): the ds_read_b128 of 8 lanes
-// (8 rows, one chunk index) then covers 8 distinct 16-byte slots of a 128-byte bank window, like the f32 slab.
+// W plane rows are 64 B (4 chunks of 8 bf16); chunk c of row n sits at position c ^ ((n >> 2) & 3): a ds_read_b128 is served in the
+// 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32), four 64-byte rows share a 256-byte bank row, and the four rows of a group
+// with equal n mod 4 differ in (n >> 2) & 3 -- conflict-free (round 2 used (n >> 1) & 3: two-way conflicts, SQ_LDS_BANK_CONFLICT =
+// half of SQ_LDS_IDX_ACTIVE, profiles/r03_i_pmc_gemm_h2.txt).
 #include "common.h"
 #include <mutex>
 
@@ -89,7 +91,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
   for (int t = 0; t < LB; ++t) {
     const int u = wave * LB + t;                       // instruction index: plane u / (BN/16), 16-row block u % (BN/16)
     const int plane = u / (BN / 16), row = (u % (BN / 16)) * 16 + (lane >> 2), pos = lane & 3;
-    b_lane[t] = ((plane * p.N + row) * p.K) * 2 + ((pos ^ ((row >> 1) & 3)) * 16);
+    b_lane[t] = ((plane * p.N + row) * p.K) * 2 + ((pos ^ ((row >> 2) & 3)) * 16);
   }
   const float* ia = p.x; const char* ib = (const char*)p.wp;
   int i_bm0 = 0, i_bn0 = 0, i_g = 0;
@@ -130,7 +132,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
   zero_acc();
   const int frow = lane & 31, khalf = lane >> 5;
   // fragment byte offsets inside a stage: A row (wm0 + i*32 + frow), 16-byte chunk c at c ^ ((row>>1)&7); W plane row, chunk c at c ^ ((row>>1)&3)
-  const int a_sw = (frow >> 1) & 7, b_sw = (frow >> 1) & 3;
+  const int a_sw = (frow >> 1) & 7, b_sw = (frow >> 2) & 3;
   const int a_row = (wm0 + frow) * 128, b_row = A_BYTES + (wn0 + frow) * 64;
 
   int c_bm0, c_bn0, c_g;

@@ -93,11 +93,13 @@ __C = AttrDict(
     # H2_TRUNK_PLANES: inside a run of h2 bottleneck units with identity shortcuts the unit output (the residual trunk) is kept as operand
     # planes ONLY -- the next unit's conv1 reads them as its input and its conv3 reads them as the residual ((h + l) * 2^-e, >= 22
     # significant bits: the stored trunk rounds at 2^-23 relative instead of 2^-24); the float32 tensor is written only where a
-    # non-GEMM consumer follows (block ends, RPN / crop, the spatial mean).  Saves a third of conv3's HBM traffic.
+    # non-GEMM consumer follows (block ends, RPN / crop, the spatial mean).  Saves a third of conv3's HBM traffic; measured +0.6 %
+    # images/s (profiles/r03_h_ab.txt), so it is OFF by default: the trunk stays exact float32.
+    # H2_TILE_CFG: -1 = tile shape by launch size (csrc/gemm_h2.hip), else a frcnn_gemm_h2 configuration id for every launch (A/B runs).
     HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=64, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=("block1", "block2"), WINOGRAD_DIRECT_SCOPES=(),
              WINOGRAD_TRAIN=True,
              WINOGRAD_7X7=True, FUSE_TAIL_MEAN=False, OVERLAP_TAIL_ENTRY=False, MFMA_X3=True,
-             MFMA_H2=True, H2_LAZY_SPLIT=True, H2_MIN_TILES=150, H2_TRUNK_PLANES=True))
+             MFMA_H2=True, H2_LAZY_SPLIT=True, H2_MIN_TILES=150, H2_TRUNK_PLANES=False, H2_TILE_CFG=-1))
 __C.DATA_DIR = osp.abspath(osp.join(__C.ROOT_DIR, 'data'))
 cfg = __C
 

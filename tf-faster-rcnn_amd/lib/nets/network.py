@@ -120,8 +120,9 @@ class Network(object):
             res = residual
             if residual is not None and residual.data_ptr() in self._f32_missing:
                 res = self._h2_of[residual.data_ptr()]              # the trunk exists as operand planes only (cfg.HIP.H2_TRUNK_PLANES)
+            tcfg = int(cfg.HIP.H2_TILE_CFG)
             sess.mark("conv:h2:" + scope, flops, lambda: ops.gemm_h2(xp, wp, 1, M, Cout, Cin, b, res, act, out=y, out_planes=yp,
-                                                                      want_f32=False),
+                                                                      want_f32=False, cfg=tcfg),
                       nbytes=4 * M * Cin + 4 * w.numel() + (4 * out.numel() if y is not None else 0)
                       + (4 * out.numel() if yp is not None else 0) + (4 * out.numel() if residual is not None else 0))
             self._wrote(out, yp, y is not None)
@@ -216,7 +217,8 @@ class Network(object):
         if self._h2_eligible(T, Cout, Cin, G):
             vp, wp = sess.h2_buf(self._tag + "/wino_v", G * T, Cin), sess.h2_planes(u)
             sess.mark("op:wino_in", 0, lambda: ops.winograd_input_transform_h2(x, vp, m), nbytes=4 * (x.numel() + G * T * Cin))
-            sess.mark("conv:h2:" + scope, flops, lambda: ops.gemm_h2(vp, wp, G, T, Cout, Cin, out=mm),
+            tcfg = int(cfg.HIP.H2_TILE_CFG)
+            sess.mark("conv:h2:" + scope, flops, lambda: ops.gemm_h2(vp, wp, G, T, Cout, Cin, out=mm, cfg=tcfg),
                       nbytes=4 * (G * T * Cin + mm.numel()) + 4 * u.numel())
         else:
             v = sess.buf(self._tag + "/wino_v", (G, T, Cin))
@@ -617,7 +619,7 @@ class Network(object):
                c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH, cfg.TEST.RPN_TOP_N, cfg.POOLING_SIZE,
                bool(cfg.HIP.WINOGRAD), int(cfg.HIP.WINOGRAD_MIN_CIN), int(cfg.HIP.WINOGRAD_M), tuple(cfg.HIP.WINOGRAD_F2_SCOPES),
                tuple(cfg.HIP.WINOGRAD_DIRECT_SCOPES), bool(cfg.HIP.WINOGRAD_7X7), bool(cfg.HIP.FUSE_TAIL_MEAN), bool(cfg.HIP.OVERLAP_TAIL_ENTRY), bool(cfg.HIP.MFMA_X3), bool(cfg.USE_E2E_TF),
-               bool(cfg.HIP.MFMA_H2), bool(cfg.HIP.H2_LAZY_SPLIT), int(cfg.HIP.H2_MIN_TILES), bool(cfg.HIP.H2_TRUNK_PLANES))
+               bool(cfg.HIP.MFMA_H2), bool(cfg.HIP.H2_LAZY_SPLIT), int(cfg.HIP.H2_MIN_TILES), bool(cfg.HIP.H2_TRUNK_PLANES), int(cfg.HIP.H2_TILE_CFG))
         cur = torch.cuda.current_stream(sess.device)
         if not use_graph or sess.profile is not None:
             sess.flops_last_forward = 0
