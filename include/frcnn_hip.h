@@ -156,7 +156,8 @@ int frcnn_detect_set_tuning(int key, int value);
 /* ---- test-time post-processing: replaces lib/model/test.py:95-102 (im_detect) and :162-180
  * (test_net per-class NMS + max_per_image cut) ----------------------------------------------- */
 size_t frcnn_detect_post_workspace_bytes(int R, int C);
-/* cls_prob_d [R,C], bbox_pred_d [R,4C] (already *stds+means), rois_d [R,5] (scaled image coords),
+/* cls_prob_d [R,C], bbox_pred_d [R,4C] (already *stds+means; NULL = cfg.TEST.BBOX_REG False: every class takes the un-regressed,
+ * un-clipped rois / scale, test.py:103-105 -- also in frcnn_detect_post_batched and frcnn_im_detect_boxes), rois_d [R,5] (scaled image coords),
  * num_rois_d: device int (rows >= it are ignored) or NULL.  im_scale: float64 like im_scales[0];
  * im_h, im_w: ORIGINAL image size.  out_dets_d [max_out,6] = x1,y1,x2,y2,score,class (class-major,
  * score-descending inside a class == all_boxes[j][i] order), *out_count_d = number of detections
@@ -253,7 +254,7 @@ int frcnn_prep_image(const void* src_d, int src_is_float, int h, int w, const do
 
 /* G independent NT GEMMs in one launch (f32 MFMA): y[g][m][n] = sum_k x[g][m][k] * w[g][n][k];  K % 32 == 0. */
 int frcnn_gemm_batched_nt(const float* x_d, const float* w_d, float* y_d, int G, int M, int N, int K, void* stream);
-/* f32 "NT" GEMM on the bf16 matrix pipe with exactly split operands (csrc/gemm_x3.hip; opt-in, cfg.HIP.MFMA_X3): every f32 value
+/* f32 "NT" GEMM on the bf16 matrix pipe with exactly split operands (csrc/gemm_x3.hip; cfg.HIP.MFMA_X3, default on in TEST mode; finite operands below the bf16 maximum -- an inf operand yields NaN, not inf): every f32 value
  * = h + m + l (three bf16 pieces, exact), a product = the six leading cross terms on v_mfma_f32_32x32x16_bf16 with f32 accumulation
  * (dropped terms <= 2^-24 relative).  Results agree with frcnn_gemm_batched_nt / frcnn_conv2d_nhwc to f32 rounding, NOT bit for bit.
  *   frcnn_gemm_x3_pack: W [G][N][K] f32 (device) -> planes [G][3][N][K] bf16 (frcnn_gemm_x3_pack_bytes bytes), once per filter.
@@ -341,11 +342,13 @@ int frcnn_copy_cols(const float* src_d, int R, int ld_src, int col0, int cols, f
  * regenerated from base_d (float64 [A,4]).  Outputs in the reference layouts: labels_d [1,1,A*H,W],
  * bbox_targets_d / inside_w_d / outside_w_d [1,H,W,4A].  seed >= 0: fg/bg subsampling to rpn_batchsize with a
  * counter-based hash (same distribution as npr.choice without replacement, not the same stream);
- * seed < 0: no subsampling (every fg/bg anchor keeps its label) -- the deterministic part, used for parity. */
+ * seed < 0: no subsampling (every fg/bg anchor keeps its label) -- the deterministic part, used for parity.
+ * opts (HOST, may be NULL = the reference's defaults): double[6] = {TRAIN.RPN_CLOBBER_POSITIVES (0 / 1, :57-70), TRAIN.RPN_POSITIVE_WEIGHT
+ * (< 0: uniform 1 / num_examples; 0 < p < 1: p / #positives and (1 - p) / #negatives, :96-109), TRAIN.RPN_BBOX_INSIDE_WEIGHTS[4] (:91-93)}. */
 size_t frcnn_anchor_target_workspace_bytes(int H, int W, int A, int max_gt);
 int frcnn_anchor_target_layer(const float* gt_boxes_d, int G, float im_h, float im_w, int H, int W, int A,
                               int feat_stride, const double* base_d, int rpn_batchsize, double fg_fraction,
-                              double pos_overlap, double neg_overlap, long long seed, float* labels_d,
+                              double pos_overlap, double neg_overlap, long long seed, const double* opts, float* labels_d,
                               float* bbox_targets_d, float* inside_w_d, float* outside_w_d, void* ws,
                               size_t ws_bytes, void* stream);
 /* Host-oracle sampling mode: the reference draws its fg/bg subsamples from numpy's GLOBAL
@@ -355,17 +358,19 @@ int frcnn_anchor_target_layer(const float* gt_boxes_d, int G, float im_h, float 
  * n_disable = 0: nothing is disabled and nothing is sampled. */
 int frcnn_anchor_target_layer_inject(const float* gt_boxes_d, int G, float im_h, float im_w, int H, int W, int A, int feat_stride,
                                      const double* base_d, int rpn_batchsize, double fg_fraction, double pos_overlap,
-                                     double neg_overlap, const int* disable_d, int n_disable, float* labels_d,
+                                     double neg_overlap, const int* disable_d, int n_disable, const double* opts, float* labels_d,
                                      float* bbox_targets_d, float* inside_w_d, float* outside_w_d, void* ws, size_t ws_bytes,
                                      void* stream);
-/* proposal_target_layer (lib/layer_utils/proposal_target_layer.py:18-152, USE_GT False).  rpn_rois_d [N,5],
- * rpn_scores_d [N], N <= 3072.  Outputs: rois_d [B,5], roi_scores_d [B], labels_d [B], bbox_targets_d /
+/* proposal_target_layer (lib/layer_utils/proposal_target_layer.py:18-152).  rpn_rois_d [N,5], rpn_scores_d [N], N (+ G with
+ * TRAIN.USE_GT) <= 3072.  means4 / stds4: HOST double[4] (np.array(cfg.TRAIN.BBOX_NORMALIZE_*), float64 arithmetic like the reference).
+ * opts (HOST, may be NULL = defaults): double[5] = {TRAIN.USE_GT (0 / 1: the G gt boxes join the candidates as rows (0, box), score 0,
+ * :30-36), TRAIN.BBOX_INSIDE_WEIGHTS[4] (:78; outside weight = inside > 0, :53)}.  Outputs: rois_d [B,5], roi_scores_d [B], labels_d [B], bbox_targets_d /
  * inside_w_d / outside_w_d [B,4*num_classes], counts_d[4] = {fg sampled, bg sampled, fg candidates, bg candidates}.
  * fg rows first, then bg rows (np.append(fg_inds, bg_inds), :138). */
 int frcnn_proposal_target_layer(const float* rpn_rois_d, const float* rpn_scores_d, int N, const float* gt_boxes_d,
                                 int G, int num_classes, int batch_size, double fg_fraction, double fg_thresh,
                                 double bg_thresh_hi, double bg_thresh_lo, const double* means4, const double* stds4,
-                                long long seed, float* rois_d, float* roi_scores_d, float* labels_d,
+                                long long seed, const double* opts, float* rois_d, float* roi_scores_d, float* labels_d,
                                 float* bbox_targets_d, float* inside_w_d, float* outside_w_d, int* counts_d,
                                 void* stream);
 /* Same with the valid row count on the device (*num_rois_d = the proposal layer's num output; rows beyond it are ignored):
@@ -373,13 +378,15 @@ int frcnn_proposal_target_layer(const float* rpn_rois_d, const float* rpn_scores
 int frcnn_proposal_target_layer_dn(const float* rpn_rois_d, const float* rpn_scores_d, int max_rois, const int* num_rois_d,
                                    const float* gt_boxes_d, int G, int num_classes, int batch_size, double fg_fraction,
                                    double fg_thresh, double bg_thresh_hi, double bg_thresh_lo, const double* means4,
-                                   const double* stds4, long long seed, float* rois_d, float* roi_scores_d, float* labels_d,
-                                   float* bbox_targets_d, float* inside_w_d, float* outside_w_d, int* counts_d, void* stream);
+                                   const double* stds4, long long seed, const double* opts, float* rois_d, float* roi_scores_d,
+                                   float* labels_d, float* bbox_targets_d, float* inside_w_d, float* outside_w_d, int* counts_d,
+                                   void* stream);
 /* Host-oracle sampling mode: keep_inds_d [batch_size] int32 = np.append(fg_inds, bg_inds) as the caller drew them with
- * npr.choice (proposal_target_layer.py:119-138), the first n_fg rows are foreground; outputs as above, in that row order. */
+ * npr.choice (proposal_target_layer.py:119-138) -- indices into the candidate set (the N proposals, then the gt boxes with
+ * TRAIN.USE_GT) --, the first n_fg rows are foreground; outputs as above, in that row order. */
 int frcnn_proposal_target_layer_inject(const float* rpn_rois_d, const float* rpn_scores_d, int N, const float* gt_boxes_d, int G,
                                        int num_classes, int batch_size, const int* keep_inds_d, int n_fg, const double* means4,
-                                       const double* stds4, float* rois_d, float* roi_scores_d, float* labels_d,
+                                       const double* stds4, const double* opts, float* rois_d, float* roi_scores_d, float* labels_d,
                                        float* bbox_targets_d, float* inside_w_d, float* outside_w_d, void* stream);
 /* Losses of lib/nets/network.py:264-321, value + gradient w.r.t. the logits / predictions in one call.
  * softmax CE: logits [R,C] rows (rpn_A = 0) or the RPN pair layout (rpn_A = A: logits [H*W,2A], element

@@ -412,9 +412,11 @@ def crop_and_resize(feat, rois, feat_stride, pool, max_pool=False):
 
 # ----------------------------------------------------------------------------- training targets
 def anchor_target_layer(rpn_cls_score, gt_boxes, im_info, _feat_stride, all_anchors, num_anchors,
-                        rng=np.random, batchsize=256, fg_fraction=0.5, pos_ov=0.7, neg_ov=0.3):
-    """layer_utils/anchor_target_layer.py:18-138 (CLOBBER False, POSITIVE_WEIGHT -1).  `rng` must
-    expose numpy's legacy `choice` (the reference uses the global numpy.random state)."""
+                        rng=np.random, batchsize=256, fg_fraction=0.5, pos_ov=0.7, neg_ov=0.3, clobber_positives=False,
+                        positive_weight=-1.0, inside_weights=(1.0, 1.0, 1.0, 1.0)):
+    """layer_utils/anchor_target_layer.py:18-138; clobber_positives / positive_weight / inside_weights = TRAIN.RPN_CLOBBER_POSITIVES
+    (:57-70), RPN_POSITIVE_WEIGHT (:96-109), RPN_BBOX_INSIDE_WEIGHTS (:91-93).  `rng` must expose numpy's legacy `choice` (the
+    reference uses the global numpy.random state)."""
     A = num_anchors
     total = all_anchors.shape[0]
     height, width = rpn_cls_score.shape[1:3]
@@ -427,9 +429,12 @@ def anchor_target_layer(rpn_cls_score, gt_boxes, im_info, _feat_stride, all_anch
     maxov = ov[np.arange(len(inds_inside)), argmax]
     gt_max = ov[ov.argmax(axis=0), np.arange(ov.shape[1])]
     gt_argmax = np.where(ov == gt_max)[0]                                                                # :52-55
-    labels[maxov < neg_ov] = 0
+    if not clobber_positives:
+        labels[maxov < neg_ov] = 0
     labels[gt_argmax] = 1
     labels[maxov >= pos_ov] = 1
+    if clobber_positives:
+        labels[maxov < neg_ov] = 0
     num_fg = int(fg_fraction * batchsize)
     fg = np.where(labels == 1)[0]
     if len(fg) > num_fg:
@@ -440,11 +445,16 @@ def anchor_target_layer(rpn_cls_score, gt_boxes, im_info, _feat_stride, all_anch
         labels[rng.choice(bg, size=(len(bg) - num_bg), replace=False)] = -1                              # :81-86
     targets = bbox_transform(anchors, gt_boxes[argmax, :][:, :4]).astype(f32, copy=False)               # :88-89,155-162
     inside_w = np.zeros((len(inds_inside), 4), dtype=f32)
-    inside_w[labels == 1, :] = np.array((1.0, 1.0, 1.0, 1.0))
+    inside_w[labels == 1, :] = np.array(inside_weights)
     outside_w = np.zeros((len(inds_inside), 4), dtype=f32)
-    num_examples = np.sum(labels >= 0)
-    outside_w[labels == 1, :] = np.ones((1, 4)) * 1.0 / num_examples
-    outside_w[labels == 0, :] = np.ones((1, 4)) * 1.0 / num_examples
+    if positive_weight < 0:
+        num_examples = np.sum(labels >= 0)
+        pos_w = neg_w = np.ones((1, 4)) * 1.0 / num_examples
+    else:
+        pos_w = positive_weight / np.sum(labels == 1)
+        neg_w = (1.0 - positive_weight) / np.sum(labels == 0)
+    outside_w[labels == 1, :] = pos_w
+    outside_w[labels == 0, :] = neg_w
 
     def unmap(data, fill):
         if data.ndim == 1:
@@ -463,8 +473,13 @@ def anchor_target_layer(rpn_cls_score, gt_boxes, im_info, _feat_stride, all_anch
 
 def proposal_target_layer(rpn_rois, rpn_scores, gt_boxes, num_classes, rng=np.random, batch_size=256,
                           fg_fraction=0.25, fg_thresh=0.5, bg_hi=0.5, bg_lo=0.0,
-                          means=(0.0, 0.0, 0.0, 0.0), stds=(0.1, 0.1, 0.2, 0.2)):
-    """layer_utils/proposal_target_layer.py:18-152 (USE_GT False, IMS_PER_BATCH 1)."""
+                          means=(0.0, 0.0, 0.0, 0.0), stds=(0.1, 0.1, 0.2, 0.2), use_gt=False, inside_weights=(1.0, 1.0, 1.0, 1.0)):
+    """layer_utils/proposal_target_layer.py:18-152 (IMS_PER_BATCH 1); use_gt = TRAIN.USE_GT (:30-36), inside_weights =
+    TRAIN.BBOX_INSIDE_WEIGHTS (:78)."""
+    if use_gt:
+        zeros = np.zeros((gt_boxes.shape[0], 1), dtype=gt_boxes.dtype)
+        rpn_rois = np.vstack((rpn_rois, np.hstack((zeros, gt_boxes[:, :-1]))))
+        rpn_scores = np.vstack((rpn_scores, zeros))
     rois_per_image = batch_size
     fg_per_image = int(np.round(fg_fraction * rois_per_image))
     ov = bbox_overlaps(rpn_rois[:, 1:5], gt_boxes[:, :4])
@@ -499,7 +514,7 @@ def proposal_target_layer(rpn_rois, rpn_scores, gt_boxes, num_classes, rng=np.ra
     for i in np.where(labels > 0)[0]:                                                                    # :58-80
         c = int(4 * labels[i])
         bbox_targets[i, c:c + 4] = data[i, 1:]
-        inside[i, c:c + 4] = (1.0, 1.0, 1.0, 1.0)
+        inside[i, c:c + 4] = inside_weights
     rois = rois.reshape(-1, 5)
     roi_scores = roi_scores.reshape(-1)
     labels = labels.reshape(-1, 1)

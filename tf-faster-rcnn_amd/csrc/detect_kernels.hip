@@ -1115,9 +1115,12 @@ __global__ void k_im_detect_boxes(const float* __restrict__ rois, const float* _
   const float* ro = rois + 5 * (size_t)r;
   const float4 box = make_float4((float)((double)ro[1] / im_scale), (float)((double)ro[2] / im_scale),
                                  (float)((double)ro[3] / im_scale), (float)((double)ro[4] / im_scale));
-  float4 b = decode_box(box, ((const float4*)bbox_pred)[t]);
-  b.x = rmax(b.x, 0.0f); b.y = rmax(b.y, 0.0f);
-  b.z = rmin(b.z, hi_x); b.w = rmin(b.w, hi_y);
+  float4 b = box;                                                          // TEST.BBOX_REG False (test.py:103-105): np.tile(boxes), no clip
+  if (bbox_pred) {
+    b = decode_box(box, ((const float4*)bbox_pred)[t]);
+    b.x = rmax(b.x, 0.0f); b.y = rmax(b.y, 0.0f);
+    b.z = rmin(b.z, hi_x); b.w = rmin(b.w, hi_y);
+  }
   out[t] = b;
 }
 
@@ -1125,7 +1128,7 @@ extern "C" int frcnn_im_detect_boxes(const float* rois_d, const float* bbox_pred
                                      int im_w, float* boxes_d, void* stream) {
   if (R < 0 || C <= 0 || !(im_scale > 0)) return FRCNN_E_ARG;
   if (R == 0) return FRCNN_OK;
-  if (!rois_d || !bbox_pred_d || !boxes_d) return FRCNN_E_ARG;
+  if (!rois_d || !boxes_d) return FRCNN_E_ARG;          // bbox_pred_d NULL: cfg.TEST.BBOX_REG False
   hipLaunchKernelGGL(k_im_detect_boxes, dim3(cdiv(R * C, 256)), dim3(256), 0, (hipStream_t)stream, rois_d, bbox_pred_d, R, C,
                      im_scale, (float)(im_w - 1), (float)(im_h - 1), (float4*)boxes_d);
   LAUNCH_CHECK();
@@ -1175,10 +1178,13 @@ __global__ __launch_bounds__(PC_THREADS) void k_perclass_nms(const float* __rest
       const float* ro = rois + 5 * (size_t)r;
       const float4 box = make_float4((float)((double)ro[1] / im_scale), (float)((double)ro[2] / im_scale),
                                      (float)((double)ro[3] / im_scale), (float)((double)ro[4] / im_scale));  // test.py:95
-      const float4 d = *(const float4*)(bbox_pred + (size_t)r * 4 * C + 4 * j);
-      b = decode_box(box, d);                                                              // test.py:101
-      b.x = rmax(b.x, 0.0f); b.y = rmax(b.y, 0.0f);                                        // test.py:67-77
-      b.z = rmin(b.z, hi_x); b.w = rmin(b.w, hi_y);
+      b = box;                                                                             // TEST.BBOX_REG False: test.py:103-105
+      if (bbox_pred_all) {
+        const float4 d = *(const float4*)(bbox_pred + (size_t)r * 4 * C + 4 * j);
+        b = decode_box(box, d);                                                            // test.py:101
+        b.x = rmax(b.x, 0.0f); b.y = rmax(b.y, 0.0f);                                      // test.py:67-77
+        b.z = rmin(b.z, hi_x); b.w = rmin(b.w, hi_y);
+      }
       atomicAdd(&nvalid_s, 1);
     }
     boxes[r] = b;
@@ -1317,7 +1323,7 @@ extern "C" int frcnn_detect_post_batched(const float* cls_prob_d, const float* b
                                          double nms_thresh, int rule, float score_thresh, int max_per_image, float* out_dets_d,
                                          int* out_count_d, int max_out, long long out_stride, void* ws, size_t ws_bytes,
                                          void* stream) {
-  if (!cls_prob_d || !bbox_pred_d || !rois_d || !out_dets_d || !out_count_d || !ws) return FRCNN_E_ARG;
+  if (!cls_prob_d || !rois_d || !out_dets_d || !out_count_d || !ws) return FRCNN_E_ARG;          // bbox_pred_d NULL: TEST.BBOX_REG False
   if (B <= 0 || R <= 0 || C < 2 || max_out <= 0 || !(im_scale > 0) || !rule_ok(rule)) return FRCNN_E_ARG;
   if (out_stride == 0) out_stride = (long long)max_out * 6;
   if (out_stride < (long long)max_out * 6) return FRCNN_E_ARG;

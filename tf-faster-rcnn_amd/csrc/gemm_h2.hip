@@ -20,6 +20,9 @@
 // block takes C = 0) and folded into the running f32 sum with ONE fma per element by the block's exact scale -- 128 VALU per 96 MFMAs
 // per wave, instead of the 176 per 48 of the in-register bf16 split of gemm_x3.
 //
+// Domain: finite operands.  An inf / nan element makes its block's scale tiny and its own pieces inf / nan (l = inf - inf = nan): the
+// output rows that read the block come out nan, where an f32 kernel would return +-inf for a plain overflow (both mean overflow).
+//
 // Orientation.  The MFMA computes D = Wfrag x Xfrag^T: accumulator lane l holds output ROW m = l & 31 (+ sub-tile), registers walk
 // the columns n = 8 (r >> 2) + 4 (l >> 5) + (r & 3).  The activation scale is then ONE value per lane, residual / result / planes move
 // as 16- / 8-byte accesses of 4 consecutive n, and the row maximum for the output planes is a per-lane reduction over registers.

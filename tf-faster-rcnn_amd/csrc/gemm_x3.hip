@@ -5,10 +5,12 @@
 // v_mfma_f32_32x32x16_bf16 with f32 accumulation; the three dropped terms are <= 2^-24 |a*w|, the size of ONE f32 rounding of the product.
 // The leading term and the five small terms go to separate accumulators.  Six bf16 MFMAs (8 passes, 16 k) replace eight f32 MFMAs
 // (16 passes, 2 k each): 192 instead of 512 matrix-pipe cycles per 16 k.  NOT the f32 MFMA: results agree with k_conv_igemm to
-// f32 rounding, not bit for bit -- opt-in (cfg.HIP.MFMA_X3 / bench.py --mfma x3), labelled wherever a number is reported.
+// f32 rounding, not bit for bit -- cfg.HIP.MFMA_X3 (default on, TEST mode; bench.py --mfma x3 / f32), labelled wherever a number is reported.
+// Domain: finite operands below the bf16 maximum (3.39e38).  x = +-inf or |x| >= 2^128 - 2^119 gives h = +-inf and x - h = NaN: where the
+// f32 MFMA would return +-inf for an overflowing activation, this kernel returns NaN for the whole output row (both mean overflow).
 //
-// Compared with csrc/conv_igemm_b3.hip (round 1: both operands staged through registers, split once, three planes in LDS --
-// LDS-read bound with single-tile waves, one slab of prefetch):
+// Compared with round 1's experiment (both operands staged through registers, split once, three planes in LDS -- LDS-read bound with
+// single-tile waves, one slab of prefetch; removed in round 3):
 //   * W is static: it is split ONCE on the device into three bf16 planes [3][N][K] (frcnn_gemm_x3_pack) and travels HBM/L2 -> LDS
 //     by direct-to-LDS loads like an f32 slab -- no VALU work, no registers;
 //   * A stays f32 in HBM and in LDS (direct-to-LDS slab ring of k_conv_igemm unchanged); each wave splits the fragments it has

@@ -91,20 +91,21 @@ __global__ void k_at_overlaps(const double* __restrict__ base, int A, int W, int
 // pass 2: labels before sampling (:57-66) + sampling keys
 __global__ void k_at_labels(const double* __restrict__ base, int A, int W, int stride, int N, const float* __restrict__ gt,
                             int G, const double* __restrict__ maxov, const u64* __restrict__ gtmax, double neg_ov,
-                            double pos_ov, u64 seed, u64* __restrict__ fgkey, u64* __restrict__ bgkey,
+                            double pos_ov, int clobber, u64 seed, u64* __restrict__ fgkey, u64* __restrict__ bgkey,
                             u32* __restrict__ fgrank, u32* __restrict__ bgrank, int* __restrict__ counts) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   int label = -1;
   const double mo = maxov[n];
   if (mo >= 0.0) {                                   // inside the image
-    if (mo < neg_ov) label = 0;                      // negatives first (RPN_CLOBBER_POSITIVES False)
+    if (!clobber && mo < neg_ov) label = 0;          // :57-60 negatives first, so that positives can clobber them
     const float4 an = anchor_f32(base, n, A, W, stride);
     bool is_gt_argmax = false;                       // `overlaps == gt_max_overlaps` (:55): ALL ties, zeros included
     for (int g = 0; g < G; ++g)
       is_gt_argmax = is_gt_argmax || ((u64)__double_as_longlong(iou_f64(an, gt + 5 * (size_t)g)) == gtmax[g]);
     if (is_gt_argmax) label = 1;
     if (mo >= pos_ov) label = 1;
+    if (clobber && mo < neg_ov) label = 0;           // :68-70 TRAIN.RPN_CLOBBER_POSITIVES: negatives last, they clobber positives
   }
   fgkey[n] = (label == 1) ? hash_key(seed, (u32)n) : ~0ull;
   bgkey[n] = (label == 0) ? hash_key(seed ^ 0xA5A5A5A5DEADBEEFull, (u32)n) : ~0ull;
@@ -128,8 +129,8 @@ __global__ __launch_bounds__(256) void k_key_rank(const u64* __restrict__ keys, 
 __global__ void k_at_finish(const double* __restrict__ base, int A, int H, int W, int stride, int N,
                             const float* __restrict__ gt, const int* __restrict__ argmax, const u64* __restrict__ fgkey,
                             const u64* __restrict__ bgkey, const u32* __restrict__ fgrank, const u32* __restrict__ bgrank,
-                            const int* __restrict__ counts, int batchsize, int num_fg, int do_sample,
-                            float* __restrict__ labels, float4* __restrict__ targets, float4* __restrict__ inside_w,
+                            const int* __restrict__ counts, int batchsize, int num_fg, int do_sample, double pos_weight,
+                            float4 inside_v, float* __restrict__ labels, float4* __restrict__ targets, float4* __restrict__ inside_w,
                             float4* __restrict__ outside_w) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
@@ -145,10 +146,13 @@ __global__ void k_at_finish(const double* __restrict__ base, int A, int H, int W
   const int am = argmax[n];
   if (am >= 0) {                                                         // inside anchors get targets (:88-89)
     t = encode_box(anchor_f32(base, n, A, W, stride), gt + 5 * (size_t)am);
-    if (label == 1.0f) iw = make_float4(1.f, 1.f, 1.f, 1.f);             // :91-93
-    if (label >= 0.0f) {                                                 // uniform 1/num_examples (:96-109)
-      const float v = (float)(1.0 / (double)(fg_keep + bg_keep));
-      ow = make_float4(v, v, v, v);
+    if (label == 1.0f) iw = inside_v;                                    // :91-93 TRAIN.RPN_BBOX_INSIDE_WEIGHTS
+    if (label >= 0.0f) {
+      // :96-109.  RPN_POSITIVE_WEIGHT < 0: uniform 1 / num_examples; else p / #positives for the positives and (1 - p) / #negatives
+      // for the negatives (counts AFTER the subsampling), float64 quotients stored as float32 like the reference's array assignment
+      double v = 1.0 / (double)(fg_keep + bg_keep);
+      if (pos_weight >= 0.0) v = label == 1.0f ? pos_weight / (double)fg_keep : (1.0 - pos_weight) / (double)bg_keep;
+      ow = make_float4((float)v, (float)v, (float)v, (float)v);
     }
   }
   targets[n] = t; inside_w[n] = iw; outside_w[n] = ow;                   // (1,H,W,4A): index n*4 (:123-135)
@@ -185,11 +189,16 @@ static int launch_key_rank(const u64* keys, int N, u32* rank, hipStream_t st) {
 
 static int anchor_target_impl(const float* gt_boxes_d, int G, float im_h, float im_w, int H, int W, int A, int feat_stride,
                               const double* base_d, int rpn_batchsize, double fg_fraction, double pos_overlap,
-                              double neg_overlap, long long seed, const int* disable_d, int n_disable, float* labels_d,
-                              float* bbox_targets_d, float* inside_w_d, float* outside_w_d, void* ws, size_t ws_bytes,
-                              void* stream) {
+                              double neg_overlap, long long seed, const int* disable_d, int n_disable, const double* opts,
+                              float* labels_d, float* bbox_targets_d, float* inside_w_d, float* outside_w_d, void* ws,
+                              size_t ws_bytes, void* stream) {
   if (!gt_boxes_d || !base_d || !labels_d || !bbox_targets_d || !inside_w_d || !outside_w_d || !ws) return FRCNN_E_ARG;
   if (G <= 0 || H <= 0 || W <= 0 || A <= 0 || rpn_batchsize <= 0 || n_disable < 0 || (n_disable > 0 && !disable_d)) return FRCNN_E_ARG;
+  // opts (host, may be null = the reference defaults): {TRAIN.RPN_CLOBBER_POSITIVES, TRAIN.RPN_POSITIVE_WEIGHT, RPN_BBOX_INSIDE_WEIGHTS[4]}
+  const int clobber = opts ? (opts[0] != 0.0) : 0;
+  const double pos_weight = opts ? opts[1] : -1.0;
+  if (pos_weight >= 0.0 && !(pos_weight > 0.0 && pos_weight < 1.0)) return FRCNN_E_ARG;          // the reference asserts 0 < p < 1 (:103-104)
+  const float4 inside_v = opts ? make_float4((float)opts[2], (float)opts[3], (float)opts[4], (float)opts[5]) : make_float4(1.f, 1.f, 1.f, 1.f);
   const int N = H * W * A;
   AtWs s = at_carve(ws, N, G);
   if (s.bytes > ws_bytes) return FRCNN_E_WS;
@@ -201,7 +210,7 @@ static int anchor_target_impl(const float* gt_boxes_d, int G, float im_h, float 
                      s.maxov, s.argmax, s.gtmax);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(k_at_labels, dim3(nb), dim3(256), 0, st, base_d, A, W, feat_stride, N, gt_boxes_d, G, s.maxov, s.gtmax,
-                     neg_overlap, pos_overlap, (u64)seed, s.fgkey, s.bgkey, s.fgrank, s.bgrank, s.counts);
+                     neg_overlap, pos_overlap, clobber, (u64)seed, s.fgkey, s.bgkey, s.fgrank, s.bgrank, s.counts);
   LAUNCH_CHECK();
   const int do_sample = (seed >= 0 && !disable_d) ? 1 : 0;
   if (do_sample) {
@@ -215,29 +224,29 @@ static int anchor_target_impl(const float* gt_boxes_d, int G, float im_h, float 
     LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(k_at_finish, dim3(nb), dim3(256), 0, st, base_d, A, H, W, feat_stride, N, gt_boxes_d, s.argmax, s.fgkey,
-                     s.bgkey, s.fgrank, s.bgrank, s.counts, rpn_batchsize, (int)(fg_fraction * rpn_batchsize), do_sample,
-                     labels_d, (float4*)bbox_targets_d, (float4*)inside_w_d, (float4*)outside_w_d);
+                     s.bgkey, s.fgrank, s.bgrank, s.counts, rpn_batchsize, (int)(fg_fraction * rpn_batchsize), do_sample, pos_weight,
+                     inside_v, labels_d, (float4*)bbox_targets_d, (float4*)inside_w_d, (float4*)outside_w_d);
   LAUNCH_CHECK();
   return FRCNN_OK;
 }
 
 extern "C" int frcnn_anchor_target_layer(const float* gt_boxes_d, int G, float im_h, float im_w, int H, int W, int A,
                                          int feat_stride, const double* base_d, int rpn_batchsize, double fg_fraction,
-                                         double pos_overlap, double neg_overlap, long long seed, float* labels_d,
+                                         double pos_overlap, double neg_overlap, long long seed, const double* opts, float* labels_d,
                                          float* bbox_targets_d, float* inside_w_d, float* outside_w_d, void* ws,
                                          size_t ws_bytes, void* stream) {
   return anchor_target_impl(gt_boxes_d, G, im_h, im_w, H, W, A, feat_stride, base_d, rpn_batchsize, fg_fraction, pos_overlap,
-                            neg_overlap, seed, nullptr, 0, labels_d, bbox_targets_d, inside_w_d, outside_w_d, ws, ws_bytes, stream);
+                            neg_overlap, seed, nullptr, 0, opts, labels_d, bbox_targets_d, inside_w_d, outside_w_d, ws, ws_bytes, stream);
 }
 
 extern "C" int frcnn_anchor_target_layer_inject(const float* gt_boxes_d, int G, float im_h, float im_w, int H, int W, int A,
                                                 int feat_stride, const double* base_d, int rpn_batchsize, double fg_fraction,
                                                 double pos_overlap, double neg_overlap, const int* disable_d, int n_disable,
-                                                float* labels_d, float* bbox_targets_d, float* inside_w_d, float* outside_w_d,
-                                                void* ws, size_t ws_bytes, void* stream) {
+                                                const double* opts, float* labels_d, float* bbox_targets_d, float* inside_w_d,
+                                                float* outside_w_d, void* ws, size_t ws_bytes, void* stream) {
   static const int none = 0;      // n_disable == 0 still means "no device sampling": pass a non-null list
   return anchor_target_impl(gt_boxes_d, G, im_h, im_w, H, W, A, feat_stride, base_d, rpn_batchsize, fg_fraction, pos_overlap,
-                            neg_overlap, -1, n_disable > 0 ? disable_d : &none, n_disable, labels_d, bbox_targets_d, inside_w_d,
+                            neg_overlap, -1, n_disable > 0 ? disable_d : &none, n_disable, opts, labels_d, bbox_targets_d, inside_w_d,
                             outside_w_d, ws, ws_bytes, stream);
 }
 
@@ -245,11 +254,24 @@ extern "C" int frcnn_anchor_target_layer_inject(const float* gt_boxes_d, int G, 
 // proposal_target_layer (layer_utils/proposal_target_layer.py:18-152), one workgroup (N <= 4096 rois)
 // ------------------------------------------------------------------------------------------------
 #define PT_MAXN 3072
+// The candidate set of _sample_rois: the N proposal rows and, with TRAIN.USE_GT (:30-36), the G ground-truth boxes appended as
+// rows (0, x1, y1, x2, y2) with score 0.
+struct PtCand {
+  const float* rois; const float* scores; const float* gt; int N, G, use_gt;
+  __device__ __forceinline__ int count() const { return N + (use_gt ? G : 0); }
+  __device__ __forceinline__ float4 box(int i) const {
+    const float* r = i < N ? rois + 5 * (size_t)i + 1 : gt + 5 * (size_t)(i - N);
+    return make_float4(r[0], r[1], r[2], r[3]);
+  }
+  __device__ __forceinline__ float image(int i) const { return i < N ? rois[5 * (size_t)i] : 0.f; }
+  __device__ __forceinline__ float score(int i) const { return i < N ? scores[i] : 0.f; }
+};
+struct PtNorm { double mean[4], std[4]; float inside[4]; };     // TRAIN.BBOX_NORMALIZE_MEANS / _STDS (float64 like np.array(cfg...)), BBOX_INSIDE_WEIGHTS
+
 // one output row of _sample_rois (:137-152): the sampled roi, its score, label (bg rows clamped to 0, :142), class-expanded
-// normalised regression targets and weights (:58-96)
-__device__ __forceinline__ void pt_emit_row(int s, int src, bool is_fg, int assigned, const float* __restrict__ rois,
-                                            const float* __restrict__ scores, const float* __restrict__ gt, int C, float4 means,
-                                            float4 stds, float* __restrict__ out_rois, float* __restrict__ out_scores,
+// normalised regression targets and weights (:58-96; outside = inside > 0, :53)
+__device__ __forceinline__ void pt_emit_row(int s, int src, bool is_fg, int assigned, const PtCand& cand, int C, const PtNorm& nm,
+                                            float* __restrict__ out_rois, float* __restrict__ out_scores,
                                             float* __restrict__ out_labels, float* __restrict__ out_targets,
                                             float* __restrict__ out_inside, float* __restrict__ out_outside) {
   float* orow = out_rois + 5 * (size_t)s;
@@ -258,26 +280,26 @@ __device__ __forceinline__ void pt_emit_row(int s, int src, bool is_fg, int assi
   float* urow = out_outside + (size_t)s * 4 * C;
   for (int c = 0; c < 4 * C; ++c) { trow[c] = 0.f; irow[c] = 0.f; urow[c] = 0.f; }
   if (src < 0) { orow[0] = orow[1] = orow[2] = orow[3] = orow[4] = 0.f; out_scores[s] = 0.f; out_labels[s] = 0.f; return; }
-  const float* r = rois + 5 * (size_t)src;
-  orow[0] = r[0]; orow[1] = r[1]; orow[2] = r[2]; orow[3] = r[3]; orow[4] = r[4];
-  out_scores[s] = scores[src];
-  const float* g = gt + 5 * (size_t)assigned;
+  const float4 b = cand.box(src);
+  orow[0] = cand.image(src); orow[1] = b.x; orow[2] = b.y; orow[3] = b.z; orow[4] = b.w;
+  out_scores[s] = cand.score(src);
+  const float* g = cand.gt + 5 * (size_t)assigned;
   const float label = is_fg ? g[4] : 0.0f;                         // bg labels clamped to 0 (:142)
   out_labels[s] = label;
   if (label > 0.f) {                                               // :58-80, targets :83-96
-    const float4 t = encode_box(make_float4(r[1], r[2], r[3], r[4]), g);
+    const float4 t = encode_box(b, g);
+    const float tv[4] = {t.x, t.y, t.z, t.w};
     const int c4 = 4 * (int)label;
-    trow[c4 + 0] = (float)(((double)t.x - (double)means.x) / (double)stds.x);
-    trow[c4 + 1] = (float)(((double)t.y - (double)means.y) / (double)stds.y);
-    trow[c4 + 2] = (float)(((double)t.z - (double)means.z) / (double)stds.z);
-    trow[c4 + 3] = (float)(((double)t.w - (double)means.w) / (double)stds.w);
-    for (int q = 0; q < 4; ++q) { irow[c4 + q] = 1.f; urow[c4 + q] = 1.f; }
+    for (int q = 0; q < 4; ++q) {
+      trow[c4 + q] = (float)(((double)tv[q] - nm.mean[q]) / nm.std[q]);
+      irow[c4 + q] = nm.inside[q];
+      urow[c4 + q] = nm.inside[q] > 0.f ? 1.f : 0.f;
+    }
   }
 }
-__global__ __launch_bounds__(1024) void k_proposal_target(const float* __restrict__ rois, const float* __restrict__ scores,
-                                                          int Nmax, const int* __restrict__ num_d, const float* __restrict__ gt, int G, int C, int batch,
+__global__ __launch_bounds__(1024) void k_proposal_target(const PtCand cand, int Nmax, const int* __restrict__ num_d, int C, int batch,
                                                           int fg_per_image, double fg_thresh, double bg_hi, double bg_lo,
-                                                          u64 seed, float4 means, float4 stds, float* __restrict__ out_rois,
+                                                          u64 seed, const PtNorm nm, float* __restrict__ out_rois,
                                                           float* __restrict__ out_scores, float* __restrict__ out_labels,
                                                           float* __restrict__ out_targets, float* __restrict__ out_inside,
                                                           float* __restrict__ out_outside, int* __restrict__ out_counts) {
@@ -287,12 +309,14 @@ __global__ __launch_bounds__(1024) void k_proposal_target(const float* __restric
   __shared__ short fg_list[PT_MAXN], bg_list[PT_MAXN];   // candidates in random (key) order
   __shared__ int nfg_s, nbg_s;
   const int tid = threadIdx.x;
-  const int N = num_d ? max(0, min(*num_d, Nmax)) : Nmax;      // device-resident proposal count: no host round trip
+  PtCand cd = cand;
+  cd.N = num_d ? max(0, min(*num_d, Nmax)) : Nmax;             // device-resident proposal count: no host round trip
+  const int N = cd.count(), G = cd.G;
+  const float* gt = cd.gt;
   if (tid == 0) { nfg_s = 0; nbg_s = 0; }
   __syncthreads();
   for (int i = tid; i < N; i += 1024) {
-    const float* r = rois + 5 * (size_t)i;
-    const float4 b = make_float4(r[1], r[2], r[3], r[4]);
+    const float4 b = cd.box(i);
     double best = -1.0; int bi = 0;
     for (int g = 0; g < G; ++g) {
       const double o = iou_f64(b, gt + 5 * (size_t)g);
@@ -329,54 +353,58 @@ __global__ __launch_bounds__(1024) void k_proposal_target(const float* __restric
       const int t = s - n_fg_out;
       src = bg_list[bg_repl ? (int)((u32)(hash_key(seed ^ 0x7654321ull, (u32)s) >> 32) % (u32)nbg) : t];
     }
-    pt_emit_row(s, src, is_fg, src >= 0 ? (int)assign[src] : 0, rois, scores, gt, C, means, stds, out_rois, out_scores, out_labels,
-                out_targets, out_inside, out_outside);
+    pt_emit_row(s, src, is_fg, src >= 0 ? (int)assign[src] : 0, cd, C, nm, out_rois, out_scores, out_labels, out_targets, out_inside,
+                out_outside);
   }
 }
 
 // host-oracle sampling mode: keep_inds [batch] = np.append(fg_inds, bg_inds) as drawn by the caller from numpy's global
-// stream (proposal_target_layer.py:119-138); the first n_fg rows are foreground.  gt assignment (argmax IoU, f64) is
-// recomputed here for the selected rows.
-__global__ __launch_bounds__(256) void k_proposal_target_inject(const float* __restrict__ rois, const float* __restrict__ scores, int N,
-                                                                const float* __restrict__ gt, int G, int C, int batch,
-                                                                const int* __restrict__ keep_inds, int n_fg, float4 means, float4 stds,
-                                                                float* __restrict__ out_rois, float* __restrict__ out_scores,
-                                                                float* __restrict__ out_labels, float* __restrict__ out_targets,
-                                                                float* __restrict__ out_inside, float* __restrict__ out_outside) {
+// stream (proposal_target_layer.py:119-138), indices into the candidate set (proposals, then the gt boxes with TRAIN.USE_GT); the
+// first n_fg rows are foreground.  gt assignment (argmax IoU, f64) is recomputed here for the selected rows.
+__global__ __launch_bounds__(256) void k_proposal_target_inject(const PtCand cand, int C, int batch, const int* __restrict__ keep_inds,
+                                                                int n_fg, const PtNorm nm, float* __restrict__ out_rois,
+                                                                float* __restrict__ out_scores, float* __restrict__ out_labels,
+                                                                float* __restrict__ out_targets, float* __restrict__ out_inside,
+                                                                float* __restrict__ out_outside) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= batch) return;
   int src = keep_inds[s];
-  if (src < 0 || src >= N) src = -1;
+  if (src < 0 || src >= cand.count()) src = -1;
   int bi = 0;
   if (src >= 0) {
-    const float* r = rois + 5 * (size_t)src;
-    const float4 b = make_float4(r[1], r[2], r[3], r[4]);
+    const float4 b = cand.box(src);
     double best = -1.0;
-    for (int g = 0; g < G; ++g) {
-      const double o = iou_f64(b, gt + 5 * (size_t)g);
+    for (int g = 0; g < cand.G; ++g) {
+      const double o = iou_f64(b, cand.gt + 5 * (size_t)g);
       if (o > best) { best = o; bi = g; }
     }
   }
-  pt_emit_row(s, src, s < n_fg, bi, rois, scores, gt, C, means, stds, out_rois, out_scores, out_labels, out_targets, out_inside,
-              out_outside);
+  pt_emit_row(s, src, s < n_fg, bi, cand, C, nm, out_rois, out_scores, out_labels, out_targets, out_inside, out_outside);
+}
+
+// opts (host, may be null = the reference defaults): {TRAIN.USE_GT, TRAIN.BBOX_INSIDE_WEIGHTS[4]}
+static PtNorm pt_norm(const double* means4, const double* stds4, const double* opts) {
+  PtNorm nm;
+  for (int q = 0; q < 4; ++q) { nm.mean[q] = means4[q]; nm.std[q] = stds4[q]; nm.inside[q] = opts ? (float)opts[1 + q] : 1.f; }
+  return nm;
 }
 
 static int proposal_target_impl(const float* rpn_rois_d, const float* rpn_scores_d, int N, const int* num_d, const float* gt_boxes_d,
                                 int G, int num_classes, int batch_size, double fg_fraction, double fg_thresh,
                                 double bg_thresh_hi, double bg_thresh_lo, const double* means4, const double* stds4,
-                                long long seed, float* rois_d, float* roi_scores_d, float* labels_d,
+                                long long seed, const double* opts, float* rois_d, float* roi_scores_d, float* labels_d,
                                 float* bbox_targets_d, float* inside_w_d, float* outside_w_d, int* counts_d,
                                 void* stream) {
   if (!rpn_rois_d || !rpn_scores_d || !gt_boxes_d || !means4 || !stds4 || !rois_d || !roi_scores_d || !labels_d ||
       !bbox_targets_d || !inside_w_d || !outside_w_d || !counts_d)
     return FRCNN_E_ARG;
   if (N <= 0 || G <= 0 || num_classes < 2 || batch_size <= 0) return FRCNN_E_ARG;
-  if (N > PT_MAXN || G > 32767) return FRCNN_E_UNSUPPORTED;
+  const int use_gt = opts ? (opts[0] != 0.0) : 0;
+  if (N + (use_gt ? G : 0) > PT_MAXN || G > 32767) return FRCNN_E_UNSUPPORTED;
   const int fg_per_image = (int)nearbyint(fg_fraction * batch_size);     // np.round (:40)
-  hipLaunchKernelGGL(k_proposal_target, dim3(1), dim3(1024), 0, (hipStream_t)stream, rpn_rois_d, rpn_scores_d, N, num_d, gt_boxes_d,
-                     G, num_classes, batch_size, fg_per_image, fg_thresh, bg_thresh_hi, bg_thresh_lo, (u64)seed,
-                     make_float4((float)means4[0], (float)means4[1], (float)means4[2], (float)means4[3]),
-                     make_float4((float)stds4[0], (float)stds4[1], (float)stds4[2], (float)stds4[3]), rois_d, roi_scores_d,
+  const PtCand cand{rpn_rois_d, rpn_scores_d, gt_boxes_d, N, G, use_gt};
+  hipLaunchKernelGGL(k_proposal_target, dim3(1), dim3(1024), 0, (hipStream_t)stream, cand, N, num_d, num_classes, batch_size,
+                     fg_per_image, fg_thresh, bg_thresh_hi, bg_thresh_lo, (u64)seed, pt_norm(means4, stds4, opts), rois_d, roi_scores_d,
                      labels_d, bbox_targets_d, inside_w_d, outside_w_d, counts_d);
   LAUNCH_CHECK();
   return FRCNN_OK;
@@ -385,11 +413,11 @@ static int proposal_target_impl(const float* rpn_rois_d, const float* rpn_scores
 extern "C" int frcnn_proposal_target_layer(const float* rpn_rois_d, const float* rpn_scores_d, int N, const float* gt_boxes_d,
                                            int G, int num_classes, int batch_size, double fg_fraction, double fg_thresh,
                                            double bg_thresh_hi, double bg_thresh_lo, const double* means4, const double* stds4,
-                                           long long seed, float* rois_d, float* roi_scores_d, float* labels_d,
+                                           long long seed, const double* opts, float* rois_d, float* roi_scores_d, float* labels_d,
                                            float* bbox_targets_d, float* inside_w_d, float* outside_w_d, int* counts_d,
                                            void* stream) {
   return proposal_target_impl(rpn_rois_d, rpn_scores_d, N, nullptr, gt_boxes_d, G, num_classes, batch_size, fg_fraction, fg_thresh,
-                              bg_thresh_hi, bg_thresh_lo, means4, stds4, seed, rois_d, roi_scores_d, labels_d, bbox_targets_d,
+                              bg_thresh_hi, bg_thresh_lo, means4, stds4, seed, opts, rois_d, roi_scores_d, labels_d, bbox_targets_d,
                               inside_w_d, outside_w_d, counts_d, stream);
 }
 
@@ -398,29 +426,28 @@ extern "C" int frcnn_proposal_target_layer(const float* rpn_rois_d, const float*
 extern "C" int frcnn_proposal_target_layer_dn(const float* rpn_rois_d, const float* rpn_scores_d, int max_rois, const int* num_rois_d,
                                               const float* gt_boxes_d, int G, int num_classes, int batch_size, double fg_fraction,
                                               double fg_thresh, double bg_thresh_hi, double bg_thresh_lo, const double* means4,
-                                              const double* stds4, long long seed, float* rois_d, float* roi_scores_d,
+                                              const double* stds4, long long seed, const double* opts, float* rois_d, float* roi_scores_d,
                                               float* labels_d, float* bbox_targets_d, float* inside_w_d, float* outside_w_d,
                                               int* counts_d, void* stream) {
   if (!num_rois_d) return FRCNN_E_ARG;
   return proposal_target_impl(rpn_rois_d, rpn_scores_d, max_rois, num_rois_d, gt_boxes_d, G, num_classes, batch_size, fg_fraction,
-                              fg_thresh, bg_thresh_hi, bg_thresh_lo, means4, stds4, seed, rois_d, roi_scores_d, labels_d,
+                              fg_thresh, bg_thresh_hi, bg_thresh_lo, means4, stds4, seed, opts, rois_d, roi_scores_d, labels_d,
                               bbox_targets_d, inside_w_d, outside_w_d, counts_d, stream);
 }
 
 extern "C" int frcnn_proposal_target_layer_inject(const float* rpn_rois_d, const float* rpn_scores_d, int N, const float* gt_boxes_d,
                                                   int G, int num_classes, int batch_size, const int* keep_inds_d, int n_fg,
-                                                  const double* means4, const double* stds4, float* rois_d, float* roi_scores_d,
-                                                  float* labels_d, float* bbox_targets_d, float* inside_w_d, float* outside_w_d,
-                                                  void* stream) {
+                                                  const double* means4, const double* stds4, const double* opts, float* rois_d,
+                                                  float* roi_scores_d, float* labels_d, float* bbox_targets_d, float* inside_w_d,
+                                                  float* outside_w_d, void* stream) {
   if (!rpn_rois_d || !rpn_scores_d || !gt_boxes_d || !means4 || !stds4 || !rois_d || !roi_scores_d || !labels_d ||
       !bbox_targets_d || !inside_w_d || !outside_w_d || !keep_inds_d)
     return FRCNN_E_ARG;
   if (N <= 0 || G <= 0 || num_classes < 2 || batch_size <= 0 || n_fg < 0 || n_fg > batch_size) return FRCNN_E_ARG;
-  hipLaunchKernelGGL(k_proposal_target_inject, dim3(cdiv(batch_size, 256)), dim3(256), 0, (hipStream_t)stream, rpn_rois_d,
-                     rpn_scores_d, N, gt_boxes_d, G, num_classes, batch_size, keep_inds_d, n_fg,
-                     make_float4((float)means4[0], (float)means4[1], (float)means4[2], (float)means4[3]),
-                     make_float4((float)stds4[0], (float)stds4[1], (float)stds4[2], (float)stds4[3]), rois_d, roi_scores_d,
-                     labels_d, bbox_targets_d, inside_w_d, outside_w_d);
+  const PtCand cand{rpn_rois_d, rpn_scores_d, gt_boxes_d, N, G, opts ? (opts[0] != 0.0) : 0};
+  hipLaunchKernelGGL(k_proposal_target_inject, dim3(cdiv(batch_size, 256)), dim3(256), 0, (hipStream_t)stream, cand, num_classes,
+                     batch_size, keep_inds_d, n_fg, pt_norm(means4, stds4, opts), rois_d, roi_scores_d, labels_d, bbox_targets_d,
+                     inside_w_d, outside_w_d);
   LAUNCH_CHECK();
   return FRCNN_OK;
 }

@@ -91,14 +91,14 @@ SIGNATURES = {
     "frcnn_copy_cols": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "frcnn_anchor_target_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "frcnn_anchor_target_layer": (c_int, [_P, c_int, c_float, c_float, c_int, c_int, c_int, c_int, _P, c_int, c_double, c_double,
-                                          c_double, c_longlong, _P, _P, _P, _P, _P, c_size_t, _P]),
+                                          c_double, c_longlong, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "frcnn_anchor_target_layer_inject": (c_int, [_P, c_int, c_float, c_float, c_int, c_int, c_int, c_int, _P, c_int, c_double, c_double,
-                                                 c_double, _P, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
-    "frcnn_proposal_target_layer_inject": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                                 c_double, _P, c_int, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "frcnn_proposal_target_layer_inject": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "frcnn_proposal_target_layer": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_double, c_double, c_double, c_double, _P, _P,
-                                            c_longlong, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                            c_longlong, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "frcnn_proposal_target_layer_dn": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, c_int, c_double, c_double, c_double, c_double, _P, _P,
-                                               c_longlong, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                               c_longlong, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "frcnn_loss_workspace_bytes": (c_size_t, [c_longlong]),
     "frcnn_softmax_ce_loss": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_size_t, _P]),
     "frcnn_smooth_l1_loss": (c_int, [_P, _P, _P, _P, c_longlong, c_float, c_float, _P, _P, _P, c_size_t, _P]),

@@ -238,8 +238,11 @@ def crop_and_resize_bias_act(feat, rois, feat_stride, pool, bias, act, out=None)
 def detect_post(cls_prob, bbox_pred, rois, num_rois, im_scale, im_h, im_w, nms_thresh=0.3, score_thresh=0.0,
                 max_per_image=100, max_out=None, out=None, count=None, batch=1, rule=NMS_RULE_CPU):
     """lib/model/test.py:95-102 + :162-180 on device.  batch = 1: (dets [max_out,6], count [1]).  batch = B: cls_prob
-    [B*R,C] (R rows per image), num_rois [B] -> (dets [B,max_out,6], count [B]), one launch pair for all images."""
-    _chk(cls_prob), _chk(bbox_pred), _chk(rois)
+    [B*R,C] (R rows per image), num_rois [B] -> (dets [B,max_out,6], count [B]), one launch pair for all images.
+    bbox_pred = None: cfg.TEST.BBOX_REG False (the rois themselves, un-regressed and un-clipped, test.py:103-105)."""
+    _chk(cls_prob), _chk(rois)
+    if bbox_pred is not None:
+        _chk(bbox_pred)
     B = int(batch)
     R, C = cls_prob.shape[0] // B, cls_prob.shape[1]
     if cls_prob.shape[0] != B * R or rois.shape[0] != B * R:
@@ -261,10 +264,14 @@ def detect_post(cls_prob, bbox_pred, rois, num_rois, im_scale, im_h, im_w, nms_t
     return out, count
 
 
-def im_detect_boxes(rois, bbox_pred, im_scale, im_h, im_w):
-    """lib/model/test.py:95-102 on device: -> pred_boxes [R,4C]."""
-    _chk(rois), _chk(bbox_pred)
-    R, C4 = bbox_pred.shape
+def im_detect_boxes(rois, bbox_pred, im_scale, im_h, im_w, num_classes=None):
+    """lib/model/test.py:95-105 on device: -> pred_boxes [R,4C].  bbox_pred = None (cfg.TEST.BBOX_REG False): np.tile(boxes, (1, C))."""
+    _chk(rois)
+    if bbox_pred is None:
+        R, C4 = rois.shape[0], 4 * int(num_classes)
+    else:
+        _chk(bbox_pred)
+        R, C4 = bbox_pred.shape
     out = torch.empty((R, C4), dtype=torch.float32, device=rois.device)
     call("frcnn_im_detect_boxes", _ptr(rois), _ptr(bbox_pred), R, C4 // 4, float(im_scale), int(im_h), int(im_w), _ptr(out),
          _stream())
@@ -519,22 +526,39 @@ def copy_cols(src, col0, cols, out=None):
 
 
 # ------------------------------------------------------------------------------------------ training
+def _host_doubles(values):
+    a = np.ascontiguousarray(values, dtype=np.float64)
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+def rpn_target_opts(clobber_positives=False, positive_weight=-1.0, inside_weights=(1.0, 1.0, 1.0, 1.0)):
+    """opts block of frcnn_anchor_target_layer*: TRAIN.RPN_CLOBBER_POSITIVES, TRAIN.RPN_POSITIVE_WEIGHT, TRAIN.RPN_BBOX_INSIDE_WEIGHTS."""
+    return [1.0 if clobber_positives else 0.0, float(positive_weight)] + [float(v) for v in inside_weights]
+
+
+def roi_target_opts(use_gt=False, inside_weights=(1.0, 1.0, 1.0, 1.0)):
+    """opts block of frcnn_proposal_target_layer*: TRAIN.USE_GT, TRAIN.BBOX_INSIDE_WEIGHTS."""
+    return [1.0 if use_gt else 0.0] + [float(v) for v in inside_weights]
+
+
 def anchor_target_layer(gt_boxes, im_h, im_w, H, W, base_d, feat_stride=16, rpn_batchsize=256, fg_fraction=0.5,
-                        pos_overlap=0.7, neg_overlap=0.3, seed=0):
-    """lib/layer_utils/anchor_target_layer.py:18-138 on device -> (labels [1,1,A*H,W], targets, inside, outside [1,H,W,4A])."""
+                        pos_overlap=0.7, neg_overlap=0.3, seed=0, opts=None):
+    """lib/layer_utils/anchor_target_layer.py:18-138 on device -> (labels [1,1,A*H,W], targets, inside, outside [1,H,W,4A]).
+    opts: rpn_target_opts(...) or None (reference defaults)."""
     _chk(gt_boxes), _chk(base_d, torch.float64)
     A, G, dev = base_d.shape[0], gt_boxes.shape[0], gt_boxes.device
     labels = torch.empty((1, 1, A * H, W), dtype=torch.float32, device=dev)
     tg, iw, ow = (torch.empty((1, H, W, 4 * A), dtype=torch.float32, device=dev) for _ in range(3))
     ws = workspace(lib().frcnn_anchor_target_workspace_bytes(H, W, A, G), dev, "anchor_target")
+    o = _host_doubles(opts) if opts is not None else (None, None)
     call("frcnn_anchor_target_layer", _ptr(gt_boxes), G, float(im_h), float(im_w), H, W, A, int(feat_stride), _ptr(base_d),
-         int(rpn_batchsize), float(fg_fraction), float(pos_overlap), float(neg_overlap), int(seed), _ptr(labels), _ptr(tg),
+         int(rpn_batchsize), float(fg_fraction), float(pos_overlap), float(neg_overlap), int(seed), o[1], _ptr(labels), _ptr(tg),
          _ptr(iw), _ptr(ow), _ptr(ws), ws.numel(), _stream())
     return labels, tg, iw, ow
 
 
 def anchor_target_layer_inject(gt_boxes, im_h, im_w, H, W, base_d, disable, feat_stride=16, rpn_batchsize=256, fg_fraction=0.5,
-                               pos_overlap=0.7, neg_overlap=0.3):
+                               pos_overlap=0.7, neg_overlap=0.3, opts=None):
     """anchor_target_layer with the reference's host-drawn `disable_inds` (int32 device tensor of ALL-anchor indices, may be
     empty): see frcnn_anchor_target_layer_inject."""
     _chk(gt_boxes), _chk(base_d, torch.float64), _chk(disable, torch.int32)
@@ -542,33 +566,33 @@ def anchor_target_layer_inject(gt_boxes, im_h, im_w, H, W, base_d, disable, feat
     labels = torch.empty((1, 1, A * H, W), dtype=torch.float32, device=dev)
     tg, iw, ow = (torch.empty((1, H, W, 4 * A), dtype=torch.float32, device=dev) for _ in range(3))
     ws = workspace(lib().frcnn_anchor_target_workspace_bytes(H, W, A, G), dev, "anchor_target")
+    o = _host_doubles(opts) if opts is not None else (None, None)
     call("frcnn_anchor_target_layer_inject", _ptr(gt_boxes), G, float(im_h), float(im_w), H, W, A, int(feat_stride), _ptr(base_d),
          int(rpn_batchsize), float(fg_fraction), float(pos_overlap), float(neg_overlap), _ptr(disable) if disable.numel() else None,
-         int(disable.numel()), _ptr(labels), _ptr(tg), _ptr(iw), _ptr(ow), _ptr(ws), ws.numel(), _stream())
+         int(disable.numel()), o[1], _ptr(labels), _ptr(tg), _ptr(iw), _ptr(ow), _ptr(ws), ws.numel(), _stream())
     return labels, tg, iw, ow
 
 
 def proposal_target_layer_inject(rpn_rois, rpn_scores, gt_boxes, num_classes, keep_inds, n_fg, means=(0.0, 0.0, 0.0, 0.0),
-                                 stds=(0.1, 0.1, 0.2, 0.2)):
-    """proposal_target_layer for host-drawn keep_inds (int32 device [batch], fg rows first): frcnn_proposal_target_layer_inject."""
+                                 stds=(0.1, 0.1, 0.2, 0.2), opts=None):
+    """proposal_target_layer for host-drawn keep_inds (int32 device [batch], fg rows first): frcnn_proposal_target_layer_inject.
+    opts: roi_target_opts(...) or None."""
     _chk(rpn_rois), _chk(rpn_scores), _chk(gt_boxes), _chk(keep_inds, torch.int32)
     dev, N, G, B, C = rpn_rois.device, rpn_rois.shape[0], gt_boxes.shape[0], keep_inds.numel(), int(num_classes)
     rois = torch.empty((B, 5), dtype=torch.float32, device=dev)
     sc = torch.empty((B,), dtype=torch.float32, device=dev)
     labels = torch.empty((B, 1), dtype=torch.float32, device=dev)
     tg, iw, ow = (torch.empty((B, 4 * C), dtype=torch.float32, device=dev) for _ in range(3))
-    m = np.ascontiguousarray(means, dtype=np.float64)
-    s = np.ascontiguousarray(stds, dtype=np.float64)
+    m, s, o = _host_doubles(means), _host_doubles(stds), (_host_doubles(opts) if opts is not None else (None, None))
     call("frcnn_proposal_target_layer_inject", _ptr(rpn_rois), _ptr(rpn_scores), N, _ptr(gt_boxes), G, C, B, _ptr(keep_inds), int(n_fg),
-         m.ctypes.data_as(ctypes.c_void_p), s.ctypes.data_as(ctypes.c_void_p), _ptr(rois), _ptr(sc), _ptr(labels), _ptr(tg), _ptr(iw),
-         _ptr(ow), _stream())
+         m[1], s[1], o[1], _ptr(rois), _ptr(sc), _ptr(labels), _ptr(tg), _ptr(iw), _ptr(ow), _stream())
     return rois, sc, labels, tg, iw, ow
 
 
 def proposal_target_layer(rpn_rois, rpn_scores, gt_boxes, num_classes, batch_size=256, fg_fraction=0.25, fg_thresh=0.5,
-                          bg_hi=0.5, bg_lo=0.0, means=(0.0, 0.0, 0.0, 0.0), stds=(0.1, 0.1, 0.2, 0.2), seed=0, num=None):
+                          bg_hi=0.5, bg_lo=0.0, means=(0.0, 0.0, 0.0, 0.0), stds=(0.1, 0.1, 0.2, 0.2), seed=0, num=None, opts=None):
     """lib/layer_utils/proposal_target_layer.py:18-152 on device.  num: int32 [1] device tensor = valid rows of rpn_rois
-    (the proposal layer's count); without it every row is a proposal."""
+    (the proposal layer's count); without it every row is a proposal.  opts: roi_target_opts(...) or None."""
     _chk(rpn_rois), _chk(rpn_scores), _chk(gt_boxes)
     dev, N, G, B, C = rpn_rois.device, rpn_rois.shape[0], gt_boxes.shape[0], int(batch_size), int(num_classes)
     rois = torch.empty((B, 5), dtype=torch.float32, device=dev)
@@ -576,17 +600,15 @@ def proposal_target_layer(rpn_rois, rpn_scores, gt_boxes, num_classes, batch_siz
     labels = torch.empty((B, 1), dtype=torch.float32, device=dev)
     tg, iw, ow = (torch.empty((B, 4 * C), dtype=torch.float32, device=dev) for _ in range(3))
     counts = torch.zeros((4,), dtype=torch.int32, device=dev)
-    m = np.ascontiguousarray(means, dtype=np.float64)
-    s = np.ascontiguousarray(stds, dtype=np.float64)
+    m, s, o = _host_doubles(means), _host_doubles(stds), (_host_doubles(opts) if opts is not None else (None, None))
     if num is not None:
         call("frcnn_proposal_target_layer_dn", _ptr(rpn_rois), _ptr(rpn_scores), N, _ptr(num), _ptr(gt_boxes), G, C, B,
-             float(fg_fraction), float(fg_thresh), float(bg_hi), float(bg_lo), m.ctypes.data_as(ctypes.c_void_p),
-             s.ctypes.data_as(ctypes.c_void_p), int(seed), _ptr(rois), _ptr(sc), _ptr(labels), _ptr(tg), _ptr(iw), _ptr(ow),
-             _ptr(counts), _stream())
+             float(fg_fraction), float(fg_thresh), float(bg_hi), float(bg_lo), m[1], s[1], int(seed), o[1], _ptr(rois), _ptr(sc),
+             _ptr(labels), _ptr(tg), _ptr(iw), _ptr(ow), _ptr(counts), _stream())
         return rois, sc, labels, tg, iw, ow, counts
     call("frcnn_proposal_target_layer", _ptr(rpn_rois), _ptr(rpn_scores), N, _ptr(gt_boxes), G, C, B, float(fg_fraction),
-         float(fg_thresh), float(bg_hi), float(bg_lo), m.ctypes.data_as(ctypes.c_void_p), s.ctypes.data_as(ctypes.c_void_p),
-         int(seed), _ptr(rois), _ptr(sc), _ptr(labels), _ptr(tg), _ptr(iw), _ptr(ow), _ptr(counts), _stream())
+         float(fg_thresh), float(bg_hi), float(bg_lo), m[1], s[1], int(seed), o[1], _ptr(rois), _ptr(sc), _ptr(labels), _ptr(tg),
+         _ptr(iw), _ptr(ow), _ptr(counts), _stream())
     return rois, sc, labels, tg, iw, ow, counts
 
 

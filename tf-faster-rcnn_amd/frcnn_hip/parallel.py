@@ -91,8 +91,9 @@ class BucketedAllReduce(object):
     `bucket_bytes` of not-yet-sent gradient is final, one asynchronous `all_reduce(SUM)` over that contiguous range is issued
     (torch.distributed orders it after the kernels already enqueued on the current stream and runs it on the communicator's
     own stream, so the remaining backward kernels overlap it).  `finish(flat)` sends what is left (the front of the buffer)
-    and waits for every range.  A parameter shared by two tape records is only final at its FIRST occurrence in the forward
-    order, which is what a monotonically decreasing watermark guarantees.  xGMI is point-to-point: 64 MiB buckets keep the
+    and waits for every range.  INVARIANT (asserted): the offsets passed to ready() never increase, i.e. the flat buffer is laid
+    out in the reverse of the backward visiting order and every parameter has exactly ONE tape record (a filter shared by two
+    records would be final only after its second visit; TrainState.build refuses such graphs).  xGMI is point-to-point: 64 MiB buckets keep the
     ring bandwidth-bound (a ResNet-152 step exchanges 253 MB)."""
 
     def __init__(self, group=None, bucket_bytes=64 << 20):
@@ -116,7 +117,10 @@ class BucketedAllReduce(object):
         off = (int(data_ptr) - flat.data_ptr()) // 4
         if off < 0 or off > n:
             return
-        self.final_from = off if self.final_from is None else min(self.final_from, off)
+        if self.final_from is not None and off > self.final_from:
+            raise RuntimeError("BucketedAllReduce.ready: offsets must not increase (%d after %d): the flat gradient buffer is not in "
+                               "reverse backward order, or a parameter has more than one tape record" % (off, self.final_from))
+        self.final_from = off
         while self.sent_from - self.final_from >= self.bucket:
             lo = self.sent_from - self.bucket
             self._send(flat, lo, self.sent_from)

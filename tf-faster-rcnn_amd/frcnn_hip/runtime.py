@@ -40,12 +40,24 @@ class VariableStore(object):
         for RPN/cls/bbox (lib/nets/network.py:239-240), zero biases (:420), synthetic frozen-BN
         statistics."""
         rng = np.random.RandomState(self.seed if seed is None else seed)
+        truncated = False
+        try:
+            from model.config import cfg
+            truncated = bool(cfg.TRAIN.TRUNCATED)
+        except ImportError:
+            pass
         for name, sp in specs.items():
             if sp.init == "he":
                 fan_in = int(np.prod(sp.shape[:-1]))
                 v = rng.randn(*sp.shape) * np.sqrt(2.0 / fan_in)
             elif sp.init == "normal":
-                v = rng.randn(*sp.shape) * sp.arg
+                v = rng.randn(*sp.shape)
+                if truncated:                 # cfg.TRAIN.TRUNCATED (network.py:235-240): tf.truncated_normal_initializer re-draws |z| > 2
+                    bad = np.abs(v) > 2.0
+                    while bad.any():
+                        v[bad] = rng.randn(int(bad.sum()))
+                        bad = np.abs(v) > 2.0
+                v = v * sp.arg
             elif sp.init == "zeros":
                 v = np.zeros(sp.shape)
             elif sp.init == "bn_gamma":
@@ -193,6 +205,20 @@ class Session(VariableStore):
             ent = (ops.gemm_x3_pack(w), w)
             self.x3[key] = ent
         return ent[0]
+
+    def wino_refresh(self):
+        """Recompute every cached TEST-mode Winograd filter U (winograd_params) from the LIVE folded device filter, into its existing
+        buffer: the solver updates filters in place, and a TEST-mode network sharing the session must not keep multiplying by the
+        transform of the pre-training 3x3 filters (x3_refresh / h2_refresh then re-split U like any other filter).  Returns the count."""
+        n = 0
+        for key, val in list(self.packed.items()):
+            if isinstance(key, tuple) and key and key[0] == "wino":
+                u = val[0]
+                info = self.conv_info.get(key[1])
+                if info is not None and info["w"].dim() == 4 and info["w"].shape[1] == 3:
+                    ops.winograd_filter_transform_device(info["w"], key[3], False, out=u)
+                    n += 1
+        return n
 
     def x3_refresh(self):
         """Re-split every cached filter into its EXISTING plane buffer (addresses captured by hipGraphs stay valid): the solver

@@ -75,7 +75,11 @@ class TrainState(object):
         sess, net = self.sess, self.net
         scopes = []                                             # (kind, scope) in forward order: the flat buffer follows the tape
         for rec in net._tape:
-            if rec["kind"] in ("conv", "dwconv") and net.trainable_scope(rec["scope"]) and (rec["kind"], rec["scope"]) not in scopes:
+            if rec["kind"] in ("conv", "dwconv") and net.trainable_scope(rec["scope"]):
+                if (rec["kind"], rec["scope"]) in scopes:
+                    # one tape record per trainable filter: the reverse sweep OVERWRITES grad_w per record, and the overlapped
+                    # all-reduce (parallel.BucketedAllReduce) ships a gradient range as soon as its record has been visited
+                    raise NotImplementedError("trainable scope %s is used by two layers of the TRAIN graph (shared filters)" % rec["scope"])
                 scopes.append((rec["kind"], rec["scope"]))
         total = 0
         sizes = []
@@ -265,7 +269,9 @@ class TrainState(object):
         for p in self.params.values():
             if getattr(p, "dw", False):
                 ops.dwconv3x3_refold(p.w, p.scale, p.wf)
-        if self.sess.x3:                             # a TEST-mode network on the same session (cfg.HIP.MFMA_X3) reads pre-split filters
+        if self.sess.x3 or self.sess.h2:             # a TEST-mode network on the same session reads derived filter images: Winograd U
+            self.sess.wino_refresh()                 # of the 3x3 filters first, then the pre-split planes of everything (x3 / h2)
+        if self.sess.x3:
             self.sess.x3_refresh()
         if self.sess.h2:                             # the same for cfg.HIP.MFMA_H2
             self.sess.h2_refresh()

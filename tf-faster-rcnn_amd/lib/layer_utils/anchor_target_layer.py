@@ -26,7 +26,8 @@ def anchor_target_layer(rpn_cls_score, gt_boxes, im_info, _feat_stride, all_anch
     t = cfg.TRAIN
     args = (gt, float(im_info[0]), float(im_info[1]), int(height), int(width), base_d)
     kw = dict(feat_stride=stride, rpn_batchsize=int(t.RPN_BATCHSIZE), fg_fraction=float(t.RPN_FG_FRACTION),
-              pos_overlap=float(t.RPN_POSITIVE_OVERLAP), neg_overlap=float(t.RPN_NEGATIVE_OVERLAP))
+              pos_overlap=float(t.RPN_POSITIVE_OVERLAP), neg_overlap=float(t.RPN_NEGATIVE_OVERLAP),
+              opts=ops.rpn_target_opts(t.RPN_CLOBBER_POSITIVES, t.RPN_POSITIVE_WEIGHT, t.RPN_BBOX_INSIDE_WEIGHTS))     # :57-70, :91-109
     # labels before subsampling, in the reference's output layout (1,1,A*H,W) -> per-anchor order (h, w, a)
     pre = ops.anchor_target_layer(*args, seed=-1, **kw)[0].cpu().numpy()
     labels_all = pre.reshape(1, A, height, width).transpose(0, 2, 3, 1).reshape(-1)

@@ -81,7 +81,7 @@ __C = AttrDict(
     # change.  Off by default: the same image gives bit-identical detections in every batch slot
     # (tests/test_network_gpu.py::test_batched_forward_equals_single_image_forward).
     # WINOGRAD_7X7: 7x7 maps (per-RoI crops) use the mixed F(4,3)+F(3,3) scheme (121 instead of 144 products per RoI)
-    # MFMA_X3: TEST mode, the large pointwise convolutions and Winograd products (plain GEMMs with Cout % 128 == 0) run on the bf16
+    # MFMA_X3: TEST mode, the large pointwise convolutions and Winograd products (plain GEMMs with Cout % 64 == 0, Cin % 32 == 0, >= 150 tiles) run on the bf16
     # matrix pipe with EXACTLY split f32 operands (csrc/gemm_x3.hip: x = h + m + l, six bf16 MFMAs per f32 product, f32 accumulation,
     # dropped terms <= 2^-24 relative): 1.3-1.6x faster than the f32 MFMA and, measured against float64, slightly MORE accurate than
     # it (profiles/r02_m_x3_sweep.txt).  False = every product on v_mfma_f32_32x32x2_f32 (bench.py --mfma f32).

@@ -20,8 +20,8 @@ def im_detect(sess, net, blob, im_scale, im_shape):
     img = net._stage_image(sess, blob)
     p = net.forward_device(sess, img, im_info)
     n = p["rois"].shape[0] if net._num_rois is None else int(net._num_rois.item())
-    rois, bbox_pred = p["rois"][:n].contiguous(), p["bbox_pred"][:n].contiguous()
-    pred_boxes = ops.im_detect_boxes(rois, bbox_pred, im_scale, im_shape[0], im_shape[1])      # test.py:95-102
+    rois, bbox_pred = p["rois"][:n].contiguous(), (p["bbox_pred"][:n].contiguous() if cfg.TEST.BBOX_REG else None)
+    pred_boxes = ops.im_detect_boxes(rois, bbox_pred, im_scale, im_shape[0], im_shape[1], net._num_classes)      # test.py:95-105
     return p["cls_prob"][:n].cpu().numpy(), pred_boxes.cpu().numpy()
 
 
@@ -42,7 +42,8 @@ def im_detect_bgr(sess, net, im):
     im_info = np.array([img.shape[1], img.shape[2], im_scale], dtype=np.float32)
     p = net.forward_device(sess, img, im_info)
     n = p["rois"].shape[0] if net._num_rois is None else int(net._num_rois.item())
-    pred_boxes = ops.im_detect_boxes(p["rois"][:n].contiguous(), p["bbox_pred"][:n].contiguous(), im_scale, im.shape[0], im.shape[1])
+    pred_boxes = ops.im_detect_boxes(p["rois"][:n].contiguous(), p["bbox_pred"][:n].contiguous() if cfg.TEST.BBOX_REG else None, im_scale,
+                                     im.shape[0], im.shape[1], net._num_classes)
     return p["cls_prob"][:n].cpu().numpy(), pred_boxes.cpu().numpy()
 
 

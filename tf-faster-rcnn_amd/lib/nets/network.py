@@ -369,7 +369,9 @@ class Network(object):
         t = cfg.TRAIN
         labels, tg, iw, ow = ops.anchor_target_layer(self._gt_boxes, self._im_info[0], self._im_info[1], H, W, self._base_anchors,
                                                      self._feat_stride[0], t.RPN_BATCHSIZE, t.RPN_FG_FRACTION, t.RPN_POSITIVE_OVERLAP,
-                                                     t.RPN_NEGATIVE_OVERLAP, seed=self._sample_seed)
+                                                     t.RPN_NEGATIVE_OVERLAP, seed=self._sample_seed,
+                                                     opts=ops.rpn_target_opts(t.RPN_CLOBBER_POSITIVES, t.RPN_POSITIVE_WEIGHT,
+                                                                              t.RPN_BBOX_INSIDE_WEIGHTS))
         self._anchor_targets = dict(rpn_labels=labels, rpn_bbox_targets=tg, rpn_bbox_inside_weights=iw, rpn_bbox_outside_weights=ow)
         return labels
 
@@ -379,7 +381,8 @@ class Network(object):
         # the padded proposal buffer goes in whole; the kernel reads the valid row count on the device (no host sync here)
         out = ops.proposal_target_layer(rois, roi_scores.view(-1), self._gt_boxes, self._num_classes,
                                         t.BATCH_SIZE, t.FG_FRACTION, t.FG_THRESH, t.BG_THRESH_HI, t.BG_THRESH_LO,
-                                        t.BBOX_NORMALIZE_MEANS, t.BBOX_NORMALIZE_STDS, seed=self._sample_seed + 1, num=self._num_rois)
+                                        t.BBOX_NORMALIZE_MEANS, t.BBOX_NORMALIZE_STDS, seed=self._sample_seed + 1, num=self._num_rois,
+                                        opts=ops.roi_target_opts(t.USE_GT, t.BBOX_INSIDE_WEIGHTS))
         rois, roi_scores, labels, tg, iw, ow, counts = out
         self._proposal_targets = dict(rois=rois, labels=labels, bbox_targets=tg, bbox_inside_weights=iw, bbox_outside_weights=ow,
                                       counts=counts)
@@ -557,13 +560,14 @@ class Network(object):
 
     @staticmethod
     def _check_supported_cfg(mode):
-        """Config keys the kernels implement for ONE value only: refuse the others instead of silently ignoring them."""
+        """Config keys implemented for ONE value only: refuse the others instead of silently ignoring them.  (TRAIN.USE_GT,
+        RPN_CLOBBER_POSITIVES, RPN_POSITIVE_WEIGHT, the two INSIDE_WEIGHTS, TRAIN.TRUNCATED and TEST.BBOX_REG are kernel / initialiser
+        arguments since round 3; POOLING_MODE is 'crop' only in the reference as well, network.py:393-396.)"""
         t = cfg.TRAIN
-        fixed = [("TRAIN.RPN_CLOBBER_POSITIVES", t.RPN_CLOBBER_POSITIVES, False), ("TRAIN.RPN_POSITIVE_WEIGHT", float(t.RPN_POSITIVE_WEIGHT), -1.0),
-                 ("TRAIN.RPN_BBOX_INSIDE_WEIGHTS", tuple(t.RPN_BBOX_INSIDE_WEIGHTS), (1.0, 1.0, 1.0, 1.0)),
-                 ("TRAIN.BBOX_INSIDE_WEIGHTS", tuple(t.BBOX_INSIDE_WEIGHTS), (1.0, 1.0, 1.0, 1.0)), ("TRAIN.USE_GT", t.USE_GT, False),
-                 ("TRAIN.TRUNCATED", t.TRUNCATED, False), ("TEST.BBOX_REG", cfg.TEST.BBOX_REG, True), ("POOLING_MODE", cfg.POOLING_MODE, "crop")]
+        fixed = [("POOLING_MODE", cfg.POOLING_MODE, "crop")]
         bad = ["%s = %r (only %r is implemented)" % (k, v, want) for k, v, want in fixed if v != want]
+        if float(t.RPN_POSITIVE_WEIGHT) >= 0 and not (0.0 < float(t.RPN_POSITIVE_WEIGHT) < 1.0):
+            bad.append("TRAIN.RPN_POSITIVE_WEIGHT = %r (the reference asserts 0 < p < 1, anchor_target_layer.py:103-104)" % (t.RPN_POSITIVE_WEIGHT,))
         if bad:
             raise NotImplementedError("unsupported configuration for the HIP path: " + "; ".join(bad))
 
@@ -719,6 +723,6 @@ class Network(object):
             out = sess.buf(self._tag + "/dets", (B, max_out, 6)) if out is None else out
             count = sess.buf(self._tag + "/det_count", (B,), torch.int32) if count is None else count
         return sess.mark("op:detect_post", 0, lambda: ops.detect_post(
-            p["cls_prob"], p["bbox_pred"], p["rois"], self._num_rois, float(im_info[2]), int(im_shape[0]), int(im_shape[1]),
+            p["cls_prob"], p["bbox_pred"] if cfg.TEST.BBOX_REG else None, p["rois"], self._num_rois, float(im_info[2]), int(im_shape[0]), int(im_shape[1]),
             float(cfg.TEST.NMS), float(thresh), int(max_per_image), max_out=max_out, out=out, count=count, batch=B,
             rule=self._nms_rule()), nbytes=B * R * 20 * C)
