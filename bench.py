@@ -255,6 +255,63 @@ def train_bench(args, c, dev, world, rank, dist):
     return time.perf_counter() - t0, sess
 
 
+def exchange_records(rec, count_i32, gathered, rank, stamp=None):
+    """The data-path collective of one step: the batch's fixed-size detection records [B][dets | count | stamp] of
+    this rank are all-gathered (RCCL over xGMI on GPUs, gloo in the CPU test).  stamp (the untimed self-check step only: it costs a
+    host-to-device copy): (rank, stamp) goes into two padding floats so that check_exchange can tell WHOSE record of WHICH step sits
+    in every slot."""
+    from frcnn_hip import parallel
+    parallel.set_count(rec, count_i32)
+    if stamp is not None:
+        parallel.set_stamp(rec, rank, stamp)
+    parallel.all_gather_records(rec, gathered)
+
+
+def check_exchange(rec, gathered, rank, world, step_no):
+    """One untimed verification of what the timed steps do: slot r of the gathered tensor must be rank r's record of THIS step
+    (stamp), this rank's own slot must equal what it sent bit for bit, and every count must fit the record.  Raises on mismatch."""
+    from frcnn_hip import parallel
+    g = gathered.detach().cpu()
+    mine = rec.detach().cpu()
+    if not torch.equal(g[rank], mine):
+        raise RuntimeError("rank %d: its own slot of the all-gather differs from the record it sent" % rank)
+    flat = g.reshape(world, -1, parallel.REC_FLOATS)
+    for r in range(world):
+        for b in range(flat.shape[1]):
+            st = parallel.get_stamp(flat[r, b])
+            if st != (r, step_no):
+                raise RuntimeError("rank %d: slot %d image %d carries stamp %r, expected (%d, %d)" % (rank, r, b, st, r, step_no))
+            n = float(flat[r, b, parallel.REC_ROWS * 6])
+            if not (0 <= n <= 16777216 and n == int(n)):
+                raise RuntimeError("rank %d: slot %d image %d has detection count %r" % (rank, r, b, n))
+    return True
+
+
+def run_timed(step, steps, warmup, dist=None, sync=None, between=None):
+    """The bench contract's timed region: `warmup` untimed steps, then EXACTLY `steps` steps between barrier + device-synchronize
+    pairs; returns the seconds of this rank (the caller takes the max over ranks).  `sync` = torch.cuda.synchronize on GPUs (a no-op in
+    the CPU test), `between` = per-step host hook (eager mode resets the profile list)."""
+    sync = sync or (lambda: None)
+    for k in range(warmup):
+        step(k)
+        if between:
+            between()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(k)
+        if between:
+            between()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    return time.perf_counter() - t0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -280,9 +337,9 @@ def main():
     ap.add_argument("--h2-min-tiles", type=int, default=-1, help="cfg.HIP.H2_MIN_TILES (A/B)")
     ap.add_argument("--h2-cfg", type=int, default=-1, help="cfg.HIP.H2_TILE_CFG (A/B): -1 = tile shape by launch size, else one frcnn_gemm_h2 configuration id")
     ap.add_argument("--h2-trunk-planes", type=int, default=-1, help="cfg.HIP.H2_TRUNK_PLANES (A/B): 0 keeps the residual trunk in float32")
-    ap.add_argument("--x3-terms", type=int, choices=[6, 9], default=6, help="with --mfma x3: 6 = the three cross terms below 2^-24 are dropped "
-                    "(default), 9 = all nine cross terms, every f32 product exact (frcnn_gemm_x3_set_terms)")
-    ap.add_argument("--x3-config", type=int, default=-1, help="A/B knob: frcnn_gemm_x3_set_config (-1 = by shape)")
+    ap.add_argument("--x3-terms", type=int, choices=[6, 9], default=6, help="x3 launches: 6 = the three cross terms below 2^-24 are dropped "
+                    "(default), 9 = all nine cross terms, every f32 product exact (cfg.HIP.X3_TERMS)")
+    ap.add_argument("--x3-config", type=int, default=-1, help="A/B knob: cfg.HIP.X3_TILE_CFG, the frcnn_gemm_x3 tile configuration (-1 = by shape)")
     ap.add_argument("--no-f32-variant", action="store_true", help="skip the extra timed regions (x3-only / all-f32-MFMA variants)")
     ap.add_argument("--winograd-f2", default=None, help="comma list of scope tokens run as F(2x2,3x3) instead of F(4x4,3x3) (default: cfg.HIP)")
     ap.add_argument("--winograd-direct", default=None, help="comma list of scope tokens that keep the direct kernel (default: cfg.HIP)")
@@ -308,13 +365,13 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")      # a failed / stuck collective tears the process down instead of hanging
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=300))
 
     import frcnn_hip
     frcnn_hip.lib()
-    frcnn_hip.lib().frcnn_gemm_x3_set_terms(args.x3_terms)
-    frcnn_hip.lib().frcnn_gemm_x3_set_config(args.x3_config)
     from frcnn_hip.runtime import Session
     from model.config import cfg
 
@@ -325,6 +382,7 @@ def main():
     if args.h2_min_tiles >= 0:
         cfg.HIP.H2_MIN_TILES = args.h2_min_tiles
     cfg.HIP.H2_TILE_CFG = args.h2_cfg
+    cfg.HIP.X3_TILE_CFG, cfg.HIP.X3_TERMS = args.x3_config, args.x3_terms
     if args.h2_trunk_planes >= 0:
         cfg.HIP.H2_TRUNK_PLANES = bool(args.h2_trunk_planes)
     if args.winograd_f2 is not None:
@@ -405,39 +463,35 @@ def main():
     run_stream = streams[0]
     img_d, dets_view, count_i32 = imgs[0], views[0], counts[0]
 
-    def step(k):
+    def step(k, stamp=None):
         i = k % S
         with torch.cuda.stream(streams[i]):
             nets[i].detect_device(sess, imgs[i], im_info, orig_shape, out=views[i], count=counts[i])
             if world > 1:
-                parallel.set_count(recs[i], counts[i])
-                parallel.all_gather_records(recs[i], gathered[i])
+                exchange_records(recs[i], counts[i], gathered[i], rank, stamp)
 
     def timed_region():
         """W untimed warm-up steps (first use of a configuration also builds / captures its graphs), then exactly K steps between
-        barrier + synchronize pairs."""
+        barrier + synchronize pairs (run_timed)."""
         if args.no_graph:
             sess.profile = []                            # forward_device runs eagerly while profile is not None
-        for k in range(max(args.warmup, S)):
-            step(k)
+
+        def reset_profile():
             if args.no_graph:
                 sess.profile = []
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            step(k)
-            if args.no_graph:
-                sess.profile = []
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        return time.perf_counter() - t0
+        return run_timed(step, args.steps, max(args.warmup, S), dist, torch.cuda.synchronize, reset_profile)
 
     elapsed = timed_region()
+    exchange_ok = None
+    if world > 1:
+        # self-check of the collective, untimed: one more step on every chain, then every rank verifies every slot (a wrong or stale
+        # record, or an RCCL failure, ends the run with a non-zero exit instead of a silently wrong number)
+        for i in range(S):
+            step(i, stamp=1000 + i)
+        torch.cuda.synchronize()
+        for i in range(S):
+            check_exchange(recs[i], gathered[i], rank, world, 1000 + i)
+        exchange_ok = True
     n_det = int(count_i32[0].item())
     n_rois = int(net._num_rois[0].item())
     flops_per_image = sess.flops_last_forward / B        # launched MFMA FLOPs (Winograd / commuted crop already taken out)
@@ -512,6 +566,9 @@ def main():
                                         "v_mfma_f32_32x32x2_f32", "f32": "v_mfma_f32_32x32x2_f32 everywhere"}[args.mfma],
                          "gflop_per_image_launched": round(flops_per_image / 1e9, 2), "gflop_per_image_reference_graph": c["gflop_ref"]}
         out["telemetry"] = telemetry
+        if exchange_ok is not None:
+            out["all_gather_self_check"] = "ok: every rank found every rank's record of the checked step in its slot (untimed extra step per chain); " \
+                                           "expected scaling: %d B per image in the all-gather, no other coupling -> linear in N" % (4 * parallel.REC_FLOATS)
         if x3_variant is not None:
             out["x3_variant"] = x3_variant
         if f32_variant is not None:
@@ -580,4 +637,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as e:                     # incl. RCCL errors surfacing as exceptions: non-zero exit, never a hang in teardown
+        if isinstance(e, SystemExit) and not e.code:
+            raise
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)

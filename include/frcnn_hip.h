@@ -228,9 +228,10 @@ size_t frcnn_conv1x1_mean_workspace_bytes(int M, int Cout);
 int frcnn_conv1x1_mean(const float* x_d, int M, int Cin, const float* w_d, const float* bias_d, const float* residual_d, int Cout,
                        int act, int group_rows, float* mean_out_d, void* ws, size_t ws_bytes, void* stream);
 
-/* Tuning knobs for A/B experiments (process-wide debugging switches read at launch time: set them while no other thread is
- * launching; they are NOT part of the thread-safety contract above and no product path changes them): key 0 = force conv tile configuration id (-1 = automatic); key 1 = ablation bits;
- * key 5 = phase stagger of co-resident workgroups; key 6 = 0 keeps the short-K GEMMs off k_gemm_stream. */
+/* Tuning overrides for A/B measurements and for tests that must reach every tile configuration: THREAD-LOCAL (they affect only the
+ * launches the calling thread makes afterwards, so the thread-safety contract above holds); no product path sets them.  key 0 = force a
+ * conv tile configuration id (-1 = automatic); key 1 = ablation bits; key 5 = phase stagger of co-resident workgroups; key 6 = 0 keeps
+ * the short-K GEMMs off k_gemm_stream.  frcnn_gemm_x3 / frcnn_gemm_h2 take their configuration per call instead. */
 int frcnn_set_tuning(int key, int value);
 /* HOST: CRC-32C (Castagnoli) of n bytes, crc = 0 to start or a previous result to extend: the checksum of TensorFlow
  * checkpoint shards / index blocks (frcnn_hip/tensor_bundle.py replaces pywrap_tensorflow.NewCheckpointReader,
@@ -262,7 +263,9 @@ int frcnn_gemm_batched_nt(const float* x_d, const float* w_d, float* y_d, int G,
 size_t frcnn_gemm_x3_pack_bytes(int G, int N, int K);
 int frcnn_gemm_x3_pack(const float* w_d, int G, int N, int K, void* planes_d, void* stream);
 int frcnn_gemm_x3(const float* x_d, const void* planes_d, const float* bias_d, const float* res_d, float* y_d, int G, int M, int N,
-                  int K, int act, void* stream);
+                  int K, int act, int cfg, int terms, void* stream);   /* cfg: -1 = tiles by shape (else a configuration id, A/B runs); terms: 6
+                                                                          (default: am*wl, al*wm, al*wl dropped, <= 2^-24 relative) or 9 (every f32
+                                                                          product exact); per call -- no process-wide tuning state */
 /* f32 "NT" GEMM on the 16-bit matrix pipe with block-scaled two-piece fp16 operands (csrc/gemm_h2.hip; cfg.HIP.MFMA_H2): a float32
  * value x of a 128-k block is h + l (two fp16 pieces, rounded to nearest) times ONE exact power-of-two block scale; a product = the three
  * leading cross terms on v_mfma_f32_32x32x16_f16, f32 accumulation, each block folded into the f32 sum by its exact scale.  Dropped terms
@@ -281,8 +284,6 @@ int frcnn_h2_split(const float* x_d, long long M, int K, void* planes_d, float* 
 int frcnn_gemm_h2(const void* x_planes_d, const float* x_inv_d, const void* w_planes_d, const float* w_inv_d, const float* bias_d,
                   const float* res_d, const void* res_planes_d, const float* res_inv_d, float* y_d, void* y_planes_d, float* y_inv_d,
                   int G, int M, int N, int K, int act, int cfg, void* stream);
-int frcnn_gemm_x3_set_terms(int terms);         /* 6 (default): cross terms am*wl, al*wm, al*wl dropped (<= 2^-24 relative); 9: all nine -> every f32 product exact */
-int frcnn_gemm_x3_set_config(int cfg);          /* A/B runs: -1 = by shape (default), 0 = 128x128 tiles / 64x64 waves, 1 = 128x128 / 32x64, 2 = 64x128 / 32x64 */
 /* Winograd F(m x m, 3x3), m = 2 or 4, for stride-1 pad-1 3x3 convolutions (exact algebra, f32): filter transform on the
  * host (U [(m+2)^2][Cout][Cin], optional folded BN scale), input transform V [(m+2)^2][T][C] with
  * T = N*ceil(H/m)*ceil(W/m), the (m+2)^2 GEMMs via frcnn_gemm_batched_nt, output transform (+bias, ReLU) back to NHWC

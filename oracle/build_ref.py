@@ -5,7 +5,8 @@ Recipe: the two first-party Cython sources of the refere
 (/root/reference/lib/nms/cpu_nms.pyx, /root/reference/lib/utils/bbox.pyx) are compiled
 *from where they lie* with a type-alias-only patch applied to a scratch copy under /tmp
 (np.int_t -> np.intp_t, `np.float thresh` -> `double thresh`, np.float -> np.float64;
-Cython 3 / numpy 2 no longer know the removed aliases).  Only the resulting .so files are
+Cython 3 / numpy 2 no longer know the removed aliases).  The CUDA suppression kernel lib/nms/nms_kernel.cu is translated by
+hipify-perl and cross-compiled for gfx950 (build_gpu_nms below).  Only the resulting .so files are
 written into oracle/_ref/ (git-ignored, but shipped to the GPU box by gpurun).
 No reference source is copied into this repository.
 
@@ -68,6 +69,36 @@ def build(force=False):
     return True
 
 
+def build_gpu_nms(force=False):
+    """The reference's CUDA suppression kernel (lib/nms/nms_kernel.cu:24-144: devIoU, nms_kernel, the host loop _nms) as a gfx950
+    library: `hipify-perl` translates the file where it lies (runtime API names only; the kernel body is untouched), hipcc
+    cross-compiles it.  Two builds, because nvcc contracts a*b+c into FMAs by default and the rounding of Sa + Sb - interS depends on it:
+    libref_gpu_nms.so (-ffp-contract=off, separate roundings like lib/nms/py_cpu_nms.py) and libref_gpu_nms_fma.so (-ffp-contract=fast).
+    Entry: _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim, float thresh, int device_id),
+    C++-mangled `_Z4_nmsPiS_PKfiifi`.  tests/test_detect_gpu.py pins FRCNN_NMS_RULE_GPU against it on the GPU box."""
+    src = os.path.join(REF, "lib", "nms", "nms_kernel.cu")
+    hipify, hipcc = shutil.which("hipify-perl") or "/opt/rocm/bin/hipify-perl", shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not (os.path.isfile(src) and os.path.exists(hipify) and os.path.exists(hipcc)):
+        return False
+    outs = [os.path.join(OUT, "nms", "libref_gpu_nms.so"), os.path.join(OUT, "nms", "libref_gpu_nms_fma.so")]
+    if all(os.path.exists(o) for o in outs) and not force:
+        return True
+    work = tempfile.mkdtemp(prefix="frcnn_ref_gpu_")
+    try:
+        hip = subprocess.run([hipify, src], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        open(os.path.join(work, "nms_kernel.hip"), "wb").write(hip)
+        os.makedirs(os.path.join(OUT, "nms"), exist_ok=True)
+        for out, contract in zip(outs, ("off", "fast")):
+            subprocess.check_call([hipcc, "-O2", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=" + contract, "-include", "cstring",
+                                   "-I" + os.path.join(REF, "lib", "nms"), os.path.join(work, "nms_kernel.hip"), "-o", out],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return True
+
+
 if __name__ == "__main__":
     ok = build(force="--force" in sys.argv)
+    if ok:
+        print("reference CUDA NMS kernel (hipified) built" if build_gpu_nms(force="--force" in sys.argv) else "reference CUDA NMS kernel: not built")
     print("oracle/_ref built" if ok else "reference tree not present: nothing built")

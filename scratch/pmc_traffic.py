@@ -8,10 +8,10 @@ def avg(counter, name_filter):
     rows = list(csv.DictReader(open(os.path.join(root, counter, "p_counter_collection.csv"))))
     v = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == counter and any(n in r["Kernel_Name"] for n in name_filter)]
     return sum(v) / len(v), len(v)
-GEMMS = ("k_conv_igemm", "k_gemm_stream", "k_gemm_x3")
+GEMMS = ("k_conv_igemm", "k_gemm_stream", "k_gemm_x3", "k_gemm_h2")
 f, n = avg("FETCH_SIZE", GEMMS)
 w, _ = avg("WRITE_SIZE", GEMMS)
-res = {"kernel": "k_conv_igemm + k_gemm_stream + k_gemm_x3", "launches": n, "FETCH_SIZE_avg": f, "WRITE_SIZE_avg": w,
+res = {"kernel": "k_conv_igemm + k_gemm_stream + k_gemm_x3 + k_gemm_h2", "launches": n, "FETCH_SIZE_avg": f, "WRITE_SIZE_avg": w,
        "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0, "note": "bench.py --batch 4 --streams 1; (2*FETCH_SIZE + WRITE_SIZE)*1024"}
 rows = list(csv.DictReader(open(os.path.join(root, "SQ_VALU_MFMA_BUSY_CYCLES", "p_counter_collection.csv"))))
 agg = {}

@@ -14,7 +14,7 @@ shapes = {  # name: (G, M, N, K, residual, act)
  "b4c3x1": (1, 14700, 2048, 512, True, 1), "w7x1": (121, 300, 512, 512, False, 0), "b2c3x4": (1, 37500, 512, 128, True, 1), "b2c1x4": (1, 37500, 128, 512, False, 1),
 }
 cfgs = [int(c) for c in sys.argv[1].split(",")]
-L.frcnn_gemm_x3_set_terms(int(os.environ.get("X3_TERMS", "6")))
+X3_TERMS = int(os.environ.get("X3_TERMS", "6"))
 only = sys.argv[2].split(",") if len(sys.argv) > 2 else list(shapes)
 rounds = 5
 print("%-7s %-6s %9s %9s %8s  %s" % ("shape", "kernel", "med_us", "min_us", "TFLOP/s", "max err vs f64 / scale   (f32 kernel err)"))
@@ -50,11 +50,10 @@ for name in only:
     for c in cfgs:
         def mk(c):
             def f():
-                L.frcnn_gemm_x3_set_config(c)
                 if G == 1:
-                    ops.gemm_x3(x, planes, 1, M, N, K, b, res, act, out=out[0, :M])
+                    ops.gemm_x3(x, planes, 1, M, N, K, b, res, act, out=out[0, :M], cfg=c, terms=X3_TERMS)
                 else:
-                    ops.gemm_x3(x, planes, G, M, N, K, b, res, act, out=y3)
+                    ops.gemm_x3(x, planes, G, M, N, K, b, res, act, out=y3, cfg=c, terms=X3_TERMS)
             return f
         runs["x3/%d" % c] = mk(c)
     y3 = torch.empty(G, M, N, device=dev)

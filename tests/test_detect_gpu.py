@@ -111,6 +111,59 @@ def test_nms_sorted_and_host_compat__nms(dev):
     assert keep_h[:n_h.value].tolist() == ora.gpu_nms(ds, 0.3)             # the CUDA kernel's rule (nms_kernel.cu:71), float threshold
 
 
+def _ref_gpu_nms(name):
+    """The reference's CUDA kernel + host loop, hipified and compiled from /root/reference/lib/nms/nms_kernel.cu by
+    oracle/build_ref.py::build_gpu_nms into oracle/_ref/nms/ (the binaries travel with the snapshot)."""
+    import ctypes
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "nms", name)
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/nms/%s not built (python oracle/build_ref.py where /root/reference exists)" % name)
+    fn = ctypes.CDLL(path)._Z4_nmsPiS_PKfiifi
+    fn.restype = None
+
+    def run(ds, thresh):
+        keep = np.zeros(ds.shape[0], dtype=np.int32)
+        n = ctypes.c_int(0)
+        fn(keep.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n), np.ascontiguousarray(ds, dtype=f32).ctypes.data_as(ctypes.c_void_p),
+           ctypes.c_int(ds.shape[0]), ctypes.c_int(ds.shape[1]), ctypes.c_float(thresh), ctypes.c_int(0))
+        return keep[:n.value].tolist()
+    return run
+
+
+@pytest.mark.parametrize("k,thr,cl,seed", [(3000, 0.3, 12, 11), (6000, 0.7, 40, 3), (12000, 0.7, 200, 5), (257, 0.5, 3, 2), (64, 0.3, 1, 9)])
+def test_gpu_rule_bit_exact_vs_the_reference_cuda_kernel(dev, k, thr, cl, seed):
+    """FRCNN_NMS_RULE_GPU (`_nms`, what nms_wrapper picks under cfg.USE_GPU_NMS) against the reference's OWN CUDA kernel
+    (lib/nms/nms_kernel.cu:24-144, hipified + compiled for gfx950 into oracle/_ref, separate roundings): identical keep lists,
+    incl. boxes engineered to sit on the threshold.  The FMA-contracted build of the same file (what nvcc's default -fmad=true may
+    produce) is run beside it: where it differs, the product follows the un-contracted arithmetic of lib/nms/py_cpu_nms.py:18-38."""
+    import ctypes
+    import frcnn_hip
+    ref, ref_fma = _ref_gpu_nms("libref_gpu_nms.so"), _ref_gpu_nms("libref_gpu_nms_fma.so")
+    d = synth.random_dets(k, seed=seed, cluster=cl)
+    # pairs exactly at the threshold: box j = box i shrunk so that IoU == thr in float32 for several i
+    rng = np.random.RandomState(seed)
+    for i in rng.choice(k, size=min(24, k // 4), replace=False):
+        x1, y1 = np.floor(d[i, 0]), np.floor(d[i, 1])
+        d[i, :4] = (x1, y1, x1 + 99, y1 + 99)                          # 100 x 100 px with the +1 rule
+        j = (i + 1) % k
+        w = int(round(100 * thr / 1.0))                                 # inter / union = (w * 100) / (100 * 100) = thr when w = 100 thr
+        d[j, :4] = (x1, y1, x1 + w - 1, y1 + 99)
+    order = ora.order_desc(d[:, 4])
+    ds = np.ascontiguousarray(d[order])
+    keep_h = np.zeros(k, dtype=np.int32)
+    n_h = ctypes.c_int(0)
+    frcnn_hip.lib()._nms(keep_h.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n_h), ds.ctypes.data_as(ctypes.c_void_p), k, 5,
+                         ctypes.c_float(thr), 0)
+    got = keep_h[:n_h.value].tolist()
+    want = ref(ds, thr)
+    fma = ref_fma(ds, thr)
+    print("k %d thr %.1f: kept %d; reference CUDA kernel (contract off) %d, FMA-contracted build %d (differs in %d positions)"
+          % (k, thr, len(got), len(want), len(fma), sum(1 for a, b in zip(want, fma) if a != b) + abs(len(want) - len(fma))))
+    assert got == want
+    assert got == ora.gpu_nms(ds, thr)
+
+
 def _proposal_case(dev, H, W, scales, key, post, info, seed=3):
     from frcnn_hip import ops
     A = 3 * len(scales)

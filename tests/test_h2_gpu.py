@@ -68,7 +68,7 @@ H2_CASES = [
 ]
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 3, 4, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("cfg", [0, 1, 3, 8, 9, 12, 14, 18])
 @pytest.mark.parametrize("case", H2_CASES, ids=[str(i) for i in range(len(H2_CASES))])
 def test_gemm_h2_is_f32_class(dev, case, cfg):
     from frcnn_hip import ops

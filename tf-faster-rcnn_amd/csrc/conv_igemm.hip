@@ -724,7 +724,7 @@ static int launch_stream_cfg(int id, const ConvParams& p, hipStream_t st) {
 
 // tuning knob (experiments / A-B runs): key 0 = force a tile configuration id for every non-stem conv
 // (-1 = automatic choice).
-static int g_force_cfg = -1, g_dbg = 0, g_stagger = 0, g_stream = 1;
+static thread_local int g_force_cfg = -1, g_dbg = 0, g_stagger = 0, g_stream = 1;      // per calling thread: no state shared between threads
 extern "C" int frcnn_set_tuning(int key, int value) {
   if (key == 0) { g_force_cfg = value; return FRCNN_OK; }
   if (key == 1) { g_dbg = value; return FRCNN_OK; }

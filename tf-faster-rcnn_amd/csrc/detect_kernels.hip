@@ -956,7 +956,7 @@ __global__ __launch_bounds__(256) void k_crop_and_resize(const float4* __restric
   }
 }
 
-static int g_crop_slabs = -1;      // tuning (frcnn_set_tuning key 4): -1 automatic, else the channel-slab count
+static thread_local int g_crop_slabs = -1;      // tuning (frcnn_set_tuning key 4): -1 automatic, else the channel-slab count
 
 static int launch_crop(const float* feat_d, int NIMG, int H, int W, int C, const float* rois_d, int R, float feat_stride, int pool,
                        int fuse_max2x2, const float* bias_d, int act, float* out_d, void* stream) {

@@ -615,23 +615,13 @@ extern "C" int frcnn_gemm_h2(const void* x_planes_d, const float* x_inv_d, const
   switch (cfg) {
     case 0: return launch_h2<128, 128, 64, 64, 2>(p, st);        // 67 KB: 2 workgroups / CU
     case 1: return launch_h2<128, 128, 64, 64, 3>(p, st);        // 100 KB: 1 workgroup / CU, 2 slabs in flight
-    case 2: return launch_h2<128, 128, 64, 64, 4>(p, st);        // 133 KB
     case 3: return launch_h2<256, 128, 64, 64, 2>(p, st);        // 8 waves, 100 KB
-    case 4: return launch_h2<256, 128, 64, 64, 3>(p, st);        // 8 waves, 149 KB
-    case 5: return launch_h2<128, 128, 32, 64, 2>(p, st);        // 8 waves of 32 x 64
-    case 6: return launch_h2<128, 128, 32, 64, 3>(p, st);
-    case 7: return launch_h2<128, 128, 32, 64, 2, 4>(p, st);     // 8 waves of 32 x 64 in <= 128 registers: 2 workgroups = 4 waves / SIMD
     case 8: return launch_h2<128, 128, 64, 64, 2, 2, 1>(p, st);  // cfg 0 with the loads issued in two halves
-    case 9: return launch_h2<128, 128, 64, 64, 2, 2, 2>(p, st);  // cfg 0 with the scales sent once per 128-k block
-    case 10: return launch_h2<128, 128, 64, 64, 2, 2, 3>(p, st);
-    case 11: return launch_h2<128, 128, 32, 64, 2, 4, 3>(p, st);
-    case 14: return launch_h2<128, 128, 64, 64, 2, 2, 4>(p, st);  // cfg 0 with the loads spread between the MFMAs
-    case 15: return launch_h2<128, 128, 64, 64, 2, 2, 6>(p, st);  // ... and the scales sent once per 128-k block
-    case 16: return launch_h2<256, 128, 64, 64, 2, 2, 4>(p, st);  // 8 waves, loads spread
-    case 17: return launch_h2<64, 128, 32, 64, 2, 2, 4>(p, st);
-    case 18: return launch_h2<128, 128, 64, 64, 2, 2, 10>(p, st); // cfg 9 with the (r >> 1) & 3 swizzle
-    case 12: return launch_h2<64, 128, 32, 64, 2>(p, st);        // 64-row tiles, 4 waves of 32 x 64, 51 KB: 3 workgroups / CU (under-filled launches)
-    case 13: return launch_h2<64, 128, 32, 64, 3>(p, st);
+    case 9: return launch_h2<128, 128, 64, 64, 2, 2, 2>(p, st);  // cfg 0 with the scales sent once per 128-k block (the default)
+    case 12: return launch_h2<64, 128, 32, 64, 2>(p, st);        // 64-row tiles, 4 waves of 32 x 64, 51 KB: 3 workgroups / CU (faster alone on
+                                                                  // under-filled launches, slower in the pipeline: profiles/r03_l_ab.txt)
+    case 14: return launch_h2<128, 128, 64, 64, 2, 2, 4>(p, st);  // cfg 0 with the loads spread between the MFMAs (measured slower: r03_k)
+    case 18: return launch_h2<128, 128, 64, 64, 2, 2, 10>(p, st); // cfg 9 with round 2's (r >> 1) & 3 swizzle (two-way LDS bank conflicts)
     default: return FRCNN_E_ARG;
   }
 }

@@ -300,19 +300,12 @@ static int launch_x3(const GemmX3Params& q, hipStream_t st) {
   return FRCNN_OK;
 }
 
-static int g_x3_cfg = -1;                   // -1: by shape
-static int g_x3_terms = 6;                  // 6: dropped cross terms <= 2^-24 relative; 9: every product exact
-extern "C" int frcnn_gemm_x3_set_terms(int terms) {
-  if (terms != 6 && terms != 9) return FRCNN_E_ARG;
-  g_x3_terms = terms;
-  return FRCNN_OK;
-}
-extern "C" int frcnn_gemm_x3_set_config(int cfg) { g_x3_cfg = cfg; return FRCNN_OK; }
-
 // y[g] = act(x[g] W[g]^T + bias + res[g]) for g < G; x [G][M][K] f32, planes = frcnn_gemm_x3_pack(W [G][N][K]); res / y [G][M][N].
+// cfg: -1 = tile configuration by shape, else a configuration id (A/B runs); terms: 6 (cross terms below 2^-24 dropped) or 9 (every
+// f32 product exact).  Both are per call: the library keeps no tuning state.
 extern "C" int frcnn_gemm_x3(const float* x_d, const void* planes_d, const float* bias_d, const float* res_d, float* y_d, int G, int M,
-                             int N, int K, int act, void* stream) {
-  if (!x_d || !planes_d || !y_d || G <= 0 || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 2) return FRCNN_E_ARG;
+                             int N, int K, int act, int cfg, int terms, void* stream) {
+  if (!x_d || !planes_d || !y_d || G <= 0 || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 2 || (terms != 6 && terms != 9)) return FRCNN_E_ARG;
   if (K % 32 || N % 64 || (long long)M * N >= (1ll << 31) || (long long)N * K >= (1ll << 28) || K >= (1 << 22))     // 32-bit per-lane byte offsets
     return FRCNN_E_UNSUPPORTED;
   GemmX3Params p;
@@ -321,13 +314,12 @@ extern "C" int frcnn_gemm_x3(const float* x_d, const void* planes_d, const float
   p.gx = (long long)M * K; p.gwp = 3ll * N * K; p.gy = (long long)M * N;
   p.nsteps = p.mtiles = p.ntiles = 0;
   hipStream_t st = (hipStream_t)stream;
-  int cfg = g_x3_cfg;
   if (cfg >= 0 && cfg < 10 && (N % 128) && cfg != 6) cfg = -1;       // a forced A/B configuration that cannot tile this N: by shape
   if (cfg < 0)       // 64x64 wave tiles (fewest LDS reads and operand splits per MFMA) from 256 tiles up: alone, a 150..1000-tile launch is
                      // 5-10 % faster with 8 x (32x64) waves (profiles/r02_p_x3_sweep.txt), but in the power-limited pipeline the 64x64
                      // tiles win (profiles/r02_t_x3_config_in_pipeline.txt: 427 vs 424 images/s); N = 64 (block1): 128x64 tiles
     cfg = (N % 128) ? 6 : ((long long)cdiv(M, 128) * (N / 128) * G >= 256) ? 0 : 1;
-  if (g_x3_terms == 9) {
+  if (terms == 9) {
     switch (cfg) {
       case 0: return launch_x3<128, 128, 64, 64, 0, 9>(p, st);
       case 1: return launch_x3<128, 128, 32, 64, 0, 9>(p, st);
@@ -343,12 +335,14 @@ extern "C" int frcnn_gemm_x3(const float* x_d, const void* planes_d, const float
     case 4: return launch_x3<256, 128, 64, 64>(p, st);        // 8 waves, 112 KB: 1 workgroup / CU, W slab shared by twice the rows
     case 5: return launch_x3<128, 256, 64, 64>(p, st);        // 8 waves, 128 KB
     case 6: return launch_x3<128, 64, 64, 32>(p, st);         // N % 64 == 0: 4 waves of 64x32, 56 KB
-    case 10: return launch_x3<128, 128, 64, 64, 1>(p, st);      // ablations (wrong results by construction)
+#ifdef FRCNN_ABLATION                                          // measurement builds only (wrong results by construction): not in the shipped library
+    case 10: return launch_x3<128, 128, 64, 64, 1>(p, st);
     case 11: return launch_x3<128, 128, 64, 64, 2>(p, st);
     case 12: return launch_x3<128, 128, 64, 64, 3>(p, st);
     case 13: return launch_x3<128, 128, 32, 64, 1>(p, st);
     case 14: return launch_x3<128, 128, 32, 64, 2>(p, st);
     case 15: return launch_x3<128, 128, 32, 64, 3>(p, st);
+#endif
     default: return FRCNN_E_ARG;
   }
 }

@@ -110,13 +110,11 @@ SIGNATURES = {
     "frcnn_relu_bwd": (c_int, [_P, _P, c_longlong, _P]),
     "frcnn_gemm_x3_pack_bytes": (c_size_t, [c_int, c_int, c_int]),
     "frcnn_gemm_x3_pack": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
-    "frcnn_gemm_x3": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
-    "frcnn_gemm_x3_set_config": (c_int, [c_int]),
+    "frcnn_gemm_x3": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "frcnn_h2_planes_bytes": (c_size_t, [c_longlong, c_int]),
     "frcnn_h2_pack_w": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     "frcnn_h2_split": (c_int, [_P, c_longlong, c_int, _P, _P, _P]),
     "frcnn_gemm_h2": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
-    "frcnn_gemm_x3_set_terms": (c_int, [c_int]),
     "frcnn_relu6_bwd": (c_int, [_P, _P, c_longlong, _P]),
     "frcnn_maxpool_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, _P, _P]),
     "frcnn_dropout": (c_int, [_P, c_longlong, c_ulonglong, c_float, _P, _P]),

@@ -690,11 +690,13 @@ def gemm_x3_pack(w, planes=None):
     return planes
 
 
-def gemm_x3(x, planes, G, M, N, K, bias=None, residual=None, act=ACT_NONE, out=None):
-    """out[g] = act(x[g] W[g]^T + bias + residual[g]) through frcnn_gemm_x3 (products on the bf16 pipe as exact 3-way splits)."""
+def gemm_x3(x, planes, G, M, N, K, bias=None, residual=None, act=ACT_NONE, out=None, cfg=-1, terms=6):
+    """out[g] = act(x[g] W[g]^T + bias + residual[g]) through frcnn_gemm_x3 (products on the bf16 pipe as exact 3-way splits).
+    cfg: -1 = tiles by shape; terms: 6 (default) or 9 (all cross terms: every f32 product exact)."""
     _chk(x)
     out = torch.empty((G, M, N) if G > 1 else (M, N), dtype=torch.float32, device=x.device) if out is None else out
-    call("frcnn_gemm_x3", _ptr(x), _ptr(planes), _ptr(bias), _ptr(residual), _ptr(out), int(G), int(M), int(N), int(K), int(act), _stream())
+    call("frcnn_gemm_x3", _ptr(x), _ptr(planes), _ptr(bias), _ptr(residual), _ptr(out), int(G), int(M), int(N), int(K), int(act),
+         int(cfg), int(terms), _stream())
     return out
 
 

@@ -3,7 +3,8 @@ an all-gather of a fixed-size padded detection record (new relativ
 which is strictly single-GPU / batch-1: lib/model/test.py:88).
 
 Record layout (float32, REC_FLOATS long): rows [0, REC_ROWS) = (x1,y1,x2,y2,score,class) padded with
-zeros, then the detection count as a float32 (exact below 2**24), then padding to a 32-byte multiple.
+zeros, then the detection count as a float32 (exact below 2**24), then (rank, step) stamps (set_stamp, optional) and padding to
+a 32-byte multiple.
 The same code runs over RCCL/xGMI (backend "nccl", GPU tensors) and over gloo (CPU tensors, tests).
 """
 import torch
@@ -28,6 +29,20 @@ def set_count(rec, count_i32):
         rec[REC_ROWS * 6] = count_i32[0].to(torch.float32)
     else:
         rec[:, REC_ROWS * 6] = count_i32.to(torch.float32)
+
+
+def set_stamp(rec, rank, step):
+    """(rank, step mod 2^20) into two of the record's padding floats (exact in float32): lets a receiver verify whose record of which
+    step occupies a slot of the all-gather (bench.py's self-check)."""
+    v = torch.tensor([float(rank), float(int(step) & 0xfffff)], dtype=torch.float32, device=rec.device)
+    if rec.dim() == 1:
+        rec[REC_ROWS * 6 + 1:REC_ROWS * 6 + 3] = v
+    else:
+        rec[:, REC_ROWS * 6 + 1:REC_ROWS * 6 + 3] = v
+
+
+def get_stamp(rec_row):
+    return int(rec_row[REC_ROWS * 6 + 1].item()), int(rec_row[REC_ROWS * 6 + 2].item())
 
 
 def shard_images(num_images, rank, world):

@@ -130,7 +130,8 @@ class Network(object):
             # ... on the bf16 matrix pipe with exact bf16x3 operand splits (cfg.HIP.MFMA_X3)
             self._need_f32(x), self._need_f32(residual)
             planes = sess.x3_planes(w)
-            sess.mark("conv:x3:" + scope, flops, lambda: ops.gemm_x3(x, planes, 1, M, Cout, Cin, b, residual, act, out=out),
+            xc, xt = int(cfg.HIP.X3_TILE_CFG), int(cfg.HIP.X3_TERMS)
+            sess.mark("conv:x3:" + scope, flops, lambda: ops.gemm_x3(x, planes, 1, M, Cout, Cin, b, residual, act, out=out, cfg=xc, terms=xt),
                       nbytes=4 * (x.numel() + out.numel() + (out.numel() if residual is not None else 0)) + 6 * w.numel())
             self._wrote(out)
         else:
@@ -225,7 +226,8 @@ class Network(object):
             sess.mark("op:wino_in", 0, lambda: ops.winograd_input_transform(x, v, m), nbytes=4 * (x.numel() + v.numel()))
             if self._x3_eligible(T, Cout, Cin, G):
                 planes = sess.x3_planes(u)
-                sess.mark("conv:x3:" + scope, flops, lambda: ops.gemm_x3(v, planes, G, T, Cout, Cin, out=mm),
+                xc, xt = int(cfg.HIP.X3_TILE_CFG), int(cfg.HIP.X3_TERMS)
+                sess.mark("conv:x3:" + scope, flops, lambda: ops.gemm_x3(v, planes, G, T, Cout, Cin, out=mm, cfg=xc, terms=xt),
                           nbytes=4 * (v.numel() + mm.numel()) + 6 * u.numel())
             else:
                 sess.mark("conv:" + scope, flops, lambda: ops.gemm_batched_nt(v, u, mm), nbytes=4 * (v.numel() + u.numel() + mm.numel()))
@@ -623,7 +625,7 @@ class Network(object):
                c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH, cfg.TEST.RPN_TOP_N, cfg.POOLING_SIZE,
                bool(cfg.HIP.WINOGRAD), int(cfg.HIP.WINOGRAD_MIN_CIN), int(cfg.HIP.WINOGRAD_M), tuple(cfg.HIP.WINOGRAD_F2_SCOPES),
                tuple(cfg.HIP.WINOGRAD_DIRECT_SCOPES), bool(cfg.HIP.WINOGRAD_7X7), bool(cfg.HIP.FUSE_TAIL_MEAN), bool(cfg.HIP.OVERLAP_TAIL_ENTRY), bool(cfg.HIP.MFMA_X3), bool(cfg.USE_E2E_TF),
-               bool(cfg.HIP.MFMA_H2), bool(cfg.HIP.H2_LAZY_SPLIT), int(cfg.HIP.H2_MIN_TILES), bool(cfg.HIP.H2_TRUNK_PLANES), int(cfg.HIP.H2_TILE_CFG))
+               bool(cfg.HIP.MFMA_H2), bool(cfg.HIP.H2_LAZY_SPLIT), int(cfg.HIP.H2_MIN_TILES), bool(cfg.HIP.H2_TRUNK_PLANES), int(cfg.HIP.H2_TILE_CFG), int(cfg.HIP.X3_TILE_CFG), int(cfg.HIP.X3_TERMS))
         cur = torch.cuda.current_stream(sess.device)
         if not use_graph or sess.profile is not None:
             sess.flops_last_forward = 0
