@@ -75,7 +75,7 @@ def make_net(c):
 
 
 def calibrate_rpn(sess, net, img_d, im_info):
-    """Random-init RPN heads give near-constant scores and ~0 deltas, so NMS collapses the 6000 candidates to ~140 boxes.
+    """(RPN heads and the class head.)  Random-init RPN heads give near-constant scores and ~0 deltas, so NMS collapses the 6000 candidates to ~140 boxes.
     Rescale the two 1x1 RPN heads so the proposal stage sees the statistics SURVEY.md 8d prescribes (logit spread ~1,
     deltas ~N(0,0.2^2)) and the full post_nms_topN proposals survive, as they do with a trained model.  Weights only; the
     architecture and every shape stay those of the reference."""
@@ -84,9 +84,13 @@ def calibrate_rpn(sess, net, img_d, im_info):
         sess.stream.synchronize()
         s_cls = float(p["rpn_cls_score"].std().item())
         s_box = float(p["rpn_bbox_pred"].std().item())
+        s_head = float(p["cls_score"].std().item())
     scope = net._scope
     sess.variables[scope + "/rpn_cls_score/weights"] *= np.float32(1.0 / max(s_cls, 1e-12))
     sess.variables[scope + "/rpn_bbox_pred/weights"] *= np.float32(0.2 / max(s_box, 1e-12))
+    # class logits of spread ~2.5: random-init heads on a random backbone saturate the softmax (scores of exactly 1.0 that tie at the
+    # max_per_image cut -- 303 "detections" for the 81-class config in round 2); a trained head's scores are distinct
+    sess.variables[scope + "/cls_score/weights"] *= np.float32(2.5 / max(s_head, 1e-12))
     sess.packed.clear()
     sess.graphs.clear()
 
