@@ -47,6 +47,9 @@ struct GemmH2Params {
   const float* bias; const float* res; const unsigned short* resp; const float* resp_inv; float* y; unsigned short* yp; float* y_inv;
   int M, N, K, batch, act, nsteps, mtiles, ntiles;
   long long Mtot;                     // rows of x / res / y / yp over all batch entries (= batch * M)
+#ifdef FRCNN_H2_TRACE
+  unsigned long long* trace;          // measurement builds only (scratch/h2_trace.py): s_memtime stamps of the first slabs of a few workgroups
+#endif
 };
 
 // one direct-to-LDS load: 64 lanes x 16 B from (scalar base + per-lane 32-bit byte offset) to LDS [lds_base, +1 KiB), lane-linear.
@@ -398,19 +401,32 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
 
   // one slab of the stream: wait for it, let the ring slot it frees be refilled (loads spread over nothing here: they are issued
   // right after the barrier, G + SL instructions, and land under the 24 * TM * TN / 4 MFMAs of this slab and the next NS - 2)
+#ifdef FRCNN_H2_TRACE
+  int tr_slab = 0;
+  auto stamp = [&](int point) {       // [workgroup < 16][wave][slab < 64][point < 8]
+    if (p.trace && blockIdx.x < 16 && tr_slab < 64 && lane == 0)
+      p.trace[(((size_t)blockIdx.x * NW + wave) * 64 + tr_slab) * 8 + point] = __builtin_amdgcn_s_memtime();
+  };
+#else
+  auto stamp = [](int) {};
+#endif
   auto slab = [&](auto first_c, bool fold) {
+    stamp(0);
     if (left >= 1) {                                   // steady state: NS - 2 younger slabs may stay in flight
       if (wave == 0) h2_wait_vmcnt<(NS - 2) * (G + SL)>(); else h2_wait_vmcnt<(NS - 2) * G>();
     } else {
       h2_wait_vmcnt<0>();                              // tail of the stream: nothing more will be issued
     }
+    stamp(1);
     __builtin_amdgcn_s_barrier();
+    stamp(2);
     const bool more = left > 0;
     constexpr int HALF = (TUNE & 4) ? 0 : (TUNE & 1) ? (G + SL) / 2 : G + SL;
     if (more) {
 #pragma unroll
       for (int t = 0; t < HALF; ++t) issue_one(nxt, t);
     }
+    stamp(3);
     float ainv[TM];
     if (fold) {
       const int soff = (TUNE & 2) ? S2_OFF + c_par * 1024 : cur * STAGE + S_OFF;
@@ -420,6 +436,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
     }
     if (!(TUNE & 4)) {
       slab_mfma(cur, first_c, [&]() {
+        stamp(4);
         if (more) {
 #pragma unroll
           for (int t = HALF; t < G + SL; ++t) issue_one(nxt, t);
@@ -434,6 +451,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
     } else {
       slab_mfma(cur, first_c, []() {}, [](int) {});
     }
+    stamp(5);
     if (more) {
       issue_advance();
       nxt = nxt + 1 == NS ? 0 : nxt + 1;
@@ -447,6 +465,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
           for (int r = 0; r < 16; ++r) tot[i][j][r] = __builtin_fmaf(tmp[i][j][r], ainv[i], tot[i][j][r]);
     }
     cur = cur + 1 == NS ? 0 : cur + 1;
+    stamp(6);
+#ifdef FRCNN_H2_TRACE
+    ++tr_slab;
+#endif
   };
 
   // ---- prologue: NS - 1 slabs ahead ---------------------------------------------------------------------------------------------
@@ -536,6 +558,11 @@ __global__ __launch_bounds__(256) void k_h2_pack_w(const float* __restrict__ w, 
   if (l == 0) inv_out[row] = inv;
 }
 
+#ifdef FRCNN_H2_TRACE
+unsigned long long* g_h2_trace = nullptr;
+extern "C" void frcnn_h2_set_trace(unsigned long long* buf) { g_h2_trace = buf; }
+#endif
+
 extern "C" size_t frcnn_h2_planes_bytes(long long rows, int K) {
   if (rows <= 0 || K <= 0) return 0;
   return (size_t)2 * (size_t)rows * (size_t)K * sizeof(unsigned short);
@@ -610,6 +637,9 @@ extern "C" int frcnn_gemm_h2(const void* x_planes_d, const float* x_inv_d, const
   p.bias = bias_d; p.res = res_d; p.resp = (const unsigned short*)res_planes_d; p.resp_inv = res_inv_d; p.y = y_d; p.yp = (unsigned short*)y_planes_d; p.y_inv = y_inv_d;
   p.M = M; p.N = N; p.K = K; p.batch = G; p.act = act; p.Mtot = Mtot;
   p.nsteps = p.mtiles = p.ntiles = 0;
+#ifdef FRCNN_H2_TRACE
+  p.trace = g_h2_trace;
+#endif
   hipStream_t st = (hipStream_t)stream;
   if (cfg < 0) cfg = 9;      // by measurement in the pipeline (profiles/r03_l_ab.txt): 128 x 128 tiles, scales once per 128-k block, for every launch
   switch (cfg) {
