@@ -328,6 +328,10 @@ int frcnn_maxpool_nhwc(const float* x_d, int N, int H, int W, int C, int k, int 
 /* depthwise 3x3 (MobileNet, lib/nets/mobilenet_v1.py:21-49): w_d [3][3][C], bias, act. */
 int frcnn_dwconv3x3_nhwc(const float* x_d, int N, int H, int W, int C, const float* w_d, const float* bias_d,
                          float* y_d, int OH, int OW, int stride, int pad_top, int pad_left, int act, void* stream);
+/* ... with the result as frcnn_gemm_h2 operand planes [2][N*OH*OW][C] + y_inv [C/128][N*OH*OW] for the pointwise convolution that
+ * follows (mobilenet_v1.py:21-49); y_d NULL = planes only.  C % 128 == 0. */
+int frcnn_dwconv3x3_nhwc_h2(const float* x_d, int N, int H, int W, int C, const float* w_d, const float* bias_d, float* y_d,
+                            void* y_planes_d, float* y_inv_d, int OH, int OW, int stride, int pad_top, int pad_left, int act, void* stream);
 /* mean over the HW positions of [N,HW,C] -> [N,C]  (resnet_v1.py:124, mobilenet_v1.py:249). */
 int frcnn_spatial_mean(const float* x_d, int N, int HW, int C, float* y_d, void* stream);
 /* row softmax [R,C] (network.py:80-86, cls_prob). */

@@ -212,3 +212,25 @@ def test_winograd_transforms_emit_the_planes_of_their_f32_results(dev, m, N, H, 
         rec = yp.to_float().double().cpu().numpy()
         want = y.view(N * H * W, C).double().cpu().numpy()
         assert np.all(np.abs(rec - want) <= np.maximum(np.abs(want) * 2.0 ** -22, np.abs(want).max() * 2.0 ** -30))
+
+
+@pytest.mark.parametrize("N,H,W,C,stride", [(2, 19, 25, 128, 1), (1, 38, 63, 256, 2), (3, 7, 7, 512, 1)])
+def test_depthwise_conv_emits_the_planes_of_its_f32_result(dev, N, H, W, C, stride):
+    """frcnn_dwconv3x3_nhwc_h2: the depthwise result as operand planes == frcnn_h2_split of the float32 result (bit for bit), with and
+    without the float32 tensor."""
+    from frcnn_hip import ops
+    rng = np.random.RandomState(C + stride)
+    x = (rng.randn(N, H, W, C) * np.exp(rng.uniform(-2, 2, size=(1, 1, 1, C)))).astype(np.float32)
+    w = rng.randn(3, 3, C).astype(np.float32)
+    b = rng.randn(C).astype(np.float32)
+    xd, wd, bd = T(x, dev), T(w, dev), T(b, dev)
+    y = ops.dwconv3x3(xd, wd, bd, stride, (1, 1, 1, 1), 2)
+    rows = y.numel() // C
+    yp = ops.H2.empty(rows, C, dev)
+    yp.planes.fill_(0x5a); yp.inv.fill_(-1.0)
+    y2 = ops.dwconv3x3(xd, wd, bd, stride, (1, 1, 1, 1), 2, out_planes=yp, want_f32=True)
+    assert torch.equal(y, y2)
+    _same_planes(yp, ops.h2_split(y.view(rows, C)))
+    yp2 = ops.H2.empty(rows, C, dev)
+    assert ops.dwconv3x3(xd, wd, bd, stride, (1, 1, 1, 1), 2, out_planes=yp2, want_f32=False) is None
+    _same_planes(yp2, yp)

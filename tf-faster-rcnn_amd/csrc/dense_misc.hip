@@ -1,6 +1,6 @@
 // Bandwidth-bound dense helpers (NHWC f32, float4 along the channel axis) + stream-capture glue.
 // Citations relative to /root/reference/lib.
-#include "common.h"
+#include "h2_common.h"
 
 extern "C" int frcnn_abi_version(void) { return 2; }
 extern "C" const char* frcnn_build_info(void) { return "libfrcnn_hip gfx950 (CDNA4, wave64, f32 MFMA 32x32x2) abi 2"; }
@@ -54,14 +54,18 @@ extern "C" int frcnn_maxpool_nhwc(const float* x_d, int N, int H, int W, int C, 
 }
 
 // ---- depthwise 3x3 (nets/mobilenet_v1.py:21-49): VALU / bandwidth bound by nature.
+// H2: the result also / only leaves as frcnn_gemm_h2 operand planes (the pointwise convolution that follows reads nothing else): the
+// 32 consecutive threads of a pixel's 128 channels are one half-wave (C4 % 32 == 0) and reduce the block maximum with DPP moves.
+template <bool H2>
 __global__ void k_dwconv3x3(const float4* __restrict__ x, int N, int H, int W, int C4, const float4* __restrict__ w,
-                            const float4* __restrict__ bias, float4* __restrict__ y, int OH, int OW, int stride, int pt,
-                            int pl, int act) {
+                            const float4* __restrict__ bias, float4* __restrict__ y, unsigned short* __restrict__ planes,
+                            float* __restrict__ inv, int OH, int OW, int stride, int pt, int pl, int act) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long tot = (long long)N * OH * OW * C4;
   if (t >= tot) return;
   const int c4 = (int)(t % C4);
   long long pix = t / C4;
+  const size_t row = (size_t)pix;
   const int ow = (int)(pix % OW); pix /= OW;
   const int oh = (int)(pix % OH);
   const int img = (int)(pix / OH);
@@ -80,7 +84,12 @@ __global__ void k_dwconv3x3(const float4* __restrict__ x, int N, int H, int W, i
   if (act == FRCNN_ACT_RELU) a = make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f));
   else if (act == FRCNN_ACT_RELU6)
     a = make_float4(fminf(fmaxf(a.x, 0.f), 6.f), fminf(fmaxf(a.y, 0.f), 6.f), fminf(fmaxf(a.z, 0.f), 6.f), fminf(fmaxf(a.w, 0.f), 6.f));
-  y[t] = a;
+  if (!H2 || y) y[t] = a;
+  if (H2) {
+    const size_t rows = (size_t)N * OH * OW, e = (row * C4 + c4) * 4;
+    float* slot = inv + (size_t)(c4 >> 5) * rows + row;
+    h2_emit_rows32<1>(&a, &e, &slot, 1u, planes, rows * (size_t)C4 * 4, c4 & 31);
+  }
 }
 
 extern "C" int frcnn_dwconv3x3_nhwc(const float* x_d, int N, int H, int W, int C, const float* w_d, const float* bias_d,
@@ -88,8 +97,24 @@ extern "C" int frcnn_dwconv3x3_nhwc(const float* x_d, int N, int H, int W, int C
   if (!x_d || !w_d || !y_d || N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || stride <= 0) return FRCNN_E_ARG;
   if (C % 4) return FRCNN_E_UNSUPPORTED;
   const long long tot = (long long)N * OH * OW * (C / 4);
-  hipLaunchKernelGGL(k_dwconv3x3, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x_d,
-                     N, H, W, C / 4, (const float4*)w_d, (const float4*)bias_d, (float4*)y_d, OH, OW, stride, pad_top, pad_left, act);
+  hipLaunchKernelGGL(k_dwconv3x3<false>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x_d,
+                     N, H, W, C / 4, (const float4*)w_d, (const float4*)bias_d, (float4*)y_d, (unsigned short*)nullptr, (float*)nullptr, OH, OW,
+                     stride, pad_top, pad_left, act);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// ... with the result as operand planes [2][N*OH*OW][C] + y_inv [C/128][N*OH*OW] for the pointwise convolution that follows
+// (mobilenet_v1.py:21-49: depthwise -> BN -> ReLU6 -> pointwise); y_d NULL = planes only.  C % 128 == 0.
+extern "C" int frcnn_dwconv3x3_nhwc_h2(const float* x_d, int N, int H, int W, int C, const float* w_d, const float* bias_d,
+                                       float* y_d, void* y_planes_d, float* y_inv_d, int OH, int OW, int stride, int pad_top,
+                                       int pad_left, int act, void* stream) {
+  if (!x_d || !w_d || !y_planes_d || !y_inv_d || N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || stride <= 0) return FRCNN_E_ARG;
+  if (C % H2_KB) return FRCNN_E_UNSUPPORTED;
+  const long long tot = (long long)N * OH * OW * (C / 4);
+  hipLaunchKernelGGL(k_dwconv3x3<true>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x_d,
+                     N, H, W, C / 4, (const float4*)w_d, (const float4*)bias_d, (float4*)y_d, (unsigned short*)y_planes_d, y_inv_d, OH, OW,
+                     stride, pad_top, pad_left, act);
   LAUNCH_CHECK();
   return FRCNN_OK;
 }

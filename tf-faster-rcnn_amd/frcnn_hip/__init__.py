@@ -85,6 +85,7 @@ SIGNATURES = {
     "frcnn_pack_filter_hwio": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "frcnn_maxpool_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     "frcnn_dwconv3x3_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "frcnn_dwconv3x3_nhwc_h2": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "frcnn_spatial_mean": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "frcnn_softmax_rows": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "frcnn_rpn_softmax": (c_int, [_P, c_int, c_int, c_int, _P, _P]),

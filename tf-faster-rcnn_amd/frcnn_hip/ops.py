@@ -478,15 +478,24 @@ def maxpool(x, k, stride, pad=(0, 0, 0, 0), out=None):
     return out
 
 
-def dwconv3x3(x, w, bias, stride=1, pad=(1, 1, 1, 1), act=ACT_NONE, out=None):
+def dwconv3x3(x, w, bias, stride=1, pad=(1, 1, 1, 1), act=ACT_NONE, out=None, out_planes=None, want_f32=True):
+    """Depthwise 3x3 (+ folded BN bias, activation).  out_planes: an H2 of [N*OH*OW, C] that receives the result as frcnn_gemm_h2
+    operand planes (frcnn_dwconv3x3_nhwc_h2); want_f32 = False then skips the float32 tensor (returns None for it)."""
     _chk(x), _chk(w)
     N, H, W, C = x.shape
     OH = conv_out_size(H, 3, stride, pad[0], pad[1])
     OW = conv_out_size(W, 3, stride, pad[2], pad[3])
-    out = torch.empty((N, OH, OW, C), dtype=torch.float32, device=x.device) if out is None else out
-    call("frcnn_dwconv3x3_nhwc", _ptr(x), N, H, W, C, _ptr(w), _ptr(bias), _ptr(out), OH, OW, int(stride),
-         int(pad[0]), int(pad[2]), int(act), _stream())
-    return out
+    if out_planes is None:
+        out = torch.empty((N, OH, OW, C), dtype=torch.float32, device=x.device) if out is None else out
+        call("frcnn_dwconv3x3_nhwc", _ptr(x), N, H, W, C, _ptr(w), _ptr(bias), _ptr(out), OH, OW, int(stride),
+             int(pad[0]), int(pad[2]), int(act), _stream())
+        return out
+    assert isinstance(out_planes, H2) and out_planes.rows == N * OH * OW and out_planes.K == C
+    if want_f32 and out is None:
+        out = torch.empty((N, OH, OW, C), dtype=torch.float32, device=x.device)
+    call("frcnn_dwconv3x3_nhwc_h2", _ptr(x), N, H, W, C, _ptr(w), _ptr(bias), _ptr(out if want_f32 else None), _ptr(out_planes.planes),
+         _ptr(out_planes.inv), OH, OW, int(stride), int(pad[0]), int(pad[2]), int(act), _stream())
+    return out if want_f32 else None
 
 
 def spatial_mean(x, out=None):

@@ -69,8 +69,19 @@ class mobilenetv1(Network):
         pad = (1, 1, 1, 1)                                   # SAME (stride 1) == explicit pad 1 (stride 2) for k=3
         OH, OW = ops.conv_out_size(H, 3, stride, 1, 1), ops.conv_out_size(W, 3, stride, 1, 1)
         out = self._sess.buf(self._tag + "/" + dw_scope, (N, OH, OW, C))
-        y = self._sess.mark("op:dwconv3x3", 0, lambda: ops.dwconv3x3(x, w, b, stride, pad, ACT_RELU6, out=out), nbytes=4 * (x.numel() + out.numel()))
-        self._wrote(out)
+        self._need_f32(x)
+        cout = self._depth(_SEP[i - 1][1])
+        if C % 128 == 0 and self._h2_eligible(N * OH * OW, cout, C, 1):
+            # cfg.HIP.MFMA_H2 (TEST mode): the pointwise convolution is the only reader -- the depthwise kernel hands it operand planes
+            # and no float32 tensor
+            yp = self._sess.h2_buf(self._tag + "/" + dw_scope, N * OH * OW, C)
+            self._sess.mark("op:dwconv3x3", 0, lambda: ops.dwconv3x3(x, w, b, stride, pad, ACT_RELU6, out_planes=yp, want_f32=False),
+                            nbytes=4 * (x.numel() + out.numel()))
+            self._wrote(out, yp, False)
+            y = out
+        else:
+            y = self._sess.mark("op:dwconv3x3", 0, lambda: ops.dwconv3x3(x, w, b, stride, pad, ACT_RELU6, out=out), nbytes=4 * (x.numel() + out.numel()))
+            self._wrote(out)
         if self._mode == "TRAIN":
             self._tape.append(dict(kind="dwconv", scope=dw_scope, x=x, y=out, stride=stride, pad=pad, act=ACT_RELU6))
             if self.trainable_scope(dw_scope) or x.data_ptr() in self._requires_grad:
