@@ -210,7 +210,7 @@ POLICIES = {
     "f4_b12_direct": dict(WINOGRAD=True, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=(), WINOGRAD_DIRECT_SCOPES=("block1", "block2"), WINOGRAD_7X7=True),
 }
 TRAIN_POLICIES = {
-    "direct": dict(WINOGRAD=False, WINOGRAD_TRAIN=False),           # every convolution and gradient on the direct f32-MFMA kernels
+    "direct": dict(WINOGRAD=False, WINOGRAD_TRAIN=False, H2_TRAIN=False),   # every convolution and gradient on the direct f32-MFMA kernels
     "shipped": dict(),                                               # cfg.HIP defaults (Winograd forward + data gradient for 3x3 stride 1)
 }
 GRAD_TOL = 2e-4              # of the tensor's largest entry; or GRAD_CTRL_FACTOR x the float32 control's own distance to float64

@@ -136,24 +136,29 @@ def test_losses_value_and_gradient_vs_torch_float64(dev, golden):
         assert np.allclose(grad.cpu().numpy(), p.grad.numpy(), rtol=1e-5, atol=1e-9)
 
 
-@pytest.mark.parametrize("wino", [False, True], ids=["direct", "winograd"])
-def test_full_train_step_matches_torch_autograd(dev, wino):
+@pytest.mark.parametrize("wino,h2", [(False, False), (True, False), (True, True)], ids=["direct", "winograd", "winograd_h2"])
+def test_full_train_step_matches_torch_autograd(dev, wino, h2):
     """TRAIN forward + reverse sweep + momentum SGD on the device vs torch float64
     autograd of the reference graph, with the device-sampled rois/targets fed to the reference as constants.
     wino: the 3x3 stride-1 layers' forward and data gradient as Winograd F(4x4,3x3) with device-transformed filters
-    (cfg.HIP.WINOGRAD_TRAIN, the default) or on the direct kernels -- same bounds."""
+    (cfg.HIP.WINOGRAD_TRAIN, the default) or on the direct kernels -- same bounds.  h2: cfg.HIP.H2_TRAIN forced onto this small
+    network (H2_MIN_TILES = 1): the pointwise convolutions of the forward pass and their data gradients run in frcnn_gemm_h2
+    (filters re-split after the solver step) -- same bounds again."""
     from dense_ref import TrainRef
+    from frcnn_hip import ops as ops_mod
     from frcnn_hip.runtime import Session
     from frcnn_hip.train import TrainState
     from model.config import cfg
     from nets.resnet_v1 import resnetv1
     SC, RT = (4, 8, 16), (0.5, 1, 2)
     old = (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.WINOGRAD_TRAIN)
+    old_h2 = (cfg.HIP.H2_TRAIN, cfg.HIP.H2_MIN_TILES)
     cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.WINOGRAD_TRAIN = 64, 0.0, wino
+    cfg.HIP.H2_TRAIN, cfg.HIP.H2_MIN_TILES = bool(h2), (1 if h2 else cfg.HIP.H2_MIN_TILES)
     try:
         sess = Session(device=dev, seed=5)
         net = resnetv1(num_layers=50)
-        net.create_architecture("TRAIN", 21, tag="train_w%d" % int(wino), anchor_scales=SC, anchor_ratios=RT)
+        net.create_architecture("TRAIN", 21, tag="train_w%d_h%d" % (int(wino), int(h2)), anchor_scales=SC, anchor_ratios=RT)
         sess.init_variables(net.variable_specs())
         rng = np.random.RandomState(2)
         H, W = 128, 160
@@ -166,6 +171,9 @@ def test_full_train_step_matches_torch_autograd(dev, wino):
         assert counts[0] > 0 and counts[0] + counts[1] == 64
         ts = TrainState(sess, net, momentum=0.9, weight_decay=1e-4).build()
         ts.winograd = (4, 64, True) if wino else None
+        ts.h2_train = 1 if h2 else None
+        if h2:
+            assert len(sess.h2) >= 20, "the forward pass did not take the h2 path"
         ts.backward(net._loss_seeds)
         torch.cuda.synchronize()
         ref = TrainRef(sess.variables, 50, 21, SC, RT, net.trainable_scope)
@@ -206,8 +214,13 @@ def test_full_train_step_matches_torch_autograd(dev, wino):
         ts.lr = 0.001
         out = net.train_step(sess, blobs, ts)
         assert len(out) == 5 and all(np.isfinite(out)) and out[4] > sum(out[:4])   # total includes the L2 term
+        if h2:                                       # the filter planes follow the solver: re-split in place after apply()
+            wq, wsrc = next(iter(sess.h2.values()))
+            fresh = ops_mod.h2_pack_w(wsrc)
+            assert torch.equal(fresh[0], wq[0]) and torch.equal(fresh[1], wq[1])
     finally:
         cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.WINOGRAD_TRAIN = old
+        cfg.HIP.H2_TRAIN, cfg.HIP.H2_MIN_TILES = old_h2
 
 
 def test_sgd_steps_on_a_fixed_batch_reduce_the_loss(dev):

@@ -249,6 +249,15 @@ class Session(VariableStore):
             t = self.buffers[key] = ops.H2.empty(rows, K, self.device)
         return t
 
+    def buf_pair(self, name, N, K):
+        """Static (planes, w_inv) pair for ops.h2_pack_w(out=...) of a [N, K] filter that changes every step (training)."""
+        key = ("h2w", name, int(N), int(K))
+        t = self.buffers.get(key)
+        if t is None:
+            t = self.buffers[key] = (torch.empty(int(ops.lib().frcnn_h2_planes_bytes(int(N), int(K))), dtype=torch.uint8, device=self.device),
+                                     torch.empty((1, int(N)), dtype=torch.float32, device=self.device))
+        return t
+
     def mark(self, tag, flops, fn, nbytes=0):
         """nbytes: algorithmic HBM bytes of the launch (operands read once + result written once), for the roofline report."""
         self.flops_last_forward += flops

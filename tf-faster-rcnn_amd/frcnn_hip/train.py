@@ -234,8 +234,18 @@ class TrainState(object):
                                          m_buf=sess.buf("bwd/wino_m", (G, T, Cin)))
                 elif stride == 1 and Cout % 32 == 0:
                     wd = ops.flip_transpose_filter(wf, out=sess.buf("bwd/wflip/" + sc, (wf.shape[3], k, k, Cout)))
-                    dpad = (k - 1 - pad[0], k - 1 - pad[1], k - 1 - pad[2], k - 1 - pad[3])
-                    ops.conv2d(gy, wd, None, k, k, 1, dpad, ACT_NONE, gx if had else None, 1, out=gx)
+                    Cin = wf.shape[3]
+                    if (k == 1 and tuple(pad) == (0, 0, 0, 0) and getattr(self, "h2_train", None) is not None
+                            and Cout % 128 == 0 and Cin % 128 == 0 and ((M + 127) // 128) * (Cin // 128) >= self.h2_train
+                            and 4 * M * Cout < (1 << 32) and M * Cin < (1 << 29)):
+                        # dX = dY W: a plain GEMM with K = Cout -- frcnn_gemm_h2 on the split of dY and of the transposed filter
+                        # (cfg.HIP.H2_TRAIN; both change every step, so both are split here: 8 B per element of dY, a few MB of filter)
+                        gp = ops.h2_split(gy.view(M, Cout), out=sess.h2_buf("bwd/gy", M, Cout))
+                        wq = ops.h2_pack_w(wd.view(Cin, Cout), out=sess.buf_pair("bwd/wflip_h2/" + sc, Cin, Cout))
+                        ops.gemm_h2(gp, wq, 1, M, Cin, Cout, None, gx.view(M, Cin) if had else None, ACT_NONE, out=gx.view(M, Cin))
+                    else:
+                        dpad = (k - 1 - pad[0], k - 1 - pad[1], k - 1 - pad[2], k - 1 - pad[3])
+                        ops.conv2d(gy, wd, None, k, k, 1, dpad, ACT_NONE, gx if had else None, 1, out=gx)
                 else:
                     ops.conv2d_dgrad_strided(gy, wf, stride, pad, x.shape[1], x.shape[2], gx, had)
         return grads

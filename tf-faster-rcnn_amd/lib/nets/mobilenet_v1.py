@@ -72,12 +72,13 @@ class mobilenetv1(Network):
         self._need_f32(x)
         cout = self._depth(_SEP[i - 1][1])
         if C % 128 == 0 and self._h2_eligible(N * OH * OW, cout, C, 1):
-            # cfg.HIP.MFMA_H2 (TEST mode): the pointwise convolution is the only reader -- the depthwise kernel hands it operand planes
-            # and no float32 tensor
+            # cfg.HIP.MFMA_H2: the depthwise kernel hands the pointwise convolution its operand planes; in TEST mode that is the only
+            # reader, so no float32 tensor is written (TRAIN: the tape needs it -- both forms)
             yp = self._sess.h2_buf(self._tag + "/" + dw_scope, N * OH * OW, C)
-            self._sess.mark("op:dwconv3x3", 0, lambda: ops.dwconv3x3(x, w, b, stride, pad, ACT_RELU6, out_planes=yp, want_f32=False),
-                            nbytes=4 * (x.numel() + out.numel()))
-            self._wrote(out, yp, False)
+            keep = self._mode == "TRAIN"
+            self._sess.mark("op:dwconv3x3", 0, lambda: ops.dwconv3x3(x, w, b, stride, pad, ACT_RELU6, out=out, out_planes=yp, want_f32=keep),
+                            nbytes=4 * (x.numel() + out.numel() * (2 if keep else 1)))
+            self._wrote(out, yp, keep)
             y = out
         else:
             y = self._sess.mark("op:dwconv3x3", 0, lambda: ops.dwconv3x3(x, w, b, stride, pad, ACT_RELU6, out=out), nbytes=4 * (x.numel() + out.numel()))

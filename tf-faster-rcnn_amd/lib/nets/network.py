@@ -116,7 +116,7 @@ class Network(object):
             # a plain GEMM with a static filter on the fp16 matrix pipe, block-scaled two-piece operands (cfg.HIP.MFMA_H2)
             xp, wp = self._h2_input(x), sess.h2_planes(w)
             yp = sess.h2_buf(self._tag + "/" + scope, M, Cout) if emit_h2 else None
-            y = out if (want_f32 or yp is None) else None
+            y = out if (want_f32 or yp is None or self._mode == "TRAIN") else None
             res = residual
             if residual is not None and residual.data_ptr() in self._f32_missing:
                 res = self._h2_of[residual.data_ptr()]              # the trunk exists as operand planes only (cfg.HIP.H2_TRUNK_PLANES)
@@ -151,10 +151,12 @@ class Network(object):
 
     # ---- cfg.HIP.MFMA_H2 plumbing -------------------------------------------------------------------------------------------------
     def _h2_eligible(self, M, N, K, G):
-        """TEST mode (static filters), K % 128 == 0 (scale blocks), N % 128 == 0 (tiles), enough tiles to fill the chip, and the
-        32-bit offset limits of frcnn_gemm_h2."""
+        """K % 128 == 0 (scale blocks), N % 128 == 0 (tiles), enough tiles to fill the chip, and the 32-bit offset limits of
+        frcnn_gemm_h2.  TEST mode: static filters, split once.  TRAIN mode (cfg.HIP.H2_TRAIN): the pointwise convolutions of the
+        forward pass take the same kernel -- the solver re-splits the updated filters after every step (Session.h2_refresh), the
+        float32 outputs the tape needs are always written, inputs without planes are split by a separate pass."""
         rows = G * M
-        return (bool(cfg.HIP.MFMA_H2) and self._mode == "TEST" and K % 128 == 0 and N % 128 == 0
+        return (bool(cfg.HIP.MFMA_H2) and (self._mode == "TEST" or bool(cfg.HIP.H2_TRAIN)) and K % 128 == 0 and N % 128 == 0
                 and ((M + 127) // 128) * (N // 128) * G >= int(cfg.HIP.H2_MIN_TILES)
                 and 4 * rows * K < (1 << 32) and 4 * N * K < (1 << 32) and M * N < (1 << 29))
 
@@ -625,7 +627,7 @@ class Network(object):
                c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH, cfg.TEST.RPN_TOP_N, cfg.POOLING_SIZE,
                bool(cfg.HIP.WINOGRAD), int(cfg.HIP.WINOGRAD_MIN_CIN), int(cfg.HIP.WINOGRAD_M), tuple(cfg.HIP.WINOGRAD_F2_SCOPES),
                tuple(cfg.HIP.WINOGRAD_DIRECT_SCOPES), bool(cfg.HIP.WINOGRAD_7X7), bool(cfg.HIP.FUSE_TAIL_MEAN), bool(cfg.HIP.OVERLAP_TAIL_ENTRY), bool(cfg.HIP.MFMA_X3), bool(cfg.USE_E2E_TF),
-               bool(cfg.HIP.MFMA_H2), bool(cfg.HIP.H2_LAZY_SPLIT), int(cfg.HIP.H2_MIN_TILES), bool(cfg.HIP.H2_TRUNK_PLANES), int(cfg.HIP.H2_TILE_CFG), int(cfg.HIP.X3_TILE_CFG), int(cfg.HIP.X3_TERMS))
+               bool(cfg.HIP.MFMA_H2), bool(cfg.HIP.H2_LAZY_SPLIT), int(cfg.HIP.H2_MIN_TILES), bool(cfg.HIP.H2_TRUNK_PLANES), int(cfg.HIP.H2_TILE_CFG), int(cfg.HIP.X3_TILE_CFG), int(cfg.HIP.X3_TERMS), bool(cfg.HIP.H2_TRAIN))
         cur = torch.cuda.current_stream(sess.device)
         if not use_graph or sess.profile is not None:
             sess.flops_last_forward = 0
@@ -696,6 +698,7 @@ class Network(object):
                 train_op.pending_slots = None
         train_op.winograd = ((int(cfg.HIP.WINOGRAD_M), int(cfg.HIP.WINOGRAD_MIN_CIN), bool(cfg.HIP.WINOGRAD_7X7))
                              if (cfg.HIP.WINOGRAD and cfg.HIP.WINOGRAD_TRAIN) else None)
+        train_op.h2_train = int(cfg.HIP.H2_MIN_TILES) if (cfg.HIP.MFMA_H2 and cfg.HIP.H2_TRAIN) else None
         train_op.backward(self._loss_seeds)
         total = torch.empty((1,), dtype=torch.float32, device=sess.device)
         train_op.regularization_loss(total)
