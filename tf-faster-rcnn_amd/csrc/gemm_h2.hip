@@ -20,7 +20,10 @@
 // block takes C = 0) and folded into the running f32 sum with ONE fma per element by the block's exact scale -- 128 VALU per 96 MFMAs
 // per wave, instead of the 176 per 48 of the in-register bf16 split of gemm_x3.
 //
-// Domain: finite operands.  An inf / nan element makes its block's scale tiny and its own pieces inf / nan (l = inf - inf = nan): the
+// Domain: finite operands whose 128-k blocks span less than ~2^20 between the block maximum and the elements that matter: an element
+// e below the maximum m of ITS block carries an absolute error of max(2^-23 |e|, 2^-38 m), so a 1e6 outlier next to O(1) values
+// still gives 6e-7 at GEMM level, a 1e8 outlier 8e-5 (tests/test_h2_math_cpu.py::test_domain_outliers_inside_a_scale_block; the exact
+// split of csrc/gemm_x3.hip has no such limit).  Post-ReLU / batch-normalised activations span a few decades per pixel.  An inf / nan element makes its block's scale tiny and its own pieces inf / nan (l = inf - inf = nan): the
 // output rows that read the block come out nan, where an f32 kernel would return +-inf for a plain overflow (both mean overflow).
 //
 // Orientation.  The MFMA computes D = Wfrag x Xfrag^T: accumulator lane l holds output ROW m = l & 31 (+ sub-tile), registers walk
