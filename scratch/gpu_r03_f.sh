@@ -1,24 +1,35 @@
-# round 3: MFMA_H2 pipeline after the write-invalidation fix, per-row scale loads (any M), row-group scales in the transforms
+#!/bin/bash
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-TAG=r03_f
-mkdir -p gpurun_out
-rm -f gpurun_out/fullsize_parity.txt
-(timeout 900 python -m pytest tests/test_h2_gpu.py tests/test_network_gpu.py -m gpu -q -x -s 2>&1 | grep -E "h2 launches|h2 path|passed|failed|Error|error|assert|fused tail" | tail -40) > gpurun_out/${TAG}_tests_a.log
-cat gpurun_out/${TAG}_tests_a.log
-(timeout 900 python -m pytest tests/test_fullsize_gpu.py -m gpu -q -k "shipped and not x3 and not f32 and not train" 2>&1 | tail -5) > gpurun_out/${TAG}_tests_fullsize.log
-cat gpurun_out/${TAG}_tests_fullsize.log
-cp gpurun_out/fullsize_parity.txt gpurun_out/${TAG}_fullsize_parity.txt
-timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --layer-report gpurun_out/${TAG}_layer_table.txt 2>&1 | tail -1 > gpurun_out/${TAG}_bench.json
-python - <<'PY'
-import json
-d = json.loads(open("gpurun_out/r03_f_bench.json").read())
-print("bench:", d["value"], d["ms_per_step"], "x3:", (d.get("x3_variant") or {}).get("value"), "f32:", (d.get("f32_mfma_variant") or {}).get("value"))
-r = d["roofline"]; print({k: r[k] for k in r if k not in ("kernel", "pipe_peaks_f32_equivalent")})
-print(json.dumps(d.get("stages")))
+O=gpurun_out/r03_ab; mkdir -p $O
+timeout 300 python bench.py --config c5 --steps 30 --warmup 5 --no-cpu-baseline > $O/c5_side.json 2> $O/c5_side.err
+timeout 300 python bench.py --config c5 --steps 30 --warmup 5 --no-cpu-baseline --no-wgrad-stream > $O/c5_main.json 2> $O/c5_main.err
+cat $O/c5_side.json $O/c5_main.json | cut -c1-900
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_c5 -- python $GRAFT_REPO_ROOT/bench.py --config c5 --steps 6 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/prof_run.txt 2>&1
+cd $GRAFT_REPO_ROOT
+f=$(find /tmp/prof_c5 -name "*kernel_trace.csv" | head -1)
+python - "$f" > $O/overlap.txt <<'PY'
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Stream_Id"] if "Stream_Id" in r else r.get("Queue_Id"), r["Kernel_Name"][:40]) for r in rows))
+# last 40% of the trace = steady steps
+t0 = ev[int(len(ev) * 0.6)][0]
+ev = [e for e in ev if e[0] >= t0]
+span = ev[-1][1] - ev[0][0]
+by = collections.defaultdict(int)
+for s, e, q, n in ev:
+    by[q] += e - s
+# union busy time
+busy = 0; cur_s, cur_e = ev[0][0], ev[0][1]
+for s, e, q, n in ev[1:]:
+    if s > cur_e:
+        busy += cur_e - cur_s; cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+busy += cur_e - cur_s
+print("kernels", len(ev), "span ms", span / 1e6, "union busy ms", busy / 1e6, "idle frac", 1 - busy / span)
+for q, t in sorted(by.items(), key=lambda x: -x[1]):
+    print("queue/stream", q, "sum ms", t / 1e6, "frac of span", t / span)
+print(list(rows[0].keys()))
 PY
-mkdir -p gpurun_out/prof
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r1 -- python $GRAFT_REPO_ROOT/bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-f32-variant --profile-steps 0 --streams 1 > $GRAFT_REPO_ROOT/gpurun_out/prof/run.log 2>&1 )
-DB=$(find gpurun_out/prof -name '*.db' | head -1); python scratch/rocpd_summary.py $DB gpurun_out/${TAG}_kernel_stats.txt > /dev/null; python scratch/rocpd_by_shape.py $DB gpurun_out/${TAG}_kernels_by_shape.txt 140 > /dev/null; find gpurun_out/prof -name '*.db' -delete
-head -40 gpurun_out/${TAG}_kernels_by_shape.txt
-rm -rf gpurun_out/prof
+cat $O/overlap.txt

@@ -114,6 +114,31 @@ class TrainState(object):
         for t, g in seeds:
             grads[t.data_ptr()] = g
         needs = net._requires_grad
+        # Filter gradients on side streams (cfg.HIP.WGRAD_STREAM = how many): a wgrad only feeds the solver, while the data-gradient
+        # chain is what the next record waits for -- at one image per step neither fills 256 CUs, so they run side by side.  Each side
+        # stream executes its wgrads in tape order with its OWN transposed-operand scratch and split-K workspace, sees dY through an
+        # event recorded after the activation gradient, and is joined before backward() returns.  Data parallel: one side stream, so
+        # that "everything behind this offset of the flat gradient is final" holds on the stream the collective is issued from.
+        main = torch.cuda.current_stream()
+        nside = int(getattr(self, "wgrad_stream", 0))
+        if getattr(self, "world_size", 1) > 1:
+            nside = min(nside, 1)
+        sides = self._wgrad_side_streams(nside)
+        turn = [0]
+
+        def on_side(fn):
+            if not sides:
+                return fn("")
+            i = turn[0] % len(sides)
+            turn[0] += 1
+            side = sides[i]
+            side.wait_stream(main)
+            scope, ops.ws_scope = ops.ws_scope, ops.ws_scope + "/wgrad%d" % i
+            try:
+                with torch.cuda.stream(side):
+                    fn("/s%d" % i if i else "")
+            finally:
+                ops.ws_scope = scope
 
         def accumulate_into(target, shape, name):
             key = target.data_ptr()
@@ -171,10 +196,12 @@ class TrainState(object):
                 (ops.relu6_bwd if rec["act"] == ACT_RELU6 else ops.relu_bwd)(gy, y)
                 p = self.params.get(sc)
                 if p is not None:
-                    ops.dwconv3x3_wgrad(gy, x, rec["stride"], rec["pad"], p.scale, p.grad_w)
-                    ar = getattr(self, "all_reduce", None)
-                    if ar is not None and getattr(self, "world_size", 1) > 1 and hasattr(ar, "ready"):
-                        ar.ready(self.flat, p.grad_w.data_ptr())
+                    def dw_wgrad(sfx, gy=gy, x=x, rec=rec, p=p):
+                        ops.dwconv3x3_wgrad(gy, x, rec["stride"], rec["pad"], p.scale, p.grad_w)
+                        ar = getattr(self, "all_reduce", None)
+                        if ar is not None and getattr(self, "world_size", 1) > 1 and hasattr(ar, "ready"):
+                            ar.ready(self.flat, p.grad_w.data_ptr())
+                    on_side(dw_wgrad)
                 if x.data_ptr() in needs:
                     gx, had = accumulate_into(x, x.shape, sc + "/in")
                     ops.dwconv3x3_dgrad(gy, sess.packed[("dw", sc)][0], rec["stride"], rec["pad"], gx, accumulate=had)
@@ -203,21 +230,24 @@ class TrainState(object):
             M = N * OH * OW
             p = self.params.get(sc)
             if p is not None:
-                Mp = (M + 31) // 32 * 32
-                gyT = ops.transpose_pad(gy.view(M, Cout), Mp, out=sess.buf("bwd/gyT", (Cout, Mp)))
-                if k == 1 and stride == 1:
-                    xT = ops.transpose_pad(x.view(M, x.shape[-1]), Mp, out=sess.buf("bwd/xT", (x.shape[-1], Mp)))
-                else:
-                    xT = ops.im2col_t(x, k, k, stride, pad, OH, OW, Mp, out=sess.buf("bwd/xT", (k * k * x.shape[-1], Mp)))
-                # dW_folded[n][(kh,kw,c)] = sum_m gyT[n][m] * xT[(kh,kw,c)][m]   -- the forward MFMA kernel
-                ops.conv2d(gyT.view(1, 1, Cout, Mp), xT.view(xT.shape[0], 1, 1, Mp), None, 1, 1, out=p.grad_w.view(1, 1, Cout, p.K))
-                if p.bias is not None:
-                    ops.colsum(gy.view(M, Cout), p.grad_b)
-                ar = getattr(self, "all_reduce", None)
-                if ar is not None and getattr(self, "world_size", 1) > 1 and hasattr(ar, "ready"):
-                    # this parameter's gradient is enqueued: everything from its offset to the end of the flat buffer is final
-                    # (the tape is walked backwards and the buffer is laid out in forward order)
-                    ar.ready(self.flat, p.grad_w.data_ptr())
+                def wgrad(sfx, gy=gy, x=x, p=p, k=k, stride=stride, pad=pad, OH=OH, OW=OW, M=M, Cout=Cout):
+                    Mp = (M + 31) // 32 * 32
+                    gyT = ops.transpose_pad(gy.view(M, Cout), Mp, out=sess.buf("bwd/gyT" + sfx, (Cout, Mp)))
+                    if k == 1 and stride == 1:
+                        xT = ops.transpose_pad(x.view(M, x.shape[-1]), Mp, out=sess.buf("bwd/xT" + sfx, (x.shape[-1], Mp)))
+                    else:
+                        xT = ops.im2col_t(x, k, k, stride, pad, OH, OW, Mp, out=sess.buf("bwd/xT" + sfx, (k * k * x.shape[-1], Mp)))
+                    # dW_folded[n][(kh,kw,c)] = sum_m gyT[n][m] * xT[(kh,kw,c)][m]   -- the forward MFMA kernel
+                    ops.conv2d(gyT.view(1, 1, Cout, Mp), xT.view(xT.shape[0], 1, 1, Mp), None, 1, 1, out=p.grad_w.view(1, 1, Cout, p.K))
+                    if p.bias is not None:
+                        ops.colsum(gy.view(M, Cout), p.grad_b)
+                    ar = getattr(self, "all_reduce", None)
+                    if ar is not None and getattr(self, "world_size", 1) > 1 and hasattr(ar, "ready"):
+                        # this parameter's gradient is enqueued: everything from its offset to the end of the flat buffer is final
+                        # (the tape is walked backwards, the buffer is laid out in forward order, and every wgrad is enqueued on the
+                        # same stream -- the collective orders itself after the stream it is issued from)
+                        ar.ready(self.flat, p.grad_w.data_ptr())
+                on_side(wgrad)
             if x.data_ptr() in needs:
                 gx, had = accumulate_into(x, x.shape, sc + "/in")
                 wf = sess.conv_info[sc]["w"]
@@ -248,7 +278,17 @@ class TrainState(object):
                         ops.conv2d(gy, wd, None, k, k, 1, dpad, ACT_NONE, gx if had else None, 1, out=gx)
                 else:
                     ops.conv2d_dgrad_strided(gy, wf, stride, pad, x.shape[1], x.shape[2], gx, had)
+        for side in sides:
+            main.wait_stream(side)               # the solver (and the next forward pass, which overwrites x) come after every wgrad
         return grads
+
+    def _wgrad_side_streams(self, n):
+        have = getattr(self, "_wgrad_stream_objs", None)
+        if have is None:
+            have = self._wgrad_stream_objs = []
+        while len(have) < n:
+            have.append(torch.cuda.Stream(device=self.sess.device))
+        return have[:n]
 
     # ---- solver --------------------------------------------------------------------------------------
     def apply(self, lr, world_size=1, all_reduce=None):

@@ -97,13 +97,16 @@ __C = AttrDict(
     # images/s (profiles/r03_h_ab.txt), so it is OFF by default: the trunk stays exact float32.
     # H2_TRAIN: TRAIN mode too -- the pointwise convolutions of the forward pass and their data gradients (>= H2_MIN_TILES tiles, i.e. the
     # RoI tail) run in frcnn_gemm_h2; filters are re-split after every solver step, float32 activations are kept for the tape.
+    # WGRAD_STREAM: the reverse sweep enqueues the filter gradients (operand transposes, split-K GEMM, bias column sum) round-robin on this
+    # many side HIP streams beside the data-gradient chain (0: all on one stream); joined before the solver.  Same kernels, same bits --
+    # only the overlap changes.  Data-parallel runs use at most one (the bucketed all-reduce orders itself after a single stream).
     # X3_TILE_CFG / X3_TERMS: frcnn_gemm_x3's per-call tile configuration (-1 = by shape) and 6 / 9 cross terms (A/B runs).
     # H2_TILE_CFG: -1 = tile shape by launch size (csrc/gemm_h2.hip), else a frcnn_gemm_h2 configuration id for every launch (A/B runs).
     HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=64, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=("block1", "block2"), WINOGRAD_DIRECT_SCOPES=(),
              WINOGRAD_TRAIN=True,
              WINOGRAD_7X7=True, FUSE_TAIL_MEAN=False, OVERLAP_TAIL_ENTRY=False, MFMA_X3=True,
              MFMA_H2=True, H2_LAZY_SPLIT=True, H2_MIN_TILES=150, H2_TRUNK_PLANES=False, H2_TILE_CFG=-1,
-             X3_TILE_CFG=-1, X3_TERMS=6, H2_TRAIN=True))
+             X3_TILE_CFG=-1, X3_TERMS=6, H2_TRAIN=True, WGRAD_STREAM=2))
 __C.DATA_DIR = osp.abspath(osp.join(__C.ROOT_DIR, 'data'))
 cfg = __C
 

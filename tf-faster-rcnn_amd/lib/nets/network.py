@@ -699,6 +699,7 @@ class Network(object):
         train_op.winograd = ((int(cfg.HIP.WINOGRAD_M), int(cfg.HIP.WINOGRAD_MIN_CIN), bool(cfg.HIP.WINOGRAD_7X7))
                              if (cfg.HIP.WINOGRAD and cfg.HIP.WINOGRAD_TRAIN) else None)
         train_op.h2_train = int(cfg.HIP.H2_MIN_TILES) if (cfg.HIP.MFMA_H2 and cfg.HIP.H2_TRAIN) else None
+        train_op.wgrad_stream = int(cfg.HIP.WGRAD_STREAM)
         train_op.backward(self._loss_seeds)
         total = torch.empty((1,), dtype=torch.float32, device=sess.device)
         train_op.regularization_loss(total)
