@@ -267,6 +267,7 @@ def train_bench(args, c, dev, world, rank, dist):
     t0 = time.perf_counter()
     sw.train_model(args.steps, verbose=False)
     sess.host_enqueue_s = time.perf_counter() - t0          # the host's share: launches enqueued, GPU not yet waited for
+    sess.train_graph_stats = dict(sw.state.graph_stats)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -354,6 +355,7 @@ def main():
                          "`f32_mfma_variant`).  x3: MFMA_H2 off.  f32: every product on v_mfma_f32_32x32x2_f32")
     ap.add_argument("--h2-lazy-split", type=int, default=-1, help="cfg.HIP.H2_LAZY_SPLIT (A/B): 1 = split un-planed inputs of eligible layers, 0 = such layers stay on x3 / f32")
     ap.add_argument("--h2-min-tiles", type=int, default=-1, help="cfg.HIP.H2_MIN_TILES (A/B)")
+    ap.add_argument("--train-graph", action="store_true", help="cfg.HIP.TRAIN_GRAPH True: the reverse sweep replayed from a hipGraph (c5 A/B)")
     ap.add_argument("--wgrad-streams", type=int, default=-1, help="cfg.HIP.WGRAD_STREAM: side streams for the filter gradients (c5 A/B; 0 = none)")
     ap.add_argument("--h2-cfg", type=int, default=-1, help="cfg.HIP.H2_TILE_CFG (A/B): -1 = tile shape by launch size, else one frcnn_gemm_h2 configuration id")
     ap.add_argument("--h2-trunk-planes", type=int, default=-1, help="cfg.HIP.H2_TRUNK_PLANES (A/B): 0 keeps the residual trunk in float32")
@@ -399,6 +401,8 @@ def main():
     cfg.HIP.MFMA_X3 = args.mfma in ("h2", "x3")
     if args.h2_lazy_split >= 0:
         cfg.HIP.H2_LAZY_SPLIT = bool(args.h2_lazy_split)
+    if args.train_graph:
+        cfg.HIP.TRAIN_GRAPH = True
     if args.wgrad_streams >= 0:
         cfg.HIP.WGRAD_STREAM = args.wgrad_streams
     if args.h2_min_tiles >= 0:
@@ -445,7 +449,9 @@ def main():
             value = world * args.steps / elapsed
             out = dict(common, value=round(value, 3), ms_per_step=round(1000.0 * elapsed / args.steps, 4),
                        config={"workload": c["label"] + "; one image per GPU per step", "parallelism": "dp%d (RCCL gradient all-reduce)" % world,
-                               "launch": "eager, filter gradients on %d side stream(s)" % min(int(cfg.HIP.WGRAD_STREAM), 1 if world > 1 else 99),
+                               "launch": "forward + solver eager, reverse sweep %s, filter gradients on %d side stream(s)" % (
+                                   "replayed from a hipGraph %s" % sess.train_graph_stats if sess.train_graph_stats["replayed"] else "eager",
+                                   min(int(cfg.HIP.WGRAD_STREAM), 1 if world > 1 else 99)),
                                "host_enqueue_ms_per_step": round(1000.0 * sess.host_enqueue_s / args.steps, 3),
                                "gflop_per_step_reference_graph": c["gflop_ref"]},
                        roofline={"bound": "mfma", "achieved": round(c["gflop_ref"] * value / world / 1e3, 2), "peak": F32_MFMA_PEAK_TFLOPS,

@@ -255,15 +255,16 @@ def test_sgd_steps_on_a_fixed_batch_reduce_the_loss(dev):
 
 
 @pytest.mark.gpu
-def test_wgrad_side_stream_changes_no_bit(dev):
-    """cfg.HIP.WGRAD_STREAM: the filter gradients run on side streams beside the data-gradient chain.  Same kernels on the same
-    operands -> the momentum slots after the first step (= the gradients) agree with the one-stream run to the noise of the one
-    order-dependent kernel of the sweep (the float atomics of crop_and_resize's backward), and the losses of the following steps agree."""
+def test_wgrad_side_streams_and_captured_sweep_change_nothing(dev):
+    """cfg.HIP.WGRAD_STREAM: the filter gradients run on side streams beside the data-gradient chain; cfg.HIP.TRAIN_GRAPH: the whole
+    reverse sweep is replayed from a hipGraph from the third step with the same tape on.  Same kernels on the same operands -> the
+    momentum slots after the first step (= the gradients) and the losses of four steps agree with the one-stream eager run to the noise
+    of the one order-dependent kernel of the sweep (the float atomics of crop_and_resize's backward)."""
     from frcnn_hip.runtime import Session
     from frcnn_hip.train import TrainState
     from model.config import cfg
     from nets.resnet_v1 import resnetv1
-    old = (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.WGRAD_STREAM)
+    old = (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.WGRAD_STREAM, cfg.HIP.TRAIN_GRAPH)
     cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO = 64, 0.0
     rng = np.random.RandomState(4)
     image = ((rng.rand(1, 160, 224, 3) * 255.0).astype(np.float32) - cfg.PIXEL_MEANS.astype(np.float32)) * np.float32(1 / 256.0)
@@ -271,30 +272,32 @@ def test_wgrad_side_stream_changes_no_bit(dev):
     blobs = dict(data=image, im_info=np.array([160, 224, 1.0], dtype=np.float32), gt_boxes=gt)
     try:
         state = []
-        for side in (0, 2):
-            cfg.HIP.WGRAD_STREAM = side
+        for n, (side, graph) in enumerate([(0, False), (2, False), (2, True)]):
+            cfg.HIP.WGRAD_STREAM, cfg.HIP.TRAIN_GRAPH = side, graph
             sess = Session(device=dev, seed=9)
             net = resnetv1(num_layers=50)
-            net.create_architecture("TRAIN", 21, tag="ws%d" % side, anchor_scales=(4, 8, 16), anchor_ratios=(0.5, 1, 2))
+            net.create_architecture("TRAIN", 21, tag="ws%d" % n, anchor_scales=(4, 8, 16), anchor_ratios=(0.5, 1, 2))
             sess.init_variables(net.variable_specs())
             ts = TrainState(sess, net, momentum=0.9, weight_decay=1e-4)
             ts.lr = 1e-3
             losses = [net.train_step(sess, blobs, ts)]
             torch.cuda.synchronize()
             slots = {sc: (p.acc_w.cpu().numpy().copy(), None if p.acc_b is None else p.acc_b.cpu().numpy().copy()) for sc, p in ts.params.items()}
-            losses += [net.train_step(sess, blobs, ts) for _ in range(2)]
+            losses += [net.train_step(sess, blobs, ts) for _ in range(3)]
             torch.cuda.synchronize()
             assert len(getattr(ts, "_wgrad_stream_objs", [])) == side
+            assert ts.graph_stats == (dict(eager=1, captured=1, replayed=2) if graph else dict(eager=4, captured=0, replayed=0)), ts.graph_stats
             state.append((losses, slots))
-        (l0, p0), (l1, p1) = state
-        assert l0[0] == l1[0], (l0, l1)                                   # the first forward pass: no order-dependent kernel
-        assert np.allclose(np.array(l0[1:]), np.array(l1[1:]), rtol=1e-4, atol=0), (l0, l1)
-        assert len(p0) == len(p1) > 40
-        for sc in p0:
-            for a, b in zip(p0[sc], p1[sc]):
-                assert (a is None and b is None) or np.abs(a - b).max() <= 1e-5 * max(np.abs(a).max(), 1e-20), sc
+        l0, p0 = state[0]
+        for l1, p1 in state[1:]:
+            assert l0[0] == l1[0], (l0, l1)                               # the first forward pass: no order-dependent kernel
+            assert np.allclose(np.array(l0[1:]), np.array(l1[1:]), rtol=1e-4, atol=0), (l0, l1)
+            assert len(p0) == len(p1) > 40
+            for sc in p0:
+                for a, b in zip(p0[sc], p1[sc]):
+                    assert (a is None and b is None) or np.abs(a - b).max() <= 1e-5 * max(np.abs(a).max(), 1e-20), sc
     finally:
-        cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.WGRAD_STREAM = old
+        cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.WGRAD_STREAM, cfg.HIP.TRAIN_GRAPH = old
 
 
 def test_snapshot_and_resume_continue_the_same_run(dev, tmp_path):

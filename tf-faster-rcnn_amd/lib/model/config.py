@@ -100,13 +100,18 @@ __C = AttrDict(
     # WGRAD_STREAM: the reverse sweep enqueues the filter gradients (operand transposes, split-K GEMM, bias column sum) round-robin on this
     # many side HIP streams beside the data-gradient chain (0: all on one stream); joined before the solver.  Same kernels, same bits --
     # only the overlap changes.  Data-parallel runs use at most one (the bucketed all-reduce orders itself after a single stream).
+    # TRAIN_GRAPH: the reverse sweep of a training step (~1000 launches, every argument a function of the tape) is captured into a
+    # hipGraph the second time the same tape comes by (= the same image shape) and replayed afterwards (frcnn_hip/train.py backward_auto);
+    # single-process runs without dropout only.  OFF: the sweep is GPU-bound, not launch-bound (one stream: 27.0 ms / step replayed vs
+    # 27.1 eager), and a replayed graph runs its side-stream branches with less overlap than the eager streams do (25.5 vs 23.8 ms,
+    # profiles/r03_ab_c5_streams_graph.txt).
     # X3_TILE_CFG / X3_TERMS: frcnn_gemm_x3's per-call tile configuration (-1 = by shape) and 6 / 9 cross terms (A/B runs).
     # H2_TILE_CFG: -1 = tile shape by launch size (csrc/gemm_h2.hip), else a frcnn_gemm_h2 configuration id for every launch (A/B runs).
     HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=64, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=("block1", "block2"), WINOGRAD_DIRECT_SCOPES=(),
              WINOGRAD_TRAIN=True,
              WINOGRAD_7X7=True, FUSE_TAIL_MEAN=False, OVERLAP_TAIL_ENTRY=False, MFMA_X3=True,
              MFMA_H2=True, H2_LAZY_SPLIT=True, H2_MIN_TILES=150, H2_TRUNK_PLANES=False, H2_TILE_CFG=-1,
-             X3_TILE_CFG=-1, X3_TERMS=6, H2_TRAIN=True, WGRAD_STREAM=2))
+             X3_TILE_CFG=-1, X3_TERMS=6, H2_TRAIN=True, WGRAD_STREAM=2, TRAIN_GRAPH=False))
 __C.DATA_DIR = osp.abspath(osp.join(__C.ROOT_DIR, 'data'))
 cfg = __C
 

@@ -388,6 +388,9 @@ class Network(object):
                                         t.BBOX_NORMALIZE_MEANS, t.BBOX_NORMALIZE_STDS, seed=self._sample_seed + 1, num=self._num_rois,
                                         opts=ops.roi_target_opts(t.USE_GT, t.BBOX_INSIDE_WEIGHTS))
         rois, roi_scores, labels, tg, iw, ow, counts = out
+        # the sampled RoIs live at ONE address for the life of the session: the tape's crop record names them, and a captured reverse
+        # sweep (cfg.HIP.TRAIN_GRAPH) is only valid for the tensors it was recorded with
+        rois = self._sess.buf(self._tag + "/" + name + "/rois", tuple(rois.shape)).copy_(rois)
         self._proposal_targets = dict(rois=rois, labels=labels, bbox_targets=tg, bbox_inside_weights=iw, bbox_outside_weights=ow,
                                       counts=counts)
         self._num_rois = None
@@ -700,7 +703,8 @@ class Network(object):
                              if (cfg.HIP.WINOGRAD and cfg.HIP.WINOGRAD_TRAIN) else None)
         train_op.h2_train = int(cfg.HIP.H2_MIN_TILES) if (cfg.HIP.MFMA_H2 and cfg.HIP.H2_TRAIN) else None
         train_op.wgrad_stream = int(cfg.HIP.WGRAD_STREAM)
-        train_op.backward(self._loss_seeds)
+        train_op.graph = bool(cfg.HIP.TRAIN_GRAPH)
+        train_op.backward_auto(self._loss_seeds)
         total = torch.empty((1,), dtype=torch.float32, device=sess.device)
         train_op.regularization_loss(total)
         parts = [losses[k].view(1) for k in ("rpn_cross_entropy", "rpn_loss_box", "cross_entropy", "loss_box")]
