@@ -417,6 +417,24 @@ int frcnn_flip_transpose_filter(const float* w_d, int Cout, int KH, int KW, int 
 int frcnn_conv2d_dgrad_strided(const float* dy_d, int N, int OH, int OW, int Cout, const float* w_d, int KH, int KW,
                                int Cin, int stride, int pad_top, int pad_left, float* dx_d, int H, int W,
                                int accumulate, void* stream);
+/* dW of a convolution straight from dY [N,OH,OW,Cout] and X [N,H,W,Cin] (csrc/wgrad_tn.hip: C = A^T B on the f32 matrix pipe, both
+ * operands read as they lie -- no transposed copies, no im2col matrix; slices of the pixel range reduced in a fixed order):
+ * dw_d [Cout][KH][KW][Cin], the layout of the packed forward filter (what the autograd of slim.conv2d hands the optimizer,
+ * train_val.py:128-145).  Needs Cin % 64 == 0 and Cout % 64 == 0 (frcnn_conv2d_wgrad_supported; the other layers keep the
+ * transpose_pad / im2col_t + frcnn_conv2d_nhwc_ws route above).  ws: frcnn_conv2d_wgrad_workspace_bytes(...) bytes (0 = none needed). */
+int frcnn_conv2d_wgrad_supported(int Cin, int Cout);
+size_t frcnn_conv2d_wgrad_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int KH, int KW);
+int frcnn_conv2d_wgrad(const float* dy_d, const float* x_d, int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
+                       int stride, int pad_top, int pad_left, float* dw_d, void* ws, size_t ws_bytes, void* stream);
+/* tuning hook of the calling thread: tile edge (64 / 128, 0 = by shape) and the workgroup count the slicing aims at (0 = 512) */
+void frcnn_conv2d_wgrad_set_plan(int tile, int min_workgroups);
+/* The same gradient on the fp16 matrix pipe in the arithmetic of frcnn_gemm_h2 (csrc/wgrad_h2.hip): every 64-pixel column segment of dY
+ * and of the X tap is split in registers into two fp16 pieces with its own exact power-of-two scale, three MFMAs per product, f32
+ * accumulation -- nothing but dY and X is read from HBM.  Same arguments, same limits (Cin, Cout % 64 == 0), its own workspace size. */
+size_t frcnn_conv2d_wgrad_h2_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int KH, int KW);
+int frcnn_conv2d_wgrad_h2(const float* dy_d, const float* x_d, int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
+                          int stride, int pad_top, int pad_left, float* dw_d, void* ws, size_t ws_bytes, void* stream);
+void frcnn_conv2d_wgrad_h2_set_plan(int tile, int min_workgroups);
 int frcnn_relu_bwd(float* grad_d, const float* y_d, long long n, void* stream);              /* grad *= (y > 0) */
 int frcnn_relu6_bwd(float* grad_d, const float* y_d, long long n, void* stream);             /* grad *= (0 < y < 6) */
 /* Reverse-sweep pieces of the VGG16 / MobileNet-v1 TRAIN graphs (lib/nets/vgg16.py:26-60, mobilenet_v1.py:114-172):

@@ -10,6 +10,7 @@ from frcnn_hip import ops
 from model.config import cfg
 from model.train_val import SolverWrapper, synthetic_data_layer
 cfg.HIP.WGRAD_STREAM = int(os.environ.get("SIDE", "2"))
+cfg.HIP.WGRAD_TN = bool(int(os.environ.get("TN", "1")))
 c = b.CONFIGS["c5"]; dev = torch.device("cuda:0")
 cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.TRAIN.DOUBLE_BIAS = 256, 0.0, False
 sess = Session(device=dev, seed=cfg.RNG_SEED)
@@ -20,6 +21,9 @@ layer = b.resident_blobs(synthetic_data_layer(c["classes"], seed=cfg.RNG_SEED, i
 sw = SolverWrapper(sess, net, layer)
 sw.train_model(5, verbose=False); torch.cuda.synchronize()
 ts = sw.state
+if os.environ.get("NOWGRAD"):
+    ops.conv2d_wgrad = lambda *a, **k: None
+    ops.colsum = lambda *a, **k: None
 n_launch = [0]
 orig_call = ops.call
 rows = []
@@ -39,7 +43,7 @@ for _ in range(6):
     net._sample_seed += 2
     rows.append(r)
 a = np.array(rows)[1:].mean(axis=0)
-print("side streams", cfg.HIP.WGRAD_STREAM)
+print("side streams", cfg.HIP.WGRAD_STREAM, "wgrad_tn", cfg.HIP.WGRAD_TN)
 print("forward : host %.2f ms, done %.2f ms" % (a[0], a[1]))
 print("backward: host %.2f ms, done %.2f ms" % (a[2], a[3]))
 print("solver  : host %.2f ms, done %.2f ms" % (a[4], a[5]))

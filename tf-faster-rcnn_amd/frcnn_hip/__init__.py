@@ -108,6 +108,15 @@ SIGNATURES = {
     "frcnn_flip_transpose_filter": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "frcnn_conv2d_dgrad_strided": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int,
                                            c_int, c_int, _P]),
+    "frcnn_conv2d_wgrad_supported": (c_int, [c_int, c_int]),
+    "frcnn_conv2d_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "frcnn_conv2d_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P,
+                                   c_size_t, _P]),
+    "frcnn_conv2d_wgrad_set_plan": (None, [c_int, c_int]),
+    "frcnn_conv2d_wgrad_h2_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "frcnn_conv2d_wgrad_h2": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P,
+                                      c_size_t, _P]),
+    "frcnn_conv2d_wgrad_h2_set_plan": (None, [c_int, c_int]),
     "frcnn_relu_bwd": (c_int, [_P, _P, c_longlong, _P]),
     "frcnn_gemm_x3_pack_bytes": (c_size_t, [c_int, c_int, c_int]),
     "frcnn_gemm_x3_pack": (c_int, [_P, c_int, c_int, c_int, _P, _P]),

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(PKG))
 CSRC = os.path.join(os.path.dirname(PKG), "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libfrcnn_hip.so")
-SOURCES = ["detect_kernels.hip", "conv_igemm.hip", "dense_misc.hip", "train_kernels.hip", "backward_kernels.hip", "winograd.hip", "winograd7.hip", "preproc.hip", "gemm_x3.hip", "gemm_h2.hip"]
+SOURCES = ["detect_kernels.hip", "conv_igemm.hip", "dense_misc.hip", "train_kernels.hip", "backward_kernels.hip", "winograd.hip", "winograd7.hip", "preproc.hip", "gemm_x3.hip", "gemm_h2.hip", "wgrad_tn.hip", "wgrad_h2.hip"]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 

@@ -683,6 +683,27 @@ def conv2d_dgrad_strided(dy, w_packed, stride, pad, H, W, dx, accumulate):
     return dx
 
 
+def conv2d_wgrad_supported(Cin, Cout):
+    return bool(lib().frcnn_conv2d_wgrad_supported(int(Cin), int(Cout)))
+
+
+def conv2d_wgrad(dy, x, KH, KW, stride, pad, out, h2=False):
+    """dW [Cout, KH, KW, Cin] of a convolution from dY [N,OH,OW,Cout] and its input X [N,H,W,Cin], both read as they lie; pad =
+    (top, bottom, left, right).  Cin % 64 == 0 and Cout % 64 == 0 (conv2d_wgrad_supported).  h2 False: f32 matrix pipe
+    (csrc/wgrad_tn.hip); True: two-piece fp16 operands split in registers, fp16 matrix pipe (csrc/wgrad_h2.hip)."""
+    _chk(dy), _chk(x), _chk(out)
+    N, OH, OW, Cout = dy.shape
+    _, H, W, Cin = x.shape
+    if out.numel() != Cout * KH * KW * Cin:
+        raise ValueError("conv2d_wgrad: out has %d elements, the filter %d" % (out.numel(), Cout * KH * KW * Cin))
+    name = "frcnn_conv2d_wgrad_h2" if h2 else "frcnn_conv2d_wgrad"
+    nb = getattr(lib(), name + "_workspace_bytes")(N, OH, OW, Cin, Cout, int(KH), int(KW))
+    ws = workspace(nb, x.device, "conv_wgrad") if nb else None
+    call(name, _ptr(dy), _ptr(x), N, H, W, Cin, OH, OW, Cout, int(KH), int(KW), int(stride), int(pad[0]), int(pad[2]),
+         _ptr(out), _ptr(ws), int(nb), _stream())
+    return out
+
+
 def relu_bwd(grad, y):
     _chk(grad), _chk(y)
     call("frcnn_relu_bwd", _ptr(grad), _ptr(y), grad.numel(), _stream())

@@ -280,6 +280,15 @@ class TrainState(object):
             p = self.params.get(sc)
             if p is not None:
                 def wgrad(sfx, gy=gy, x=x, p=p, k=k, stride=stride, pad=pad, OH=OH, OW=OW, M=M, Cout=Cout):
+                    if getattr(self, "wgrad_tn", True) and ops.conv2d_wgrad_supported(x.shape[-1], Cout) and p.K == k * k * x.shape[-1]:
+                        # dW = dY^T X straight from the two tensors as they lie (csrc/wgrad_tn.hip): no transposed copies, no im2col
+                        ops.conv2d_wgrad(gy, x, k, k, stride, pad, p.grad_w, h2=bool(getattr(self, "wgrad_h2", False)))
+                        if p.bias is not None:
+                            ops.colsum(gy.view(M, Cout), p.grad_b)
+                        ar = getattr(self, "all_reduce", None)
+                        if ar is not None and getattr(self, "world_size", 1) > 1 and hasattr(ar, "ready"):
+                            ar.ready(self.flat, p.grad_w.data_ptr())
+                        return
                     Mp = (M + 31) // 32 * 32
                     gyT = ops.transpose_pad(gy.view(M, Cout), Mp, out=sess.buf("bwd/gyT" + sfx, (Cout, Mp)))
                     if k == 1 and stride == 1:

@@ -704,6 +704,8 @@ class Network(object):
         train_op.h2_train = int(cfg.HIP.H2_MIN_TILES) if (cfg.HIP.MFMA_H2 and cfg.HIP.H2_TRAIN) else None
         train_op.wgrad_stream = int(cfg.HIP.WGRAD_STREAM)
         train_op.graph = bool(cfg.HIP.TRAIN_GRAPH)
+        train_op.wgrad_tn = bool(cfg.HIP.WGRAD_TN)
+        train_op.wgrad_h2 = bool(cfg.HIP.MFMA_H2 and cfg.HIP.H2_TRAIN and cfg.HIP.WGRAD_H2)
         train_op.backward_auto(self._loss_seeds)
         total = torch.empty((1,), dtype=torch.float32, device=sess.device)
         train_op.regularization_loss(total)
