@@ -18,8 +18,9 @@
 // Work split as in wgrad_tn.hip: grid.x = output tiles (BT x BT, a column tile inside one tap: Cin % BT == 0), grid.z = S slices
 // of the pixel range writing raw partials, k_wgrad_h2_finish adds them in a fixed order (deterministic, no atomics in HBM).
 // Pipeline per slab: [regs hold the slab's f32 values, loaded under the previous slab's MFMAs] column maxima -> barrier -> scales,
-// split, plane rows + inverse scales to LDS -> barrier -> issue the next slab's global loads -> 12 T^2 MFMAs + fold -> barrier.
-// 32 KB (BT = 64) / 64 KB (BT = 128) of LDS per workgroup: the other resident workgroups' MFMAs cover this one's split phase.
+// split, plane rows + inverse scales to LDS -> barrier -> refill the register set with a later slab -> 12 T^2 MFMAs + fold (two barriers
+// per slab: the maxima buffers alternate, so the next slab's ds_max needs no barrier after this slab's fragment reads).
+// 32 KB (BT = 64) / 64 KB (BT = 128) of LDS per workgroup, >= 2 workgroups per CU: the others' MFMAs cover this one's split phase.
 #include "h2_common.h"
 #include <type_traits>
 
@@ -36,8 +37,9 @@ struct WgradH2Params {
 };
 
 template <int BT>
-__global__ __launch_bounds__(256) void k_wgrad_h2(const WgradH2Params p) {
+__global__ __launch_bounds__(256, 2) void k_wgrad_h2(const WgradH2Params p) {
   constexpr int T = BT / 64;                 // 32x32 MFMA tiles per wave and direction (waves 2 x 2)
+  constexpr int NSET = BT == 64 ? 2 : 1;     // register sets of slab values in flight (64: two slabs ahead; 128: the VGPR file allows one)
   constexpr int KB = 64;                     // pixels per slab = per scale block
   constexpr int CG = BT / 4;                 // float4 channel groups per tile row: 16 / 32
   constexpr int RG = 256 / CG;               // pixel groups: 16 / 8
@@ -64,8 +66,8 @@ __global__ __launch_bounds__(256) void k_wgrad_h2(const WgradH2Params p) {
   const int cg = tid % CG, rg = tid / CG;
   const int ohow = p.OH * p.OW;
 
-  float4 ra[RPT], rb[RPT];
-  auto load_slab = [&](int slab) {
+  float4 rav[NSET][RPT], rbv[NSET][RPT];
+  auto load_slab = [&](float4* ra, float4* rb, int slab) {
     const int m0 = (s_begin + slab) * KB + rg * RPT;
 #pragma unroll
     for (int e = 0; e < RPT; ++e) {
@@ -103,10 +105,13 @@ __global__ __launch_bounds__(256) void k_wgrad_h2(const WgradH2Params p) {
   const int frow = lane & 31, khalf = lane >> 5;
   const int wi0 = (wave >> 1) * (BT / 2), wj0 = (wave & 1) * (BT / 2);
   for (int i = tid; i < 4 * BT; i += 256) smax[i] = 0u;
-  load_slab(0);
+#pragma unroll
+  for (int u = 0; u < NSET; ++u)
+    if (u < nloc) load_slab(rav[u], rbv[u], u);
   __syncthreads();
 
-  for (int s = 0; s < nloc; ++s) {
+  // one slab: `ra` / `rb` hold its values; once they are split the set is refilled with slab s + NSET
+  auto slab_body = [&](float4* ra, float4* rb, int s) {
     unsigned* const mxbuf = smax + (s & 1) * 2 * BT;
     // ---- column maxima of the slab: rows of this thread, lanes with the same channels, then the four waves -----------------------
     {
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(256) void k_wgrad_h2(const WgradH2Params p) {
       if (tid < 2 * BT) other[tid] = 0u;
     }
     __syncthreads();
-    if (s + 1 < nloc) load_slab(s + 1);                       // lands under the MFMAs below
+    if (s + NSET < nloc) load_slab(ra, rb, s + NSET);         // lands under the MFMAs below (and, with two sets, the next slab's phases)
     // ---- the slab's products in a scratch accumulator, folded by the two scales ------------------------------------------------------
     {
       f32x16 tmp[T][T];
@@ -242,7 +247,12 @@ __global__ __launch_bounds__(256) void k_wgrad_h2(const WgradH2Params p) {
         }
       }
     }
-    __syncthreads();
+    // no barrier here: the next slab touches only the OTHER maxima buffer before its first barrier, and writes planes / scales after it
+  };
+  for (int s = 0; s < nloc; s += NSET) {
+#pragma unroll
+    for (int u = 0; u < NSET; ++u)
+      if (s + u < nloc) slab_body(rav[u], rbv[u], s + u);
   }
 
   const int orow0 = co0 + wi0 + khalf * 4, ocol0 = kf0 + wj0 + frow;
