@@ -210,7 +210,7 @@ POLICIES = {
     "f4_b12_direct": dict(WINOGRAD=True, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=(), WINOGRAD_DIRECT_SCOPES=("block1", "block2"), WINOGRAD_7X7=True),
 }
 TRAIN_POLICIES = {
-    "direct": dict(WINOGRAD=False, WINOGRAD_TRAIN=False, H2_TRAIN=False),   # every convolution and gradient on the direct f32-MFMA kernels
+    "direct": dict(WINOGRAD=False, WINOGRAD_TRAIN=False, H2_TRAIN=False, WGRAD_TN=False, WGRAD_STREAM=0),   # every convolution and gradient on the direct f32-MFMA kernels, one stream
     "shipped": dict(),                                               # cfg.HIP defaults (Winograd forward + data gradient for 3x3 stride 1)
 }
 GRAD_TOL = 2e-4              # of the tensor's largest entry; or GRAD_CTRL_FACTOR x the float32 control's own distance to float64
@@ -441,8 +441,7 @@ def run_train_harness(config, policy, dev):
         with torch.cuda.stream(sess.stream):
             losses = net.train_forward(sess, blobs)
             ts = TrainState(sess, net, momentum=0.9, weight_decay=1e-4).build()
-            ts.winograd = ((int(cfg.HIP.WINOGRAD_M), int(cfg.HIP.WINOGRAD_MIN_CIN), bool(cfg.HIP.WINOGRAD_7X7))
-                           if (cfg.HIP.WINOGRAD and cfg.HIP.WINOGRAD_TRAIN) else None)
+            net.configure_train_op(ts)                     # the reverse sweep as the policy's cfg.HIP ships it (h2 / side streams / wgrad kernels)
             ts.backward(net._loss_seeds)
             sess.stream.synchronize()
         for k in LOSS_KEYS:

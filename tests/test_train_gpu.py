@@ -172,6 +172,9 @@ def test_full_train_step_matches_torch_autograd(dev, wino, h2):
         ts = TrainState(sess, net, momentum=0.9, weight_decay=1e-4).build()
         ts.winograd = (4, 64, True) if wino else None
         ts.h2_train = 1 if h2 else None
+        # filter gradients: "direct" keeps round 2's transposes + forward GEMM kernel, "winograd" the f32 TN kernel, "winograd_h2" the
+        # fp16-pipe TN kernel (csrc/wgrad_tn.hip, wgrad_h2.hip); the latter two on two side streams
+        ts.wgrad_tn, ts.wgrad_h2, ts.wgrad_stream = wino, h2, (2 if wino else 0)
         if h2:
             assert len(sess.h2) >= 20, "the forward pass did not take the h2 path"
         ts.backward(net._loss_seeds)

@@ -699,13 +699,7 @@ class Network(object):
             if getattr(train_op, "pending_slots", None) is not None:          # resumed run: momentum before the first update
                 train_op.import_slots(train_op.pending_slots)
                 train_op.pending_slots = None
-        train_op.winograd = ((int(cfg.HIP.WINOGRAD_M), int(cfg.HIP.WINOGRAD_MIN_CIN), bool(cfg.HIP.WINOGRAD_7X7))
-                             if (cfg.HIP.WINOGRAD and cfg.HIP.WINOGRAD_TRAIN) else None)
-        train_op.h2_train = int(cfg.HIP.H2_MIN_TILES) if (cfg.HIP.MFMA_H2 and cfg.HIP.H2_TRAIN) else None
-        train_op.wgrad_stream = int(cfg.HIP.WGRAD_STREAM)
-        train_op.graph = bool(cfg.HIP.TRAIN_GRAPH)
-        train_op.wgrad_tn = bool(cfg.HIP.WGRAD_TN)
-        train_op.wgrad_h2 = bool(cfg.HIP.MFMA_H2 and cfg.HIP.H2_TRAIN and cfg.HIP.WGRAD_H2)
+        self.configure_train_op(train_op)
         train_op.backward_auto(self._loss_seeds)
         total = torch.empty((1,), dtype=torch.float32, device=sess.device)
         train_op.regularization_loss(total)
@@ -715,6 +709,17 @@ class Network(object):
         train_op.apply(train_op.lr, getattr(train_op, "world_size", 1), getattr(train_op, "all_reduce", None))
         self._sample_seed += 2
         return out
+
+    @staticmethod
+    def configure_train_op(train_op):
+        """cfg.HIP -> the solver handle's switches for the reverse sweep (frcnn_hip/train.py)."""
+        train_op.winograd = ((int(cfg.HIP.WINOGRAD_M), int(cfg.HIP.WINOGRAD_MIN_CIN), bool(cfg.HIP.WINOGRAD_7X7))
+                             if (cfg.HIP.WINOGRAD and cfg.HIP.WINOGRAD_TRAIN) else None)
+        train_op.h2_train = int(cfg.HIP.H2_MIN_TILES) if (cfg.HIP.MFMA_H2 and cfg.HIP.H2_TRAIN) else None
+        train_op.wgrad_stream = int(cfg.HIP.WGRAD_STREAM)
+        train_op.graph = bool(cfg.HIP.TRAIN_GRAPH)
+        train_op.wgrad_tn = bool(cfg.HIP.WGRAD_TN)
+        train_op.wgrad_h2 = bool(cfg.HIP.MFMA_H2 and cfg.HIP.H2_TRAIN and cfg.HIP.WGRAD_H2)
 
     def train_step_no_return(self, sess, blobs, train_op):
         self.train_step(sess, blobs, train_op)
