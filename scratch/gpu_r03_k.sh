@@ -1,8 +1,6 @@
+#!/bin/bash
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-TAG=r03_k
-mkdir -p gpurun_out
-(timeout 900 python -m pytest tests/test_h2_gpu.py -m gpu -q -x 2>&1 | tail -4) > gpurun_out/${TAG}_tests_a.log
-cat gpurun_out/${TAG}_tests_a.log
-timeout 900 python scratch/h2_sweep.py 0,9,14,15,16,12,17 b4c1x4,b4c3x4,w7x4,b3c1x4,b3c3x4,w3x4 planes_off 2>&1 | grep -v amdgpu.ids | grep -v "+p\|=p" > gpurun_out/${TAG}_h2_sweep.txt
-cat gpurun_out/${TAG}_h2_sweep.txt
+O=gpurun_out/r03_ag; mkdir -p $O
+timeout 900 python -m pytest tests/test_train_gpu.py -x -q -m gpu > $O/train_tests.txt 2>&1; tail -3 $O/train_tests.txt
+TN=1 SIDE=2 python scratch/c5_phases.py 2>&1 | tail -4
+for a in "" ""; do timeout 300 python bench.py --config c5 --steps 40 --warmup 5 --no-cpu-baseline $a 2>$O/err.txt | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$a', d['value'], d['ms_per_step'])"; done

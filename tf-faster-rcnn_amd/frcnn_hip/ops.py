@@ -16,8 +16,30 @@ _ws_retired = []
 ws_scope = "default"     # set by callers that run several independent chains concurrently (one scope per stream)
 
 
+stream_pin = None        # a ctypes stream handle: every launch of this module goes there instead of torch's current stream (see pinned_stream)
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return stream_pin if stream_pin is not None else ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class pinned_stream(object):
+    """`with pinned_stream(s):` -- the launches of this module go to torch stream `s` without the per-call current_stream() lookup
+    and without making `s` torch's current stream (a `with torch.cuda.stream(...)` costs ~10 us of host time per entry; the reverse
+    sweep switches streams ~200 times a step).  Only for regions whose torch-level ops, if any, belong on torch's current stream."""
+
+    def __init__(self, stream):
+        self.handle = ctypes.c_void_p(stream.cuda_stream)
+
+    def __enter__(self):
+        global stream_pin
+        self.prev, stream_pin = stream_pin, self.handle
+        return self
+
+    def __exit__(self, *exc):
+        global stream_pin
+        stream_pin = self.prev
+        return False
 
 
 def _ptr(t):

@@ -71,6 +71,7 @@ class TrainState(object):
         self.reg_scopes = []
         self.graph, self.graph_cap = False, 32                  # backward_auto: captured reverse sweeps, keyed by the tape's tensors
         self._bwd_graphs, self._bwd_seen = {}, {}
+        self._wgrad_events = None
         self.graph_stats = dict(eager=0, captured=0, replayed=0)
 
     def build(self):
@@ -158,6 +159,11 @@ class TrainState(object):
 
     def backward(self, seeds):
         """seeds: list of (tensor, grad) for network outputs.  Fills every Param.grad_*."""
+        main = torch.cuda.current_stream()
+        with ops.pinned_stream(main):                 # ~1000 launches: one stream lookup instead of one per launch
+            return self._sweep(seeds, main)
+
+    def _sweep(self, seeds, main):
         sess, net = self.sess, self.net
         grads = {}
         for t, g in seeds:
@@ -168,24 +174,35 @@ class TrainState(object):
         # stream executes its wgrads in tape order with its OWN transposed-operand scratch and split-K workspace, sees dY through an
         # event recorded after the activation gradient, and is joined before backward() returns.  Data parallel: one side stream, so
         # that "everything behind this offset of the flat gradient is final" holds on the stream the collective is issued from.
-        main = torch.cuda.current_stream()
         nside = int(getattr(self, "wgrad_stream", 0))
         if getattr(self, "world_size", 1) > 1:
             nside = min(nside, 1)
         sides = self._wgrad_side_streams(nside)
         turn = [0]
+        if self._wgrad_events is None:
+            self._wgrad_events = [torch.cuda.Event() for _ in range(16)]
+
+        dp = getattr(self, "world_size", 1) > 1
+        pins = [ops.pinned_stream(st) for st in sides]
+        events = self._wgrad_events
 
         def on_side(fn):
             if not sides:
                 return fn("")
             i = turn[0] % len(sides)
+            ev = events[turn[0] % len(events)]                   # a small ring: a wait captures the record that precedes it
             turn[0] += 1
             side = sides[i]
-            side.wait_stream(main)
+            ev.record(main)
+            side.wait_event(ev)
             scope, ops.ws_scope = ops.ws_scope, ops.ws_scope + "/wgrad%d" % i
             try:
-                with torch.cuda.stream(side):
-                    fn("/s%d" % i if i else "")
+                if dp:                                           # the collective issued inside orders itself after torch's current stream
+                    with torch.cuda.stream(side), pins[i]:
+                        fn("/s%d" % i if i else "")
+                else:                                            # only this module's launches inside: no torch stream switch
+                    with pins[i]:
+                        fn("/s%d" % i if i else "")
             finally:
                 ops.ws_scope = scope
 
