@@ -114,6 +114,68 @@ class VariableStore(object):
         return write_bundle(ckpt_prefix, tensors)
 
 
+class PreparedFilters(object):
+    """Weight-only launches of a TRAINING step -- the Winograd transforms of the 3x3 filters (forward and gradient filter), the flipped /
+    transposed filters of the data gradients and their h2 split: ~150 tiny kernels that depend on nothing but the filters, yet sit on
+    the chain every activation waits for.  Each call site hands its launches over as `get(key, fn)`; fn() enqueues them into buffers
+    of its own and returns those.  The first time (and whenever the filters changed behind the solver's back) fn runs inline; the
+    solver calls weights_changed() + refresh() right after its update, which re-runs every remembered fn on a side stream -- beside
+    the next forward pass -- and the next get() finds the buffers done (one event wait per step, at the first use)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.enabled = True
+        self.plan = {}                          # key -> (fn, buffers), insertion order = first-use order (a flip before its split)
+        self.ready = frozenset()
+        self.version, self.ready_version = 0, -1
+        self.stream = None
+        self.events = None                      # [after the forward pass's entries (keys ("fwd", ...)), after all of them]
+        self.waited = [True, True]
+
+    def get(self, key, fn):
+        if self.enabled and self.ready_version == self.version and key in self.ready:
+            tier = 0 if key[0] == "fwd" else 1
+            if not self.waited[tier]:           # one wait per step and tier, at the first use: the forward pass does not wait for the
+                torch.cuda.current_stream(self.device).wait_event(self.events[tier])      # gradient filters queued behind its own
+                self.waited[tier] = True
+                if tier == 1:
+                    self.waited[0] = True
+            return self.plan[key][1]
+        out = fn()
+        if self.enabled:
+            self.plan[key] = (fn, out)
+        return out
+
+    def weights_changed(self):
+        self.version += 1
+
+    def refresh(self):
+        if not self.enabled or not self.plan:
+            self.ready = frozenset()
+            return
+        from . import ops
+        main = torch.cuda.current_stream(self.device)
+        if self.stream is None:
+            self.stream, self.events = torch.cuda.Stream(device=self.device), [torch.cuda.Event(), torch.cuda.Event()]
+        self.stream.wait_stream(main)           # the update itself, and the last step's reads of these buffers
+        with ops.pinned_stream(self.stream):
+            for key, (fn, _) in self.plan.items():
+                if key[0] == "fwd":
+                    fn()
+            self.events[0].record(self.stream)
+            for key, (fn, _) in self.plan.items():
+                if key[0] != "fwd":
+                    fn()
+        self.events[1].record(self.stream)
+        self.ready, self.ready_version, self.waited = frozenset(self.plan), self.version, [False, False]
+
+    def invalidate(self):
+        """The filter tensors were replaced or rewritten by somebody else than the solver (restore, initialise): forget the plan (its
+        closures hold the tensors); the next step prepares inline again."""
+        self.version += 1
+        self.plan, self.ready = {}, frozenset()
+
+
 class Session(VariableStore):
     def __init__(self, device=None, seed=3):
         if not torch.cuda.is_available():
@@ -125,6 +187,7 @@ class Session(VariableStore):
         self._side_streams = {}
         self.profile = None                             # list of (tag, flops, ev0, ev1) when profiling
         self.flops_last_forward = 0
+        self.prepared = PreparedFilters(self.device)
 
     # ---- device-side images of the variables ----------------------------------------------------
     def to_device(self, a, dtype=torch.float32):

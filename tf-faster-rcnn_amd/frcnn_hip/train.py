@@ -72,6 +72,7 @@ class TrainState(object):
         self.graph, self.graph_cap = False, 32                  # backward_auto: captured reverse sweeps, keyed by the tape's tensors
         self._bwd_graphs, self._bwd_seen = {}, {}
         self._wgrad_events = None
+        self.prep_stream = True                                 # sess.prepared: weight-only launches re-run by the solver on a side stream
         self.graph_stats = dict(eager=0, captured=0, replayed=0)
 
     def build(self):
@@ -206,6 +207,13 @@ class TrainState(object):
             finally:
                 ops.ws_scope = scope
 
+        # Weight-only launches of the data-gradient chain (transposed / flipped filters, their h2 split, the Winograd transform of
+        # the gradient filter) go through sess.prepared (runtime.PreparedFilters): after the first step the solver re-runs them on a
+        # side stream right after its update, beside the next forward pass, and this sweep finds them done.
+        prep = sess.prepared
+        prep.enabled = bool(getattr(self, "prep_stream", True)) and not getattr(self, "graph", False)      # (a captured sweep prepares inline)
+        prepared = prep.get
+
         def accumulate_into(target, shape, name):
             key = target.data_ptr()
             if key in grads:
@@ -334,11 +342,13 @@ class TrainState(object):
                     m = 7 if (wino[0] == 4 and len(wino) > 2 and wino[2] and OH == 7 and OW == 7) else wino[0]
                     G, Cin = ops.winograd_points(m), wf.shape[3]
                     T = ops.winograd_tiles(N, OH, OW, m)
-                    u = ops.winograd_filter_transform_device(wf, m, True, out=sess.buf("bwd/wino_u", (G, Cin, Cout)))
+                    u = prepared(("wino_u", sc, m), lambda wf=wf, m=m, sc=sc, G=G, Cin=Cin, Cout=Cout: ops.winograd_filter_transform_device(
+                        wf, m, True, out=sess.buf("bwd/wino_u/" + sc, (G, Cin, Cout))))
                     ops.conv3x3_winograd(gy, u, None, ACT_NONE, out=gx, v_buf=sess.buf("bwd/wino_v", (G, T, Cout)),
                                          m_buf=sess.buf("bwd/wino_m", (G, T, Cin)))
                 elif stride == 1 and Cout % 32 == 0:
-                    wd = ops.flip_transpose_filter(wf, out=sess.buf("bwd/wflip/" + sc, (wf.shape[3], k, k, Cout)))
+                    wd = prepared(("wflip", sc), lambda wf=wf, sc=sc, k=k, Cout=Cout: ops.flip_transpose_filter(
+                        wf, out=sess.buf("bwd/wflip/" + sc, (wf.shape[3], k, k, Cout))))
                     Cin = wf.shape[3]
                     if (k == 1 and tuple(pad) == (0, 0, 0, 0) and getattr(self, "h2_train", None) is not None
                             and Cout % 128 == 0 and Cin % 128 == 0 and ((M + 127) // 128) * (Cin // 128) >= self.h2_train
@@ -346,7 +356,8 @@ class TrainState(object):
                         # dX = dY W: a plain GEMM with K = Cout -- frcnn_gemm_h2 on the split of dY and of the transposed filter
                         # (cfg.HIP.H2_TRAIN; both change every step, so both are split here: 8 B per element of dY, a few MB of filter)
                         gp = ops.h2_split(gy.view(M, Cout), out=sess.h2_buf("bwd/gy", M, Cout))
-                        wq = ops.h2_pack_w(wd.view(Cin, Cout), out=sess.buf_pair("bwd/wflip_h2/" + sc, Cin, Cout))
+                        wq = prepared(("wflip_h2", sc), lambda wd=wd, sc=sc, Cin=Cin, Cout=Cout: ops.h2_pack_w(
+                            wd.view(Cin, Cout), out=sess.buf_pair("bwd/wflip_h2/" + sc, Cin, Cout)))
                         ops.gemm_h2(gp, wq, 1, M, Cin, Cout, None, gx.view(M, Cin) if had else None, ACT_NONE, out=gx.view(M, Cin))
                     else:
                         dpad = (k - 1 - pad[0], k - 1 - pad[1], k - 1 - pad[2], k - 1 - pad[3])
@@ -400,6 +411,11 @@ class TrainState(object):
             self.sess.x3_refresh()
         if self.sess.h2:                             # the same for cfg.HIP.MFMA_H2
             self.sess.h2_refresh()
+        self.sess.prepared.weights_changed()
+        self.sess.prepared.refresh()
+
+    def invalidate_prepared(self):
+        self.sess.prepared.invalidate()
 
     def _wd(self, scope):
         wd = self.net.weight_decay_for(scope) if hasattr(self.net, "weight_decay_for") else None

@@ -103,6 +103,8 @@ __C = AttrDict(
     # WGRAD_TN: filter gradients of convolutions with Cin, Cout % 64 == 0 by frcnn_conv2d_wgrad (dW = dY^T X read from the NHWC tensors as
     # they lie, csrc/wgrad_tn.hip) instead of transpose_pad / im2col_t + the forward GEMM kernel.
     # WGRAD_H2 (with MFMA_H2 and H2_TRAIN): those gradients on the fp16 matrix pipe, operands split in registers (csrc/wgrad_h2.hip).
+    # PREP_STREAM: the weight-only launches of the data-gradient chain (flipped / transposed filters, their h2 split, Winograd transforms of
+    # the gradient filters) are re-run by the solver right after the update, on their own stream beside the next forward pass.
     # TRAIN_GRAPH: the reverse sweep of a training step (~1000 launches, every argument a function of the tape) is captured into a
     # hipGraph the second time the same tape comes by (= the same image shape) and replayed afterwards (frcnn_hip/train.py backward_auto);
     # single-process runs without dropout only.  OFF: the sweep is GPU-bound, not launch-bound (one stream: 27.0 ms / step replayed vs
@@ -114,7 +116,7 @@ __C = AttrDict(
              WINOGRAD_TRAIN=True,
              WINOGRAD_7X7=True, FUSE_TAIL_MEAN=False, OVERLAP_TAIL_ENTRY=False, MFMA_X3=True,
              MFMA_H2=True, H2_LAZY_SPLIT=True, H2_MIN_TILES=150, H2_TRUNK_PLANES=False, H2_TILE_CFG=-1,
-             X3_TILE_CFG=-1, X3_TERMS=6, H2_TRAIN=True, WGRAD_STREAM=2, TRAIN_GRAPH=False, WGRAD_TN=True, WGRAD_H2=True))
+             X3_TILE_CFG=-1, X3_TERMS=6, H2_TRAIN=True, WGRAD_STREAM=2, TRAIN_GRAPH=False, WGRAD_TN=True, WGRAD_H2=True, PREP_STREAM=True))
 __C.DATA_DIR = osp.abspath(osp.join(__C.ROOT_DIR, 'data'))
 cfg = __C
 

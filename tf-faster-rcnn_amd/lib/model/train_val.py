@@ -78,6 +78,7 @@ class SolverWrapper(object):
         print('Loaded.')
         self.net.fix_variables(self.sess, pretrained_model)
         print('Fixed.')
+        self.state.invalidate_prepared()
         return cfg.TRAIN.LEARNING_RATE, 0, list(cfg.TRAIN.STEPSIZE)
 
     def snapshot(self, it, output_dir):
@@ -106,6 +107,7 @@ class SolverWrapper(object):
         from frcnn_hip.tensor_bundle import BundleReader
         print('Restoring model snapshots from {:s}'.format(sfile))
         self.sess.restore(sfile)
+        self.state.invalidate_prepared()
         self.state.pending_slots = BundleReader(sfile)           # imported right after TrainState.build(), before the first update
         with open(nfile, 'rb') as f:
             meta = pickle.load(f)

@@ -107,7 +107,9 @@ class Network(object):
             # TRAIN: the filter changes every step -> transform the live (folded) device filter, then the same Winograd chain
             m = self._winograd_scheme(scope, H, W)
             G, T = ops.winograd_points(m), ops.winograd_tiles(N, H, W, m)
-            u = ops.winograd_filter_transform_device(w, m, False, out=sess.buf(self._tag + "/wino_u", (G, Cout, Cin)))
+            # (weight-only: after the first step the solver has it re-run beside the forward pass, frcnn_hip/runtime.py PreparedFilters)
+            u = sess.prepared.get(("fwd", "wino_u", self._tag, scope, m), lambda: ops.winograd_filter_transform_device(
+                w, m, False, out=sess.buf(self._tag + "/wino_u/" + scope, (G, Cout, Cin))))
             v, mm = sess.buf(self._tag + "/wino_v", (G, T, Cin)), sess.buf(self._tag + "/wino_m", (G, T, Cout))
             sess.mark("conv:" + scope, 2 * G * T * Cout * Cin, lambda: ops.conv3x3_winograd(x, u, b, act, out=out, v_buf=v, m_buf=mm),
                       nbytes=4 * (v.numel() + u.numel() + mm.numel()))
@@ -682,6 +684,7 @@ class Network(object):
         self._gt_boxes = gt if torch.is_tensor(gt) else sess.to_device(np.ascontiguousarray(gt, dtype=np.float32))
         ops.ws_scope = self._tag
         sess.flops_last_forward = 0
+        sess.prepared.enabled = bool(cfg.HIP.PREP_STREAM) and not cfg.HIP.TRAIN_GRAPH
         self._build_network(True)
         return self._add_losses()
 
@@ -719,6 +722,7 @@ class Network(object):
         train_op.wgrad_stream = int(cfg.HIP.WGRAD_STREAM)
         train_op.graph = bool(cfg.HIP.TRAIN_GRAPH)
         train_op.wgrad_tn = bool(cfg.HIP.WGRAD_TN)
+        train_op.prep_stream = bool(cfg.HIP.PREP_STREAM)
         train_op.wgrad_h2 = bool(cfg.HIP.MFMA_H2 and cfg.HIP.H2_TRAIN and cfg.HIP.WGRAD_H2)
 
     def train_step_no_return(self, sess, blobs, train_op):
