@@ -152,9 +152,10 @@ def test_full_train_step_matches_torch_autograd(dev, wino, h2):
     from nets.resnet_v1 import resnetv1
     SC, RT = (4, 8, 16), (0.5, 1, 2)
     old = (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.WINOGRAD_TRAIN)
-    old_h2 = (cfg.HIP.H2_TRAIN, cfg.HIP.H2_MIN_TILES)
+    old_h2 = (cfg.HIP.H2_TRAIN, cfg.HIP.H2_MIN_TILES, cfg.HIP.H2_TRAIN_WINO)
     cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.WINOGRAD_TRAIN = 64, 0.0, wino
     cfg.HIP.H2_TRAIN, cfg.HIP.H2_MIN_TILES = bool(h2), (1 if h2 else cfg.HIP.H2_MIN_TILES)
+    cfg.HIP.H2_TRAIN_WINO = bool(h2)              # (off by default: measured +-0) the Winograd products of both passes in frcnn_gemm_h2 too
     try:
         sess = Session(device=dev, seed=5)
         net = resnetv1(num_layers=50)
@@ -172,6 +173,7 @@ def test_full_train_step_matches_torch_autograd(dev, wino, h2):
         ts = TrainState(sess, net, momentum=0.9, weight_decay=1e-4).build()
         ts.winograd = (4, 64, True) if wino else None
         ts.h2_train = 1 if h2 else None
+        ts.h2_train_wino = bool(h2)
         # filter gradients: "direct" keeps round 2's transposes + forward GEMM kernel, "winograd" the f32 TN kernel, "winograd_h2" the
         # fp16-pipe TN kernel (csrc/wgrad_tn.hip, wgrad_h2.hip); the latter two on two side streams
         ts.wgrad_tn, ts.wgrad_h2, ts.wgrad_stream = wino, h2, (2 if wino else 0)
@@ -223,7 +225,7 @@ def test_full_train_step_matches_torch_autograd(dev, wino, h2):
             assert torch.equal(fresh[0], wq[0]) and torch.equal(fresh[1], wq[1])
     finally:
         cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.WINOGRAD_TRAIN = old
-        cfg.HIP.H2_TRAIN, cfg.HIP.H2_MIN_TILES = old_h2
+        cfg.HIP.H2_TRAIN, cfg.HIP.H2_MIN_TILES, cfg.HIP.H2_TRAIN_WINO = old_h2
 
 
 def test_sgd_steps_on_a_fixed_batch_reduce_the_loss(dev):

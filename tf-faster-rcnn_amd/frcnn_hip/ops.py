@@ -474,18 +474,25 @@ def winograd_output_transform(mm, bias, act, out, m=2):
     return out
 
 
-def conv3x3_winograd(x, u, bias, act=ACT_NONE, out=None, v_buf=None, m_buf=None):
-    """3x3 / stride 1 / pad 1 convolution as Winograd F(m x m,3x3): x [N,H,W,Cin], u [(m+2)^2,Cout,Cin] -> [N,H,W,Cout]."""
+def conv3x3_winograd(x, u, bias, act=ACT_NONE, out=None, v_buf=None, m_buf=None, u_planes=None, v_planes=None):
+    """3x3 / stride 1 / pad 1 convolution as Winograd F(m x m,3x3): x [N,H,W,Cin], u [(m+2)^2,Cout,Cin] -> [N,H,W,Cout].
+    u_planes = h2_pack_w(u) and v_planes (an H2 of [points * tiles, Cin]): the input transform emits V as operand planes and the
+    products run in frcnn_gemm_h2 instead of the f32-MFMA batched GEMM."""
     N, H, W, Cin = x.shape
     G, Cout = u.shape[0], u.shape[1]
     m = {16: 2, 36: 4, 121: 7}[G]
     T = winograd_tiles(N, H, W, m)
     dev = x.device
-    v = torch.empty((G, T, Cin), dtype=torch.float32, device=dev) if v_buf is None else v_buf
     mm = torch.empty((G, T, Cout), dtype=torch.float32, device=dev) if m_buf is None else m_buf
     out = torch.empty((N, H, W, Cout), dtype=torch.float32, device=dev) if out is None else out
-    winograd_input_transform(x, v, m)
-    gemm_batched_nt(v, u, mm)
+    if u_planes is not None:
+        v_planes = H2.empty(G * T, Cin, dev) if v_planes is None else v_planes
+        winograd_input_transform_h2(x, v_planes, m)
+        gemm_h2(v_planes, u_planes, G, T, Cout, Cin, out=mm.view(G * T, Cout))
+    else:
+        v = torch.empty((G, T, Cin), dtype=torch.float32, device=dev) if v_buf is None else v_buf
+        winograd_input_transform(x, v, m)
+        gemm_batched_nt(v, u, mm)
     return winograd_output_transform(mm, bias, act, out, m)
 
 

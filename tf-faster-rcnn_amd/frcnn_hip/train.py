@@ -344,8 +344,16 @@ class TrainState(object):
                     T = ops.winograd_tiles(N, OH, OW, m)
                     u = prepared(("wino_u", sc, m), lambda wf=wf, m=m, sc=sc, G=G, Cin=Cin, Cout=Cout: ops.winograd_filter_transform_device(
                         wf, m, True, out=sess.buf("bwd/wino_u/" + sc, (G, Cin, Cout))))
-                    ops.conv3x3_winograd(gy, u, None, ACT_NONE, out=gx, v_buf=sess.buf("bwd/wino_v", (G, T, Cout)),
-                                         m_buf=sess.buf("bwd/wino_m", (G, T, Cin)))
+                    if (getattr(self, "h2_train", None) is not None and getattr(self, "h2_train_wino", False) and Cout % 128 == 0 and Cin % 128 == 0
+                            and ((T + 127) // 128) * (Cin // 128) * G >= self.h2_train and 4 * G * T * Cout < (1 << 32) and T * Cin < (1 << 29)):
+                        # cfg.HIP.H2_TRAIN: the products of the transformed gradient in frcnn_gemm_h2 (K = Cout, N = Cin)
+                        up = prepared(("wino_u_h2", sc, m), lambda u=u, sc=sc, G=G, Cin=Cin, Cout=Cout: ops.h2_pack_w(
+                            u, out=sess.buf_pair("bwd/wino_u_h2/" + sc, G * Cin, Cout)))
+                        ops.conv3x3_winograd(gy, u, None, ACT_NONE, out=gx, m_buf=sess.buf("bwd/wino_m", (G, T, Cin)), u_planes=up,
+                                             v_planes=sess.h2_buf("bwd/wino_v", G * T, Cout))
+                    else:
+                        ops.conv3x3_winograd(gy, u, None, ACT_NONE, out=gx, v_buf=sess.buf("bwd/wino_v", (G, T, Cout)),
+                                             m_buf=sess.buf("bwd/wino_m", (G, T, Cin)))
                 elif stride == 1 and Cout % 32 == 0:
                     wd = prepared(("wflip", sc), lambda wf=wf, sc=sc, k=k, Cout=Cout: ops.flip_transpose_filter(
                         wf, out=sess.buf("bwd/wflip/" + sc, (wf.shape[3], k, k, Cout))))

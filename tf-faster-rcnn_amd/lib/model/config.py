@@ -110,13 +110,15 @@ __C = AttrDict(
     # single-process runs without dropout only.  OFF: the sweep is GPU-bound, not launch-bound (one stream: 27.0 ms / step replayed vs
     # 27.1 eager), and a replayed graph runs its side-stream branches with less overlap than the eager streams do (25.5 vs 23.8 ms,
     # profiles/r03_ab_c5_streams_graph.txt).
+    # H2_TRAIN_WINO: with H2_TRAIN, also the (m+2)^2 products of the TRAIN-mode Winograd convolutions and of their data gradients (the RoI
+    # tail's 3x3 layers and the RPN convolution qualify at 600x1000).  OFF: measured +-0 (20.08-20.22 vs 20.06-20.23 ms / step, three pairs).
     # X3_TILE_CFG / X3_TERMS: frcnn_gemm_x3's per-call tile configuration (-1 = by shape) and 6 / 9 cross terms (A/B runs).
     # H2_TILE_CFG: -1 = tile shape by launch size (csrc/gemm_h2.hip), else a frcnn_gemm_h2 configuration id for every launch (A/B runs).
     HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=64, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=("block1", "block2"), WINOGRAD_DIRECT_SCOPES=(),
              WINOGRAD_TRAIN=True,
              WINOGRAD_7X7=True, FUSE_TAIL_MEAN=False, OVERLAP_TAIL_ENTRY=False, MFMA_X3=True,
              MFMA_H2=True, H2_LAZY_SPLIT=True, H2_MIN_TILES=150, H2_TRUNK_PLANES=False, H2_TILE_CFG=-1,
-             X3_TILE_CFG=-1, X3_TERMS=6, H2_TRAIN=True, WGRAD_STREAM=2, TRAIN_GRAPH=False, WGRAD_TN=True, WGRAD_H2=True, PREP_STREAM=True))
+             X3_TILE_CFG=-1, X3_TERMS=6, H2_TRAIN=True, WGRAD_STREAM=2, TRAIN_GRAPH=False, WGRAD_TN=True, WGRAD_H2=True, PREP_STREAM=True, H2_TRAIN_WINO=False))
 __C.DATA_DIR = osp.abspath(osp.join(__C.ROOT_DIR, 'data'))
 cfg = __C
 

@@ -110,9 +110,19 @@ class Network(object):
             # (weight-only: after the first step the solver has it re-run beside the forward pass, frcnn_hip/runtime.py PreparedFilters)
             u = sess.prepared.get(("fwd", "wino_u", self._tag, scope, m), lambda: ops.winograd_filter_transform_device(
                 w, m, False, out=sess.buf(self._tag + "/wino_u/" + scope, (G, Cout, Cin))))
-            v, mm = sess.buf(self._tag + "/wino_v", (G, T, Cin)), sess.buf(self._tag + "/wino_m", (G, T, Cout))
-            sess.mark("conv:" + scope, 2 * G * T * Cout * Cin, lambda: ops.conv3x3_winograd(x, u, b, act, out=out, v_buf=v, m_buf=mm),
-                      nbytes=4 * (v.numel() + u.numel() + mm.numel()))
+            mm = sess.buf(self._tag + "/wino_m", (G, T, Cout))
+            if cfg.HIP.H2_TRAIN_WINO and self._h2_eligible(T, Cout, Cin, G):
+                # cfg.HIP.H2_TRAIN: the (m+2)^2 products in frcnn_gemm_h2 -- the split of U is one more weight-only launch (prepared)
+                up = sess.prepared.get(("fwd", "wino_u_h2", self._tag, scope, m), lambda: ops.h2_pack_w(
+                    u, out=sess.buf_pair(self._tag + "/wino_u_h2/" + scope, G * Cout, Cin)))
+                vp = sess.h2_buf(self._tag + "/wino_v", G * T, Cin)
+                sess.mark("conv:h2:" + scope, 2 * G * T * Cout * Cin,
+                          lambda: ops.conv3x3_winograd(x, u, b, act, out=out, m_buf=mm, u_planes=up, v_planes=vp),
+                          nbytes=4 * (G * T * Cin + u.numel() + mm.numel()))
+            else:
+                v = sess.buf(self._tag + "/wino_v", (G, T, Cin))
+                sess.mark("conv:" + scope, 2 * G * T * Cout * Cin, lambda: ops.conv3x3_winograd(x, u, b, act, out=out, v_buf=v, m_buf=mm),
+                          nbytes=4 * (v.numel() + u.numel() + mm.numel()))
             self._wrote(out)
         elif plain and self._h2_eligible(M, Cout, Cin, 1) and self._h2_input(x) is not None:
             # a plain GEMM with a static filter on the fp16 matrix pipe, block-scaled two-piece operands (cfg.HIP.MFMA_H2)
@@ -719,6 +729,7 @@ class Network(object):
         train_op.winograd = ((int(cfg.HIP.WINOGRAD_M), int(cfg.HIP.WINOGRAD_MIN_CIN), bool(cfg.HIP.WINOGRAD_7X7))
                              if (cfg.HIP.WINOGRAD and cfg.HIP.WINOGRAD_TRAIN) else None)
         train_op.h2_train = int(cfg.HIP.H2_MIN_TILES) if (cfg.HIP.MFMA_H2 and cfg.HIP.H2_TRAIN) else None
+        train_op.h2_train_wino = bool(cfg.HIP.H2_TRAIN_WINO)
         train_op.wgrad_stream = int(cfg.HIP.WGRAD_STREAM)
         train_op.graph = bool(cfg.HIP.TRAIN_GRAPH)
         train_op.wgrad_tn = bool(cfg.HIP.WGRAD_TN)
