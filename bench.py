@@ -468,7 +468,9 @@ def main():
                                "gflop_per_step_reference_graph": c["gflop_ref"]},
                        roofline={"bound": "mfma", "achieved": round(c["gflop_ref"] * value / world / 1e3, 2), "peak": F32_MFMA_PEAK_TFLOPS,
                                  "unit": "TFLOP/s", "frac": round(c["gflop_ref"] * value / world / 1e3 / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                                 "kernel": "whole training step, reference-graph FLOPs (fwd + 2x trainable part) / step time"})
+                                 "kernel": "whole training step, reference-graph FLOPs (fwd + 2x trainable part) / step time; priced against the f32-MFMA "
+                                           "peak although the pointwise GEMMs and the filter gradients issue on the fp16 pipe (ceiling 833.3): "
+                                           "a rate in reference FLOPs, not a pipe utilisation"})
             print(json.dumps(out), flush=True)
         if dist is not None:
             dist.barrier()
