@@ -434,7 +434,7 @@ void frcnn_conv2d_wgrad_set_plan(int tile, int min_workgroups);
 size_t frcnn_conv2d_wgrad_h2_workspace_bytes(int N, int OH, int OW, int Cin, int Cout, int KH, int KW);
 int frcnn_conv2d_wgrad_h2(const float* dy_d, const float* x_d, int N, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW,
                           int stride, int pad_top, int pad_left, float* dw_d, void* ws, size_t ws_bytes, void* stream);
-void frcnn_conv2d_wgrad_h2_set_plan(int tile, int min_workgroups);
+void frcnn_conv2d_wgrad_h2_set_plan(int tile, int min_workgroups);      /* as above; 0 = 256 workgroups */
 int frcnn_relu_bwd(float* grad_d, const float* y_d, long long n, void* stream);              /* grad *= (y > 0) */
 int frcnn_relu6_bwd(float* grad_d, const float* y_d, long long n, void* stream);             /* grad *= (0 < y < 6) */
 /* Reverse-sweep pieces of the VGG16 / MobileNet-v1 TRAIN graphs (lib/nets/vgg16.py:26-60, mobilenet_v1.py:114-172):

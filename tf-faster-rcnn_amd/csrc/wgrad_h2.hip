@@ -281,7 +281,10 @@ extern "C" void frcnn_conv2d_wgrad_h2_set_plan(int tile, int min_workgroups) { t
 
 // 128-wide tiles from 32 of them on (measured on the ResNet-152 shapes, profiles/r03_ae_wgrad_bench.txt: the RoI tail's 1x1 layers
 // 186 vs 266 us, block3's 3x3 43 vs 46 us; block3's 1x1 layers with 16 such tiles 31 vs 23 us), else 64; slices so that the launch has
-// >= 512 workgroups while a slice keeps >= 2 slabs of 64 pixels
+// >= 256 workgroups (one per CU) while a slice keeps >= 2 slabs of 64 pixels.  More slices fill the chip better in isolation but write
+// and re-read more partial tiles than the operands themselves, and the sweep runs these launches BESIDE the data-gradient chain:
+// the ResNet-152 step takes 19.65 ms at 128 / 256, 20.4 at 512, 20.75 at 1024, 22.8 at 64, 27.2 with one slice
+// (profiles/r03_an_wgrad_slices.txt)
 static void wgrad_h2_plan(int M, int Cout, int Kf, int Cin, int& BT, int& S, int& chunk) {
   const int nslabs = cdiv(M, 64);
   BT = 64;
@@ -289,7 +292,7 @@ static void wgrad_h2_plan(int M, int Cout, int Kf, int Cin, int& BT, int& S, int
   if (ok128 && (Cout / 128) * (Kf / 128) >= 32) BT = 128;
   if (t_wh2_bt == 64 || (t_wh2_bt == 128 && ok128)) BT = t_wh2_bt;
   const int tiles = (Cout / BT) * (Kf / BT);
-  int want = cdiv(t_wh2_wgs > 0 ? t_wh2_wgs : 512, tiles);
+  int want = cdiv(t_wh2_wgs > 0 ? t_wh2_wgs : 256, tiles);
   want = max(1, min(want, nslabs / 2));
   chunk = cdiv(nslabs, max(want, 1));
   S = cdiv(nslabs, chunk);
