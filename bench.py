@@ -361,6 +361,7 @@ def main():
     ap.add_argument("--no-prep-stream", action="store_true", help="cfg.HIP.PREP_STREAM False: gradient filters prepared inside the sweep (c5 A/B)")
     ap.add_argument("--no-h2-train-wino", action="store_true", help="cfg.HIP.H2_TRAIN_WINO False: TRAIN-mode Winograd products on the f32 MFMA (c5 A/B)")
     ap.add_argument("--wgrad-plan", default=None, help="tile,workgroups override of frcnn_conv2d_wgrad_h2's slicing plan (c5 A/B), e.g. 0,256")
+    ap.add_argument("--splitk-target", type=int, default=0, help="frcnn_set_tuning(7, N): workgroups a split-K convolution launch aims at (A/B; default 640)")
     ap.add_argument("--wgrad-streams", type=int, default=-1, help="cfg.HIP.WGRAD_STREAM: side streams for the filter gradients (c5 A/B; 0 = none)")
     ap.add_argument("--h2-cfg", type=int, default=-1, help="cfg.HIP.H2_TILE_CFG (A/B): -1 = tile shape by launch size, else one frcnn_gemm_h2 configuration id")
     ap.add_argument("--h2-trunk-planes", type=int, default=-1, help="cfg.HIP.H2_TRUNK_PLANES (A/B): 0 keeps the residual trunk in float32")
@@ -419,6 +420,9 @@ def main():
     if args.wgrad_plan:
         from frcnn_hip import lib as _lib
         _lib().frcnn_conv2d_wgrad_h2_set_plan(*[int(v) for v in args.wgrad_plan.split(",")])
+    if args.splitk_target > 0:
+        from frcnn_hip import lib as _lib2
+        _lib2().frcnn_set_tuning(7, args.splitk_target)
     if args.wgrad_streams >= 0:
         cfg.HIP.WGRAD_STREAM = args.wgrad_streams
     if args.h2_min_tiles >= 0:

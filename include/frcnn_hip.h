@@ -231,7 +231,8 @@ int frcnn_conv1x1_mean(const float* x_d, int M, int Cin, const float* w_d, const
 /* Tuning overrides for A/B measurements and for tests that must reach every tile configuration: THREAD-LOCAL (they affect only the
  * launches the calling thread makes afterwards, so the thread-safety contract above holds); no product path sets them.  key 0 = force a
  * conv tile configuration id (-1 = automatic); key 1 = ablation bits; key 5 = phase stagger of co-resident workgroups; key 6 = 0 keeps
- * the short-K GEMMs off k_gemm_stream.  frcnn_gemm_x3 / frcnn_gemm_h2 take their configuration per call instead. */
+ * the short-K GEMMs off k_gemm_stream; key 7 = the workgroup count a split-K launch aims at (0 = the default 640; 160 ... 640 move the
+ * ResNet-152 training step by +-1 %).  frcnn_gemm_x3 / frcnn_gemm_h2 take their configuration per call instead. */
 int frcnn_set_tuning(int key, int value);
 /* HOST: CRC-32C (Castagnoli) of n bytes, crc = 0 to start or a previous result to extend: the checksum of TensorFlow
  * checkpoint shards / index blocks (frcnn_hip/tensor_bundle.py replaces pywrap_tensorflow.NewCheckpointReader,

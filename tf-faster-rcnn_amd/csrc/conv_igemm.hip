@@ -724,12 +724,13 @@ static int launch_stream_cfg(int id, const ConvParams& p, hipStream_t st) {
 
 // tuning knob (experiments / A-B runs): key 0 = force a tile configuration id for every non-stem conv
 // (-1 = automatic choice).
-static thread_local int g_force_cfg = -1, g_dbg = 0, g_stagger = 0, g_stream = 1;      // per calling thread: no state shared between threads
+static thread_local int g_force_cfg = -1, g_dbg = 0, g_stagger = 0, g_stream = 1, g_split_target = 640;      // per calling thread: no state shared between threads
 extern "C" int frcnn_set_tuning(int key, int value) {
   if (key == 0) { g_force_cfg = value; return FRCNN_OK; }
   if (key == 1) { g_dbg = value; return FRCNN_OK; }
   if (key == 5) { g_stagger = value; return FRCNN_OK; }        // 0 off; n > 0: second-slot workgroups start n/8 of a tile late
   if (key == 6) { g_stream = value; return FRCNN_OK; }         // 0: never dispatch to k_gemm_stream (A/B runs)
+  if (key == 7) { g_split_target = value > 0 ? value : 640; return FRCNN_OK; }   // workgroups a split-K launch aims at (plan_splits)
   return FRCNN_E_ARG;
 }
 
@@ -774,7 +775,7 @@ static int plan_splits(int M, int Cout, int nsteps) {
   if (Cout >= 96 && big >= 384 && nsteps >= 8) return 1;
   const long long tiles = (long long)cdiv(M, 64) * cdiv(Cout, Cout > 32 ? 64 : 32);
   if (tiles >= 384 || nsteps < 16) return 1;
-  int S = (int)min((long long)8, (640 + tiles - 1) / tiles);
+  int S = (int)min((long long)8, (g_split_target + tiles - 1) / tiles);
   S = min(S, nsteps / 8);
   if (S < 2) return 1;
   const int kchunk = cdiv(nsteps, S);
