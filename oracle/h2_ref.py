@@ -79,3 +79,23 @@ def gemm_terms(x, w, terms=3):
             blk = blk + xl[:, s] @ wl[:, s].T
         out += blk * xinv[kb].astype(np.float64)[:, None]
     return out * winv[None, :]
+
+
+def wgrad_terms(dy, x, slab=64):
+    """What csrc/wgrad_h2.hip evaluates for dW = dY^T X (dY [M, Cout], X [M, K] float32, the reduction over the M pixels), with exact
+    (float64) accumulation: every (column, `slab`-pixel segment) of both operands gets its own block_scale from the segment's
+    largest magnitude (rows past M count as zeros), the scaled values are split into two fp16 pieces, a slab's product keeps the
+    three leading cross terms, and the slab's sum is folded by the two inverse scales.  -> float64 [Cout, K]."""
+    dy, x = np.asarray(dy, dtype=np.float32), np.asarray(x, dtype=np.float32)
+    M = dy.shape[0]
+    out = np.zeros((dy.shape[1], x.shape[1]), dtype=np.float64)
+    for m0 in range(0, M, slab):
+        a, b = dy[m0:m0 + slab], x[m0:m0 + slab]
+        sa, ia = block_scale(np.abs(a).max(axis=0))                     # per column of dY
+        sb, ib = block_scale(np.abs(b).max(axis=0))                     # per column of X
+        ah, al = split_scaled(a, sa[None, :])
+        bh, bl = split_scaled(b, sb[None, :])
+        ah, al, bh, bl = (t.astype(np.float64) for t in (ah, al, bh, bl))
+        blk = ah.T @ bh + al.T @ bh + ah.T @ bl
+        out += blk * ia.astype(np.float64)[:, None] * ib.astype(np.float64)[None, :]
+    return out

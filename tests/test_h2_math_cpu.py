@@ -129,3 +129,27 @@ def test_domain_outliers_inside_a_scale_block():
         errs[ratio] = np.abs(h2_ref.gemm_terms(a, w, 3) - exact).max() / np.abs(exact).max()
     assert errs[1e2] <= 3e-7 and errs[1e4] <= 3e-7 and errs[1e6] <= 2e-6
     assert 1e-6 < errs[1e8] < 1e-3                            # documented limit, not an accident
+
+
+def test_weight_gradient_in_two_piece_fp16_is_below_float32_accumulation_noise():
+    """csrc/wgrad_h2.hip in numpy (h2_ref.wgrad_terms): dW = dY^T X over 2394 pixels (a 38 x 63 map) with post-ReLU activations and
+    gated gradients whose magnitude varies over the map; scales per (channel, 64-pixel segment), three cross terms.  With exact
+    accumulation the format's own error is ~1e-7 of max |dW| -- below what a float32 dot product of this length accumulates."""
+    rng = np.random.RandomState(11)
+    M, Cout, Cin = 2394, 48, 64
+    x = (np.maximum(rng.randn(M, Cin), 0) * np.exp(rng.uniform(-2, 2, size=(M, 1)))).astype(np.float32)
+    dy = (rng.randn(M, Cout) * (rng.rand(M, Cout) < 0.4) * np.exp(rng.uniform(-3, 3, size=(M, 1)))).astype(np.float32)
+    exact = dy.astype(np.float64).T @ x.astype(np.float64)
+    got = h2_ref.wgrad_terms(dy, x)
+    err = np.abs(got - exact).max() / np.abs(exact).max()
+    f32 = np.zeros((Cout, Cin), dtype=np.float32)                                          # a float32 accumulation in pixel order
+    for m0 in range(0, M, 2):                                                              # (k = 2 per f32 MFMA)
+        f32 = (f32 + dy[m0:m0 + 2].T @ x[m0:m0 + 2]).astype(np.float32)
+    err32 = np.abs(f32.astype(np.float64) - exact).max() / np.abs(exact).max()
+    print("wgrad h2 format error %.2e, float32 accumulation %.2e" % (err, err32))
+    assert err <= 2e-7 and err <= err32
+    # a whole segment of zeros in ONE operand (rows past M, a padding tap) contributes exactly nothing, whatever the other holds
+    d0, x0 = dy[:37 * 64], x[:37 * 64]
+    base = h2_ref.wgrad_terms(d0, x0)
+    more = h2_ref.wgrad_terms(np.vstack([d0, np.zeros((64, Cout), np.float32)]), np.vstack([x0, 7 * np.ones((64, Cin), np.float32)]))
+    assert np.array_equal(base, more)
