@@ -37,7 +37,11 @@ extern "C" {
 #define FRCNN_ACT_RELU6 2
 
 /* ---- library ------------------------------------------------------------------------------- */
-int frcnn_abi_version(void);                 /* bumps when a signature changes (2: batched detection stages, NMS rule) */
+/* Bumps when an exported signature changes.  2: batched detection stages, NMS rule.  3: `opts` argument of the target-layer entries,
+ * per-call cfg / terms of frcnn_gemm_x3 (frcnn_gemm_x3_set_* removed), frcnn_gemm_h2 + operand planes.  A caller compiled against
+ * this header compares frcnn_abi_version() with FRCNN_ABI_VERSION before its first call (the ctypes binding does, on load). */
+#define FRCNN_ABI_VERSION 3
+int frcnn_abi_version(void);
 const char* frcnn_build_info(void);          /* "gfx950 ..." */
 
 /* ---- NMS: replaces lib/nms/gpu_nms.hpp:1-2 (`_nms`), lib/nms/cpu_nms.pyx:17-68 -------------- */

@@ -8,7 +8,7 @@ sys.path[:0] = [os.path.join(ROOT, "tf-faster-rcnn_amd")]
 csrc = os.path.join(ROOT, "tf-faster-rcnn_amd", "csrc")
 so = "/tmp/libh2trace.so"
 subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
-                       "-I" + csrc, "-DFRCNN_H2_TRACE", "-shared", os.path.join(csrc, "gemm_h2.hip"), "-o", so])
+                       "-I" + csrc, "-DFRCNN_H2_TRACE", "-DFRCNN_ABLATION", "-shared", os.path.join(csrc, "gemm_h2.hip"), "-o", so])
 L = ctypes.CDLL(so)
 from frcnn_hip import ops
 dev = torch.device("cuda:0")

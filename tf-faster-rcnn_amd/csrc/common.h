@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "frcnn_hip.h"
 
 typedef unsigned long long u64;
@@ -21,6 +23,32 @@ typedef unsigned int u32;
     hipError_t _e = hipGetLastError();                 \
     if (_e != hipSuccess) return FRCNN_E_HIP(_e);      \
   } while (0)
+
+// One-time setup of a kernel instance PER DEVICE -- the dynamic-LDS attribute and, for the resident-workgroup kernels, how many workgroups
+// the device holds -- safe when several host threads drive distinct streams or distinct devices of one process (include/frcnn_hip.h:
+// "distinct streams are thread-safe").  One static KernelOnce per kernel instantiation.
+struct KernelOnce {
+  static constexpr int MAXDEV = 64;
+  std::once_flag flag[MAXDEV];
+  hipError_t rc[MAXDEV];
+  int slots[MAXDEV];
+};
+static inline hipError_t kernel_once(KernelOnce& k, const void* kern, int threads, size_t lds, int* slots_out = nullptr) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= KernelOnce::MAXDEV) return hipErrorInvalidDevice;
+  std::call_once(k.flag[dev], [&] {
+    hipError_t r = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int per_cu = 0, cus = 0;
+    if (r == hipSuccess && slots_out) r = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds);
+    if (r == hipSuccess && slots_out) r = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    k.rc[dev] = r;
+    k.slots[dev] = per_cu * cus;
+  });
+  if (slots_out) *slots_out = k.slots[dev];
+  return k.rc[dev];
+}
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -422,10 +422,8 @@ static int launch_conv(ConvParams p, hipStream_t st) {
   constexpr size_t lds = ring > epi ? ring : epi;     // the epilogue tile reuses the ring memory
   auto kern = k_conv_igemm<BM, BN, WM, WN, NS, FOLDW, ILV, RF, MEAN>;
   // once per instantiation, safe when several host threads drive distinct streams ("distinct streams are thread-safe")
-  static std::once_flag attr_once;
-  static hipError_t attr_rc = hipSuccess;
-  std::call_once(attr_once, [&] { attr_rc = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-  HIP_TRY(attr_rc);
+  static KernelOnce once;
+  HIP_TRY(kernel_once(once, (const void*)kern, NT, lds));
   p.mtiles = cdiv(p.M, BM);
   p.ntiles = cdiv(p.Cout, BN);
   hipLaunchKernelGGL(kern, dim3(p.mtiles * p.ntiles, p.batch, p.splits), dim3(NT), lds, st, p);
@@ -670,18 +668,9 @@ static int launch_stream(const ConvParams& c, hipStream_t st) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   constexpr size_t lds = sizeof(float) * 2 * (BM + BN) * 32;
   auto kern = k_gemm_stream<BM, BN, WM, WN, ILV, RF, RESPF>;
-  static std::once_flag once;
-  static hipError_t rc0 = hipSuccess;
-  static int slots = 0;                     // resident workgroups on the device
-  std::call_once(once, [&] {
-    rc0 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    int per_cu = 0, dev = 0, cus = 0;
-    if (rc0 == hipSuccess) rc0 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, NT, lds);
-    if (rc0 == hipSuccess) rc0 = hipGetDevice(&dev);
-    if (rc0 == hipSuccess) rc0 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    slots = per_cu * cus;
-  });
-  HIP_TRY(rc0);
+  static KernelOnce once;
+  int slots = 0;                            // resident workgroups on the CURRENT device
+  HIP_TRY(kernel_once(once, (const void*)kern, NT, lds, &slots));
   const bool plain = c.KH == 1 && c.KW == 1 && c.stride == 1 && c.pad_top == 0 && c.pad_left == 0 && c.OH == c.H && c.OW == c.W;
   if (slots < 8 || !plain || c.Cout % BN || c.splits != 1 || (c.res && c.res_stride != 1) || (long long)c.M * c.Cout >= (1ll << 31) ||
       (long long)c.M * c.Cin >= (1ll << 31) || (long long)c.Cout * c.Cin >= (1ll << 31))

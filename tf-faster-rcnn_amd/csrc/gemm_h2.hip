@@ -134,6 +134,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
   for (int t = 0; t < LB; ++t) {
     const int u = wave * LB + t, plane = u / (BN / 16), row = (u % (BN / 16)) * 16 + (lane >> 2), pos = lane & 3;
     b_off[t] = (unsigned)((size_t)plane * wplane + (size_t)row * p.K * 2 + ((pos ^ ((row >> ((TUNE & 8) ? 1 : 2)) & 3)) * 16));
+#ifdef FRCNN_ABLATION     // TUNE & 16: the same bytes as 8 rows x one full 128-byte line per instruction (timing only: wrong LDS image)
+    if (TUNE & 16) b_off[t] = (unsigned)((size_t)(u * 8 + (lane >> 3)) * p.K * 2 + (lane & 7) * 16);
+#endif
   }
   auto set_tile = [&](int tl) {
     const int g = tl / per, rem = tl - g * per;
@@ -148,6 +151,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
       const int u = wave * LA + t, plane = u / (BM / 16), row = (u % (BM / 16)) * 16 + (lane >> 2), pos = lane & 3;
       const int rr = min(row, p.M - 1 - bm0);                                           // rows past M re-read row M - 1
       a_off[t] = (unsigned)((size_t)plane * xplane + (size_t)rr * p.K * 2 + ((pos ^ ((row >> ((TUNE & 8) ? 1 : 2)) & 3)) * 16));
+#ifdef FRCNN_ABLATION
+      if (TUNE & 16) a_off[t] = (unsigned)((size_t)min(u * 8 + (lane >> 3), p.M - 1 - bm0) * p.K * 2 + (lane & 7) * 16);
+#endif
     }
     // block scales of the tile's rows: one float per lane and 64-row group; rows past the tensor re-read its last row (unused)
     const long long last = p.Mtot - 1 - (long long)row0;
@@ -180,6 +186,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
       i_step = 0; i_tile += W8;
       if (left > 0) set_tile(i_tile);
     } else {
+#ifdef FRCNN_ABLATION
+      if (TUNE & 16) {          // line s of plane (s & 1): every 128-byte line of both planes is fetched exactly once
+        if (i_step & 1) { i_xb += xplane - 64; i_wb += wplane - 64; } else { i_xb += 128 - xplane - 64; i_wb += 128 - wplane - 64; }
+      }
+#endif
       i_xb += 64; i_wb += 64;
       if ((i_step & 3) == 0) i_sb += (size_t)p.Mtot * 4;       // next 128-k block: next row of x_inv [K/128][Mtot]
     }
@@ -595,18 +606,9 @@ static int launch_h2(const GemmH2Params& q, hipStream_t st) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   constexpr size_t lds = (size_t)NS * (2 * BM * 64 + 2 * BN * 64 + 1024) + (size_t)(BN / WN) * BM * 4 + ((TUNE & 2) ? 2048 : 0);
   auto kern = k_gemm_h2<BM, BN, WM, WN, NS, WPE, TUNE>;
-  static std::once_flag once;
-  static hipError_t rc0 = hipSuccess;
-  static int slots = 0;
-  std::call_once(once, [&] {
-    rc0 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    int per_cu = 0, dev = 0, cus = 0;
-    if (rc0 == hipSuccess) rc0 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, NT, lds);
-    if (rc0 == hipSuccess) rc0 = hipGetDevice(&dev);
-    if (rc0 == hipSuccess) rc0 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    slots = per_cu * cus;
-  });
-  HIP_TRY(rc0);
+  static KernelOnce once;
+  int slots = 0;                            // resident workgroups on the CURRENT device
+  HIP_TRY(kernel_once(once, (const void*)kern, NT, lds, &slots));
   if (slots < 8 || q.N % BN) return FRCNN_E_UNSUPPORTED;
   if (q.yp && BN != H2_KB) return FRCNN_E_UNSUPPORTED;            // the emitted block scale spans exactly the workgroup's columns
   GemmH2Params p = q;
@@ -655,6 +657,9 @@ extern "C" int frcnn_gemm_h2(const void* x_planes_d, const float* x_inv_d, const
                                                                   // under-filled launches, slower in the pipeline: profiles/r03_l_ab.txt)
     case 14: return launch_h2<128, 128, 64, 64, 2, 2, 4>(p, st);  // cfg 0 with the loads spread between the MFMAs (measured slower: r03_k)
     case 18: return launch_h2<128, 128, 64, 64, 2, 2, 10>(p, st); // cfg 9 with round 2's (r >> 1) & 3 swizzle (two-way LDS bank conflicts)
+#ifdef FRCNN_ABLATION
+    case 20: return launch_h2<128, 128, 64, 64, 2, 2, 18>(p, st); // cfg 9's byte count as full-line loads (wrong results by construction)
+#endif
     default: return FRCNN_E_ARG;
   }
 }

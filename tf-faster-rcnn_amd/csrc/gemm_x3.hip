@@ -277,18 +277,9 @@ static int launch_x3(const GemmX3Params& q, hipStream_t st) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   constexpr size_t lds = 2 * (size_t)(BM * 128 + 3 * BN * 64);
   auto kern = k_gemm_x3<BM, BN, WM, WN, ABL, TERMS>;
-  static std::once_flag once;
-  static hipError_t rc0 = hipSuccess;
-  static int slots = 0;
-  std::call_once(once, [&] {
-    rc0 = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    int per_cu = 0, dev = 0, cus = 0;
-    if (rc0 == hipSuccess) rc0 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, NT, lds);
-    if (rc0 == hipSuccess) rc0 = hipGetDevice(&dev);
-    if (rc0 == hipSuccess) rc0 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    slots = per_cu * cus;
-  });
-  HIP_TRY(rc0);
+  static KernelOnce once;
+  int slots = 0;                            // resident workgroups on the CURRENT device
+  HIP_TRY(kernel_once(once, (const void*)kern, NT, lds, &slots));
   if (slots < 8 || q.N % BN) return FRCNN_E_UNSUPPORTED;
   GemmX3Params p = q;
   p.mtiles = cdiv(p.M, BM); p.ntiles = p.N / BN; p.nsteps = p.K / 32;

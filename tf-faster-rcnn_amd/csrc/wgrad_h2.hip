@@ -328,11 +328,8 @@ extern "C" int frcnn_conv2d_wgrad_h2(const float* gy_d, const float* x_d, int N,
   const dim3 grid((unsigned)((Cout / BT) * (Kf / BT)), 1, (unsigned)S);
   const size_t lds = (size_t)4 * BT * 64 * 2 + (size_t)6 * BT * 4;
   if (BT == 128) {
-    static bool attr = false;
-    if (!attr) {
-      HIP_TRY(hipFuncSetAttribute((const void*)k_wgrad_h2<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr = true;
-    }
+    static KernelOnce once;
+    HIP_TRY(kernel_once(once, (const void*)k_wgrad_h2<128>, 256, lds));
     hipLaunchKernelGGL((k_wgrad_h2<128>), grid, dim3(256), lds, st, p);
   } else {
     hipLaunchKernelGGL((k_wgrad_h2<64>), grid, dim3(256), lds, st, p);

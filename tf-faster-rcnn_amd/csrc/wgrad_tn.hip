@@ -237,11 +237,8 @@ extern "C" int frcnn_conv2d_wgrad(const float* gy_d, const float* x_d, int N, in
   if (BT == 128) {
     constexpr int NS = 3;
     const size_t lds = (size_t)NS * 2 * 32 * 128 * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-      HIP_TRY(hipFuncSetAttribute((const void*)k_wgrad_tn<128, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr = true;
-    }
+    static KernelOnce once;
+    HIP_TRY(kernel_once(once, (const void*)k_wgrad_tn<128, NS>, 256, lds));
     hipLaunchKernelGGL((k_wgrad_tn<128, NS>), grid, dim3(256), lds, st, p);
   } else {
     constexpr int NS = 3;

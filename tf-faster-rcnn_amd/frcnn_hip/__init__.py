@@ -12,6 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libfrcnn_hip.so")
 _lib = None
 
+ABI_VERSION = 3                          # include/frcnn_hip.h FRCNN_ABI_VERSION: the signatures below are this version's
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 NMS_RULE_CPU, NMS_RULE_GPU = 0, 1        # FRCNN_NMS_RULE_*: `(double)ovr >= thresh` (cpu_nms.pyx:65) / `ovr > (float)thresh` (nms_kernel.cu:71)
 
@@ -163,6 +164,10 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the symbol is missing: loud by design
             fn.restype, fn.argtypes = res, args
+        got = L.frcnn_abi_version()
+        if got != ABI_VERSION:             # a stale .so would take shifted arguments silently
+            raise ImportError("libfrcnn_hip.so has ABI version %d, this binding is written for %d: rebuild (python -m frcnn_hip.build)"
+                              % (got, ABI_VERSION))
         _lib = L
     return _lib
 

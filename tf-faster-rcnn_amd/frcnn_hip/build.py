@@ -4,6 +4,7 @@ The .so is git-ignored but travels to the GPU box with the gpurun snapshot.  hip
 without a GPU.  `-ffp-contract=off`: the detection kernels must keep numpy's one-rounding-per-op
 arithmetic ("No FMA contraction"); the conv kernels do their math on MFMA and
 are unaffected."""
+import glob
 import os
 import subprocess
 import sys
@@ -35,7 +36,9 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
-    hdrs = [os.path.join(ROOT, "include", "frcnn_hip.h"), os.path.join(CSRC, "common.h")]
+    # every header a translation unit may include: the C ABI + all of csrc/*.h (h2_common.h holds the operand-format rule that the
+    # GEMM, the weight-gradient kernel, the splitter and the Winograd transforms must derive identically -- never link a mix)
+    hdrs = [os.path.join(ROOT, "include", "frcnn_hip.h")] + sorted(glob.glob(os.path.join(CSRC, "*.h")))
     objs, jobs = [], []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s.replace(".hip", ".o"))

@@ -73,17 +73,25 @@ class VariableStore(object):
             else:
                 raise ValueError(sp.init)
             self.variables[name] = v.astype(np.float32)
-        self.packed.clear()
         self.conv_info.clear()
+        self._drop_derived()
+
+    def _drop_derived(self):
+        """Everything computed FROM the variables: packed device images, pre-split x3 / h2 filter planes, captured graphs and (Session)
+        the prepared-filter plan whose closures hold the filter tensors -- a direct load / restore between training steps must not leave
+        the data-gradient chain reading flipped / Winograd / h2 filters derived from tensors that were just dropped."""
+        self.packed.clear()
+        self.x3.clear()
+        self.h2.clear()
         self.graphs.clear()
+        prepared = getattr(self, "prepared", None)
+        if prepared is not None:
+            prepared.invalidate()
 
     def load_variables(self, values):
         for k, v in values.items():
             self.variables[k] = np.asarray(v, dtype=np.float32)
-        self.packed.clear()
-        self.x3.clear()                                 # planes of the filters just dropped (no graph is left that reads them)
-        self.h2.clear()
-        self.graphs.clear()
+        self._drop_derived()
 
     def restore(self, ckpt_prefix, names=None, verify=True):
         """tf.train.Saver(...).restore(sess, ckpt) without TensorFlow (tools/test_net.py:110-114, train_val.py:185-190):

@@ -413,8 +413,9 @@ class TrainState(object):
         for p in self.params.values():
             if getattr(p, "dw", False):
                 ops.dwconv3x3_refold(p.w, p.scale, p.wf)
-        if self.sess.x3 or self.sess.h2:             # a TEST-mode network on the same session reads derived filter images: Winograd U
-            self.sess.wino_refresh()                 # of the 3x3 filters first, then the pre-split planes of everything (x3 / h2)
+        # a TEST-mode network on the same session reads derived filter images: Winograd U of the 3x3 filters first (also with x3 / h2
+        # off: a no-op when no ('wino', ...) entry is cached), then the pre-split planes of everything (x3 / h2)
+        self.sess.wino_refresh()
         if self.sess.x3:
             self.sess.x3_refresh()
         if self.sess.h2:                             # the same for cfg.HIP.MFMA_H2
