@@ -17,6 +17,7 @@ dev = torch.device("cuda:0")
 P = ctypes.c_void_p
 shapes = {"b4c1x4": (1, 58800, 512, 2048), "b4c3x4": (1, 58800, 2048, 512), "w7x4": (121, 1200, 512, 512), "b3c1x4": (1, 9576, 256, 1024),
           "b3c3x4": (1, 9576, 1024, 256), "b3c1x12": (1, 28728, 256, 1024)}
+if len(sys.argv) > 2: shapes = {k: v for k, v in shapes.items() if k in sys.argv[2].split(",")}
 cfgs = [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else "9,20").split(",")]
 for name, (G, M, N, K) in shapes.items():
     torch.manual_seed(1)

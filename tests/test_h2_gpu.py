@@ -68,7 +68,7 @@ H2_CASES = [
 ]
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 3, 8, 9, 12, 14, 18])
+@pytest.mark.parametrize("cfg", [0, 1, 3, 8, 9, 12, 14, 18, 21])
 @pytest.mark.parametrize("case", H2_CASES, ids=[str(i) for i in range(len(H2_CASES))])
 def test_gemm_h2_is_f32_class(dev, case, cfg):
     from frcnn_hip import ops
@@ -234,3 +234,29 @@ def test_depthwise_conv_emits_the_planes_of_its_f32_result(dev, N, H, W, C, stri
     yp2 = ops.H2.empty(rows, C, dev)
     assert ops.dwconv3x3(xd, wd, bd, stride, (1, 1, 1, 1), 2, out_planes=yp2, want_f32=False) is None
     _same_planes(yp2, yp)
+
+
+@pytest.mark.parametrize("shape", [(1, 256 * 300 + 40, 512, 512, True), (1, 58800, 512, 2048, False), (121, 1200, 512, 512, False),
+                                   (1, 9576, 1024, 256, True), (3, 300, 128, 128, False)], ids=["many_tiles", "b4c1", "w7", "b3c3", "tiny"])
+def test_gemm_h2_ping_pong_is_bit_identical_to_the_one_barrier_schedule(dev, shape):
+    """cfg 21 (256 x 128 tiles, two wave groups a segment apart, 3-slot ring) multiplies and folds in the same order as cfg 9: the f32
+    result, the emitted planes and the block scales must be the same BITS, on every one of several launches (a schedule with a race
+    differs from launch to launch), with several tiles per resident workgroup and M tails."""
+    from frcnn_hip import ops
+    G, M, N, K, with_res = shape
+    torch.manual_seed(G + M)
+    x = torch.randn(G * M, K, device=dev).clamp(min=0) * torch.exp(torch.rand(G * M, K, device=dev) * 6 - 3)
+    w = torch.randn(G, N, K, device=dev) / K ** 0.5
+    b = torch.randn(N, device=dev) if G == 1 else None
+    r = torch.randn(G * M, N, device=dev) if with_res else None
+    xp, wp = ops.h2_split(x), ops.h2_pack_w(w)
+    ref, refp = torch.empty(G * M, N, device=dev), ops.H2.empty(G * M, N, dev)
+    ops.gemm_h2(xp, wp, G, M, N, K, b, r, 1, out=ref, out_planes=refp, cfg=9)
+    torch.cuda.synchronize()
+    for rep in range(6):
+        got, gotp = torch.full((G * M, N), float("nan"), device=dev), ops.H2.empty(G * M, N, dev)
+        gotp.planes.zero_(); gotp.inv.zero_()
+        ops.gemm_h2(xp, wp, G, M, N, K, b, r, 1, out=got, out_planes=gotp, cfg=21)
+        torch.cuda.synchronize()
+        assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), "f32 result, launch %d" % rep
+        assert torch.equal(gotp.planes.view(torch.int16), refp.planes.view(torch.int16)) and torch.equal(gotp.inv, refp.inv), "planes, launch %d" % rep

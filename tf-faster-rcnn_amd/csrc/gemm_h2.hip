@@ -86,6 +86,26 @@ __device__ __forceinline__ void h2_glds4(unsigned voff, const void* sbase, unsig
       : "memory");
 }
 
+// the same two loads with M0 declared clobbered instead of saved / restored (the ping-pong schedule: 3 scalar instructions per load)
+__device__ __forceinline__ void h2_glds16c(unsigned voff, const void* sbase, unsigned lds_base) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, %1"
+      :
+      : "v"(voff), "s"(sbase), "s"(lds_base)
+      : "memory");
+}
+__device__ __forceinline__ void h2_glds4c(unsigned voff, const void* sbase, unsigned lds_base) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dword %0, %1"
+      :
+      : "v"(voff), "s"(sbase), "s"(lds_base)
+      : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void h2_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -102,9 +122,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
   constexpr int G = LA + LB;                      // per wave per slab (wave 0 issues SL more: the block scales, 64 rows each)
   constexpr int SL = BM / 64;
   constexpr int XP = BM * 64, WP = BN * 64;       // bytes of one plane of a stage
-  constexpr int S_OFF = 2 * XP + 2 * WP, STAGE = S_OFF + 1024;
+  constexpr bool PP = (TUNE & 32) != 0;           // the ping-pong schedule (below): 8 waves in two groups, one barrier apart
+  constexpr int S_OFF = 2 * XP + 2 * WP, STAGE = S_OFF + (PP ? 0 : 1024);
   constexpr int RED_OFF = NS * STAGE;             // row-maximum exchange of the plane-emitting epilogue: [BN / WN][BM] floats
   constexpr int S2_OFF = RED_OFF + (BN / WN) * BM * 4;      // TUNE & 2: two 1 KB block-scale regions, alternating per 128-k block
+                                                            // PP: [wave][parity] 256 B: each wave's own 64 row scales
+  static_assert(!PP || (NW == 8 && NS == 3 && WM == 64 && BM == 256 && (TUNE & 2)), "ping-pong geometry");
   static_assert((2 * BM / 16) % NW == 0 && (2 * BN / 16) % NW == 0, "tile/wave mismatch");
   static_assert(BM <= 256 && NS >= 2 && NS <= 4, "stage layout");
   static_assert((NS - 2) * (G + SL) <= 63, "vmcnt range");
@@ -144,6 +167,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
     const int bm0 = mt * BM, bn0 = nt * BN;
     const size_t row0 = (size_t)g * p.M + bm0;
     i_xb = (const char*)p.x + row0 * p.K * 2;
+#ifdef FRCNN_ABLATION     // TUNE & 64: every tile reads the FIRST tile's X rows (cache-resident operands: what does the HBM latency cost?)
+    if (TUNE & 64) i_xb = (const char*)p.x;
+#endif
     i_wb = (const char*)p.w + ((size_t)g * 2 * p.N + bn0) * p.K * 2;
     i_sb = (const char*)(p.x_inv + row0);
 #pragma unroll
@@ -158,7 +184,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
     // block scales of the tile's rows: one float per lane and 64-row group; rows past the tensor re-read its last row (unused)
     const long long last = p.Mtot - 1 - (long long)row0;
 #pragma unroll
-    for (int j = 0; j < SL; ++j) s_off[j] = (unsigned)(min((long long)(j * 64 + lane), last) * 4);
+    for (int j = 0; j < SL; ++j) s_off[j] = (unsigned)(min((long long)((PP ? wm0 : j * 64) + lane), last) * 4);
   };
   const unsigned lds0 = (unsigned)(size_t)(LDS_AS char*)smem;
   auto uniform_ptr = [](const char* q) {
@@ -168,6 +194,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
   };
   auto issue_one = [&](int buf, int t) {
     const unsigned sb = lds0 + (unsigned)(buf * STAGE);
+    if constexpr (PP) {       // t < G: the wave's share of the slab; t == G: its own 64 block scales, with the first slab of a 128-k block
+      if (t < LA) h2_glds16c(a_off[t], uniform_ptr(i_xb), __builtin_amdgcn_readfirstlane(sb + (wave * LA + t) * 1024));
+      else if (t < G) h2_glds16c(b_off[t - LA], uniform_ptr(i_wb), __builtin_amdgcn_readfirstlane(sb + 2 * XP + (wave * LB + (t - LA)) * 1024));
+      else if (t == G && (i_step & 3) == 0) {
+        h2_glds4c(s_off[0], uniform_ptr(i_sb), __builtin_amdgcn_readfirstlane(lds0 + S2_OFF + (wave * 2 + i_par) * 256));
+        i_par ^= 1;
+      }
+      return;
+    }
     if (t < LA) h2_glds16(a_off[t], uniform_ptr(i_xb), __builtin_amdgcn_readfirstlane(sb + (wave * LA + t) * 1024));
     else if (t < G) h2_glds16(b_off[t - LA], uniform_ptr(i_wb), __builtin_amdgcn_readfirstlane(sb + 2 * XP + (wave * LB + (t - LA)) * 1024));
     else if (wave == 0) {
@@ -179,7 +214,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
       }
     }
   };
-  static_assert(!(TUNE & 2) || NS == 2, "scales-once needs the uncounted wait of the two-stage ring");
+  static_assert(!(TUNE & 2) || NS == 2 || PP, "scales-once needs the uncounted wait of the two-stage ring");
   auto issue_advance = [&]() {                      // after the last piece of a slab
     --left;
     if (++i_step == p.nsteps) {
@@ -378,7 +413,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
         if (BN / WN > 1 && khalf == 0) red[wni * BM + wm0 + i * 32 + frow] = m;
       }
       if (BN / WN > 1) {
-        __syncthreads();
+        if constexpr (PP) {          // raw barrier: __syncthreads() would also drain the slabs in flight (vmcnt(0))
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        } else {
+          __syncthreads();
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -409,12 +449,17 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
           }
         }
       }
-      if (BN / WN > 1) __syncthreads();                                          // red[] is reused by the next tile
+      if (BN / WN > 1) {                                                         // red[] is reused by the next tile
+        if constexpr (PP) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        } else {
+          __syncthreads();
+        }
+      }
     }
   };
 
-  // one slab of the stream: wait for it, let the ring slot it frees be refilled (loads spread over nothing here: they are issued
-  // right after the barrier, G + SL instructions, and land under the 24 * TM * TN / 4 MFMAs of this slab and the next NS - 2)
 #ifdef FRCNN_H2_TRACE
   int tr_slab = 0;
   auto stamp = [&](int point) {       // [workgroup < 16][wave][slab < 64][point < 8]
@@ -424,6 +469,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
 #else
   auto stamp = [](int) {};
 #endif
+  // one slab of the stream: wait for it, let the ring slot it frees be refilled (loads spread over nothing here: they are issued
+  // right after the barrier, G + SL instructions, and land under the 24 * TM * TN / 4 MFMAs of this slab and the next NS - 2)
   auto slab = [&](auto first_c, bool fold) {
     stamp(0);
     if (left >= 1) {                                   // steady state: NS - 2 younger slabs may stay in flight
@@ -485,9 +532,155 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
 #endif
   };
 
-  // ---- prologue: NS - 1 slabs ahead ---------------------------------------------------------------------------------------------
   set_tile(i_tile);
   set_ctile(c_tile);
+  if constexpr (PP) {
+    // ---- the ping-pong schedule ----------------------------------------------------------------------------------------------------
+    // 8 waves = two groups of 4 (rows 0..127 / 128..255 of the 256 x 128 tile).  A wave's slab q is two SEGMENTS, each closed by the
+    // workgroup barrier:   MEM(q):  all 16 fragments of slab q LDS -> registers, the wave's share of slab q + 2 issued into the ring
+    //                               slot that slab q - 1 just left, the fold of the previous 128-k block;
+    //                      MFMA(q): the 24 MFMAs, nothing else (s_setprio 1).
+    // Group 1 executes one extra barrier before its first segment, so it runs one segment behind: while one group multiplies, the other
+    // reads LDS and issues loads -- one wave per SIMD is in its MFMA segment at any time, and the loads of a slab are issued three to
+    // four segments before its first read (the one-barrier-per-slab schedule above: one slab = its own duration, which the loaded
+    // latency of ~2 500 cycles exceeds, profiles/r03_t_h2_trace.txt).  Same arithmetic, same order: bit-identical to the other configs.
+    //   RAW  slab q + 1 is first read in group 0's MEM(q + 1).  The barrier in front of it closes group 0's MFMA(q) and group 1's
+    //        MEM(q); each wave waits for ITS loads of slab q + 1 (vmcnt counted: the slab q + 2 loads stay in flight) before it.
+    //   WAR  slot (q + 2) % 3 = (q - 1) % 3 was last read in group 1's MEM(q - 1), closed by lgkmcnt(0) + the barrier that precedes
+    //        group 0's MEM(q), the first segment to issue into it.
+    // The epilogue's barriers (two when planes are emitted) are executed by both groups once per tile, so the one-barrier offset holds.
+    const int grp = wave >> 2;
+    h8 fxh[2][TM], fxl[2][TM], fwh[2][TN], fwl[2][TN];
+    auto seg_barrier = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto fold = [&]() {
+      float ainv[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) ainv[i] = *(const float*)(smem + S2_OFF + (wave * 2 + c_par) * 256 + (i * 32 + frow) * 4);
+      c_par ^= 1;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tot[i][j][r] = __builtin_fmaf(tmp[i][j][r], ainv[i], tot[i][j][r]);
+    };
+    // returns whether slab q + 2 was issued (the group-0 wait at the end of MFMA(q) needs to know)
+    auto pp_mem = [&](auto pos_c, bool fold_prev) -> bool {
+      constexpr int POS = decltype(pos_c)::value;
+      const char* sb = smem + cur * STAGE;
+      stamp(0);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const char* q = sb + w_row + j * 32 * 64 + (((2 * t + khalf) ^ sw) * 16);
+          fwh[t][j] = __builtin_bit_cast(h8, *(const uint4*)(q));
+          fwl[t][j] = __builtin_bit_cast(h8, *(const uint4*)(q + WP));
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const char* q = sb + x_row + i * 32 * 64 + (((2 * t + khalf) ^ sw) * 16);
+          fxh[t][i] = __builtin_bit_cast(h8, *(const uint4*)(q));
+          fxl[t][i] = __builtin_bit_cast(h8, *(const uint4*)(q + XP));
+        }
+      }
+      const bool more = left > 0;
+      if (more) {
+#pragma unroll
+        for (int t = 0; t <= G; ++t) issue_one(nxt, t);
+        issue_advance();
+        nxt = nxt + 1 == NS ? 0 : nxt + 1;
+      }
+      if (fold_prev) fold();
+      stamp(1);
+      if (grp == 1) {                        // slab q + 1 of THIS wave has landed (the slab q + 2 loads, G or G + 1 of them, stay in flight)
+        if (more) h2_wait_vmcnt<(POS == 2 ? G + 1 : G)>(); else h2_wait_vmcnt<0>();
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stamp(2);
+      seg_barrier();
+      stamp(3);
+      return more;
+    };
+    auto pp_mfma = [&](auto pos_c, bool issued) {
+      constexpr int POS = decltype(pos_c)::value;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            if (POS == 0 && t == 0) {
+              f32x16 z;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) z[r] = 0.f;
+              tmp[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh[t][j], fxh[t][i], z, 0, 0, 0);
+            } else {
+              tmp[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh[t][j], fxh[t][i], tmp[i][j], 0, 0, 0);
+            }
+          }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) tmp[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwl[t][j], fxh[t][i], tmp[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) tmp[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh[t][j], fxl[t][i], tmp[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      stamp(4);
+      if (grp == 0) {
+        if (issued) h2_wait_vmcnt<(POS == 2 ? G + 1 : G)>(); else h2_wait_vmcnt<0>();
+      }
+      cur = cur + 1 == NS ? 0 : cur + 1;
+      stamp(5);
+      seg_barrier();
+      stamp(6);
+#ifdef FRCNN_H2_TRACE
+      ++tr_slab;
+#endif
+    };
+    // prologue: slabs 0 and 1 issued, slab 0 landed everywhere
+    bool two = false;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      if (left > 0) {
+#pragma unroll
+        for (int t = 0; t <= G; ++t) issue_one(nxt, t);
+        issue_advance();
+        nxt = nxt + 1 == NS ? 0 : nxt + 1;
+        two = s2 == 1;
+      }
+    }
+    if (two) h2_wait_vmcnt<G>(); else h2_wait_vmcnt<0>();       // slab 1 carries no scales (nsteps % 4 == 0)
+    seg_barrier();
+    if (grp == 1) seg_barrier();                                // one segment behind from here on
+    const int nkb = p.nsteps >> 2;
+    for (int tl = 0; tl < my_tiles; ++tl) {
+      init_tot();
+      for (int kb = 0; kb < nkb; ++kb) {
+        bool is;
+        is = pp_mem(std::integral_constant<int, 0>{}, kb > 0); pp_mfma(std::integral_constant<int, 0>{}, is);
+        is = pp_mem(std::integral_constant<int, 1>{}, false);  pp_mfma(std::integral_constant<int, 1>{}, is);
+        is = pp_mem(std::integral_constant<int, 2>{}, false);  pp_mfma(std::integral_constant<int, 2>{}, is);
+        is = pp_mem(std::integral_constant<int, 3>{}, false);  pp_mfma(std::integral_constant<int, 3>{}, is);
+      }
+      fold();
+      epilogue();
+      c_tile += W8;
+      if (tl + 1 < my_tiles) set_ctile(c_tile);
+    }
+    if (grp == 0) seg_barrier();                                // the barrier group 1 spent in front
+    h2_wait_vmcnt<0>();
+    return;
+  }
+  // ---- prologue: NS - 1 slabs ahead ---------------------------------------------------------------------------------------------
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s) {
     if (left > 0) {
@@ -604,7 +797,8 @@ extern "C" int frcnn_h2_split(const float* x_d, long long M, int K, void* planes
 template <int BM, int BN, int WM, int WN, int NS, int WPE = 2, int TUNE = 0>
 static int launch_h2(const GemmH2Params& q, hipStream_t st) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
-  constexpr size_t lds = (size_t)NS * (2 * BM * 64 + 2 * BN * 64 + 1024) + (size_t)(BN / WN) * BM * 4 + ((TUNE & 2) ? 2048 : 0);
+  constexpr size_t lds = (TUNE & 32) ? (size_t)NS * (2 * BM * 64 + 2 * BN * 64) + (size_t)(BN / WN) * BM * 4 + (size_t)(NT / 64) * 512
+                                     : (size_t)NS * (2 * BM * 64 + 2 * BN * 64 + 1024) + (size_t)(BN / WN) * BM * 4 + ((TUNE & 2) ? 2048 : 0);
   auto kern = k_gemm_h2<BM, BN, WM, WN, NS, WPE, TUNE>;
   static KernelOnce once;
   int slots = 0;                            // resident workgroups on the CURRENT device
@@ -646,7 +840,15 @@ extern "C" int frcnn_gemm_h2(const void* x_planes_d, const float* x_inv_d, const
   p.trace = g_h2_trace;
 #endif
   hipStream_t st = (hipStream_t)stream;
-  if (cfg < 0) cfg = 9;      // by measurement in the pipeline (profiles/r03_l_ab.txt): 128 x 128 tiles, scales once per 128-k block, for every launch
+  if (cfg < 0) {
+    // By shape.  Every configuration multiplies and folds in the same order (bit-identical results), so this is a speed choice only.
+    // The ping-pong schedule (cfg 21) keeps the matrix pipe busier per joule (profiles/r04_e_h2_power.txt: every configuration sits at
+    // the 1 400 W socket limit, so time follows energy) but owns a whole CU per 256 x 128 tile: it pays on long-K launches whose tile
+    // epilogues are a small part (K >= 1024: 64 slabs per tile), with at least one tile per CU and 256-row tiles that waste < 4 % of M.
+    const long long mt256 = (M + 255) / 256;
+    const bool pp = K >= 1024 && mt256 * 256 * 100 <= (long long)M * 104 && mt256 * (N / 128) * G >= 256;
+    cfg = pp ? 21 : 9;       // 9: 128 x 128 tiles, two workgroups per CU, one barrier per slab (profiles/r03_l_ab.txt)
+  }
   switch (cfg) {
     case 0: return launch_h2<128, 128, 64, 64, 2>(p, st);        // 67 KB: 2 workgroups / CU
     case 1: return launch_h2<128, 128, 64, 64, 3>(p, st);        // 100 KB: 1 workgroup / CU, 2 slabs in flight
@@ -657,7 +859,10 @@ extern "C" int frcnn_gemm_h2(const void* x_planes_d, const float* x_inv_d, const
                                                                   // under-filled launches, slower in the pipeline: profiles/r03_l_ab.txt)
     case 14: return launch_h2<128, 128, 64, 64, 2, 2, 4>(p, st);  // cfg 0 with the loads spread between the MFMAs (measured slower: r03_k)
     case 18: return launch_h2<128, 128, 64, 64, 2, 2, 10>(p, st); // cfg 9 with round 2's (r >> 1) & 3 swizzle (two-way LDS bank conflicts)
+    case 21: return launch_h2<256, 128, 64, 64, 3, 2, 34>(p, st); // ping-pong: 256 x 128, 8 waves in two groups a segment apart, 3-slot ring
 #ifdef FRCNN_ABLATION
+    case 22: return launch_h2<256, 128, 64, 64, 3, 2, 34 + 64>(p, st);   // ping-pong with cache-resident X (wrong results by construction)
+    case 23: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 64>(p, st);    // cfg 9 with cache-resident X
     case 20: return launch_h2<128, 128, 64, 64, 2, 2, 18>(p, st); // cfg 9's byte count as full-line loads (wrong results by construction)
 #endif
     default: return FRCNN_E_ARG;
