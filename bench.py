@@ -254,11 +254,17 @@ def train_bench(args, c, dev, world, rank, dist):
     net.create_architecture("TRAIN", c["classes"], tag="c5", anchor_scales=c["scales"], anchor_ratios=ANCHOR_RATIOS)
     sess.init_variables(net.variable_specs())
     ar = None
-    if world > 1:
+    if world > 1 or args.dp_constrained:
         from frcnn_hip import parallel
+        if world == 1:                                    # a one-rank RCCL group: the same torch.distributed / RCCL calls an N-GPU run makes
+            import torch.distributed as dist1
+            import datetime
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            dist1.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=120))
         ar = parallel.make_grad_all_reduce()
     sw = SolverWrapper(sess, net, resident_blobs(synthetic_data_layer(c["classes"], seed=cfg.RNG_SEED + rank, image_gain=1 / 256.0), dev),
-                       all_reduce=ar, world_size=world)
+                       all_reduce=ar, world_size=world, force_dp=args.dp_constrained)
     sw.train_model(max(args.warmup, 1), verbose=False)
     torch.cuda.synchronize()
     if dist is not None:
@@ -272,7 +278,21 @@ def train_bench(args, c, dev, world, rank, dist):
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    return time.perf_counter() - t0, sess
+    elapsed = time.perf_counter() - t0
+    # matrix work of ONE step per matrix pipe (an extra, untimed step with the host-side ledgers on): forward pass from the launch tags
+    # (Session.mark), reverse sweep from TrainState.count_flops
+    sess.flops_by_pipe, sw.state.flop_ledger = {}, {}
+    sw.train_model(1, verbose=False)
+    torch.cuda.synchronize()
+    sess.step_flops_by_pipe = {k: sess.flops_by_pipe.get(k, 0) + sw.state.flop_ledger.get(k, 0) for k in ("h2", "x3", "f32")}
+    sess.flops_by_pipe, sw.state.flop_ledger = None, None
+    sess.dp_note = None
+    if args.dp_constrained and world == 1:
+        import torch.distributed as dist1
+        sess.dp_note = "one replica under the data-parallel rules: <= 1 filter-gradient side stream, bucketed all-reduce (64 MiB) issued from " \
+                       "inside the sweep over a one-rank RCCL group (backend %s), eager sweep" % dist1.get_backend()
+        dist1.destroy_process_group()
+    return elapsed, sess
 
 
 def exchange_records(rec, count_i32, gathered, rank, stamp=None):
@@ -332,6 +352,76 @@ def run_timed(step, steps, warmup, dist=None, sync=None, between=None):
     return time.perf_counter() - t0
 
 
+def child_line(extra, timeout_s):
+    """One short run of this script in a child process (its own cfg globals / Session / graphs), returns its parsed JSON line or an
+    {"error": ...} record.  Used by the default N = 1 invocation to put the other BASELINE configs and the batch-1 latency into the
+    driver-observed line; the parent's timed region is over by then and its buffers simply stay resident beside the child's."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--no-f32-variant", "--no-other-configs"] + list(extra)
+    t0 = time.time()
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, env=dict(os.environ, MASTER_PORT=str(29500 + os.getpid() % 2000 + 1)))
+    except subprocess.TimeoutExpired:
+        return {"error": "timeout after %ds" % timeout_s}
+    lines = [l for l in r.stdout.decode("utf-8", "replace").splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "rc %d: %s" % (r.returncode, r.stderr.decode("utf-8", "replace")[-300:])}
+    d = json.loads(lines[-1])
+    d["wall_s"] = round(time.time() - t0, 1)
+    return d
+
+
+def other_configs(budget_s, t_start):
+    """BASELINE.json's other configs (configs[0] as the same VGG16 workload on the device, configs[2], [3], [4]) for 5 steps each, the
+    training step once more under the data-parallel rules, and configs[1] with one image on one chain (latency) -- each a child run of
+    this script, value / ms per step / per-pipe roofline fraction copied from its line.  Stops adding runs once `budget_s` seconds of
+    wall clock have passed since t_start (the skipped ones are named)."""
+    runs = [("latency_batch1", ["--config", "c2", "--batch", "1", "--streams", "1", "--steps", "20", "--warmup", "5", "--profile-steps", "0"]),
+            ("c3", ["--config", "c3", "--steps", "5", "--warmup", "3", "--profile-steps", "1"]),
+            ("c5", ["--config", "c5", "--steps", "5", "--warmup", "3"]),
+            ("c5_dp_constrained", ["--config", "c5", "--steps", "5", "--warmup", "3", "--dp-constrained"]),
+            ("c4", ["--config", "c4", "--steps", "5", "--warmup", "3", "--profile-steps", "1"]),
+            ("c1", ["--config", "c1", "--steps", "5", "--warmup", "3", "--profile-steps", "1"])]
+    out = {}
+    for name, extra in runs:
+        if time.time() - t_start > budget_s:
+            out[name] = {"skipped": "wall-clock budget of %ds for the appended runs used up" % budget_s}
+            continue
+        d = child_line(extra, 90)
+        if "error" in d:
+            out[name] = d
+            continue
+        rf = d.get("roofline") or {}
+        rec = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "workload": d["config"]["workload"],
+               "images_per_step": d["config"].get("images_per_gpu_per_step", 1), "chains": d["config"].get("chains_in_flight_per_gpu", 1),
+               "roofline_frac": rf.get("frac"), "roofline_peak_f32_equivalent": rf.get("peak"),
+               "pipes": {k: (v.get("frac_of_pipe_peak") if "frac_of_pipe_peak" in v else v.get("share_of_launched_flops")) for k, v in (rf.get("pipes") or {}).items()},
+               "wall_s": d["wall_s"]}
+        if "data_parallel_rules" in d["config"]:
+            rec["data_parallel_rules"] = d["config"]["data_parallel_rules"]
+        out[name] = rec
+    return out
+
+
+def train_roofline(by_pipe, step_s, gflop_ref):
+    """Roofline object of the training step, priced like the inference line: frac = sum over launches (FLOPs_i / dense peak of the pipe
+    launch i issues on) / step time -- the fraction of the matrix pipes' peak the issued instruction mix reaches over the WHOLE timed step
+    (forward, losses, reverse sweep, solver; there is no per-launch event pass for the sweep, so the denominator is the step, not the sum
+    of the GEMM launches).  `achieved` / `peak` are the same ratio in f32-equivalent TFLOP/s."""
+    peaks = {"h2": H2_PEAK_TFLOPS, "x3": X3_PEAK_TFLOPS, "f32": F32_MFMA_PEAK_TFLOPS}
+    total = float(sum(by_pipe.values()))
+    t_peak = sum(by_pipe[k] / (peaks[k] * 1e12) for k in by_pipe)
+    ceiling = total / t_peak / 1e12 if t_peak > 0 else None
+    return {"bound": "mfma", "achieved": round(total / step_s / 1e12, 2), "peak": None if ceiling is None else round(ceiling, 1), "unit": "TFLOP/s",
+            "frac": round(t_peak / step_s, 4), "traffic": None,
+            "gflop_per_step_launched": round(total / 1e9, 1), "gflop_per_step_reference_graph": gflop_ref,
+            "pipes": {k: {"share_of_launched_flops": round(v / total, 4), "gflop_per_step": round(v / 1e9, 1),
+                          "seconds_at_pipe_peak_per_step": round(v / (peaks[k] * 1e12), 6)} for k, v in by_pipe.items() if v},
+            "kernel": "whole training step (forward k_gemm_h2 / k_conv_igemm, reverse sweep: data gradients on the same kernels, filter gradients "
+                      "k_wgrad_h2 / k_wgrad_tn): launched f32-equivalent FLOPs per pipe / that pipe's dense peak (833.3 h2, 157.3 f32), over the "
+                      "timed step"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -377,6 +467,11 @@ def main():
     ap.add_argument("--crop-slabs", type=int, default=-1, help="A/B knob: channel-slab count of the crop kernels (frcnn_detect_set_tuning key 4)")
     ap.add_argument("--overlap", action="store_true", help="A/B knob: tail-entry 1x1 convs on a graph branch beside the proposal layer (cfg.HIP.OVERLAP_TAIL_ENTRY)")
     ap.add_argument("--fused-mean", action="store_true", help="A/B knob: the tail's last conv3 + reduce_mean in one kernel (cfg.HIP.FUSE_TAIL_MEAN)")
+    ap.add_argument("--dp-constrained", action="store_true", help="c5: ONE replica under the data-parallel rules -- at most one filter-gradient side "
+                    "stream, the bucketed all-reduce issued from inside the reverse sweep over a one-rank RCCL group, no captured sweep: the step "
+                    "every GPU of an N-GPU run executes, timed at N = 1")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the other BASELINE configs / the batch-1 latency run that the "
+                    "default invocation appends as `other_configs` / `latency_ms_batch1`")
     ap.add_argument("--layer-report", default=None, help="write a per-layer table of the event pass to this file")
     args = ap.parse_args()
     c = CONFIGS[args.config]
@@ -474,11 +569,9 @@ def main():
                                    min(int(cfg.HIP.WGRAD_STREAM), 1 if world > 1 else 99)),
                                "host_enqueue_ms_per_step": round(1000.0 * sess.host_enqueue_s / args.steps, 3),
                                "gflop_per_step_reference_graph": c["gflop_ref"]},
-                       roofline={"bound": "mfma", "achieved": round(c["gflop_ref"] * value / world / 1e3, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                                 "unit": "TFLOP/s", "frac": round(c["gflop_ref"] * value / world / 1e3 / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                                 "kernel": "whole training step, reference-graph FLOPs (fwd + 2x trainable part) / step time; priced against the f32-MFMA "
-                                           "peak although the pointwise GEMMs and the filter gradients issue on the fp16 pipe (ceiling 833.3): "
-                                           "a rate in reference FLOPs, not a pipe utilisation"})
+                       roofline=train_roofline(sess.step_flops_by_pipe, elapsed / args.steps, c["gflop_ref"]))
+            if sess.dp_note:
+                out["config"]["data_parallel_rules"] = sess.dp_note
             print(json.dumps(out), flush=True)
         if dist is not None:
             dist.barrier()
@@ -551,7 +644,7 @@ def main():
     # ---- HIP-event pass: events around every launch group, on the stream the kernels run on, over `profile_steps` further
     #      steps of the same workload (a hipGraph replay cannot carry events, so this pass launches eagerly on ONE chain)
     per_layer, conv = {}, [0.0, 0, 0, 0]
-    pipes = {"h2": [0.0, 0, 0], "x3": [0.0, 0, 0], "f32": [0.0, 0, 0]}          # ms, f32-equivalent FLOPs, launches per matrix pipe
+    pipes = {"h2": [0.0, 0, 0, 0], "x3": [0.0, 0, 0, 0], "f32": [0.0, 0, 0, 0]}   # ms, f32-equivalent FLOPs, launches, algorithmic bytes per matrix pipe
     if rank == 0 and args.profile_steps > 0:
         with torch.cuda.stream(run_stream):
             sess.profile = []
@@ -565,7 +658,7 @@ def main():
                 if tag.startswith("conv:"):
                     conv[0] += ms; conv[1] += fl; conv[2] += 1; conv[3] += nb
                     pp = pipes["h2" if tag.startswith("conv:h2:") else "x3" if tag.startswith("conv:x3:") else "f32"]
-                    pp[0] += ms; pp[1] += fl; pp[2] += 1
+                    pp[0] += ms; pp[1] += fl; pp[2] += 1; pp[3] += nb
             sess.profile = None
         if args.layer_report:
             with open(args.layer_report, "w") as f:
@@ -631,20 +724,38 @@ def main():
             # HBM bytes per GEMM launch and matrix-pipe busy fraction from the committed rocprofv3 PMC passes of THIS command
             # (scratch/pmc_traffic.py; regenerated per round, the file names the commit it was taken at)
             traffic, tsrc, busy = None, None, None
-            for name in ("r03_pmc_traffic.json",):
+            for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):          # the newest committed pass
                 tpath = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(tpath) and args.config == "c2" and B == 4 and not args.reference_order and args.mfma == "h2":
                     try:
                         pj = json.load(open(tpath))
                         traffic, tsrc, busy = round(pj["hbm_bytes_per_launch"]), "profiles/" + name, round(pj["mfma_util_conv_launches"], 4)
+                        break
                     except Exception:
                         traffic = None
             whole_launched = flops_per_image * value / world / 1e12
             peaks = {"h2": H2_PEAK_TFLOPS, "x3": X3_PEAK_TFLOPS, "f32": F32_MFMA_PEAK_TFLOPS}
             t_at_peak = sum(pp[1] / (peaks[k] * 1e12) for k, pp in pipes.items())       # seconds the issued MFMA mix needs at its pipes' peaks
             ceiling = conv[1] / t_at_peak / 1e12                                         # f32-equivalent TFLOP/s of that mix at peak
+            # which resource binds, per pipe: the time the pipe's launches need at the matrix pipe's dense peak against the time their
+            # algorithmic bytes need at the HBM peak (8 TB/s); the larger one names the bound
+            t_hbm = {k: pp[3] / (HBM_PEAK_GBS * 1e9) for k, pp in pipes.items()}
+            t_mfma = {k: pp[1] / (peaks[k] * 1e12) for k, pp in pipes.items()}
+            bound_by_pipe = {k: ("hbm" if t_hbm[k] > t_mfma[k] else "mfma") for k, pp in pipes.items() if pp[2]}
+            all_bytes_step = sum(v[3] for v in per_layer.values()) / steps_p            # every launch group of a step: GEMMs, transforms, crop, ...
+            step_s = elapsed / args.steps
             out["roofline"] = {
-                "bound": "mfma", "achieved": round(ach, 2), "peak": round(ceiling, 1), "unit": "TFLOP/s",
+                "bound": "hbm" if sum(t_hbm.values()) > t_at_peak else "mfma", "achieved": round(ach, 2), "peak": round(ceiling, 1), "unit": "TFLOP/s",
+                "bound_by_pipe": bound_by_pipe,
+                "seconds_at_peak_per_step": {"mfma": round(t_at_peak / steps_p, 6), "hbm_8TBs_gemm_launches": round(sum(t_hbm.values()) / steps_p, 6),
+                                             "hbm_8TBs_all_launches": round(all_bytes_step / (HBM_PEAK_GBS * 1e9), 6), "timed_step": round(step_s, 6)},
+                # achieved / peak / frac below are the MATRIX-PIPE figures of the GEMM launches whichever resource `bound` names; the HBM
+                # side of the same launches and of the whole step:
+                "hbm": {"gemm_achieved_GBs": round(conv[3] / (conv[0] * 1e-3) / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
+                        "gemm_frac": round(conv[3] / (conv[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "algorithmic_GB_per_step_all_launches": round(all_bytes_step / 1e9, 3),
+                        "hbm_frac_timed_region": round(all_bytes_step / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                        "gemm_arithmetic_intensity_flop_per_byte": round(conv[1] / max(conv[3], 1), 1)},
                 # frac = sum_launch (FLOPs_i / peak of the pipe launch i issues on) / sum_launch time_i  (event pass, one chain):
                 # the fraction of the matrix pipes' dense peak the issued instruction mix achieves.  `achieved` / `peak` are the same
                 # ratio in f32-equivalent TFLOP/s (peak = what this mix of 3-MFMA / 6-MFMA / f32-MFMA products could reach)
@@ -660,6 +771,10 @@ def main():
                 "frac_timed_region": round(whole_launched / ceiling, 4),
                 "mfma_busy": busy, "traffic": traffic, "traffic_source": tsrc,
                 "sclk_mhz": None if telemetry is None else telemetry["sclk_mhz"], "socket_w": None if telemetry is None else telemetry["socket_w"],
+                # the dense peaks above are quoted at the 2.4 GHz boost clock; every configuration of this pipeline runs at the socket
+                # power limit (1 400 W) with the firmware picking the clock (profiles/r04_e_h2_power.txt), so the same fraction against
+                # the peak AT THE CLOCK THE RUN HELD is reported too
+                "frac_at_running_clock": None if (telemetry is None or not telemetry["sclk_mhz"]) else round(t_at_peak / (conv[0] * 1e-3) * 2400.0 / telemetry["sclk_mhz"], 4),
                 "kernel": "k_gemm_h2 (fp16 pipe, block-scaled two-piece operands) + k_gemm_x3 (bf16 pipe, exact 3-way split) + k_conv_igemm / "
                           "k_gemm_stream (f32 MFMA 32x32x2), all tile shapes; Winograd GEMMs included",
                 "algorithmic_bytes_per_launch": conv[3] // max(conv[2], 1), "launches_per_step": conv[2] // steps_p,
@@ -682,6 +797,16 @@ def main():
             out["stages"] = stages
         if world == 1 and not args.no_cpu_baseline and c["net"] == "res101":
             out["cpu_baseline"] = cpu_baseline(sess.variables, image, c)
+        if world == 1 and args.config == "c2" and not args.no_other_configs and not args.no_graph and not (args.batch or args.streams):
+            oc = other_configs(75, time.time())
+            lat = oc.pop("latency_batch1", None)
+            if lat and "ms_per_step" in lat:
+                out["latency_ms_batch1"] = lat["ms_per_step"]
+                out["latency_batch1"] = {"images_per_sec": lat["value"], "what": "configs[1], ONE image on ONE chain (hipGraph replay): the time "
+                                         "from image in HBM to detections in HBM", "steps": lat["steps"]}
+            elif lat:
+                out["latency_batch1"] = lat
+            out["other_configs"] = oc
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -195,6 +195,7 @@ class Session(VariableStore):
         self._side_streams = {}
         self.profile = None                             # list of (tag, flops, ev0, ev1) when profiling
         self.flops_last_forward = 0
+        self.flops_by_pipe = None                       # dict while somebody wants the split (Session.mark)
         self.prepared = PreparedFilters(self.device)
 
     # ---- device-side images of the variables ----------------------------------------------------
@@ -332,6 +333,9 @@ class Session(VariableStore):
     def mark(self, tag, flops, fn, nbytes=0):
         """nbytes: algorithmic HBM bytes of the launch (operands read once + result written once), for the roofline report."""
         self.flops_last_forward += flops
+        if flops and self.flops_by_pipe is not None:        # bench.py: a forward pass's matrix work per matrix pipe (host bookkeeping)
+            pipe = "h2" if tag.startswith("conv:h2:") else "x3" if tag.startswith("conv:x3:") else "f32"
+            self.flops_by_pipe[pipe] = self.flops_by_pipe.get(pipe, 0) + flops
         if self.profile is None:
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

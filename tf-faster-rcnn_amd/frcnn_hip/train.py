@@ -112,6 +112,19 @@ class TrainState(object):
         return self
 
     # ---- gradients -----------------------------------------------------------------------------------
+    def data_parallel(self):
+        """True when the step runs under the data-parallel rules: more than one replica, or `force_dp` (bench.py --dp-constrained: one
+        replica with everything a multi-GPU step does -- at most one filter-gradient side stream, the bucketed all-reduce issued from inside
+        the sweep over a one-rank RCCL group, no captured sweep -- so that the step an 8-GPU run executes per GPU can be timed at N = 1)."""
+        return int(getattr(self, "world_size", 1)) > 1 or bool(getattr(self, "force_dp", False))
+
+    def count_flops(self, pipe, flops):
+        """Ledger of the reverse sweep's matrix work per matrix pipe ("h2": frcnn_gemm_h2 / frcnn_conv2d_wgrad_h2, "f32": the f32-MFMA
+        kernels); bench.py prices a training step per pipe with it (host arithmetic on launch shapes, nothing on the device)."""
+        led = getattr(self, "flop_ledger", None)
+        if led is not None:
+            led[pipe] = led.get(pipe, 0) + int(flops)
+
     def backward_auto(self, seeds):
         """backward() through a captured hipGraph (cfg.HIP.TRAIN_GRAPH).  The reverse sweep is ~1000 launches whose every argument is
         a function of the tape -- static activation / gradient buffers and shapes -- so the SECOND time a tape with the same tensors comes
@@ -120,7 +133,7 @@ class TrainState(object):
         they are copied into static seed buffers first.  Not captured: data-parallel runs (the bucketed all-reduce is issued from
         inside the sweep), tapes with dropout (the mask seed is a launch argument), more than `graph_cap` distinct tapes."""
         net = self.net
-        if (not getattr(self, "graph", False) or getattr(self, "world_size", 1) > 1 or len(seeds) == 0
+        if (not getattr(self, "graph", False) or self.data_parallel() or len(seeds) == 0
                 or any(rec["kind"] == "dropout" for rec in net._tape)):
             self.graph_stats["eager"] += 1
             return self.backward(seeds)
@@ -176,14 +189,14 @@ class TrainState(object):
         # event recorded after the activation gradient, and is joined before backward() returns.  Data parallel: one side stream, so
         # that "everything behind this offset of the flat gradient is final" holds on the stream the collective is issued from.
         nside = int(getattr(self, "wgrad_stream", 0))
-        if getattr(self, "world_size", 1) > 1:
+        if self.data_parallel():
             nside = min(nside, 1)
         sides = self._wgrad_side_streams(nside)
         turn = [0]
         if self._wgrad_events is None:
             self._wgrad_events = [torch.cuda.Event() for _ in range(16)]
 
-        dp = getattr(self, "world_size", 1) > 1
+        dp = self.data_parallel()
         pins = [ops.pinned_stream(st) for st in sides]
         events = self._wgrad_events
 
@@ -273,7 +286,7 @@ class TrainState(object):
                     def dw_wgrad(sfx, gy=gy, x=x, rec=rec, p=p):
                         ops.dwconv3x3_wgrad(gy, x, rec["stride"], rec["pad"], p.scale, p.grad_w)
                         ar = getattr(self, "all_reduce", None)
-                        if ar is not None and getattr(self, "world_size", 1) > 1 and hasattr(ar, "ready"):
+                        if ar is not None and self.data_parallel() and hasattr(ar, "ready"):
                             ar.ready(self.flat, p.grad_w.data_ptr())
                     on_side(dw_wgrad)
                 if x.data_ptr() in needs:
@@ -308,10 +321,11 @@ class TrainState(object):
                     if getattr(self, "wgrad_tn", True) and ops.conv2d_wgrad_supported(x.shape[-1], Cout) and p.K == k * k * x.shape[-1]:
                         # dW = dY^T X straight from the two tensors as they lie (csrc/wgrad_tn.hip): no transposed copies, no im2col
                         ops.conv2d_wgrad(gy, x, k, k, stride, pad, p.grad_w, h2=bool(getattr(self, "wgrad_h2", False)))
+                        self.count_flops("h2" if getattr(self, "wgrad_h2", False) else "f32", 2 * M * Cout * p.K)
                         if p.bias is not None:
                             ops.colsum(gy.view(M, Cout), p.grad_b)
                         ar = getattr(self, "all_reduce", None)
-                        if ar is not None and getattr(self, "world_size", 1) > 1 and hasattr(ar, "ready"):
+                        if ar is not None and self.data_parallel() and hasattr(ar, "ready"):
                             ar.ready(self.flat, p.grad_w.data_ptr())
                         return
                     Mp = (M + 31) // 32 * 32
@@ -322,10 +336,11 @@ class TrainState(object):
                         xT = ops.im2col_t(x, k, k, stride, pad, OH, OW, Mp, out=sess.buf("bwd/xT" + sfx, (k * k * x.shape[-1], Mp)))
                     # dW_folded[n][(kh,kw,c)] = sum_m gyT[n][m] * xT[(kh,kw,c)][m]   -- the forward MFMA kernel
                     ops.conv2d(gyT.view(1, 1, Cout, Mp), xT.view(xT.shape[0], 1, 1, Mp), None, 1, 1, out=p.grad_w.view(1, 1, Cout, p.K))
+                    self.count_flops("f32", 2 * M * Cout * p.K)
                     if p.bias is not None:
                         ops.colsum(gy.view(M, Cout), p.grad_b)
                     ar = getattr(self, "all_reduce", None)
-                    if ar is not None and getattr(self, "world_size", 1) > 1 and hasattr(ar, "ready"):
+                    if ar is not None and self.data_parallel() and hasattr(ar, "ready"):
                         # this parameter's gradient is enqueued: everything from its offset to the end of the flat buffer is final
                         # (the tape is walked backwards, the buffer is laid out in forward order, and every wgrad is enqueued on the
                         # same stream -- the collective orders itself after the stream it is issued from)
@@ -351,9 +366,11 @@ class TrainState(object):
                             u, out=sess.buf_pair("bwd/wino_u_h2/" + sc, G * Cin, Cout)))
                         ops.conv3x3_winograd(gy, u, None, ACT_NONE, out=gx, m_buf=sess.buf("bwd/wino_m", (G, T, Cin)), u_planes=up,
                                              v_planes=sess.h2_buf("bwd/wino_v", G * T, Cout))
+                        self.count_flops("h2", 2 * G * T * Cin * Cout)
                     else:
                         ops.conv3x3_winograd(gy, u, None, ACT_NONE, out=gx, v_buf=sess.buf("bwd/wino_v", (G, T, Cout)),
                                              m_buf=sess.buf("bwd/wino_m", (G, T, Cin)))
+                        self.count_flops("f32", 2 * G * T * Cin * Cout)
                 elif stride == 1 and Cout % 32 == 0:
                     wd = prepared(("wflip", sc), lambda wf=wf, sc=sc, k=k, Cout=Cout: ops.flip_transpose_filter(
                         wf, out=sess.buf("bwd/wflip/" + sc, (wf.shape[3], k, k, Cout))))
@@ -367,11 +384,14 @@ class TrainState(object):
                         wq = prepared(("wflip_h2", sc), lambda wd=wd, sc=sc, Cin=Cin, Cout=Cout: ops.h2_pack_w(
                             wd.view(Cin, Cout), out=sess.buf_pair("bwd/wflip_h2/" + sc, Cin, Cout)))
                         ops.gemm_h2(gp, wq, 1, M, Cin, Cout, None, gx.view(M, Cin) if had else None, ACT_NONE, out=gx.view(M, Cin))
+                        self.count_flops("h2", 2 * M * Cin * Cout)
                     else:
                         dpad = (k - 1 - pad[0], k - 1 - pad[1], k - 1 - pad[2], k - 1 - pad[3])
                         ops.conv2d(gy, wd, None, k, k, 1, dpad, ACT_NONE, gx if had else None, 1, out=gx)
+                        self.count_flops("f32", 2 * M * Cin * Cout * k * k)
                 else:
                     ops.conv2d_dgrad_strided(gy, wf, stride, pad, x.shape[1], x.shape[2], gx, had)
+                    self.count_flops("f32", 2 * M * Cout * k * k * wf.shape[3])
         for side in sides:
             main.wait_stream(side)               # the solver (and the next forward pass, which overwrites x) come after every wgrad
         return grads
@@ -390,7 +410,7 @@ class TrainState(object):
         gradient is summed over the ranks (RCCL) -- bucket by bucket during the reverse sweep when `all_reduce` has the
         bucketed interface (parallel.BucketedAllReduce: backward() hands it every finished range), otherwise in one call
         here -- and the mean over replicas is folded into the SGD kernel (grad_scale = 1 / world_size)."""
-        if all_reduce is not None and world_size > 1:
+        if all_reduce is not None and (world_size > 1 or self.data_parallel()):
             if hasattr(all_reduce, "finish"):
                 all_reduce.finish(self.flat)              # ranges not yet handed over + wait for the ones in flight
             else:

@@ -49,12 +49,13 @@ def remove_snapshot(np_paths, ss_paths):
 
 
 class SolverWrapper(object):
-    def __init__(self, sess, network, data_layer, all_reduce=None, world_size=1, write_snapshots=True):
+    def __init__(self, sess, network, data_layer, all_reduce=None, world_size=1, write_snapshots=True, force_dp=False):
         self.sess, self.net, self.data_layer = sess, network, data_layer
         self.write_snapshots = bool(write_snapshots)               # data-parallel runs: every rank READS snapshots, rank 0 writes them
         self.state = TrainState(sess, network, momentum=cfg.TRAIN.MOMENTUM, weight_decay=cfg.TRAIN.WEIGHT_DECAY,
                                 double_bias=cfg.TRAIN.DOUBLE_BIAS, bias_decay=cfg.TRAIN.BIAS_DECAY)
         self.state.all_reduce, self.state.world_size = all_reduce, world_size
+        self.state.force_dp = bool(force_dp)                      # one replica under the data-parallel rules (TrainState.data_parallel)
         self.np_paths, self.ss_paths = [], []                     # snapshots written / found so far, oldest first
 
     # ---- checkpoints -------------------------------------------------------------------------------------------------
