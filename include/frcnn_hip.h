@@ -233,10 +233,14 @@ int frcnn_conv1x1_mean(const float* x_d, int M, int Cin, const float* w_d, const
                        int act, int group_rows, float* mean_out_d, void* ws, size_t ws_bytes, void* stream);
 
 /* Tuning overrides for A/B measurements and for tests that must reach every tile configuration: THREAD-LOCAL (they affect only the
- * launches the calling thread makes afterwards, so the thread-safety contract above holds); no product path sets them.  key 0 = force a
+ * launches the calling thread makes afterwards, so the thread-safety contract above holds); no product path sets keys 0-7.  key 0 = force a
  * conv tile configuration id (-1 = automatic); key 1 = ablation bits; key 5 = phase stagger of co-resident workgroups; key 6 = 0 keeps
  * the short-K GEMMs off k_gemm_stream; key 7 = the workgroup count a split-K launch aims at (0 = the default 640; 160 ... 640 move the
- * ResNet-152 training step by +-1 %).  frcnn_gemm_x3 / frcnn_gemm_h2 take their configuration per call instead. */
+ * ResNet-152 training step by +-1 %).  frcnn_gemm_x3 / frcnn_gemm_h2 take their configuration per call instead.
+ * key 8 is NOT a measurement knob but launch context, set by the TEST-mode graph builder around its launches (lib/nets/network.py
+ * _build_network): the number of independent images that share the following launches.  Split-K changes a sum's order, so
+ * frcnn_conv2d_nhwc_ws plans it for the launch as it would look in a 4-image batch (per-image rows x 4) whatever the batch is -- the
+ * same image gives the same bits at batch 1, 4 or 8 (the reference is batch-1: lib/model/test.py:88).  0 (default): plan by the launch. */
 int frcnn_set_tuning(int key, int value);
 /* HOST: CRC-32C (Castagnoli) of n bytes, crc = 0 to start or a previous result to extend: the checksum of TensorFlow
  * checkpoint shards / index blocks (frcnn_hip/tensor_bundle.py replaces pywrap_tensorflow.NewCheckpointReader,

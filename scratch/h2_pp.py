@@ -11,6 +11,8 @@ shapes = {  # name: (G, M, N, K, residual, planes out)
  "b3c1x4": (1, 9576, 256, 1024, False, True), "b3c3x4": (1, 9576, 1024, 256, True, True), "w3x4": (36, 640, 256, 256, False, False),
  "b3c1x12": (1, 28728, 256, 1024, False, True), "b3c3x12": (1, 28728, 1024, 256, True, True),
  "b4c1x1": (1, 14700, 512, 2048, False, True), "b4c3x1": (1, 14700, 2048, 512, True, True),
+ "b3c1x1": (1, 2394, 256, 1024, False, True), "b3c3x1": (1, 2394, 1024, 256, True, True), "w3x1": (36, 160, 256, 256, False, False),
+ "b2c1x4": (1, 37500, 128, 512, False, True), "b2c3x4": (1, 37500, 512, 128, True, True), "b3scx4": (1, 9576, 1024, 512, False, True),
 }
 cfgs = [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else "9,3,21").split(",")]
 only = sys.argv[2].split(",") if len(sys.argv) > 2 else list(shapes)

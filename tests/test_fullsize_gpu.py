@@ -71,3 +71,61 @@ def test_fullsize_train_step_parity(dev, policy):
     with open(os.path.join(out, "fullsize_parity.txt"), "a") as f:
         f.write(text + "\n")
     assert rep["ok"], text
+
+
+def test_fullsize_batch_invariance_under_the_shipped_configuration(dev):
+    """configs[1], calibrated weights, shipped cfg.HIP: the harness image ALONE (batch 1: latency mode, tools/test_net.py) and in slots
+    0 and 3 of a 4-image batch whose other slots hold other images (bench.py's step) must give the same BITS -- RPN tensors, proposals,
+    head outputs, detections.  The reference is strictly batch-1 (lib/model/test.py:88, lib/nets/network.py:388): a result that
+    depends on the neighbours in a launch would make tie-breaks and eps-close NMS decisions depend on them too.  What it takes: the
+    pipe a GEMM runs on and every split-K plan follow the PER-IMAGE shape (lib/nets/network.py _plan_rows, csrc/conv_igemm.hip
+    plan_splits), and every tile configuration of a kernel multiplies in the same order (tests/test_h2_gpu.py)."""
+    import numpy as np
+    import torch
+    from frcnn_hip.runtime import Session
+    from model.config import cfg
+    _shipped_policy()
+    c = fs.CONFIGS["c2"]
+    net, v, image, im_info, fx = fs.build("c2", "calibrated")
+    saved = {k: cfg.HIP[k] for k in cfg.HIP}
+    saved_post, saved_nms = cfg.TEST.RPN_POST_NMS_TOP_N, cfg.USE_GPU_NMS
+    try:
+        for k, val in fs.POLICIES[SHIPPED].items():
+            cfg.HIP[k] = val
+        cfg.TEST.RPN_POST_NMS_TOP_N, cfg.USE_GPU_NMS = c["post"], False
+        sess = Session(device=dev, seed=3)
+        sess.load_variables(v)
+        net._fuse_tail_entry = hasattr(net, "_fused_tail_entry")
+        orig = (int(c["H"] / c["scale"]), int(c["W"] / c["scale"]))
+        keys = ("rpn_cls_prob", "rpn_bbox_pred", "rois", "cls_score", "cls_prob", "bbox_pred")
+
+        def run(batch_np):
+            img_d = net._stage_image(sess, batch_np)
+            dets, cnt = net.detect_device(sess, img_d, im_info, orig, max_per_image=c["max_per_image"])
+            torch.cuda.synchronize()
+            out = {k: net._predictions[k].cpu().numpy().copy() for k in keys}
+            out["head"] = net._layers["head"].cpu().numpy().copy()
+            out["dets"], out["cnt"] = dets.cpu().numpy().copy(), cnt.cpu().numpy().copy()
+            if out["dets"].ndim == 2:                      # one image: dets [max_out, 6]
+                out["dets"] = out["dets"][None]
+            out["per"] = int(net._rois_per_image)
+            return out
+        one = run(image)
+        four = run(np.concatenate([image, fs.synth_image(c, 11), fs.synth_image(c, 12), image], axis=0))
+        per = four["per"]
+        assert one["per"] == per
+        for slot in (0, 3):
+            sl = slice(slot * per, (slot + 1) * per)
+            assert np.array_equal(four["head"][slot], one["head"][0]), "head, slot %d" % slot
+            for k in ("rpn_cls_prob", "rpn_bbox_pred"):
+                assert np.array_equal(four[k][slot], one[k][0]), "%s, slot %d" % (k, slot)
+            assert np.array_equal(four["rois"][sl, 1:], one["rois"][:, 1:]) and np.all(four["rois"][sl, 0] == slot), "rois, slot %d" % slot
+            for k in ("cls_score", "cls_prob", "bbox_pred"):
+                assert np.array_equal(four[k][sl], one[k]), "%s, slot %d" % (k, slot)
+            n = int(one["cnt"][0])
+            assert int(four["cnt"][slot]) == n and np.array_equal(four["dets"][slot, :n], one["dets"][0, :n]), "detections, slot %d" % slot
+        assert not np.array_equal(four["head"][1], one["head"][0])            # the other slots really held other images
+    finally:
+        for k, val in saved.items():
+            cfg.HIP[k] = val
+        cfg.TEST.RPN_POST_NMS_TOP_N, cfg.USE_GPU_NMS = saved_post, saved_nms

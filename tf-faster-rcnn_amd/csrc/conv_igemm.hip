@@ -714,12 +714,19 @@ static int launch_stream_cfg(int id, const ConvParams& p, hipStream_t st) {
 // tuning knob (experiments / A-B runs): key 0 = force a tile configuration id for every non-stem conv
 // (-1 = automatic choice).
 static thread_local int g_force_cfg = -1, g_dbg = 0, g_stagger = 0, g_stream = 1, g_split_target = 640;      // per calling thread: no state shared between threads
+// key 8: the launches that follow carry this many independent images (a TEST-mode batch).  Split-K changes the order in which a sum is
+// formed, so its plan must not depend on how many images share a launch: it is made for the launch as it would look in a batch of
+// PLAN_IMAGES images (per-image rows x 4: the plan of the 4-image batches the throughput configuration runs), whatever the actual
+// batch -- the same image then gives the same bits at batch 1, 4 or 8 (lib/model/test.py:88 is strictly batch-1).  0 = plan by the launch.
+static thread_local int g_plan_images = 0;
+static constexpr int PLAN_IMAGES = 4;
 extern "C" int frcnn_set_tuning(int key, int value) {
   if (key == 0) { g_force_cfg = value; return FRCNN_OK; }
   if (key == 1) { g_dbg = value; return FRCNN_OK; }
   if (key == 5) { g_stagger = value; return FRCNN_OK; }        // 0 off; n > 0: second-slot workgroups start n/8 of a tile late
   if (key == 6) { g_stream = value; return FRCNN_OK; }         // 0: never dispatch to k_gemm_stream (A/B runs)
   if (key == 7) { g_split_target = value > 0 ? value : 640; return FRCNN_OK; }   // workgroups a split-K launch aims at (plan_splits)
+  if (key == 8) { g_plan_images = value > 0 ? value : 0; return FRCNN_OK; }      // images sharing the next launches (batch-invariant split plan)
   return FRCNN_E_ARG;
 }
 
@@ -758,8 +765,14 @@ static int launch_cfg(int id, const ConvParams& p, hipStream_t st) {
 // tiles for 256 CUs x 2..5 resident workgroups.  Such launches are cut along K: grid.z = S workgroup sets, each reduces
 // kchunk slabs into its own [M][Cout] partial (plain stores, no atomics -> deterministic), then k_splitk_finish adds the S
 // partials in a fixed order and applies bias / residual / activation.
+// rows of a launch as every size-dependent rule sees them (key 8): per-image rows x PLAN_IMAGES
+static long long plan_rows(long long M) {
+  return (g_plan_images > 0 && M % g_plan_images == 0) ? M / g_plan_images * PLAN_IMAGES : M;
+}
+
 static int plan_splits(int M, int Cout, int nsteps) {
   if (g_force_cfg >= 0) return 1;
+  M = (int)min(plan_rows(M), (long long)0x7fffffff);
   const long long big = (long long)cdiv(M, 128) * cdiv(Cout, 128);
   if (Cout >= 96 && big >= 384 && nsteps >= 8) return 1;
   const long long tiles = (long long)cdiv(M, 64) * cdiv(Cout, Cout > 32 ? 64 : 32);
@@ -880,16 +893,19 @@ static int conv2d_impl(const float* x_d, int N, int H, int W, int Cin, const flo
   // Short-K pointwise convolutions (bottleneck conv3: K = Cin <= 256 into a 4x wider output + residual): a tile is only <= 8 slabs
   // (<= 128 MFMAs per wave), so per-tile launch / prologue / LDS-staged epilogue cost as much as the multiply -> resident
   // streaming workers with register epilogues (profiles/r02_h_stream_sweep.txt: 64.5 -> 51 us on 9576 x 1024 x 256).
+  // Which kernel / tile configuration: the configurations do not all add in the same order (8-wave tiles keep two accumulators per
+  // sub-tile), so like the split-K plan the choice follows the PLANNED rows (key 8), not the rows of this particular launch.
+  const long long Mp = plan_rows(p.M);
   if (g_stream && p.nsteps <= 8 && stride == 1 && KH == 1 && KW == 1 && (!residual_d || p.res_stride == 1)) {
-    if (Cout % 128 == 0 && (long long)cdiv(p.M, 64) * (Cout / 128) >= 512) {
+    if (Cout % 128 == 0 && (Mp + 63) / 64 * (Cout / 128) >= 512) {
       const int rc = launch_stream_cfg(108, p, st);
       if (rc != FRCNN_E_UNSUPPORTED) return rc;
-    } else if (Cout == 64 && cdiv(p.M, 128) >= 512) {
+    } else if (Cout == 64 && (Mp + 127) / 128 >= 512) {
       const int rc = launch_stream_cfg(106, p, st);
       if (rc != FRCNN_E_UNSUPPORTED) return rc;
     }
   }
-  const long long big = (long long)cdiv(p.M, 128) * cdiv(Cout, 128);
+  const long long big = (Mp + 127) / 128 * cdiv(Cout, 128);
   if (Cout >= 96 && big >= 384 && p.nsteps >= 8) {
     // a 128x128 tile keeps each SIMD's matrix pipe busy for nsteps * 64 MFMAs * 64 cycles; two workgroups share a CU
     if (g_stagger > 0 && big >= 1024) {
@@ -972,10 +988,11 @@ extern "C" int frcnn_gemm_batched_nt(const float* x_d, const float* w_d, float* 
   p.batch = G;
   p.splits = 1; p.kchunk = p.nsteps;
   p.mean_group = 0; p.mean_part = nullptr; p.stagger = 0; p.stagger_slots = 0;
-  const long long big = (long long)cdiv(M, 128) * cdiv(N, 128) * G;
+  const long long Mp = plan_rows(M);                            // key 8: configuration by the planned rows (see conv2d_impl)
+  const long long big = (Mp + 127) / 128 * cdiv(N, 128) * G;
   if (g_force_cfg >= 100) return launch_stream_cfg(g_force_cfg, p, (hipStream_t)stream);
   if (g_force_cfg >= 0) return launch_cfg(g_force_cfg, p, (hipStream_t)stream);
-  if (g_stream && p.nsteps <= 8 && N % 128 == 0 && (long long)cdiv(M, 64) * (N / 128) * G >= 512) {      // short-K batched products
+  if (g_stream && p.nsteps <= 8 && N % 128 == 0 && (Mp + 63) / 64 * (N / 128) * G >= 512) {      // short-K batched products
     const int rc = launch_stream_cfg(108, p, (hipStream_t)stream);
     if (rc != FRCNN_E_UNSUPPORTED) return rc;
   }

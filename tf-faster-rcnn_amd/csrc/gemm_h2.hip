@@ -127,7 +127,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
   constexpr int RED_OFF = NS * STAGE;             // row-maximum exchange of the plane-emitting epilogue: [BN / WN][BM] floats
   constexpr int S2_OFF = RED_OFF + (BN / WN) * BM * 4;      // TUNE & 2: two 1 KB block-scale regions, alternating per 128-k block
                                                             // PP: [wave][parity] 256 B: each wave's own 64 row scales
-  static_assert(!PP || (NW == 8 && NS == 3 && WM == 64 && BM == 256 && (TUNE & 2)), "ping-pong geometry");
+  static_assert(!PP || (NW == 8 && NS == 3 && (TUNE & 2) && ((BM == 256 && WM == 64) || (BM == 128 && WM == 32)) && BN == 128 && WN == 64),
+                "ping-pong geometry: 8 waves as 4 (M) x 2 (N), waves 0-3 = the upper half of the rows");
   static_assert((2 * BM / 16) % NW == 0 && (2 * BN / 16) % NW == 0, "tile/wave mismatch");
   static_assert(BM <= 256 && NS >= 2 && NS <= 4, "stage layout");
   static_assert((NS - 2) * (G + SL) <= 63, "vmcnt range");
@@ -847,18 +848,25 @@ extern "C" int frcnn_gemm_h2(const void* x_planes_d, const float* x_inv_d, const
     // epilogues are a small part (K >= 1024: 64 slabs per tile), with at least one tile per CU and 256-row tiles that waste < 4 % of M.
     const long long mt256 = (M + 255) / 256;
     const bool pp = K >= 1024 && mt256 * 256 * 100 <= (long long)M * 104 && mt256 * (N / 128) * G >= 256;
-    cfg = pp ? 21 : 9;       // 9: 128 x 128 tiles, two workgroups per CU, one barrier per slab (profiles/r03_l_ab.txt)
+    // fewer than 150 tiles of 128 x 128 (a single image's launches: batch-1 latency mode): 64-row tiles, three workgroups per CU
+    // (profiles/r03_g_h2_sweep.txt: 21.8 vs 30.9 us on one image's block3 conv1); in the 4-image pipeline these lose (r03_l_ab.txt)
+    const bool tiny = (long long)((M + 127) / 128) * (N / 128) * G < 150;
+    cfg = pp ? 21 : tiny ? 12 : 9;       // 9: 128 x 128 tiles, two workgroups per CU, one barrier per slab (profiles/r03_l_ab.txt)
   }
   switch (cfg) {
     case 0: return launch_h2<128, 128, 64, 64, 2>(p, st);        // 67 KB: 2 workgroups / CU
     case 1: return launch_h2<128, 128, 64, 64, 3>(p, st);        // 100 KB: 1 workgroup / CU, 2 slabs in flight
+    case 2: return launch_h2<128, 128, 64, 64, 4>(p, st);        // 134 KB: 1 workgroup / CU, 3 slabs in flight (launches of <= one tile per CU)
     case 3: return launch_h2<256, 128, 64, 64, 2>(p, st);        // 8 waves, 100 KB
     case 8: return launch_h2<128, 128, 64, 64, 2, 2, 1>(p, st);  // cfg 0 with the loads issued in two halves
     case 9: return launch_h2<128, 128, 64, 64, 2, 2, 2>(p, st);  // cfg 0 with the scales sent once per 128-k block (the default)
     case 12: return launch_h2<64, 128, 32, 64, 2>(p, st);        // 64-row tiles, 4 waves of 32 x 64, 51 KB: 3 workgroups / CU (faster alone on
                                                                   // under-filled launches, slower in the pipeline: profiles/r03_l_ab.txt)
+    case 13: return launch_h2<64, 128, 32, 64, 3>(p, st);        // 64-row tiles, 3-slot ring (77 KB: 2 workgroups / CU, 2 slabs in flight each)
+    case 15: return launch_h2<64, 128, 32, 64, 4>(p, st);        // ... 4-slot ring (102 KB: 1 workgroup / CU, 3 slabs in flight)
     case 14: return launch_h2<128, 128, 64, 64, 2, 2, 4>(p, st);  // cfg 0 with the loads spread between the MFMAs (measured slower: r03_k)
     case 18: return launch_h2<128, 128, 64, 64, 2, 2, 10>(p, st); // cfg 9 with round 2's (r >> 1) & 3 swizzle (two-way LDS bank conflicts)
+    case 24: return launch_h2<128, 128, 32, 64, 3, 2, 34>(p, st); // ping-pong on 128 x 128 tiles (8 waves of 32 x 64): launches of about one tile per CU
     case 21: return launch_h2<256, 128, 64, 64, 3, 2, 34>(p, st); // ping-pong: 256 x 128, 8 waves in two groups a segment apart, 3-slot ring
 #ifdef FRCNN_ABLATION
     case 22: return launch_h2<256, 128, 64, 64, 3, 2, 34 + 64>(p, st);   // ping-pong with cache-resident X (wrong results by construction)

@@ -169,7 +169,7 @@ class Network(object):
         float32 outputs the tape needs are always written, inputs without planes are split by a separate pass."""
         rows = G * M
         return (bool(cfg.HIP.MFMA_H2) and (self._mode == "TEST" or bool(cfg.HIP.H2_TRAIN)) and K % 128 == 0 and N % 128 == 0
-                and ((M + 127) // 128) * (N // 128) * G >= int(cfg.HIP.H2_MIN_TILES)
+                and ((self._plan_rows(M) + 127) // 128) * (N // 128) * G >= int(cfg.HIP.H2_MIN_TILES)
                 and 4 * rows * K < (1 << 32) and 4 * N * K < (1 << 32) and M * N < (1 << 29))
 
     def _h2_input(self, x):
@@ -202,7 +202,7 @@ class Network(object):
         """cfg.HIP.MFMA_X3: TEST mode (static filters), N % 64 == 0, K % 32 == 0 and at least 150 tiles of 128 x 128 -- below that
         the split-K f32 launches are as fast (profiles/r02_m_x3_sweep.txt, single-image rows)."""
         return (bool(cfg.HIP.MFMA_X3) and self._mode == "TEST" and N % 64 == 0 and K % 32 == 0
-                and ((M + 127) // 128) * ((N + 127) // 128) * G >= 150 and M * N < (1 << 31) and N * K < (1 << 28))
+                and ((self._plan_rows(M) + 127) // 128) * ((N + 127) // 128) * G >= 150 and M * N < (1 << 31) and N * K < (1 << 28))
 
     @staticmethod
     def _winograd_scheme(scope, H, W):
@@ -548,7 +548,26 @@ class Network(object):
         torch.cuda.current_stream(self._sess.device).wait_event(self._join_event)
         self._join_event = None
 
+    PLAN_IMAGES = 4        # csrc/conv_igemm.hip PLAN_IMAGES: every launch-size rule is evaluated for a batch of this many images
+
+    def _plan_rows(self, M):
+        """Rows of a launch as they would be in a PLAN_IMAGES-image batch.  Which matrix pipe a GEMM runs on (>= 150 tiles: h2 / x3) and
+        whether a convolution is cut along K change the bits of the result, so neither may depend on how many images share the launch:
+        TEST-mode rules see per-image rows x PLAN_IMAGES whatever the batch is (the reference is strictly batch-1, lib/model/test.py:88;
+        the same image must give the same tensors at batch 1, in any slot of a batch of 4, or of 8)."""
+        B = getattr(self, "_plan_batch", 0)
+        return M // B * self.PLAN_IMAGES if (B > 0 and M % B == 0) else M
+
     def _build_network(self, is_training=True):
+        from frcnn_hip import lib
+        self._plan_batch = 0 if is_training else int(self._image.shape[0])
+        lib().frcnn_set_tuning(8, self._plan_batch)      # the same rule inside the library (split-K plan of frcnn_conv2d_nhwc_ws)
+        try:
+            return self._build_network_impl(is_training)
+        finally:
+            lib().frcnn_set_tuning(8, 0)
+
+    def _build_network_impl(self, is_training=True):
         self._tape = []
         self._requires_grad = set()
         self._h2_of, self._f32_missing = {}, set()      # planes are facts about THIS build's launches (buffers are reused across builds)
