@@ -84,7 +84,7 @@ def ctrl_path(config, weights):
 
 
 def load_ctrl(config, weights):
-    p = ctrl_path(config, weights)
+    p = ctrl_path(config, weights.replace("+heavy", ""))
     return dict(np.load(p)) if os.path.exists(p) else None
 
 
@@ -164,12 +164,62 @@ def apply_fixture(v, scope, fx):
     return v
 
 
+def heavy_rescale(v, scope, kind, seed=7, frac=0.005, kmin=10, kmax=17):
+    """Outlier channels WITHOUT changing the function (weights mode "<base>+heavy"; VERDICT r3 item 5: real checkpoints -- VGG16 without
+    normalisation, trained bottlenecks -- carry a few channels whose activations are 10^3 ... 10^5 times the rest, which is where a
+    block-scaled operand format could lose bits that float32 keeps).  For `frac` of the output channels of a convolution (at least one)
+    the producer is scaled by s = 2^k, k in [kmin, kmax] (ResNet: BatchNorm gamma and beta of bottleneck conv1 / conv2; VGG16: filter +
+    bias of conv*_* but the last), and the consumer's filters for that INPUT channel by 1 / s.  ReLU is positively homogeneous and every
+    scale is an exact power of two, so in exact arithmetic -- and in any float32 implementation that rounds products and sums the usual
+    way -- every tensor OUTSIDE the rescaled channel is bit-identical to the base weights' and the committed float64 fixture stays the
+    reference; only the 1e3 ... 1e5 outliers inside the scaled activation (and the matching 1e-3 ... 1e-5 filter entries) are new.
+    Returns [(producer, channel, k)]."""
+    rng = np.random.RandomState(seed)
+    log = []
+
+    def pick(n):
+        m = max(1, int(round(frac * n)))
+        return rng.choice(n, size=m, replace=False), rng.randint(kmin, kmax + 1, size=m)
+    if kind == "res":
+        units = sorted({k[:k.index("/bottleneck_v1/")] for k in v if "/bottleneck_v1/conv1/weights" in k})
+        for u in units:
+            for a, b in (("conv1", "conv2"), ("conv2", "conv3")):
+                pa, pb = u + "/bottleneck_v1/" + a, u + "/bottleneck_v1/" + b
+                ch, ks = pick(v[pa + "/weights"].shape[3])
+                for c_, k_ in zip(ch, ks):
+                    s_ = np.float32(2.0 ** int(k_))
+                    v[pa + "/BatchNorm/gamma"][c_] *= s_
+                    v[pa + "/BatchNorm/beta"][c_] *= s_
+                    v[pb + "/weights"][:, :, c_, :] /= s_
+                    log.append((pa, int(c_), int(k_)))
+    elif kind == "vgg16":
+        convs = sorted({k[:-len("/weights")] for k in v if "/conv" in k and k.endswith("/weights") and v[k].ndim == 4 and v[k].shape[0] == 3},
+                       key=lambda n: [int(t) for t in n.split("/")[-1].replace("conv", "").split("_")])
+        for pa, pb in zip(convs[:-1], convs[1:]):
+            ch, ks = pick(v[pa + "/weights"].shape[3])
+            for c_, k_ in zip(ch, ks):
+                s_ = np.float32(2.0 ** int(k_))
+                v[pa + "/weights"][:, :, :, c_] *= s_
+                v[pa + "/biases"][c_] *= s_
+                v[pb + "/weights"][:, :, c_, :] /= s_
+                log.append((pa, int(c_), int(k_)))
+    else:
+        raise ValueError("heavy weights: ReLU6 (MobileNet) is not homogeneous; ResNet / VGG16 only")
+    return log
+
+
 def build(config, weights, seed=3):
-    """For the GPU tests: (net, variables, image, im_info, fixture) with the fixture's weights applied."""
+    """For the GPU tests: (net, variables, image, im_info, fixture) with the fixture's weights applied.  weights "<base>+heavy": the
+    base weights with outlier channels that leave the function unchanged (heavy_rescale); the fixture is the base one."""
     c = CONFIGS[config]
+    heavy = weights.endswith("+heavy")
+    weights = weights[:-len("+heavy")] if heavy else weights
     fx = np.load(fixture_path(config, weights))
     net, v = base_variables(config, weights, seed)
     apply_fixture(v, net._scope, fx)
+    if heavy:
+        v = {k: np.array(a, copy=True) for k, a in v.items()}
+        net.heavy_log = heavy_rescale(v, net._scope, c["net"])
     image = synth_image(c, seed)
     im_info = np.array([c["H"], c["W"], c["scale"]], dtype=np.float32)
     return net, v, image, im_info, fx
@@ -217,13 +267,15 @@ GRAD_TOL = 2e-4              # of the tensor's largest entry; or GRAD_CTRL_FACTO
 GRAD_CTRL_FACTOR = 4.0
 GATE_EPS = 2e-5              # relative to the layer's largest pre-activation: what a Winograd F(4x4,3x3) forward may move a gate by
 EPS_SCORE, EPS_IOU, TOL = 1e-4, 1e-3, 1e-4        # BASELINE.json north_star: 1e-4 on scores / box coordinates
-CTRL_FACTOR = {"direct": 1.5, "shipped": 1.5, "shipped_h2_f32trunk": 1.5, "shipped_x3": 1.5, "shipped_f32": 1.5}     # allowed multiple of the float32 control's own loss (exploratory policies: 2.5)
+CTRL_FACTOR = {"direct": 1.5, "shipped": 1.5, "shipped_trunk_planes": 1.5, "shipped_x3": 1.5, "shipped_f32": 1.5}     # allowed multiple of the float32 control's own loss (exploratory policies: 2.5)
 
 
 def tolerance(fx, key, policy):
     """1e-4 (north_star), or -- on a graph where float32 arithmetic ITSELF loses more than that against float64 (the
     fixture's torch-CPU f32 control, `ctrl_*`) -- a small multiple of the control's loss: as exact as f32 gets there."""
     ctrl = float(fx["ctrl_" + key]) if ("ctrl_" + key) in fx else 0.0
+    if policy.endswith("+heavy"):            # outlier-channel weights: the device may not lose more than the float32 control does (factor 1)
+        return max(TOL, 1.0 * ctrl)
     return max(TOL, CTRL_FACTOR.get(policy, 2.5) * ctrl)
 
 
@@ -244,6 +296,7 @@ def run_harness(config, weights, policy, dev, fuse_tail=True):
     saved = {k: cfg.HIP[k] for k in cfg.HIP}
     saved_post, saved_nms = cfg.TEST.RPN_POST_NMS_TOP_N, cfg.USE_GPU_NMS
     rep = dict(config=config, weights=weights, policy=policy, ok=True, notes=[])
+    tol_policy = policy + ("+heavy" if weights.endswith("+heavy") else "")
 
     def check(name, cond):
         if not cond:
@@ -271,8 +324,8 @@ def run_harness(config, weights, policy, dev, fuse_tail=True):
         rep["head_sub"] = rel_err(head[0, ::4, ::4, :], fx["head_sub"])
         for k in ("rpn_cls_score", "rpn_cls_prob", "rpn_bbox_pred"):
             rep[k] = rel_err(p[k], fx[k])
-            check(k, rep[k] <= tolerance(fx, k, policy))
-        check("head", rep["head_sub"] <= tolerance(fx, "head", policy))
+            check(k, rep[k] <= tolerance(fx, k, tol_policy))
+        check("head", rep["head_sub"] <= tolerance(fx, "head", tol_policy))
         rep["ctrl_head"], rep["ctrl_rpn_cls_prob"] = float(fx["ctrl_head"]), float(fx["ctrl_rpn_cls_prob"])
         rep["ctrl_cls_score"] = float(fx["ctrl_cls_score"])
         if ct is not None:            # distance to another float32 implementation of the same graph (VERDICT r2 missing #5)
@@ -326,14 +379,14 @@ def run_harness(config, weights, policy, dev, fuse_tail=True):
         rep["cls_prob_abs"] = float(np.abs(cls_prob_d[:nref].cpu().numpy() - fx["cls_prob"]).max())
         rep["bbox_pred"] = rel_err(bbox_pred_d[:nref].cpu().numpy(), fx["bbox_pred"])
         rep["logit_scale"] = float(np.abs(fx["cls_score"]).max())
-        check("cls_score", rep["cls_score"] <= tolerance(fx, "cls_score", policy))
+        check("cls_score", rep["cls_score"] <= tolerance(fx, "cls_score", tol_policy))
         if ct is not None:
             rep["dc_cls_score"] = rel_err(cls_score_d[:nref].cpu().numpy(), ct["cls_score"])
             rep["dc_bbox_pred"] = rel_err(bbox_pred_d[:nref].cpu().numpy(), ct["bbox_pred"])
             rep["dc_cls_prob_abs"] = float(np.abs(cls_prob_d[:nref].cpu().numpy() - ct["cls_prob"]).max())
             check("dev vs f32 control: cls_score", rep["dc_cls_score"] <= max(TOL, 2.5 * float(fx["ctrl_cls_score"])))
             check("dev vs f32 control: bbox_pred", rep["dc_bbox_pred"] <= max(TOL, 2.5 * float(fx["ctrl_bbox_pred"])))
-        check("bbox_pred", rep["bbox_pred"] <= tolerance(fx, "bbox_pred", policy))
+        check("bbox_pred", rep["bbox_pred"] <= tolerance(fx, "bbox_pred", tol_policy))
         # softmax of O(1e3) logits (the damped synthetic weights) amplifies a 1e-6 relative logit error past 1e-4 absolute:
         # the probability bound is asserted where the logits have a trained network's scale
         if rep["logit_scale"] <= 50.0:

@@ -13,7 +13,7 @@ Per case (oracle/fullsize.py::run_harness):
   3. RoI tail on the reference's rois: cls_score / bbox_pred / cls_prob vs float64   <= 1e-4
   4. detections vs the oracle on the device's own tensors            (score, class) bit-exact
      detections vs the reference's, per class                        within eps
-for the direct f32-MFMA path, the shipped policy (Winograd + block-scaled fp16x2 GEMMs of cfg.HIP.MFMA_H2 + exact bf16x3 GEMMs), the same without MFMA_H2 AND the shipped Winograd policy on the f32 MFMA only, on the bench's damped synthetic weights and on
+for the direct f32-MFMA path, the shipped policy (Winograd + block-scaled fp16x2 GEMMs of cfg.HIP.MFMA_H2 + exact bf16x3 GEMMs), the same with the residual trunk held as operand planes only (cfg.HIP.H2_TRUNK_PLANES), the same without MFMA_H2 AND the shipped Winograd policy on the f32 MFMA only, on the bench's damped synthetic weights and on
 "calibrated" weights whose activations have a trained network's scale (every BN gamma ~ U(0.5, 1.5)).
 The measured maxima are printed (pytest -s) and written to gpurun_out/fullsize_parity.txt."""
 import os
@@ -29,7 +29,7 @@ SHIPPED = "shipped"
 
 SHIPPED_F32 = "shipped_f32"
 SHIPPED_X3 = "shipped_x3"
-SHIPPED_H2F = "shipped_h2_f32trunk"
+SHIPPED_TP = "shipped_trunk_planes"
 
 
 def _shipped_policy():
@@ -38,14 +38,14 @@ def _shipped_policy():
     from model.config import cfg
     fs.POLICIES[SHIPPED] = {k: cfg.HIP[k] for k in ("WINOGRAD", "WINOGRAD_M", "WINOGRAD_F2_SCOPES", "WINOGRAD_DIRECT_SCOPES", "WINOGRAD_7X7",
                                                     "WINOGRAD_MIN_CIN", "MFMA_X3", "MFMA_H2", "H2_LAZY_SPLIT", "H2_MIN_TILES", "H2_TRUNK_PLANES")}
-    fs.POLICIES[SHIPPED_H2F] = dict(fs.POLICIES[SHIPPED], H2_TRUNK_PLANES=False)      # MFMA_H2 with the residual trunk kept in float32
+    fs.POLICIES[SHIPPED_TP] = dict(fs.POLICIES[SHIPPED], H2_TRUNK_PLANES=True)        # the identity-shortcut trunk as operand planes only (conv3: 8 instead of 12 B / element)
     fs.POLICIES[SHIPPED_X3] = dict(fs.POLICIES[SHIPPED], MFMA_H2=False)               # round 2's configuration (bench.py `x3_variant`)
     fs.POLICIES[SHIPPED_F32] = dict(fs.POLICIES[SHIPPED], MFMA_X3=False, MFMA_H2=False)
     return SHIPPED
 
 
 @pytest.mark.parametrize("config,weights", [("c2", "damped"), ("c2", "calibrated"), ("c3", "calibrated"), ("c1", "damped"), ("c4", "calibrated")])
-@pytest.mark.parametrize("policy", ["direct", SHIPPED, SHIPPED_H2F, SHIPPED_X3, SHIPPED_F32])
+@pytest.mark.parametrize("policy", ["direct", SHIPPED, SHIPPED_TP, SHIPPED_X3, SHIPPED_F32])
 def test_fullsize_parity(dev, config, weights, policy):
     if policy != "direct":
         _shipped_policy()
@@ -57,6 +57,64 @@ def test_fullsize_parity(dev, config, weights, policy):
     with open(os.path.join(out, "fullsize_parity.txt"), "a") as f:
         f.write(line + "\n")
     assert rep["ok"], line
+
+
+@pytest.mark.parametrize("config,weights", [("c2", "calibrated+heavy"), ("c1", "damped+heavy")])
+@pytest.mark.parametrize("policy", [SHIPPED, SHIPPED_X3, SHIPPED_F32])
+def test_fullsize_parity_with_outlier_channels(dev, config, weights, policy):
+    """The operand format of frcnn_gemm_h2 follows the largest element of a 128-k block, so channels 2^10 ... 2^17 times the rest --
+    what VGG16 (no normalisation) and trained bottlenecks have -- are where it could lose bits float32 keeps.  oracle/fullsize.py
+    heavy_rescale puts such channels into every bottleneck (ResNet-101) / every convolution but the last (VGG16) by exact powers of two
+    that cancel in the consumer's filters: the network FUNCTION, hence the committed float64 fixture, is unchanged, while the activations
+    and filters the kernels see carry the outliers.  Gate: |device - float64| <= max(1e-4, the float32 control's own loss) -- factor 1,
+    not 1.5 -- for the shipped configuration (h2), x3 only and f32-MFMA only."""
+    _shipped_policy()
+    rep = fs.run_harness(config, weights, policy, dev)
+    line = fs.format_report(rep)
+    print("\n" + line)
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "fullsize_parity.txt"), "a") as f:
+        f.write(line + "\n")
+    assert rep["ok"], line
+
+
+@pytest.mark.timeout(180)
+def test_network_level_nan_propagation(dev):
+    """One NaN pixel in the image: the head of a 101-layer network sees it everywhere (receptive field), and every stage must say so --
+    NaN in the head, the RPN tensors and the class scores, no finite garbage, no hang, and the detection stage returns a count.  (h2 /
+    x3 operand splits turn an inf / NaN element into NaN for the output rows that read its block, csrc/gemm_h2.hip header.)"""
+    import numpy as np
+    import torch
+    from frcnn_hip.runtime import Session
+    from model.config import cfg
+    _shipped_policy()
+    c = fs.CONFIGS["c2"]
+    net, v, image, im_info, fx = fs.build("c2", "damped")
+    saved = {k: cfg.HIP[k] for k in cfg.HIP}
+    saved_post, saved_nms = cfg.TEST.RPN_POST_NMS_TOP_N, cfg.USE_GPU_NMS
+    try:
+        for k, val in fs.POLICIES[SHIPPED].items():
+            cfg.HIP[k] = val
+        cfg.TEST.RPN_POST_NMS_TOP_N, cfg.USE_GPU_NMS = c["post"], False
+        sess = Session(device=dev, seed=3)
+        sess.load_variables(v)
+        net._fuse_tail_entry = hasattr(net, "_fused_tail_entry")
+        bad = image.copy()
+        bad[0, 300, 500, 1] = np.nan
+        dets, cnt = net.detect_device(sess, net._stage_image(sess, bad), im_info, (375, 625), max_per_image=100)
+        torch.cuda.synchronize()
+        head = net._layers["head"].cpu().numpy()
+        assert np.isnan(head).mean() > 0.5, "the NaN did not spread through the head: %.3f" % float(np.isnan(head).mean())
+        assert not np.isinf(head).any()
+        for k in ("rpn_cls_prob", "cls_score"):
+            t = net._predictions[k].cpu().numpy()
+            assert np.isnan(t).any(), k
+        assert 0 <= int(cnt.cpu().numpy().ravel()[0]) <= 128
+    finally:
+        for k, val in saved.items():
+            cfg.HIP[k] = val
+        cfg.TEST.RPN_POST_NMS_TOP_N, cfg.USE_GPU_NMS = saved_post, saved_nms
 
 
 @pytest.mark.parametrize("policy", ["direct", "shipped"])

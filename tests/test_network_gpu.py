@@ -424,3 +424,42 @@ def test_optional_fused_tail_mean_and_graph_branch_match_the_default_path(small_
         assert np.array_equal(got[3], base[3])                                   # same proposals
         for a, b in ((got[0], base[0]), (got[2], base[2])):                      # cls_score, bbox_pred (this fixture's logits are O(1e3))
             assert rel_err(a, b) <= 2e-5, key
+
+
+def test_h2_static_filter_criterion_falls_back_to_x3(dev):
+    """A consumer filter whose entries for one input channel are below 2^-18 of the rest (the signature of an activation channel
+    2^18 times the others) keeps that layer, and the producer feeding it, off the block-scaled fp16x2 format: the exact x3 split runs
+    instead (Session.h2_channel_spread, Network._h2_eligible); 2^-17 still runs in frcnn_gemm_h2.  Both give the f32-class result."""
+    from frcnn_hip.runtime import Session
+    from model.config import cfg
+    from nets.resnet_v1 import resnetv1
+    keep = (cfg.HIP.MFMA_H2, cfg.HIP.H2_MIN_TILES, cfg.HIP.H2_LAZY_SPLIT, cfg.TEST.RPN_POST_NMS_TOP_N)
+    cfg.HIP.MFMA_H2, cfg.HIP.H2_MIN_TILES, cfg.HIP.H2_LAZY_SPLIT, cfg.TEST.RPN_POST_NMS_TOP_N = True, 1, True, 48
+    try:
+        rng = np.random.RandomState(5)
+        image = (rng.rand(1, 128, 192, 3) * 255.0).astype(np.float32) - cfg.PIXEL_MEANS.astype(np.float32)
+        im_info = np.array([128, 192, 1.0], dtype=np.float32)
+        tags = {}
+        for k in (17, 20):
+            sess = Session(device=dev, seed=11)
+            net = resnetv1(num_layers=50)
+            net.create_architecture("TEST", 21, tag="h2crit%d" % k, anchor_scales=SCALES, anchor_ratios=RATIOS)
+            sess.init_variables(net.variable_specs())
+            u = "resnet_v1_50/block3/unit_2/bottleneck_v1"
+            s_ = np.float32(2.0 ** k)                                    # channel 5 of conv1's output is 2^k times its base value ...
+            sess.variables[u + "/conv1/BatchNorm/gamma"][5] *= s_
+            sess.variables[u + "/conv1/BatchNorm/beta"][5] *= s_
+            sess.variables[u + "/conv2/weights"][:, :, 5, :] /= s_       # ... and conv2's filters undo it: same function
+            sess._drop_derived()
+            sess.profile = []
+            net.forward_device(sess, net._stage_image(sess, image), im_info, use_graph=False)
+            torch.cuda.synchronize()
+            tags[k] = [t[0] for t in sess.profile]
+            sess.profile = None
+            spread = sess.h2_channel_spread(u + "/conv2")
+            assert (spread < 2.0 ** -18) == (k == 20), (k, spread)
+        assert ("conv:h2:" + u + "/conv2") in tags[17] and ("conv:h2:" + u + "/conv2") not in tags[20]
+        assert any(t.endswith(u + "/conv2") and not t.startswith("conv:h2:") for t in tags[20])
+        assert ("conv:h2:" + "resnet_v1_50/block3/unit_3/bottleneck_v1/conv2") in tags[20]          # the other layers are untouched
+    finally:
+        cfg.HIP.MFMA_H2, cfg.HIP.H2_MIN_TILES, cfg.HIP.H2_LAZY_SPLIT, cfg.TEST.RPN_POST_NMS_TOP_N = keep

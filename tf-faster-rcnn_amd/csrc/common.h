@@ -50,6 +50,15 @@ static inline hipError_t kernel_once(KernelOnce& k, const void* kern, int thread
   return k.rc[dev];
 }
 
+// Activations that KEEP NaN.  TensorFlow's Relu is Eigen's max(x, 0) evaluated as (x < 0) ? 0 : x, so a NaN feature stays NaN; fmaxf(NaN, 0)
+// (v_max_f32 in IEEE mode) would return 0 and turn an overflowed / poisoned activation into a plausible finite network output.
+__device__ __forceinline__ float act_clamp(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ float act_relu(float v) { return v < 0.f ? 0.f : v; }
+__device__ __forceinline__ float act_relu6(float v) { return v < 0.f ? 0.f : (v > 6.f ? 6.f : v); }
+__device__ __forceinline__ float4 act_relu(float4 v) { return make_float4(act_relu(v.x), act_relu(v.y), act_relu(v.z), act_relu(v.w)); }
+__device__ __forceinline__ float4 act_relu6(float4 v) { return make_float4(act_relu6(v.x), act_relu6(v.y), act_relu6(v.z), act_relu6(v.w)); }
+__device__ __forceinline__ float2 act_relu(float2 v) { return make_float2(act_relu(v.x), act_relu(v.y)); }
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

@@ -343,9 +343,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
         const float4 rv = *(const float4*)(p.res + (size_t)m * p.Cout + n);
         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
       }
-      if (p.act == FRCNN_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      if (p.act == FRCNN_ACT_RELU) v = act_relu(v);
       else if (p.act == FRCNN_ACT_RELU6)
-        v = make_float4(fminf(fmaxf(v.x, 0.f), 6.f), fminf(fmaxf(v.y, 0.f), 6.f), fminf(fmaxf(v.z, 0.f), 6.f), fminf(fmaxf(v.w, 0.f), 6.f));
+        v = act_relu6(v);
       const int slot = m / p.mean_group - g0;
 #pragma unroll
       for (int q = 0; q < MEAN_SLOTS; ++q)
@@ -388,9 +388,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
         const float4 rv = *(const float4*)(p.res + ro);
         v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
       }
-      if (p.act == FRCNN_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      if (p.act == FRCNN_ACT_RELU) v = act_relu(v);
       else if (p.act == FRCNN_ACT_RELU6)
-        v = make_float4(fminf(fmaxf(v.x, 0.f), 6.f), fminf(fmaxf(v.y, 0.f), 6.f), fminf(fmaxf(v.z, 0.f), 6.f), fminf(fmaxf(v.w, 0.f), 6.f));
+        v = act_relu6(v);
       *(float4*)(py + (size_t)m * p.Cout + n) = v;
     }
   } else {          // Cout not a multiple of 4 (RPN / fc heads): scalar path
@@ -408,8 +408,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
         }
         v += p.res[ro];
       }
-      if (p.act == FRCNN_ACT_RELU) v = fmaxf(v, 0.f);
-      else if (p.act == FRCNN_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+      if (p.act == FRCNN_ACT_RELU) v = act_relu(v);
+      else if (p.act == FRCNN_ACT_RELU6) v = act_relu6(v);
       py[(size_t)m * p.Cout + n] = v;
     }
   }
@@ -628,7 +628,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_gemm_stream(cons
         for (int r = 0; r < 16; ++r) {
           float t = (KSPLIT ? acc[i][j][r] + acc2[i][j][r] : acc[i][j][r]) + bv;
           if (RES) t += RESPF ? rv[RESPF ? i : 0][RESPF ? j : 0][r] : v[r];
-          v[r] = fminf(fmaxf(t, act_lo), act_hi);
+          v[r] = act_clamp(t, act_lo, act_hi);
         }
         const auto ry = rsrc_of(py, sbase);
 #pragma unroll
@@ -811,8 +811,8 @@ __global__ void k_splitk_finish(const float* __restrict__ part, int S, int M, in
       }
       v += res[ro];
     }
-    if (act == FRCNN_ACT_RELU) v = fmaxf(v, 0.f);
-    else if (act == FRCNN_ACT_RELU6) v = fminf(fmaxf(v, 0.f), 6.f);
+    if (act == FRCNN_ACT_RELU) v = act_relu(v);
+    else if (act == FRCNN_ACT_RELU6) v = act_relu6(v);
     y[i] = v;
   }
 }

@@ -81,9 +81,9 @@ __global__ void k_dwconv3x3(const float4* __restrict__ x, int N, int H, int W, i
       a.x = fmaf(v.x, f.x, a.x); a.y = fmaf(v.y, f.y, a.y); a.z = fmaf(v.z, f.z, a.z); a.w = fmaf(v.w, f.w, a.w);
     }
   }
-  if (act == FRCNN_ACT_RELU) a = make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(a.z, 0.f), fmaxf(a.w, 0.f));
+  if (act == FRCNN_ACT_RELU) a = act_relu(a);
   else if (act == FRCNN_ACT_RELU6)
-    a = make_float4(fminf(fmaxf(a.x, 0.f), 6.f), fminf(fmaxf(a.y, 0.f), 6.f), fminf(fmaxf(a.z, 0.f), 6.f), fminf(fmaxf(a.w, 0.f), 6.f));
+    a = act_relu6(a);
   if (!H2 || y) y[t] = a;
   if (H2) {
     const size_t rows = (size_t)N * OH * OW, e = (row * C4 + c4) * 4;

@@ -951,7 +951,7 @@ __global__ __launch_bounds__(256) void k_crop_and_resize(const float4* __restric
       const float4 bv = bias[c4];
       v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
     }
-    if (act == FRCNN_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    if (act == FRCNN_ACT_RELU) v = act_relu(v);
     orow[(size_t)px * C4 + c4] = v;
   }
 }

@@ -368,10 +368,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
         const float4 wi = *(const float4*)(p.w_inv + (size_t)c_g * p.N + n0 + 8 * q);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          tot[i][j][4 * q + 0] = fminf(fmaxf(tot[i][j][4 * q + 0] * wi.x, act_lo), act_hi);
-          tot[i][j][4 * q + 1] = fminf(fmaxf(tot[i][j][4 * q + 1] * wi.y, act_lo), act_hi);
-          tot[i][j][4 * q + 2] = fminf(fmaxf(tot[i][j][4 * q + 2] * wi.z, act_lo), act_hi);
-          tot[i][j][4 * q + 3] = fminf(fmaxf(tot[i][j][4 * q + 3] * wi.w, act_lo), act_hi);
+          tot[i][j][4 * q + 0] = act_clamp(tot[i][j][4 * q + 0] * wi.x, act_lo, act_hi);
+          tot[i][j][4 * q + 1] = act_clamp(tot[i][j][4 * q + 1] * wi.y, act_lo, act_hi);
+          tot[i][j][4 * q + 2] = act_clamp(tot[i][j][4 * q + 2] * wi.z, act_lo, act_hi);
+          tot[i][j][4 * q + 3] = act_clamp(tot[i][j][4 * q + 3] * wi.w, act_lo, act_hi);
         }
       }
     }

@@ -213,7 +213,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
         for (int r = 0; r < 16; ++r) {
           float t = (acc[i][j][r] + acs[i][j][r]) + bv;
           if (RES) t += v[r];
-          v[r] = fminf(fmaxf(t, act_lo), act_hi);
+          v[r] = act_clamp(t, act_lo, act_hi);
         }
         const auto ry = rsrc_of(py, sbase);
 #pragma unroll

@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256) k_wino4_output(const float4* __restrict__
       r[b] = row + ow;
       valid |= (ow < W ? 1u : 0u) << b;
       float4 v = f4add(o[b], bv);
-      if (act == FRCNN_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      if (act == FRCNN_ACT_RELU) v = act_relu(v);
       o[b] = v;
     }
     y.template putn<4>(r, o, valid, c4, C4);
@@ -269,8 +269,8 @@ __global__ void k_wino_output(const float4* __restrict__ Mx, int N, int H, int W
     float4 o0 = f4add(f4add(f4add(s[a][0], s[a][1]), s[a][2]), bv);
     float4 o1 = f4add(f4sub(f4sub(s[a][1], s[a][2]), s[a][3]), bv);
     if (act == FRCNN_ACT_RELU) {
-      o0 = make_float4(fmaxf(o0.x, 0.f), fmaxf(o0.y, 0.f), fmaxf(o0.z, 0.f), fmaxf(o0.w, 0.f));
-      o1 = make_float4(fmaxf(o1.x, 0.f), fmaxf(o1.y, 0.f), fmaxf(o1.z, 0.f), fmaxf(o1.w, 0.f));
+      o0 = act_relu(o0);
+      o1 = act_relu(o1);
     }
     const size_t row = (size_t)(img * H + oh) * W;
     const float4 o[2] = {o0, o1};

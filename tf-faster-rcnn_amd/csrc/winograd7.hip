@@ -136,7 +136,7 @@ __device__ __forceinline__ void wino7_out_segment(const float2* __restrict__ in,
 #pragma unroll
       for (int nu = 0; nu < 11; ++nu) acc_term(v, first, w7::AT[j][nu], s[nu]);
       v = make_float2(v.x + bv.x, v.y + bv.y);
-      if (act == FRCNN_ACT_RELU) v = make_float2(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f));
+      if (act == FRCNN_ACT_RELU) v = act_relu(v);
       o[j] = v;
       rw[j] = row0 + (I0 + i) * 7 + j;
     }

@@ -29,6 +29,7 @@ class VariableStore(object):
         self.packed = {}                                # layer key -> device tensors
         self.x3 = {}                                    # (filter address, shape) -> (bf16 planes, filter): frcnn_gemm_x3 operands
         self.h2 = {}                                    # (filter address, shape) -> ((fp16 planes, w_inv), filter): frcnn_gemm_h2 operands
+        self.h2_spread = {}                             # scope -> h2_channel_spread (host statistic of the filter)
         self.conv_info = {}                             # scope -> {w (folded, device), b, scale (np or None), bn}
         self.graphs = {}
         self.seed = seed
@@ -83,6 +84,7 @@ class VariableStore(object):
         self.packed.clear()
         self.x3.clear()
         self.h2.clear()
+        self.h2_spread.clear()
         self.graphs.clear()
         prepared = getattr(self, "prepared", None)
         if prepared is not None:
@@ -297,6 +299,26 @@ class Session(VariableStore):
         calls this after updating filters in place, so a TEST-mode network on the same session never multiplies by stale planes."""
         for planes, w in self.x3.values():
             ops.gemm_x3_pack(w, planes)
+
+    def h2_channel_spread(self, scope):
+        """min over input channels k of (largest |folded filter entry| that multiplies channel k) / (largest entry of the filter): host
+        arithmetic on the variables, once per scope.  A trained network with outlier activation channels (1e3 ... 1e5 times the rest)
+        carries correspondingly small filter entries for them in the consumer; below 2^-18 the block-scaled fp16x2 format of
+        frcnn_gemm_h2 would hold those entries (and the non-outlier activations sharing a 128-k block with the outlier) to fewer bits
+        than float32 does, so such a layer stays on the exact x3 split (lib/nets/network.py _h2_eligible)."""
+        got = self.h2_spread.get(scope)
+        if got is None:
+            w = np.abs(self.variables[scope + "/weights"].astype(np.float64))
+            if w.ndim == 2:
+                w = w[None, None]
+            if (scope + "/BatchNorm/gamma") in self.variables:
+                v = self.variables
+                w = w * np.abs(v[scope + "/BatchNorm/gamma"].astype(np.float64) / np.sqrt(v[scope + "/BatchNorm/moving_variance"].astype(np.float64) + 1e-5))
+            per_k = w.max(axis=(0, 1, 3))
+            top = float(per_k.max())
+            nz = per_k[per_k > 0]
+            got = self.h2_spread[scope] = (float(nz.min()) / top) if (top > 0 and nz.size) else 1.0
+        return got
 
     def h2_planes(self, w):
         """Pre-split fp16 planes + per-row scales of a static device filter [N, ...K] / [G, N, K] for frcnn_gemm_h2 (cfg.HIP.MFMA_H2),

@@ -71,7 +71,7 @@ class mobilenetv1(Network):
         out = self._sess.buf(self._tag + "/" + dw_scope, (N, OH, OW, C))
         self._need_f32(x)
         cout = self._depth(_SEP[i - 1][1])
-        if C % 128 == 0 and self._h2_eligible(N * OH * OW, cout, C, 1):
+        if C % 128 == 0 and self._h2_eligible(N * OH * OW, cout, C, 1, "%s/Conv2d_%d_pointwise" % (s, i)):
             # cfg.HIP.MFMA_H2: the depthwise kernel hands the pointwise convolution its operand planes; in TEST mode that is the only
             # reader, so no float32 tensor is written (TRAIN: the tape needs it -- both forms)
             yp = self._sess.h2_buf(self._tag + "/" + dw_scope, N * OH * OW, C)

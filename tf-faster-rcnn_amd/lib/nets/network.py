@@ -124,7 +124,7 @@ class Network(object):
                 sess.mark("conv:" + scope, 2 * G * T * Cout * Cin, lambda: ops.conv3x3_winograd(x, u, b, act, out=out, v_buf=v, m_buf=mm),
                           nbytes=4 * (v.numel() + u.numel() + mm.numel()))
             self._wrote(out)
-        elif plain and self._h2_eligible(M, Cout, Cin, 1) and self._h2_input(x) is not None:
+        elif plain and self._h2_eligible(M, Cout, Cin, 1, scope) and self._h2_input(x) is not None:
             # a plain GEMM with a static filter on the fp16 matrix pipe, block-scaled two-piece operands (cfg.HIP.MFMA_H2)
             xp, wp = self._h2_input(x), sess.h2_planes(w)
             yp = sess.h2_buf(self._tag + "/" + scope, M, Cout) if emit_h2 else None
@@ -162,12 +162,16 @@ class Network(object):
         return out
 
     # ---- cfg.HIP.MFMA_H2 plumbing -------------------------------------------------------------------------------------------------
-    def _h2_eligible(self, M, N, K, G):
+    H2_MIN_CHANNEL_RATIO = 2.0 ** -18      # see Session.h2_channel_spread
+
+    def _h2_eligible(self, M, N, K, G, scope=None):
         """K % 128 == 0 (scale blocks), N % 128 == 0 (tiles), enough tiles to fill the chip, and the 32-bit offset limits of
         frcnn_gemm_h2.  TEST mode: static filters, split once.  TRAIN mode (cfg.HIP.H2_TRAIN): the pointwise convolutions of the
         forward pass take the same kernel -- the solver re-splits the updated filters after every step (Session.h2_refresh), the
         float32 outputs the tape needs are always written, inputs without planes are split by a separate pass."""
         rows = G * M
+        if scope is not None and self._mode == "TEST" and self._sess.h2_channel_spread(scope) < self.H2_MIN_CHANNEL_RATIO:
+            return False              # a filter whose entries for one input channel are < 2^-18 of the rest: exact x3 split instead
         return (bool(cfg.HIP.MFMA_H2) and (self._mode == "TEST" or bool(cfg.HIP.H2_TRAIN)) and K % 128 == 0 and N % 128 == 0
                 and ((self._plan_rows(M) + 127) // 128) * (N // 128) * G >= int(cfg.HIP.H2_MIN_TILES)
                 and 4 * rows * K < (1 << 32) and 4 * N * K < (1 << 32) and M * N < (1 << 29))
@@ -229,7 +233,7 @@ class Network(object):
         mm = sess.buf(self._tag + "/wino_m", (G, T, Cout))
         out = sess.buf(self._tag + "/" + scope, (N, H, W, Cout))
         flops = 2 * G * T * Cout * Cin
-        if self._h2_eligible(T, Cout, Cin, G):
+        if self._h2_eligible(T, Cout, Cin, G, scope):
             vp, wp = sess.h2_buf(self._tag + "/wino_v", G * T, Cin), sess.h2_planes(u)
             sess.mark("op:wino_in", 0, lambda: ops.winograd_input_transform_h2(x, vp, m), nbytes=4 * (x.numel() + G * T * Cin))
             tcfg = int(cfg.HIP.H2_TILE_CFG)

@@ -91,18 +91,19 @@ class resnetv1(Network):
             return self._conv1x1_mean(r, prefix + "/conv3", mean_rows, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut)
         N, H, W, _ = r.shape
         M3 = N * ops.conv_out_size(H, 3, stride, pad[0], pad[1]) * ops.conv_out_size(W, 3, stride, pad[2], pad[3])
-        c3_h2 = res_stride == 1 and self._h2_eligible(M3, depth, base, 1)
+        c3_h2 = res_stride == 1 and self._h2_eligible(M3, depth, base, 1, prefix + "/conv3")
         r = self._conv(r, prefix + "/conv2", 3, stride, pad, act=ACT_RELU, bn_eps=BN_EPS, emit_h2=c3_h2, want_f32=not c3_h2)
         return self._conv(r, prefix + "/conv3", 1, 1, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut, res_stride=res_stride,
                           emit_h2=emit_out, want_f32=f32_out)
 
-    def _trunk_planes_only(self, rows, base, next_stride):
+    def _trunk_planes_only(self, rows, base, next_stride, next_prefix=None):
         """cfg.HIP.H2_TRUNK_PLANES: may a unit hand its output to the NEXT unit of the same block (identity shortcut) as operand
         planes only?  Yes when that unit's conv1 reads planes (h2-eligible), its conv3 takes the residual from planes (h2-eligible,
         stride 1) -- then nothing reads the float32 tensor.  The planes carry >= 22 significant bits (csrc/gemm_h2.hip)."""
         depth = 4 * base
-        return (bool(cfg.HIP.H2_TRUNK_PLANES) and not cfg.HIP.FUSE_TAIL_MEAN and next_stride == 1 and self._h2_eligible(rows, base, depth, 1)
-                and self._h2_eligible(rows, depth, base, 1))
+        return (bool(cfg.HIP.H2_TRUNK_PLANES) and not cfg.HIP.FUSE_TAIL_MEAN and next_stride == 1
+                and self._h2_eligible(rows, base, depth, 1, None if next_prefix is None else next_prefix + "/conv1")
+                and self._h2_eligible(rows, depth, base, 1, None if next_prefix is None else next_prefix + "/conv3"))
 
     def _run_blocks(self, x, blocks, emit_last=True):
         for bi, (name, base, n_units, stride) in enumerate(blocks):
@@ -110,7 +111,8 @@ class resnetv1(Network):
                 s_u = stride if u == n_units else 1
                 N, H, W, _ = x.shape
                 rows = N * ops.conv_out_size(H, 3, s_u, 1, 1) * ops.conv_out_size(W, 3, s_u, 1, 1) if s_u > 1 else N * H * W
-                planes_only = u < n_units and self._trunk_planes_only(rows, base, stride if u + 1 == n_units else 1)
+                planes_only = u < n_units and self._trunk_planes_only(rows, base, stride if u + 1 == n_units else 1,
+                                                                       "%s/%s/unit_%d/bottleneck_v1" % (self._scope, name, u + 1))
                 x = self._bottleneck(x, "%s/%s/unit_%d/bottleneck_v1" % (self._scope, name, u), base, s_u,
                                      emit_out=emit_last or u < n_units or bi + 1 < len(blocks), f32_out=not planes_only)
         return x
@@ -162,15 +164,17 @@ class resnetv1(Network):
         c1_out = sess.buf(self._tag + "/" + prefix + "/conv1_crop", (R, P, P, c1_map.shape[-1]))
         shortcut = self._crop_images(sc_map, rois, sc_out, bias=b_sc, act=ACT_NONE)
         r = self._crop_images(c1_map, rois, c1_out, bias=b_c1, act=ACT_RELU)
-        c3_h2 = self._h2_eligible(R * P * P, 4 * base, base, 1)
+        c3_h2 = self._h2_eligible(R * P * P, 4 * base, base, 1, prefix + "/conv3")
         r = self._conv(r, prefix + "/conv2", 3, 1, (1, 1, 1, 1), act=ACT_RELU, bn_eps=BN_EPS, emit_h2=c3_h2, want_f32=not c3_h2)
         x = self._conv(r, prefix + "/conv3", 1, 1, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut, res_stride=1, emit_h2=n_units >= 2,
-                       want_f32=not (n_units >= 2 and self._trunk_planes_only(R * P * P, base, stride if n_units == 2 else 1)))
+                       want_f32=not (n_units >= 2 and self._trunk_planes_only(R * P * P, base, stride if n_units == 2 else 1,
+                                                                              "%s/%s/unit_2/bottleneck_v1" % (self._scope, name))))
         fused = bool(cfg.HIP.FUSE_TAIL_MEAN) and stride == 1 and n_units >= 2
         for u in range(2, n_units + 1):
             x = self._bottleneck(x, "%s/%s/unit_%d/bottleneck_v1" % (self._scope, name, u), base, stride if u == n_units else 1,
                                  mean_rows=P * P if (fused and u == n_units) else 0, emit_out=u < n_units,
-                                 f32_out=not (u < n_units and self._trunk_planes_only(R * P * P, base, stride if u + 1 == n_units else 1)))
+                                 f32_out=not (u < n_units and self._trunk_planes_only(R * P * P, base, stride if u + 1 == n_units else 1,
+                                                                                      "%s/%s/unit_%d/bottleneck_v1" % (self._scope, name, u + 1))))
         if fused:
             return x                                          # [R, 2048]: the mean came out of the last conv3's epilogue
         out = sess.buf(self._tag + "/fc7", (x.shape[0], x.shape[-1]))
