@@ -273,7 +273,6 @@ def train_bench(args, c, dev, world, rank, dist):
     t0 = time.perf_counter()
     sw.train_model(args.steps, verbose=False)
     sess.host_enqueue_s = time.perf_counter() - t0          # the host's share: launches enqueued, GPU not yet waited for
-    sess.train_graph_stats = dict(sw.state.graph_stats)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -445,18 +444,14 @@ def main():
                          "`f32_mfma_variant`).  x3: MFMA_H2 off.  f32: every product on v_mfma_f32_32x32x2_f32")
     ap.add_argument("--h2-lazy-split", type=int, default=-1, help="cfg.HIP.H2_LAZY_SPLIT (A/B): 1 = split un-planed inputs of eligible layers, 0 = such layers stay on x3 / f32")
     ap.add_argument("--h2-min-tiles", type=int, default=-1, help="cfg.HIP.H2_MIN_TILES (A/B)")
-    ap.add_argument("--train-graph", action="store_true", help="cfg.HIP.TRAIN_GRAPH True: the reverse sweep replayed from a hipGraph (c5 A/B)")
     ap.add_argument("--no-wgrad-tn", action="store_true", help="cfg.HIP.WGRAD_TN False: filter gradients by transposes + the forward GEMM kernel (c5 A/B)")
     ap.add_argument("--no-wgrad-h2", action="store_true", help="cfg.HIP.WGRAD_H2 False: filter gradients on the f32 matrix pipe (c5 A/B)")
     ap.add_argument("--no-prep-stream", action="store_true", help="cfg.HIP.PREP_STREAM False: gradient filters prepared inside the sweep (c5 A/B)")
-    ap.add_argument("--no-h2-train-wino", action="store_true", help="cfg.HIP.H2_TRAIN_WINO False: TRAIN-mode Winograd products on the f32 MFMA (c5 A/B)")
     ap.add_argument("--wgrad-plan", default=None, help="tile,workgroups override of frcnn_conv2d_wgrad_h2's slicing plan (c5 A/B), e.g. 0,256")
     ap.add_argument("--splitk-target", type=int, default=0, help="frcnn_set_tuning(7, N): workgroups a split-K convolution launch aims at (A/B; default 640)")
     ap.add_argument("--wgrad-streams", type=int, default=-1, help="cfg.HIP.WGRAD_STREAM: side streams for the filter gradients (c5 A/B; 0 = none)")
     ap.add_argument("--h2-cfg", type=int, default=-1, help="cfg.HIP.H2_TILE_CFG (A/B): -1 = tile shape by launch size, else one frcnn_gemm_h2 configuration id")
     ap.add_argument("--h2-trunk-planes", type=int, default=-1, help="cfg.HIP.H2_TRUNK_PLANES (A/B): 0 keeps the residual trunk in float32")
-    ap.add_argument("--x3-terms", type=int, choices=[6, 9], default=6, help="x3 launches: 6 = the three cross terms below 2^-24 are dropped "
-                    "(default), 9 = all nine cross terms, every f32 product exact (cfg.HIP.X3_TERMS)")
     ap.add_argument("--x3-config", type=int, default=-1, help="A/B knob: cfg.HIP.X3_TILE_CFG, the frcnn_gemm_x3 tile configuration (-1 = by shape)")
     ap.add_argument("--no-f32-variant", action="store_true", help="skip the extra timed regions (x3-only / all-f32-MFMA variants)")
     ap.add_argument("--winograd-f2", default=None, help="comma list of scope tokens run as F(2x2,3x3) instead of F(4x4,3x3) (default: cfg.HIP)")
@@ -465,7 +460,6 @@ def main():
     ap.add_argument("--stagger", type=int, default=0, help="A/B knob: frcnn_set_tuning key 5 (second-slot workgroups of the big GEMM launches "
                     "start n/8 of a tile late)")
     ap.add_argument("--crop-slabs", type=int, default=-1, help="A/B knob: channel-slab count of the crop kernels (frcnn_detect_set_tuning key 4)")
-    ap.add_argument("--overlap", action="store_true", help="A/B knob: tail-entry 1x1 convs on a graph branch beside the proposal layer (cfg.HIP.OVERLAP_TAIL_ENTRY)")
     ap.add_argument("--fused-mean", action="store_true", help="A/B knob: the tail's last conv3 + reduce_mean in one kernel (cfg.HIP.FUSE_TAIL_MEAN)")
     ap.add_argument("--dp-constrained", action="store_true", help="c5: ONE replica under the data-parallel rules -- at most one filter-gradient side "
                     "stream, the bucketed all-reduce issued from inside the reverse sweep over a one-rank RCCL group, no captured sweep: the step "
@@ -508,16 +502,12 @@ def main():
     cfg.HIP.MFMA_X3 = args.mfma in ("h2", "x3")
     if args.h2_lazy_split >= 0:
         cfg.HIP.H2_LAZY_SPLIT = bool(args.h2_lazy_split)
-    if args.train_graph:
-        cfg.HIP.TRAIN_GRAPH = True
     if args.no_wgrad_tn:
         cfg.HIP.WGRAD_TN = False
     if args.no_wgrad_h2:
         cfg.HIP.WGRAD_H2 = False
     if args.no_prep_stream:
         cfg.HIP.PREP_STREAM = False
-    if args.no_h2_train_wino:
-        cfg.HIP.H2_TRAIN_WINO = False
     if args.wgrad_plan:
         from frcnn_hip import lib as _lib
         _lib().frcnn_conv2d_wgrad_h2_set_plan(*[int(v) for v in args.wgrad_plan.split(",")])
@@ -529,7 +519,7 @@ def main():
     if args.h2_min_tiles >= 0:
         cfg.HIP.H2_MIN_TILES = args.h2_min_tiles
     cfg.HIP.H2_TILE_CFG = args.h2_cfg
-    cfg.HIP.X3_TILE_CFG, cfg.HIP.X3_TERMS = args.x3_config, args.x3_terms
+    cfg.HIP.X3_TILE_CFG = args.x3_config
     if args.h2_trunk_planes >= 0:
         cfg.HIP.H2_TRUNK_PLANES = bool(args.h2_trunk_planes)
     if args.winograd_f2 is not None:
@@ -542,8 +532,6 @@ def main():
         frcnn_hip.lib().frcnn_set_tuning(6, 0)
     if args.crop_slabs > 0:
         frcnn_hip.lib().frcnn_detect_set_tuning(4, args.crop_slabs)
-    if args.overlap:
-        cfg.HIP.OVERLAP_TAIL_ENTRY = True
     if args.fused_mean:
         cfg.HIP.FUSE_TAIL_MEAN = True
     cfg.USE_GPU_NMS = False           # the reference's CPU/Cython suppression rule (cpu_nms.pyx:65): the path BASELINE.json pins
@@ -570,9 +558,8 @@ def main():
             value = world * args.steps / elapsed
             out = dict(common, value=round(value, 3), ms_per_step=round(1000.0 * elapsed / args.steps, 4),
                        config={"workload": c["label"] + "; one image per GPU per step", "parallelism": "dp%d (RCCL gradient all-reduce)" % world,
-                               "launch": "forward + solver eager, reverse sweep %s, filter gradients on %d side stream(s)" % (
-                                   "replayed from a hipGraph %s" % sess.train_graph_stats if sess.train_graph_stats["replayed"] else "eager",
-                                   min(int(cfg.HIP.WGRAD_STREAM), 1 if world > 1 else 99)),
+                               "launch": "eager (forward, reverse sweep, solver), filter gradients on %d side stream(s)" % (
+                                   min(int(cfg.HIP.WGRAD_STREAM), 1 if (world > 1 or args.dp_constrained) else 99)),
                                "host_enqueue_ms_per_step": round(1000.0 * sess.host_enqueue_s / args.steps, 3),
                                "gflop_per_step_reference_graph": c["gflop_ref"]},
                        roofline=train_roofline(sess.step_flops_by_pipe, elapsed / args.steps, c["gflop_ref"]))

@@ -2,6 +2,8 @@
 ping-pong schedule (cfg 21) on the GEMM shapes of the path: time (interleaved A/B in one process), f32-equivalent TFLOP/s, bit equality."""
 import sys, os
 sys.path[:0] = [os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tf-faster-rcnn_amd")]
+sys.path[:0] = [os.path.dirname(os.path.abspath(__file__))]
+import ablation_lib; ablation_lib.use()
 import numpy as np, torch
 from frcnn_hip import ops
 dev = torch.device("cuda:0")

@@ -34,7 +34,7 @@ def test_metric_configs_and_peaks_match_baseline():
 
 def test_driver_flags_and_variants_parse():
     src = open(os.path.join(ROOT, "bench.py")).read()
-    for flag in ("--gpus", "--steps", "--warmup", "--config", "--mfma", "--x3-terms", "--no-f32-variant", "--no-cpu-baseline", "--layer-report"):
+    for flag in ("--gpus", "--steps", "--warmup", "--config", "--mfma", "--dp-constrained", "--no-other-configs", "--no-f32-variant", "--no-cpu-baseline", "--layer-report"):
         assert '"%s"' % flag in src, flag
     # the shipped configuration and its x3-only / all-f32-MFMA twins are all reported by the default invocation
     assert 'default="h2"' in src and '"x3_variant"' in src and '"f32_mfma_variant"' in src and '"cpu_baseline"' in src and '"roofline"' in src

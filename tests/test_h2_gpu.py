@@ -68,7 +68,7 @@ H2_CASES = [
 ]
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 8, 9, 12, 13, 14, 15, 18, 21, 24])
+@pytest.mark.parametrize("cfg", [9, 12, 21, -1])
 @pytest.mark.parametrize("case", H2_CASES, ids=[str(i) for i in range(len(H2_CASES))])
 def test_gemm_h2_is_f32_class(dev, case, cfg):
     from frcnn_hip import ops
@@ -238,9 +238,9 @@ def test_depthwise_conv_emits_the_planes_of_its_f32_result(dev, N, H, W, C, stri
 
 @pytest.mark.parametrize("shape", [(1, 256 * 300 + 40, 512, 512, True), (1, 58800, 512, 2048, False), (121, 1200, 512, 512, False),
                                    (1, 9576, 1024, 256, True), (3, 300, 128, 128, False)], ids=["many_tiles", "b4c1", "w7", "b3c3", "tiny"])
-@pytest.mark.parametrize("pp", [21, 24])
+@pytest.mark.parametrize("pp", [21, 12])
 def test_gemm_h2_ping_pong_is_bit_identical_to_the_one_barrier_schedule(dev, shape, pp):
-    """cfg 21 / 24 (256 x 128 / 128 x 128 tiles, two wave groups a segment apart, 3-slot ring) multiply and fold in the same order as cfg 9: the f32
+    """cfg 21 (256 x 128 tiles, two wave groups a segment apart, 3-slot ring) and cfg 12 (64-row tiles) multiply and fold in the same order as cfg 9: the f32
     result, the emitted planes and the block scales must be the same BITS, on every one of several launches (a schedule with a race
     differs from launch to launch), with several tiles per resident workgroup and M tails."""
     from frcnn_hip import ops

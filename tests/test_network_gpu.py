@@ -407,14 +407,13 @@ def test_tools_test_net_on_a_voc_devkit_and_checkpoint(dev, tmp_path, capsys):
     assert "Applying NMS to all detections" in capsys.readouterr().out
 
 
-def test_optional_fused_tail_mean_and_graph_branch_match_the_default_path(small_net):
-    """cfg.HIP.FUSE_TAIL_MEAN (last conv3 + reduce_mean in one kernel) and cfg.HIP.OVERLAP_TAIL_ENTRY (tail-entry 1x1 convs on a
-    graph branch beside the proposal layer) are off by default (config.py says why); when switched on they must give the
-    default path's tensors up to f32 summation order."""
+def test_optional_fused_tail_mean_matches_the_default_path(small_net):
+    """cfg.HIP.FUSE_TAIL_MEAN (last conv3 + reduce_mean in one kernel) is off by default (config.py says why); when switched on it must
+    give the default path's tensors up to f32 summation order."""
     from model.config import cfg
     sess, net, image, im_info = small_net
     base = [a.copy() for a in net.test_image(sess, image, im_info)]
-    for key in ("FUSE_TAIL_MEAN", "OVERLAP_TAIL_ENTRY"):
+    for key in ("FUSE_TAIL_MEAN",):
         old = cfg.HIP[key]
         try:
             cfg.HIP[key] = True

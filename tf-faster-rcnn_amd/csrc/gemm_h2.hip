@@ -854,21 +854,22 @@ extern "C" int frcnn_gemm_h2(const void* x_planes_d, const float* x_inv_d, const
     cfg = pp ? 21 : tiny ? 12 : 9;       // 9: 128 x 128 tiles, two workgroups per CU, one barrier per slab (profiles/r03_l_ab.txt)
   }
   switch (cfg) {
-    case 0: return launch_h2<128, 128, 64, 64, 2>(p, st);        // 67 KB: 2 workgroups / CU
-    case 1: return launch_h2<128, 128, 64, 64, 3>(p, st);        // 100 KB: 1 workgroup / CU, 2 slabs in flight
-    case 2: return launch_h2<128, 128, 64, 64, 4>(p, st);        // 134 KB: 1 workgroup / CU, 3 slabs in flight (launches of <= one tile per CU)
-    case 3: return launch_h2<256, 128, 64, 64, 2>(p, st);        // 8 waves, 100 KB
-    case 8: return launch_h2<128, 128, 64, 64, 2, 2, 1>(p, st);  // cfg 0 with the loads issued in two halves
-    case 9: return launch_h2<128, 128, 64, 64, 2, 2, 2>(p, st);  // cfg 0 with the scales sent once per 128-k block (the default)
-    case 12: return launch_h2<64, 128, 32, 64, 2>(p, st);        // 64-row tiles, 4 waves of 32 x 64, 51 KB: 3 workgroups / CU (faster alone on
-                                                                  // under-filled launches, slower in the pipeline: profiles/r03_l_ab.txt)
-    case 13: return launch_h2<64, 128, 32, 64, 3>(p, st);        // 64-row tiles, 3-slot ring (77 KB: 2 workgroups / CU, 2 slabs in flight each)
-    case 15: return launch_h2<64, 128, 32, 64, 4>(p, st);        // ... 4-slot ring (102 KB: 1 workgroup / CU, 3 slabs in flight)
-    case 14: return launch_h2<128, 128, 64, 64, 2, 2, 4>(p, st);  // cfg 0 with the loads spread between the MFMAs (measured slower: r03_k)
-    case 18: return launch_h2<128, 128, 64, 64, 2, 2, 10>(p, st); // cfg 9 with round 2's (r >> 1) & 3 swizzle (two-way LDS bank conflicts)
-    case 24: return launch_h2<128, 128, 32, 64, 3, 2, 34>(p, st); // ping-pong on 128 x 128 tiles (8 waves of 32 x 64): launches of about one tile per CU
+    case 9: return launch_h2<128, 128, 64, 64, 2, 2, 2>(p, st);  // 67 KB: 2 workgroups / CU, one barrier per slab, scales once per 128-k block
+    case 12: return launch_h2<64, 128, 32, 64, 2>(p, st);        // 64-row tiles, 4 waves of 32 x 64, 51 KB: 3 workgroups / CU (single-image launches)
     case 21: return launch_h2<256, 128, 64, 64, 3, 2, 34>(p, st); // ping-pong: 256 x 128, 8 waves in two groups a segment apart, 3-slot ring
 #ifdef FRCNN_ABLATION
+    // measurement builds only (scratch/ablation_lib.py): the configurations the sweeps under profiles/r03_*, r04_* compare.  All of
+    // them multiply and fold in the same order as the three above (bit-identical results; measured, not shipped).
+    case 0: return launch_h2<128, 128, 64, 64, 2>(p, st);        // cfg 9 with the block scales in every stage
+    case 1: return launch_h2<128, 128, 64, 64, 3>(p, st);        // 100 KB: 1 workgroup / CU, 2 slabs in flight
+    case 2: return launch_h2<128, 128, 64, 64, 4>(p, st);        // 134 KB: 3 slabs in flight
+    case 3: return launch_h2<256, 128, 64, 64, 2>(p, st);        // 8 waves in lockstep, 100 KB
+    case 8: return launch_h2<128, 128, 64, 64, 2, 2, 1>(p, st);  // loads issued in two halves
+    case 13: return launch_h2<64, 128, 32, 64, 3>(p, st);        // 64-row tiles, 3-slot ring
+    case 15: return launch_h2<64, 128, 32, 64, 4>(p, st);        // ... 4-slot ring
+    case 14: return launch_h2<128, 128, 64, 64, 2, 2, 4>(p, st); // loads spread between the MFMAs (spills)
+    case 18: return launch_h2<128, 128, 64, 64, 2, 2, 10>(p, st); // round 2's (r >> 1) & 3 swizzle (two-way LDS bank conflicts)
+    case 24: return launch_h2<128, 128, 32, 64, 3, 2, 34>(p, st); // ping-pong on 128 x 128 tiles (8 waves of 32 x 64)
     case 22: return launch_h2<256, 128, 64, 64, 3, 2, 34 + 64>(p, st);   // ping-pong with cache-resident X (wrong results by construction)
     case 23: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 64>(p, st);    // cfg 9 with cache-resident X
     case 20: return launch_h2<128, 128, 64, 64, 2, 2, 18>(p, st); // cfg 9's byte count as full-line loads (wrong results by construction)

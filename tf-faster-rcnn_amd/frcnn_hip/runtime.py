@@ -194,7 +194,6 @@ class Session(VariableStore):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.stream = torch.cuda.Stream(device=self.device)
         self.buffers = {}
-        self._side_streams = {}
         self.profile = None                             # list of (tag, flops, ev0, ev1) when profiling
         self.flops_last_forward = 0
         self.flops_by_pipe = None                       # dict while somebody wants the split (Session.mark)
@@ -253,14 +252,6 @@ class Session(VariableStore):
         self.packed[key] = res
         return res
 
-    def side_stream(self, tag):
-        """One extra stream per network tag for fork / join branches inside a launch chain (Network._fork)."""
-        st = self._side_streams.get(tag)
-        if st is None:
-            st = self._side_streams[tag] = torch.cuda.Stream(device=self.device)
-        return st
-
-    # ---- static activation buffers ----------------------------------------------------------------
     def buf(self, name, shape, dtype=torch.float32, zero=False):
         key = (name, tuple(shape), dtype)
         t = self.buffers.get(key)

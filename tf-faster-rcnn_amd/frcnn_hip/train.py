@@ -69,11 +69,8 @@ class TrainState(object):
         self.params = {}
         self.flat = None
         self.reg_scopes = []
-        self.graph, self.graph_cap = False, 32                  # backward_auto: captured reverse sweeps, keyed by the tape's tensors
-        self._bwd_graphs, self._bwd_seen = {}, {}
         self._wgrad_events = None
         self.prep_stream = True                                 # sess.prepared: weight-only launches re-run by the solver on a side stream
-        self.graph_stats = dict(eager=0, captured=0, replayed=0)
 
     def build(self):
         """Call after one TRAIN forward (which packs every filter and fills net._tape)."""
@@ -124,52 +121,6 @@ class TrainState(object):
         led = getattr(self, "flop_ledger", None)
         if led is not None:
             led[pipe] = led.get(pipe, 0) + int(flops)
-
-    def backward_auto(self, seeds):
-        """backward() through a captured hipGraph (cfg.HIP.TRAIN_GRAPH).  The reverse sweep is ~1000 launches whose every argument is
-        a function of the tape -- static activation / gradient buffers and shapes -- so the SECOND time a tape with the same tensors comes
-        by (same image shape), the sweep is captured (side streams included) and from then on replayed with one host call; at one image
-        per step the host's launch rate is what bounds the eager sweep.  Only the four loss gradients are fresh tensors every step:
-        they are copied into static seed buffers first.  Not captured: data-parallel runs (the bucketed all-reduce is issued from
-        inside the sweep), tapes with dropout (the mask seed is a launch argument), more than `graph_cap` distinct tapes."""
-        net = self.net
-        if (not getattr(self, "graph", False) or self.data_parallel() or len(seeds) == 0
-                or any(rec["kind"] == "dropout" for rec in net._tape)):
-            self.graph_stats["eager"] += 1
-            return self.backward(seeds)
-        key = [int(getattr(self, "wgrad_stream", 0)), getattr(self, "winograd", None), getattr(self, "h2_train", None)]
-        for t, g in seeds:
-            key.append((t.data_ptr(), tuple(g.shape)))
-        for rec in net._tape:
-            y = rec["y"]
-            key.append((rec["kind"], y.data_ptr(), tuple(y.shape), rec["x"].data_ptr() if "x" in rec else rec["feat"].data_ptr(),
-                        rec["rois"].data_ptr() if "rois" in rec else 0))
-        key = tuple(key)
-        ent = self._bwd_graphs.get(key)
-        if ent is None:
-            seen = self._bwd_seen.get(key, 0)
-            self._bwd_seen[key] = seen + 1
-            if seen == 0 or len(self._bwd_graphs) >= self.graph_cap:
-                if len(self._bwd_seen) > 4096:
-                    self._bwd_seen.clear()
-                self.graph_stats["eager"] += 1
-                return self.backward(seeds)
-            static = [(t, torch.empty_like(g)) for t, g in seeds]
-            for (_, sg), (_, g) in zip(static, seeds):
-                sg.copy_(g)
-            self.backward(static)                       # this step's sweep (and every buffer the capture will name exists afterwards)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self.backward(static)                   # recorded, not executed
-            self._bwd_graphs[key] = (graph, static)
-            self.graph_stats["captured"] += 1
-            return None
-        graph, static = ent
-        for (_, sg), (_, g) in zip(static, seeds):
-            sg.copy_(g)
-        graph.replay()
-        self.graph_stats["replayed"] += 1
-        return None
 
     def backward(self, seeds):
         """seeds: list of (tensor, grad) for network outputs.  Fills every Param.grad_*."""
@@ -359,18 +310,9 @@ class TrainState(object):
                     T = ops.winograd_tiles(N, OH, OW, m)
                     u = prepared(("wino_u", sc, m), lambda wf=wf, m=m, sc=sc, G=G, Cin=Cin, Cout=Cout: ops.winograd_filter_transform_device(
                         wf, m, True, out=sess.buf("bwd/wino_u/" + sc, (G, Cin, Cout))))
-                    if (getattr(self, "h2_train", None) is not None and getattr(self, "h2_train_wino", False) and Cout % 128 == 0 and Cin % 128 == 0
-                            and ((T + 127) // 128) * (Cin // 128) * G >= self.h2_train and 4 * G * T * Cout < (1 << 32) and T * Cin < (1 << 29)):
-                        # cfg.HIP.H2_TRAIN: the products of the transformed gradient in frcnn_gemm_h2 (K = Cout, N = Cin)
-                        up = prepared(("wino_u_h2", sc, m), lambda u=u, sc=sc, G=G, Cin=Cin, Cout=Cout: ops.h2_pack_w(
-                            u, out=sess.buf_pair("bwd/wino_u_h2/" + sc, G * Cin, Cout)))
-                        ops.conv3x3_winograd(gy, u, None, ACT_NONE, out=gx, m_buf=sess.buf("bwd/wino_m", (G, T, Cin)), u_planes=up,
-                                             v_planes=sess.h2_buf("bwd/wino_v", G * T, Cout))
-                        self.count_flops("h2", 2 * G * T * Cin * Cout)
-                    else:
-                        ops.conv3x3_winograd(gy, u, None, ACT_NONE, out=gx, v_buf=sess.buf("bwd/wino_v", (G, T, Cout)),
-                                             m_buf=sess.buf("bwd/wino_m", (G, T, Cin)))
-                        self.count_flops("f32", 2 * G * T * Cin * Cout)
+                    ops.conv3x3_winograd(gy, u, None, ACT_NONE, out=gx, v_buf=sess.buf("bwd/wino_v", (G, T, Cout)),
+                                         m_buf=sess.buf("bwd/wino_m", (G, T, Cin)))
+                    self.count_flops("f32", 2 * G * T * Cin * Cout)
                 elif stride == 1 and Cout % 32 == 0:
                     wd = prepared(("wflip", sc), lambda wf=wf, sc=sc, k=k, Cout=Cout: ops.flip_transpose_filter(
                         wf, out=sess.buf("bwd/wflip/" + sc, (wf.shape[3], k, k, Cout))))

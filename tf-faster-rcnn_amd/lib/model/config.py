@@ -73,8 +73,6 @@ __C = AttrDict(
     # large common mean, are where the F(4x4,3x3) transforms lose digits (full-size head error 1.8x the float32 control with F(4,3)
     # everywhere, 1.0x with this policy, for 1.2 % of throughput); F(4x4,3x3) in block3 / RPN / block4 (7x7 scheme).
     # WINOGRAD_DIRECT_SCOPES: scopes containing one of these tokens keep the direct implicit-GEMM kernel.
-    # OVERLAP_TAIL_ENTRY: the tail-entry 1x1 convolutions run on a side stream / graph branch beside RPN + proposal layer.  Measured
-    # (profiles/r02_c_sweep.txt): slower -- 315 vs 322 images/s in the pipeline, 5.11 vs 4.99 ms single image -- so it stays off.
     # FUSE_TAIL_MEAN: TEST mode, the tail's last 1x1 convolution + reduce_mean in one kernel (frcnn_conv1x1_mean): +0.7 % images/s
     # (profiles/r02_c_sweep.txt), but the 49 rows of a RoI are then added in an order that depends on where the RoI falls inside the
     # 128-row GEMM tiles, i.e. on its slot in the batch: fc7 moves by an ulp between slots and tie-breaks between equal scores can
@@ -105,20 +103,16 @@ __C = AttrDict(
     # WGRAD_H2 (with MFMA_H2 and H2_TRAIN): those gradients on the fp16 matrix pipe, operands split in registers (csrc/wgrad_h2.hip).
     # PREP_STREAM: the weight-only launches of the data-gradient chain (flipped / transposed filters, their h2 split, Winograd transforms of
     # the gradient filters) are re-run by the solver right after the update, on their own stream beside the next forward pass.
-    # TRAIN_GRAPH: the reverse sweep of a training step (~1000 launches, every argument a function of the tape) is captured into a
-    # hipGraph the second time the same tape comes by (= the same image shape) and replayed afterwards (frcnn_hip/train.py backward_auto);
-    # single-process runs without dropout only.  OFF: the sweep is GPU-bound, not launch-bound (one stream: 27.0 ms / step replayed vs
-    # 27.1 eager), and a replayed graph runs its side-stream branches with less overlap than the eager streams do (25.5 vs 23.8 ms,
-    # profiles/r03_ab_c5_streams_graph.txt).
-    # H2_TRAIN_WINO: with H2_TRAIN, also the (m+2)^2 products of the TRAIN-mode Winograd convolutions and of their data gradients (the RoI
-    # tail's 3x3 layers and the RPN convolution qualify at 600x1000).  OFF: measured +-0 (20.08-20.22 vs 20.06-20.23 ms / step, three pairs).
-    # X3_TILE_CFG / X3_TERMS: frcnn_gemm_x3's per-call tile configuration (-1 = by shape) and 6 / 9 cross terms (A/B runs).
+    # X3_TILE_CFG: frcnn_gemm_x3's per-call tile configuration (-1 = by shape; A/B runs).
+    # Round-3 switches that measured no gain were removed in round 4 (OVERLAP_TAIL_ENTRY, TRAIN_GRAPH, H2_TRAIN_WINO, X3_TERMS = 9): the
+    # code is kept as scratch/r04_pruned_switches.patch (git apply -R restores it), the measurements in profiles/r02_c_sweep.txt,
+    # r03_ab_c5_streams_graph.txt, r02_r_x3_9terms.txt.
     # H2_TILE_CFG: -1 = tile shape by launch size (csrc/gemm_h2.hip), else a frcnn_gemm_h2 configuration id for every launch (A/B runs).
     HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=64, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=("block1", "block2"), WINOGRAD_DIRECT_SCOPES=(),
              WINOGRAD_TRAIN=True,
-             WINOGRAD_7X7=True, FUSE_TAIL_MEAN=False, OVERLAP_TAIL_ENTRY=False, MFMA_X3=True,
+             WINOGRAD_7X7=True, FUSE_TAIL_MEAN=False, MFMA_X3=True,
              MFMA_H2=True, H2_LAZY_SPLIT=True, H2_MIN_TILES=150, H2_TRUNK_PLANES=False, H2_TILE_CFG=-1,
-             X3_TILE_CFG=-1, X3_TERMS=6, H2_TRAIN=True, WGRAD_STREAM=2, TRAIN_GRAPH=False, WGRAD_TN=True, WGRAD_H2=True, PREP_STREAM=True, H2_TRAIN_WINO=False))
+             X3_TILE_CFG=-1, H2_TRAIN=True, WGRAD_STREAM=2, WGRAD_TN=True, WGRAD_H2=True, PREP_STREAM=True))
 __C.DATA_DIR = osp.abspath(osp.join(__C.ROOT_DIR, 'data'))
 cfg = __C
 

@@ -111,18 +111,9 @@ class Network(object):
             u = sess.prepared.get(("fwd", "wino_u", self._tag, scope, m), lambda: ops.winograd_filter_transform_device(
                 w, m, False, out=sess.buf(self._tag + "/wino_u/" + scope, (G, Cout, Cin))))
             mm = sess.buf(self._tag + "/wino_m", (G, T, Cout))
-            if cfg.HIP.H2_TRAIN_WINO and self._h2_eligible(T, Cout, Cin, G):
-                # cfg.HIP.H2_TRAIN: the (m+2)^2 products in frcnn_gemm_h2 -- the split of U is one more weight-only launch (prepared)
-                up = sess.prepared.get(("fwd", "wino_u_h2", self._tag, scope, m), lambda: ops.h2_pack_w(
-                    u, out=sess.buf_pair(self._tag + "/wino_u_h2/" + scope, G * Cout, Cin)))
-                vp = sess.h2_buf(self._tag + "/wino_v", G * T, Cin)
-                sess.mark("conv:h2:" + scope, 2 * G * T * Cout * Cin,
-                          lambda: ops.conv3x3_winograd(x, u, b, act, out=out, m_buf=mm, u_planes=up, v_planes=vp),
-                          nbytes=4 * (G * T * Cin + u.numel() + mm.numel()))
-            else:
-                v = sess.buf(self._tag + "/wino_v", (G, T, Cin))
-                sess.mark("conv:" + scope, 2 * G * T * Cout * Cin, lambda: ops.conv3x3_winograd(x, u, b, act, out=out, v_buf=v, m_buf=mm),
-                          nbytes=4 * (v.numel() + u.numel() + mm.numel()))
+            v = sess.buf(self._tag + "/wino_v", (G, T, Cin))
+            sess.mark("conv:" + scope, 2 * G * T * Cout * Cin, lambda: ops.conv3x3_winograd(x, u, b, act, out=out, v_buf=v, m_buf=mm),
+                      nbytes=4 * (v.numel() + u.numel() + mm.numel()))
             self._wrote(out)
         elif plain and self._h2_eligible(M, Cout, Cin, 1, scope) and self._h2_input(x) is not None:
             # a plain GEMM with a static filter on the fp16 matrix pipe, block-scaled two-piece operands (cfg.HIP.MFMA_H2)
@@ -142,8 +133,8 @@ class Network(object):
             # ... on the bf16 matrix pipe with exact bf16x3 operand splits (cfg.HIP.MFMA_X3)
             self._need_f32(x), self._need_f32(residual)
             planes = sess.x3_planes(w)
-            xc, xt = int(cfg.HIP.X3_TILE_CFG), int(cfg.HIP.X3_TERMS)
-            sess.mark("conv:x3:" + scope, flops, lambda: ops.gemm_x3(x, planes, 1, M, Cout, Cin, b, residual, act, out=out, cfg=xc, terms=xt),
+            xc = int(cfg.HIP.X3_TILE_CFG)
+            sess.mark("conv:x3:" + scope, flops, lambda: ops.gemm_x3(x, planes, 1, M, Cout, Cin, b, residual, act, out=out, cfg=xc),
                       nbytes=4 * (x.numel() + out.numel() + (out.numel() if residual is not None else 0)) + 6 * w.numel())
             self._wrote(out)
         else:
@@ -244,8 +235,8 @@ class Network(object):
             sess.mark("op:wino_in", 0, lambda: ops.winograd_input_transform(x, v, m), nbytes=4 * (x.numel() + v.numel()))
             if self._x3_eligible(T, Cout, Cin, G):
                 planes = sess.x3_planes(u)
-                xc, xt = int(cfg.HIP.X3_TILE_CFG), int(cfg.HIP.X3_TERMS)
-                sess.mark("conv:x3:" + scope, flops, lambda: ops.gemm_x3(v, planes, G, T, Cout, Cin, out=mm, cfg=xc, terms=xt),
+                xc = int(cfg.HIP.X3_TILE_CFG)
+                sess.mark("conv:x3:" + scope, flops, lambda: ops.gemm_x3(v, planes, G, T, Cout, Cin, out=mm, cfg=xc),
                           nbytes=4 * (v.numel() + mm.numel()) + 6 * u.numel())
             else:
                 sess.mark("conv:" + scope, flops, lambda: ops.gemm_batched_nt(v, u, mm), nbytes=4 * (v.numel() + u.numel() + mm.numel()))
@@ -527,31 +518,6 @@ class Network(object):
     def _head_to_tail(self, pool5, is_training, reuse=None):
         raise NotImplementedError
 
-    # ------------------------------------------------------------------ fork / join inside one launch chain
-    def _fork(self, fn):
-        """Run fn() on the network's side stream, ordered after everything enqueued so far on the current stream.  Inside a
-        stream capture the side stream joins the capture (event fork), so the hipGraph gets two concurrent branches."""
-        sess = self._sess
-        main = torch.cuda.current_stream(sess.device)
-        side = sess.side_stream(self._tag)
-        ev = torch.cuda.Event()
-        ev.record(main)
-        side.wait_event(ev)
-        scope = ops.ws_scope
-        ops.ws_scope = self._tag + "/side"                 # scratch (split-K partials ...) must not be shared between live streams
-        try:
-            with torch.cuda.stream(side):
-                res = fn()
-                self._join_event = torch.cuda.Event()
-                self._join_event.record(side)
-        finally:
-            ops.ws_scope = scope
-        return res
-
-    def _join(self):
-        torch.cuda.current_stream(self._sess.device).wait_event(self._join_event)
-        self._join_event = None
-
     PLAN_IMAGES = 4        # csrc/conv_igemm.hip PLAN_IMAGES: every launch-size rule is evaluated for a batch of this many images
 
     def _plan_rows(self, M):
@@ -578,18 +544,11 @@ class Network(object):
         net_conv = self._image_to_head(is_training)
         self._anchor_component()
         fused = self._fuse_tail_entry and not is_training and hasattr(self, "_fused_tail_entry")
-        maps = None
-        if fused and cfg.HIP.OVERLAP_TAIL_ENTRY and hasattr(self, "_fused_tail_maps"):
-            # the two 1x1 convolutions of the tail's entry read only the head: they run beside RPN + proposal layer (whose
-            # select / sort / NMS kernels occupy a handful of CUs) instead of after them
-            maps = self._fork(lambda: self._fused_tail_maps(net_conv))
         rois = self._region_proposal(net_conv, is_training)
-        if maps is not None:
-            self._join()
         if cfg.POOLING_MODE != "crop":
             raise NotImplementedError
         if fused:
-            fc7 = self._fused_tail_entry(net_conv, rois, maps)          # crop commuted past the first 1x1 convs (exact algebra)
+            fc7 = self._fused_tail_entry(net_conv, rois)                # crop commuted past the first 1x1 convs (exact algebra)
         else:
             pool5 = self._crop_pool_layer(net_conv, rois, "pool5")
             self._layers["pool5"] = pool5
@@ -664,8 +623,8 @@ class Network(object):
                bool(cfg.USE_GPU_NMS), tuple(image_d.shape), self._im_info[:2], self._mode, cfg.TEST.MODE, self._fuse_tail_entry,
                c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH, cfg.TEST.RPN_TOP_N, cfg.POOLING_SIZE,
                bool(cfg.HIP.WINOGRAD), int(cfg.HIP.WINOGRAD_MIN_CIN), int(cfg.HIP.WINOGRAD_M), tuple(cfg.HIP.WINOGRAD_F2_SCOPES),
-               tuple(cfg.HIP.WINOGRAD_DIRECT_SCOPES), bool(cfg.HIP.WINOGRAD_7X7), bool(cfg.HIP.FUSE_TAIL_MEAN), bool(cfg.HIP.OVERLAP_TAIL_ENTRY), bool(cfg.HIP.MFMA_X3), bool(cfg.USE_E2E_TF),
-               bool(cfg.HIP.MFMA_H2), bool(cfg.HIP.H2_LAZY_SPLIT), int(cfg.HIP.H2_MIN_TILES), bool(cfg.HIP.H2_TRUNK_PLANES), int(cfg.HIP.H2_TILE_CFG), int(cfg.HIP.X3_TILE_CFG), int(cfg.HIP.X3_TERMS), bool(cfg.HIP.H2_TRAIN))
+               tuple(cfg.HIP.WINOGRAD_DIRECT_SCOPES), bool(cfg.HIP.WINOGRAD_7X7), bool(cfg.HIP.FUSE_TAIL_MEAN), bool(cfg.HIP.MFMA_X3), bool(cfg.USE_E2E_TF),
+               bool(cfg.HIP.MFMA_H2), bool(cfg.HIP.H2_LAZY_SPLIT), int(cfg.HIP.H2_MIN_TILES), bool(cfg.HIP.H2_TRUNK_PLANES), int(cfg.HIP.H2_TILE_CFG), int(cfg.HIP.X3_TILE_CFG), bool(cfg.HIP.H2_TRAIN))
         cur = torch.cuda.current_stream(sess.device)
         if not use_graph or sess.profile is not None:
             sess.flops_last_forward = 0
@@ -717,7 +676,7 @@ class Network(object):
         self._gt_boxes = gt if torch.is_tensor(gt) else sess.to_device(np.ascontiguousarray(gt, dtype=np.float32))
         ops.ws_scope = self._tag
         sess.flops_last_forward = 0
-        sess.prepared.enabled = bool(cfg.HIP.PREP_STREAM) and not cfg.HIP.TRAIN_GRAPH
+        sess.prepared.enabled = bool(cfg.HIP.PREP_STREAM)
         self._build_network(True)
         return self._add_losses()
 
@@ -736,7 +695,7 @@ class Network(object):
                 train_op.import_slots(train_op.pending_slots)
                 train_op.pending_slots = None
         self.configure_train_op(train_op)
-        train_op.backward_auto(self._loss_seeds)
+        train_op.backward(self._loss_seeds)
         total = torch.empty((1,), dtype=torch.float32, device=sess.device)
         train_op.regularization_loss(total)
         parts = [losses[k].view(1) for k in ("rpn_cross_entropy", "rpn_loss_box", "cross_entropy", "loss_box")]
@@ -752,9 +711,7 @@ class Network(object):
         train_op.winograd = ((int(cfg.HIP.WINOGRAD_M), int(cfg.HIP.WINOGRAD_MIN_CIN), bool(cfg.HIP.WINOGRAD_7X7))
                              if (cfg.HIP.WINOGRAD and cfg.HIP.WINOGRAD_TRAIN) else None)
         train_op.h2_train = int(cfg.HIP.H2_MIN_TILES) if (cfg.HIP.MFMA_H2 and cfg.HIP.H2_TRAIN) else None
-        train_op.h2_train_wino = bool(cfg.HIP.H2_TRAIN_WINO)
         train_op.wgrad_stream = int(cfg.HIP.WGRAD_STREAM)
-        train_op.graph = bool(cfg.HIP.TRAIN_GRAPH)
         train_op.wgrad_tn = bool(cfg.HIP.WGRAD_TN)
         train_op.prep_stream = bool(cfg.HIP.PREP_STREAM)
         train_op.wgrad_h2 = bool(cfg.HIP.MFMA_H2 and cfg.HIP.H2_TRAIN and cfg.HIP.WGRAD_H2)

@@ -139,14 +139,14 @@ class resnetv1(Network):
 
     def _fused_tail_maps(self, net_conv):
         """The two 1x1 convolutions at the entry of block4/unit_1 on the whole feature map (no bias: it is added after the crop).
-        They depend on the head only, so Network._build_network may run them on a side stream beside RPN + proposal layer."""
+        They depend on the head only."""
         name = self._blocks[-1][0]
         prefix = "%s/%s/unit_1/bottleneck_v1" % (self._scope, name)
         sc_map = self._conv(net_conv, prefix + "/shortcut", 1, 1, act=ACT_NONE, bn_eps=BN_EPS, no_bias=True)
         c1_map = self._conv(net_conv, prefix + "/conv1", 1, 1, act=ACT_NONE, bn_eps=BN_EPS, no_bias=True)
         return sc_map, c1_map
 
-    def _fused_tail_entry(self, net_conv, rois, maps=None):
+    def _fused_tail_entry(self, net_conv, rois):
         """TEST-mode restructuring of the entry of block4/unit_1 (same result up to f32 rounding): the two 1x1
         convolutions that read the RoI crops (projection shortcut, conv1) are linear per pixel and the bilinear
         crop is linear too, so they run ONCE on the 38x63 map and their outputs are cropped, instead of cropping
@@ -156,7 +156,7 @@ class resnetv1(Network):
         name, base, n_units, stride = self._blocks[-1]
         prefix = "%s/%s/unit_1/bottleneck_v1" % (self._scope, name)
         R = rois.shape[0]
-        sc_map, c1_map = maps if maps is not None else self._fused_tail_maps(net_conv)
+        sc_map, c1_map = self._fused_tail_maps(net_conv)
         b_sc = sess.conv_info[prefix + "/shortcut"]["b"]
         b_c1 = sess.conv_info[prefix + "/conv1"]["b"]
         fs = float(self._feat_stride[0])
