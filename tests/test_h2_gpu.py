@@ -135,7 +135,7 @@ def test_gemm_h2_residual_as_planes(dev):
     tensor, for tiles with an M tail, batched entries and both tile shapes."""
     from frcnn_hip import ops
     rng = np.random.RandomState(8)
-    for G, M, N, K, cfg_ in ((1, 128 * 5 + 37, 256, 128, 0), (1, 9576, 1024, 256, 12), (3, 211, 128, 256, 0), (1, 2394, 1024, 256, -1)):
+    for G, M, N, K, cfg_ in ((1, 128 * 5 + 37, 256, 128, 9), (1, 9576, 1024, 256, 12), (3, 211, 128, 256, 9), (1, 2394, 1024, 256, -1), (1, 256 * 9 + 50, 256, 1024, 21)):
         x = np.maximum(rng.randn(G * M, K), 0).astype(np.float32)
         w = (rng.randn(G, N, K) / np.sqrt(K)).astype(np.float32)
         r = (np.maximum(rng.randn(G * M, N), 0) * np.exp(rng.uniform(-2, 2, size=(G * M, 1)))).astype(np.float32)

@@ -147,13 +147,12 @@ class TrainState(object):
         if self._wgrad_events is None:
             self._wgrad_events = [torch.cuda.Event() for _ in range(16)]
 
-        dp = self.data_parallel()
         pins = [ops.pinned_stream(st) for st in sides]
         events = self._wgrad_events
 
         def on_side(fn):
             if not sides:
-                return fn("")
+                return fn("", None)
             i = turn[0] % len(sides)
             ev = events[turn[0] % len(events)]                   # a small ring: a wait captures the record that precedes it
             turn[0] += 1
@@ -162,12 +161,8 @@ class TrainState(object):
             side.wait_event(ev)
             scope, ops.ws_scope = ops.ws_scope, ops.ws_scope + "/wgrad%d" % i
             try:
-                if dp:                                           # the collective issued inside orders itself after torch's current stream
-                    with torch.cuda.stream(side), pins[i]:
-                        fn("/s%d" % i if i else "")
-                else:                                            # only this module's launches inside: no torch stream switch
-                    with pins[i]:
-                        fn("/s%d" % i if i else "")
+                with pins[i]:                                    # this module's launches go to `side` without a torch stream switch; a
+                    fn("/s%d" % i if i else "", side)            # bucket that becomes ready is sent with `side` current (parallel.py)
             finally:
                 ops.ws_scope = scope
 
@@ -234,11 +229,11 @@ class TrainState(object):
                 (ops.relu6_bwd if rec["act"] == ACT_RELU6 else ops.relu_bwd)(gy, y)
                 p = self.params.get(sc)
                 if p is not None:
-                    def dw_wgrad(sfx, gy=gy, x=x, rec=rec, p=p):
+                    def dw_wgrad(sfx, side, gy=gy, x=x, rec=rec, p=p):
                         ops.dwconv3x3_wgrad(gy, x, rec["stride"], rec["pad"], p.scale, p.grad_w)
                         ar = getattr(self, "all_reduce", None)
                         if ar is not None and self.data_parallel() and hasattr(ar, "ready"):
-                            ar.ready(self.flat, p.grad_w.data_ptr())
+                            ar.ready(self.flat, p.grad_w.data_ptr(), side)
                     on_side(dw_wgrad)
                 if x.data_ptr() in needs:
                     gx, had = accumulate_into(x, x.shape, sc + "/in")
@@ -268,7 +263,7 @@ class TrainState(object):
             M = N * OH * OW
             p = self.params.get(sc)
             if p is not None:
-                def wgrad(sfx, gy=gy, x=x, p=p, k=k, stride=stride, pad=pad, OH=OH, OW=OW, M=M, Cout=Cout):
+                def wgrad(sfx, side, gy=gy, x=x, p=p, k=k, stride=stride, pad=pad, OH=OH, OW=OW, M=M, Cout=Cout):
                     if getattr(self, "wgrad_tn", True) and ops.conv2d_wgrad_supported(x.shape[-1], Cout) and p.K == k * k * x.shape[-1]:
                         # dW = dY^T X straight from the two tensors as they lie (csrc/wgrad_tn.hip): no transposed copies, no im2col
                         ops.conv2d_wgrad(gy, x, k, k, stride, pad, p.grad_w, h2=bool(getattr(self, "wgrad_h2", False)))
@@ -277,7 +272,7 @@ class TrainState(object):
                             ops.colsum(gy.view(M, Cout), p.grad_b)
                         ar = getattr(self, "all_reduce", None)
                         if ar is not None and self.data_parallel() and hasattr(ar, "ready"):
-                            ar.ready(self.flat, p.grad_w.data_ptr())
+                            ar.ready(self.flat, p.grad_w.data_ptr(), side)
                         return
                     Mp = (M + 31) // 32 * 32
                     gyT = ops.transpose_pad(gy.view(M, Cout), Mp, out=sess.buf("bwd/gyT" + sfx, (Cout, Mp)))
@@ -295,7 +290,7 @@ class TrainState(object):
                         # this parameter's gradient is enqueued: everything from its offset to the end of the flat buffer is final
                         # (the tape is walked backwards, the buffer is laid out in forward order, and every wgrad is enqueued on the
                         # same stream -- the collective orders itself after the stream it is issued from)
-                        ar.ready(self.flat, p.grad_w.data_ptr())
+                        ar.ready(self.flat, p.grad_w.data_ptr(), side)
                 on_side(wgrad)
             if x.data_ptr() in needs:
                 gx, had = accumulate_into(x, x.shape, sc + "/in")
