@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0                 # same guide: HBM3E 8.0 TB/s spec (6.29 TB
 # BASELINE.json configs; gflop_ref = the reference graph's direct-convolution FLOPs per image
 CONFIGS = {
     "c2": dict(label="configs[1]: ResNet-101 VOC 600x1000, 300 proposals, 21 classes, A=9, TEST.MODE nms", net="res101", H=600, W=1000,
-               scales=(8, 16, 32), classes=21, post=300, gflop_ref=622.29, batch=4, streams=3),
+               scales=(8, 16, 32), classes=21, post=300, gflop_ref=622.29, batch=8, streams=3),
     "c3": dict(label="configs[2]: ResNet-101 COCO 800x1333, 1000 proposals, 81 classes, A=15, TEST.MODE nms", net="res101", H=800, W=1333,
                scales=(2, 4, 8, 16, 32), classes=81, post=1000, gflop_ref=1787.9, batch=2, streams=3),
     "c4": dict(label="configs[3]: MobileNet-V1 1.0 COCO 600x1000, 300 proposals, 81 classes, A=12", net="mobile", H=600, W=1000,
@@ -719,9 +719,11 @@ def main():
             traffic, tsrc, busy = None, None, None
             for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):          # the newest committed pass
                 tpath = os.path.join(ROOT, "profiles", name)
-                if os.path.exists(tpath) and args.config == "c2" and B == 4 and not args.reference_order and args.mfma == "h2":
+                if os.path.exists(tpath) and args.config == "c2" and not args.reference_order and args.mfma == "h2":
                     try:
                         pj = json.load(open(tpath))
+                        if int(pj.get("images_per_step", 4)) != B:       # a pass taken at another batch size says nothing about this launch
+                            continue
                         traffic, tsrc, busy = round(pj["hbm_bytes_per_launch"]), "profiles/" + name, round(pj["mfma_util_conv_launches"], 4)
                         break
                     except Exception:

@@ -38,9 +38,10 @@ extern "C" {
 
 /* ---- library ------------------------------------------------------------------------------- */
 /* Bumps when an exported signature changes.  2: batched detection stages, NMS rule.  3: `opts` argument of the target-layer entries,
- * per-call cfg / terms of frcnn_gemm_x3 (frcnn_gemm_x3_set_* removed), frcnn_gemm_h2 + operand planes.  A caller compiled against
+ * per-call cfg / terms of frcnn_gemm_x3 (frcnn_gemm_x3_set_* removed), frcnn_gemm_h2 + operand planes.  4: frcnn_gemm_h2_mean replaces
+ * frcnn_conv1x1_mean (whose reduction order depended on the batch slot).  A caller compiled against
  * this header compares frcnn_abi_version() with FRCNN_ABI_VERSION before its first call (the ctypes binding does, on load). */
-#define FRCNN_ABI_VERSION 3
+#define FRCNN_ABI_VERSION 4
 int frcnn_abi_version(void);
 const char* frcnn_build_info(void);          /* "gfx950 ..." */
 
@@ -222,16 +223,6 @@ int frcnn_conv2d_nhwc_ws(const float* x_d, int N, int H, int W, int Cin, const f
                          int KW, int stride, int pad_top, int pad_left, int act, int fold_w, void* ws, size_t ws_bytes,
                          void* stream);
 
-/* 1x1 convolution fused with the mean over consecutive row groups -- the tail's last convolution followed by reduce_mean over
- * the 7x7 positions of every RoI (lib/nets/resnet_v1.py:115-125: block4/unit_3/conv3 + `tf.reduce_mean(fc7, axis=[1, 2])`;
- * mobilenet_v1.py:240-250).  x_d [M,Cin], w_d packed [Cout][Cin], residual_d [M,Cout] or NULL:
- *   mean_out_d [M/group_rows, Cout] = mean over each group of act(x W^T + bias + residual);
- * the [M,Cout] tensor is never written (C2: 482 MB stored + 482 MB re-read per 4-image batch otherwise).  Deterministic
- * (fixed summation order).  M % group_rows == 0, 43 <= group_rows, Cin % 32 == 0, Cout % 4 == 0. */
-size_t frcnn_conv1x1_mean_workspace_bytes(int M, int Cout);
-int frcnn_conv1x1_mean(const float* x_d, int M, int Cin, const float* w_d, const float* bias_d, const float* residual_d, int Cout,
-                       int act, int group_rows, float* mean_out_d, void* ws, size_t ws_bytes, void* stream);
-
 /* Tuning overrides for A/B measurements and for tests that must reach every tile configuration: THREAD-LOCAL (they affect only the
  * launches the calling thread makes afterwards, so the thread-safety contract above holds); no product path sets keys 0-7.  key 0 = force a
  * conv tile configuration id (-1 = automatic); key 1 = ablation bits; key 5 = phase stagger of co-resident workgroups; key 6 = 0 keeps
@@ -293,6 +284,16 @@ int frcnn_h2_split(const float* x_d, long long M, int K, void* planes_d, float* 
 int frcnn_gemm_h2(const void* x_planes_d, const float* x_inv_d, const void* w_planes_d, const float* w_inv_d, const float* bias_d,
                   const float* res_d, const void* res_planes_d, const float* res_inv_d, float* y_d, void* y_planes_d, float* y_inv_d,
                   int G, int M, int N, int K, int act, int cfg, void* stream);
+/* frcnn_gemm_h2_mean: the RoI tail's last 1x1 convolution + reduce_mean over each RoI's P*P positions (lib/nets/resnet_v1.py:115-125,
+ * `fc7 = tf.reduce_mean(fc7, axis=[1, 2])`) without the [G*M, N] tensor in between:
+ *   mean_out[g * (M / rows) + r][n] = mean over rows [r * rows, (r + 1) * rows) of act(x[g] W^T + bias + res[g]).
+ * G batch entries of M rows -- ONE ENTRY PER IMAGE, so that the (fixed) order in which a RoI's rows are added depends on the RoI's index
+ * inside its image only: the same RoI gives the same bits in every batch slot and at every batch size.  M % rows == 0, rows >= 32,
+ * K % 128 == 0, N % 128 == 0; operands as in frcnn_gemm_h2; ws of frcnn_gemm_h2_mean_workspace_bytes(G, M, N) bytes. */
+size_t frcnn_gemm_h2_mean_workspace_bytes(int G, int M, int N);
+int frcnn_gemm_h2_mean(const void* x_planes_d, const float* x_inv_d, const void* w_planes_d, const float* w_inv_d, const float* bias_d,
+                       const float* res_d, const void* res_planes_d, const float* res_inv_d, int G, int M, int N, int K, int act, int rows,
+                       float* mean_out_d, void* ws, size_t ws_bytes, int cfg, void* stream);
 /* Winograd F(m x m, 3x3), m = 2 or 4, for stride-1 pad-1 3x3 convolutions (exact algebra, f32): filter transform on the
  * host (U [(m+2)^2][Cout][Cin], optional folded BN scale), input transform V [(m+2)^2][T][C] with
  * T = N*ceil(H/m)*ceil(W/m), the (m+2)^2 GEMMs via frcnn_gemm_batched_nt, output transform (+bias, ReLU) back to NHWC

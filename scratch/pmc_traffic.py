@@ -4,6 +4,7 @@ corrected as /opt/skills/guides/MI355X_MICROARCH.md section HBM prescribes: FETC
 FETCH_SIZE under-counts wide coalesced reads by 2x on gfx950 -> bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024."""
 import csv, sys, json, os
 root = sys.argv[1]
+images = int(sys.argv[3]) if len(sys.argv) > 3 else 4            # images per launch chain of the profiled bench.py run
 def avg(counter, name_filter):
     rows = list(csv.DictReader(open(os.path.join(root, counter, "p_counter_collection.csv"))))
     v = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == counter and any(n in r["Kernel_Name"] for n in name_filter)]
@@ -12,7 +13,8 @@ GEMMS = ("k_conv_igemm", "k_gemm_stream", "k_gemm_x3", "k_gemm_h2")
 f, n = avg("FETCH_SIZE", GEMMS)
 w, _ = avg("WRITE_SIZE", GEMMS)
 res = {"kernel": "k_conv_igemm + k_gemm_stream + k_gemm_x3 + k_gemm_h2", "launches": n, "FETCH_SIZE_avg": f, "WRITE_SIZE_avg": w,
-       "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0, "note": "bench.py --batch 4 --streams 1; (2*FETCH_SIZE + WRITE_SIZE)*1024"}
+       "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0, "images_per_step": images,
+       "note": "bench.py --batch %d --streams 1; (2*FETCH_SIZE + WRITE_SIZE)*1024" % images}
 rows = list(csv.DictReader(open(os.path.join(root, "SQ_VALU_MFMA_BUSY_CYCLES", "p_counter_collection.csv"))))
 agg = {}
 for r in rows:

@@ -345,35 +345,6 @@ def test_conv3x3_winograd_7x7_mixed_scheme(dev, R, Cin, Cout, act, bias):
         assert np.abs(dx - rd).max() <= 1e-4 * np.abs(rd).max()
 
 
-@pytest.mark.parametrize("R,Cin,Cout,act,with_res", [(300, 512, 2048, 1, True), (37, 512, 2048, 1, True), (300, 1024, 1024, 2, False),
-                                                     (5, 64, 96, 0, False)])
-def test_conv1x1_mean_equals_conv_then_mean(dev, R, Cin, Cout, act, with_res):
-    """frcnn_conv1x1_mean (the tail's last conv3 + residual + ReLU + reduce_mean over the 7x7 positions, output never written)
-    vs the two separate kernels and vs float64 (lib/nets/resnet_v1.py:115-125)."""
-    from frcnn_hip import ops
-    rng = np.random.RandomState(R + Cout)
-    x = rng.randn(R, 7, 7, Cin).astype(np.float32)
-    w = (rng.randn(1, 1, Cin, Cout) / np.sqrt(Cin)).astype(np.float32)
-    b = rng.randn(Cout).astype(np.float32)
-    res = rng.randn(R, 7, 7, Cout).astype(np.float32) if with_res else None
-    xd, wd, bd = T(x, dev), T(ops.pack_filter_hwio(w), dev), T(b, dev)
-    rd = T(res, dev) if with_res else None
-    got = ops.conv1x1_mean(xd, wd, bd, 49, act, rd).cpu().numpy()
-    y = ops.conv2d(xd, wd, bd, 1, 1, act=act, residual=rd)
-    two = ops.spatial_mean(y).cpu().numpy()
-    ref = x.reshape(-1, Cin).astype(np.float64) @ w.reshape(Cin, Cout).astype(np.float64) + b
-    if with_res:
-        ref = ref + res.reshape(-1, Cout)
-    ref = np.maximum(ref, 0) if act else ref
-    ref = np.minimum(ref, 6) if act == 2 else ref
-    ref = ref.reshape(R, 49, Cout).mean(axis=1)
-    scale = max(1.0, float(np.abs(ref).max()))
-    assert got.shape == (R, Cout)
-    assert np.abs(got - two).max() <= 2e-6 * scale and np.abs(got - ref).max() <= 2e-5 * scale
-    again = ops.conv1x1_mean(xd, wd, bd, 49, act, rd).cpu().numpy()
-    assert np.array_equal(got, again)                                   # deterministic summation order
-
-
 STREAM_CASES = [
     # M, Cin, Cout, act, residual: shapes the dispatcher gives to k_gemm_stream (short K, wide output, >= 512 tiles), with an M tail
     (64 * 530 + 37, 64, 256, 1, True),        # bottleneck conv3 class: 64x128 tiles, last m-tile 37 rows

@@ -261,3 +261,34 @@ def test_gemm_h2_ping_pong_is_bit_identical_to_the_one_barrier_schedule(dev, sha
         torch.cuda.synchronize()
         assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), "f32 result, launch %d" % rep
         assert torch.equal(gotp.planes.view(torch.int16), refp.planes.view(torch.int16)) and torch.equal(gotp.inv, refp.inv), "planes, launch %d" % rep
+
+
+@pytest.mark.parametrize("R,K,N,with_res", [(300, 512, 2048, True), (37, 128, 256, False), (48, 256, 128, True)])
+def test_gemm_h2_mean_is_slot_invariant_and_matches_conv_then_mean(dev, R, K, N, with_res):
+    """frcnn_gemm_h2_mean (the tail's last conv3 + residual + ReLU + reduce_mean over the 49 positions of a RoI, no [R*49, N] tensor):
+    equals the float64 mean of frcnn_gemm_h2's float32 result to f32 summation noise; ONE batch entry per image makes the reduction
+    order a function of the RoI's index inside its image -- the same image gives the same bits alone (G = 1), in slot 0 and in slot 2
+    of a batch of three, and under every tile configuration."""
+    from frcnn_hip import ops
+    rng = np.random.RandomState(R + K)
+    M = R * 49
+    imgs = [np.maximum(rng.randn(M, K), 0).astype(np.float32) for _ in range(2)]
+    ress = [rng.randn(M, N).astype(np.float32) for _ in range(2)]
+    w = (rng.randn(N, K) / np.sqrt(K)).astype(np.float32)
+    b = rng.randn(N).astype(np.float32)
+    wp, bd = ops.h2_pack_w(T(w[None], dev)), T(b, dev)
+
+    def run(order, cfg):
+        x = T(np.concatenate([imgs[i] for i in order], axis=0), dev)
+        r = T(np.concatenate([ress[i] for i in order], axis=0), dev) if with_res else None
+        return ops.gemm_h2_mean(ops.h2_split(x), wp, len(order), M, N, K, bd, r, 1, 49, cfg=cfg).cpu().numpy()
+    one = run([0], 9)
+    y, _ = ops.gemm_h2(ops.h2_split(T(imgs[0], dev)), wp, 1, M, N, K, bd, T(ress[0], dev) if with_res else None, 1)
+    want = y.cpu().numpy().astype(np.float64).reshape(R, 49, N).mean(axis=1)
+    err = float(np.abs(one - want).max()) / max(1.0, float(np.abs(want).max()))
+    print("gemm_h2_mean R %d K %d N %d: max |err| / scale vs float64 mean of the f32 result = %.2e" % (R, K, N, err))
+    assert one.shape == (R, N) and err <= 2e-6
+    three = run([0, 1, 0], 9)
+    assert np.array_equal(three[:R], one) and np.array_equal(three[2 * R:], one) and not np.array_equal(three[R:2 * R], one)
+    for cfg in (12, 21, -1):
+        assert np.array_equal(run([0], cfg), one), cfg

@@ -46,10 +46,7 @@ struct ConvParams {
   int splits, kchunk;              // split-K: grid.z = splits, each covers kchunk slabs and writes raw partial sums to y + z*gz
   long long gz;
   int stagger, stagger_slots;      // > 0: workgroup in residency slot s of its CU (first dispatch round) starts s * stagger shader cycles late
-  int mean_group;                  // MEAN kernels: rows per group (49 = the 7x7 positions of one RoI); y is NOT written,
-  float* mean_part;                // per-(m-tile, group slot) column sums go here: [mtiles][MEAN_SLOTS][Cout]
 };
-#define MEAN_SLOTS 4               // a 128-row tile overlaps at most 4 groups of >= 43 rows
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
@@ -77,7 +74,7 @@ __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_base) {
       : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool FOLDW, bool ILV = false, bool RF = false, bool MEAN = false>
+template <int BM, int BN, int WM, int WN, int NS, bool FOLDW, bool ILV = false, bool RF = false>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const ConvParams p) {
   constexpr int NW = (BM / WM) * (BN / WN);
   constexpr int NT = NW * 64;
@@ -319,54 +316,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
       }
   __syncthreads();
   const int ohow = p.OH * p.OW;
-  if (MEAN) {
-    // Fused reduce_mean over row groups (lib/nets/resnet_v1.py:124, mobilenet_v1.py:249: the mean over the 7x7 positions of
-    // every RoI follows the last convolution of the tail): y = act(acc + bias + residual) is summed per group instead of being
-    // written -- saves the [M][Cout] store AND the re-read of the separate mean kernel.  Deterministic: thread (column quad c4,
-    // row slice rg) adds its rows in order, slices are added in order, tiles are added in order by k_mean_finish.
-    constexpr int C4 = BN / 4, RGN = NT / C4, RG = BM / RGN;
-    static_assert(NT % C4 == 0 && BM % RGN == 0, "mean epilogue shape");
-    const int c4 = tid % C4, rg = tid / C4;
-    const int n = bn0 + c4 * 4;
-    const int g0 = bm0 / p.mean_group;
-    float4 sum[MEAN_SLOTS];
-#pragma unroll
-    for (int q = 0; q < MEAN_SLOTS; ++q) sum[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.bias && n < p.Cout) bv = *(const float4*)(p.bias + n);
-    for (int rr = 0; rr < RG; ++rr) {
-      const int ml = rg * RG + rr, m = bm0 + ml;
-      if (m >= p.M || n >= p.Cout) continue;
-      float4 v = *(const float4*)(smem + ml * EPI_LD + c4 * 4);
-      v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-      if (p.res) {
-        const float4 rv = *(const float4*)(p.res + (size_t)m * p.Cout + n);
-        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
-      }
-      if (p.act == FRCNN_ACT_RELU) v = act_relu(v);
-      else if (p.act == FRCNN_ACT_RELU6)
-        v = act_relu6(v);
-      const int slot = m / p.mean_group - g0;
-#pragma unroll
-      for (int q = 0; q < MEAN_SLOTS; ++q)
-        if (slot == q) { sum[q].x += v.x; sum[q].y += v.y; sum[q].z += v.z; sum[q].w += v.w; }
-    }
-    __syncthreads();                                   // every tile row has been read: the LDS tile becomes the slice buffer
-    float4* sl = (float4*)smem;                        // [RGN][MEAN_SLOTS][C4]
-#pragma unroll
-    for (int q = 0; q < MEAN_SLOTS; ++q) sl[(rg * MEAN_SLOTS + q) * C4 + c4] = sum[q];
-    __syncthreads();
-    if (tid < MEAN_SLOTS * C4) {
-      const int q = tid / C4, cc = tid % C4, nn = bn0 + cc * 4;
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int g = 0; g < RGN; ++g) {
-        const float4 t = sl[(g * MEAN_SLOTS + q) * C4 + cc];
-        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
-      }
-      if (nn < p.Cout) *(float4*)(p.mean_part + ((size_t)mt * MEAN_SLOTS + q) * p.Cout + nn) = a;
-    }
-    return;
-  }
   if ((p.Cout & 3) == 0) {
     constexpr int C4 = BN / 4;
     for (int t = tid; t < BM * C4; t += NT) {
@@ -415,12 +364,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
   }
 }
 
-template <int BM, int BN, int WM, int WN, int NS, bool FOLDW, bool ILV = false, bool RF = false, bool MEAN = false>
+template <int BM, int BN, int WM, int WN, int NS, bool FOLDW, bool ILV = false, bool RF = false>
 static int launch_conv(ConvParams p, hipStream_t st) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
   constexpr size_t ring = sizeof(float) * NS * (BM + BN) * 32, epi = sizeof(float) * BM * BN;
   constexpr size_t lds = ring > epi ? ring : epi;     // the epilogue tile reuses the ring memory
-  auto kern = k_conv_igemm<BM, BN, WM, WN, NS, FOLDW, ILV, RF, MEAN>;
+  auto kern = k_conv_igemm<BM, BN, WM, WN, NS, FOLDW, ILV, RF>;
   // once per instantiation, safe when several host threads drive distinct streams ("distinct streams are thread-safe")
   static KernelOnce once;
   HIP_TRY(kernel_once(once, (const void*)kern, NT, lds));
@@ -864,7 +813,7 @@ static int conv2d_impl(const float* x_d, int N, int H, int W, int Cin, const flo
   p.gx = p.gw = p.gy = p.gz = 0;
   p.batch = 1;
   p.splits = 1; p.kchunk = p.nsteps;
-  p.mean_group = 0; p.mean_part = nullptr; p.stagger = 0; p.stagger_slots = 0;
+  p.stagger = 0; p.stagger_slots = 0;
   p.dbg = g_dbg;
   hipStream_t st = (hipStream_t)stream;
   if (fold_w) return launch_conv<128, 64, 32, 64, 3, true>(p, st);
@@ -922,56 +871,6 @@ static int conv2d_impl(const float* x_d, int N, int H, int W, int Cin, const flo
   return launch_cfg(4, p, st);
 }
 
-// ---- 1x1 convolution + reduce_mean over row groups, the output tensor never materialised ------------------------------
-// (the tail's last convolution feeds only the spatial mean: lib/nets/resnet_v1.py:115-125, mobilenet_v1.py:240-250)
-__global__ void k_mean_finish(const float* __restrict__ part, int groups, int group_rows, int Cout, int BM, float* __restrict__ out) {
-  const int C4 = Cout / 4;
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long long)groups * C4) return;
-  const int r = (int)(t / C4), c4 = (int)(t % C4);
-  const int m0 = r * group_rows, m1 = m0 + group_rows - 1;
-  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int mt = m0 / BM; mt <= m1 / BM; ++mt) {                 // the tiles this group's rows fall into, in order
-    const int slot = r - (mt * BM) / group_rows;
-    const float4 v = *(const float4*)(part + ((size_t)mt * MEAN_SLOTS + slot) * Cout + c4 * 4);
-    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-  }
-  const float inv = 1.0f / (float)group_rows;
-  *(float4*)(out + (size_t)r * Cout + c4 * 4) = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
-}
-
-extern "C" size_t frcnn_conv1x1_mean_workspace_bytes(int M, int Cout) {
-  if (M <= 0 || Cout <= 0) return 256;
-  return (size_t)cdiv(M, 128) * MEAN_SLOTS * (size_t)Cout * sizeof(float);
-}
-
-extern "C" int frcnn_conv1x1_mean(const float* x_d, int M, int Cin, const float* w_d, const float* bias_d, const float* residual_d,
-                                  int Cout, int act, int group_rows, float* mean_out_d, void* ws, size_t ws_bytes, void* stream) {
-  if (!x_d || !w_d || !mean_out_d || !ws || M <= 0 || Cin <= 0 || Cout <= 0 || group_rows <= 0) return FRCNN_E_ARG;
-  if (act < 0 || act > 2) return FRCNN_E_ARG;
-  if (Cin % 32 || Cout % 4 || M % group_rows || group_rows < 43 || M >= (1 << 29)) return FRCNN_E_UNSUPPORTED;
-  if (frcnn_conv1x1_mean_workspace_bytes(M, Cout) > ws_bytes) return FRCNN_E_WS;
-  ConvParams p;
-  p.x = x_d; p.w = w_d; p.bias = bias_d; p.res = residual_d; p.y = nullptr;
-  p.N = 1; p.H = 1; p.W = M; p.Cin = Cin; p.OH = 1; p.OW = M; p.Cout = Cout; p.KH = 1; p.KW = 1;
-  p.stride = 1; p.pad_top = 0; p.pad_left = 0; p.act = act;
-  p.RH = 1; p.RW = M; p.res_stride = 1;
-  p.M = M; p.Ktot = Cin; p.nsteps = Cin / 32; p.mtiles = p.ntiles = 0;
-  p.gx = p.gw = p.gy = p.gz = 0;
-  p.batch = 1; p.splits = 1; p.kchunk = p.nsteps; p.dbg = 0;
-  p.mean_group = group_rows; p.mean_part = (float*)ws; p.stagger = 0; p.stagger_slots = 0;
-  hipStream_t st = (hipStream_t)stream;
-  const int rc = Cout >= 1024 ? launch_conv<128, 128, 32, 64, 2, false, false, true, true>(p, st)
-                              : launch_conv<128, 128, 64, 64, 2, false, false, true, true>(p, st);
-  if (rc) return rc;
-  const int groups = M / group_rows;
-  const long long tot = (long long)groups * (Cout / 4);
-  hipLaunchKernelGGL(k_mean_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)ws, groups, group_rows, Cout,
-                     128, mean_out_d);
-  LAUNCH_CHECK();
-  return FRCNN_OK;
-}
-
 // G independent "NT" GEMMs in one launch: y[g][m][n] = sum_k x[g][m][k] * w[g][n][k]  (f32 MFMA, same kernel, grid.y = g).
 // Used by the Winograd path (16 transformed positions).  K % 32 == 0.
 extern "C" int frcnn_gemm_batched_nt(const float* x_d, const float* w_d, float* y_d, int G, int M, int N, int K, void* stream) {
@@ -987,7 +886,7 @@ extern "C" int frcnn_gemm_batched_nt(const float* x_d, const float* w_d, float* 
   p.dbg = 0;
   p.batch = G;
   p.splits = 1; p.kchunk = p.nsteps;
-  p.mean_group = 0; p.mean_part = nullptr; p.stagger = 0; p.stagger_slots = 0;
+  p.stagger = 0; p.stagger_slots = 0;
   const long long Mp = plan_rows(M);                            // key 8: configuration by the planned rows (see conv2d_impl)
   const long long big = (Mp + 127) / 128 * cdiv(N, 128) * G;
   if (g_force_cfg >= 100) return launch_stream_cfg(g_force_cfg, p, (hipStream_t)stream);

@@ -50,6 +50,7 @@ struct GemmH2Params {
   const float* bias; const float* res; const unsigned short* resp; const float* resp_inv; float* y; unsigned short* yp; float* y_inv;
   int M, N, K, batch, act, nsteps, mtiles, ntiles;
   long long Mtot;                     // rows of x / res / y / yp over all batch entries (= batch * M)
+  float* mean_part; int mean_rows;    // frcnn_gemm_h2_mean: the result is not stored; column sums of row groups go to mean_part [batch][ceil(M / 32)][2][N]
 #ifdef FRCNN_H2_TRACE
   unsigned long long* trace;          // measurement builds only (scratch/h2_trace.py): s_memtime stamps of the first slabs of a few workgroups
 #endif
@@ -374,6 +375,49 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
           tot[i][j][4 * q + 3] = act_clamp(tot[i][j][4 * q + 3] * wi.w, act_lo, act_hi);
         }
       }
+    }
+    // ---- frcnn_gemm_h2_mean: reduce_mean over row groups instead of a result tensor (the tail's last convolution feeds only the spatial
+    //      mean, lib/nets/resnet_v1.py:115-125).  A 32-row accumulator block (lanes = rows) meets at most two groups (mean_rows >= 32):
+    //      the rows of the group its first row belongs to, and of the next one, are added over the 32 lanes by a fixed xor butterfly
+    //      and written as two partial rows; k_h2_mean_finish adds a group's 2-3 blocks in ascending order.  Which rows meet in which
+    //      block depends only on the row index inside the batch entry, so with one batch entry per image the same RoI gives the same
+    //      bits in every batch slot and at every batch size.
+    if (p.mean_part) {
+      const int nblk = (p.M + 31) >> 5;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mb = c_bm0 + wm0 + i * 32;
+        if (mb >= p.M) continue;                                            // wave-uniform: the block lies past the entry's rows
+        const int m = mb + frow, g0 = mb / p.mean_rows, gid = m / p.mean_rows;
+        const bool in_a = m < p.M && gid == g0, in_b = m < p.M && gid == g0 + 1;
+        float* dst = p.mean_part + ((size_t)c_g * nblk + (mb >> 5)) * 2 * p.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n0 = c_bn0 + wn0 + j * 32 + 4 * khalf;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float a[4], b[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float v = tot[i][j][4 * q + e];
+              a[e] = in_a ? v : 0.f;
+              b[e] = in_b ? v : 0.f;
+            }
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                a[e] += __shfl_xor(a[e], o, 64);
+                b[e] += __shfl_xor(b[e], o, 64);
+              }
+            if (frow == 0) {
+              *(float4*)(dst + n0 + 8 * q) = make_float4(a[0], a[1], a[2], a[3]);
+              *(float4*)(dst + p.N + n0 + 8 * q) = make_float4(b[0], b[1], b[2], b[3]);
+            }
+          }
+        }
+      }
+      return;
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -816,6 +860,8 @@ static int launch_h2(const GemmH2Params& q, hipStream_t st) {
   return FRCNN_OK;
 }
 
+static int run_h2(GemmH2Params& p, int cfg, hipStream_t st);
+
 // y[g] = act(x[g] W[g]^T + bias + res[g]), g < G.  x: planes [2][G*M][K] + x_inv [K/128][G*M] (frcnn_h2_split or a producer's `yp`
 // output); W: frcnn_h2_pack_w(W [G][N][K]); res / y [G*M][N] f32 (y may be null when only planes are wanted); the residual may be
 // given as operand planes instead (res_planes [2][G*M][N] + res_inv [N/128][G*M], e.g. an earlier launch's `yp`);
@@ -840,7 +886,12 @@ extern "C" int frcnn_gemm_h2(const void* x_planes_d, const float* x_inv_d, const
 #ifdef FRCNN_H2_TRACE
   p.trace = g_h2_trace;
 #endif
-  hipStream_t st = (hipStream_t)stream;
+  p.mean_part = nullptr; p.mean_rows = 0;
+  return run_h2(p, cfg, (hipStream_t)stream);
+}
+
+static int run_h2(GemmH2Params& p, int cfg, hipStream_t st) {
+  const int G = p.batch, M = p.M, N = p.N, K = p.K;
   if (cfg < 0) {
     // By shape.  Every configuration multiplies and folds in the same order (bit-identical results), so this is a speed choice only.
     // The ping-pong schedule (cfg 21) keeps the matrix pipe busier per joule (profiles/r04_e_h2_power.txt: every configuration sits at
@@ -876,4 +927,60 @@ extern "C" int frcnn_gemm_h2(const void* x_planes_d, const float* x_inv_d, const
 #endif
     default: return FRCNN_E_ARG;
   }
+}
+
+// ---- frcnn_gemm_h2_mean: out[g * (M / rows) + r][n] = mean over the `rows` consecutive rows of group r of act(x[g] W^T + bias + res[g]) ------
+__global__ __launch_bounds__(256) void k_h2_mean_finish(const float* __restrict__ part, int G, int M, int N4, int rows, float4* __restrict__ out) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per = M / rows;
+  if (t >= (long long)G * per * N4) return;
+  const int n4 = (int)(t % N4);
+  const long long gr = t / N4;
+  const int g = (int)(gr / per), r = (int)(gr % per);
+  const int nblk = (M + 31) >> 5;
+  const int row0 = r * rows, row1 = row0 + rows - 1;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b = row0 >> 5; b <= (row1 >> 5); ++b) {                 // the group's blocks in ascending order
+    const int which = ((b << 5) / rows == r) ? 0 : 1;              // the block's first row belongs to this group, or to the one before
+    const float4 v = *(const float4*)(part + (((size_t)g * nblk + b) * 2 + which) * (size_t)N4 * 4 + (size_t)n4 * 4);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const float inv = 1.0f / (float)rows;                            // like k_spatial_mean
+  out[t] = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+}
+
+extern "C" size_t frcnn_gemm_h2_mean_workspace_bytes(int G, int M, int N) {
+  if (G <= 0 || M <= 0 || N <= 0) return 256;
+  return (size_t)G * (size_t)((M + 31) / 32) * 2 * (size_t)N * sizeof(float);
+}
+
+// The tail's last 1x1 convolution + reduce_mean (lib/nets/resnet_v1.py:115-125) without the [G*M, N] tensor in between: G batch entries
+// (one per IMAGE: the reduction order then depends on the RoI's index inside its image only), M rows each, groups of `rows` consecutive
+// rows (M % rows == 0, rows >= 32).  x / W / bias / residual as in frcnn_gemm_h2; mean_out [G * M / rows][N]; ws: frcnn_gemm_h2_mean_workspace_bytes.
+extern "C" int frcnn_gemm_h2_mean(const void* x_planes_d, const float* x_inv_d, const void* w_planes_d, const float* w_inv_d, const float* bias_d,
+                                  const float* res_d, const void* res_planes_d, const float* res_inv_d, int G, int M, int N, int K, int act, int rows,
+                                  float* mean_out_d, void* ws, size_t ws_bytes, int cfg, void* stream) {
+  if (!x_planes_d || !x_inv_d || !w_planes_d || !w_inv_d || !mean_out_d || !ws || G <= 0 || M <= 0 || N <= 0 || K <= 0 || act < 0 || act > 2 ||
+      rows <= 0 || (res_d && res_planes_d) || (res_planes_d && !res_inv_d))
+    return FRCNN_E_ARG;
+  const long long Mtot = (long long)G * M;
+  if (K % H2_KB || N % 128 || M % rows || rows < 32 || 4ll * Mtot * K >= (1ll << 32) || 4ll * N * K >= (1ll << 32) || (long long)M * N >= (1ll << 29))
+    return FRCNN_E_UNSUPPORTED;
+  if (frcnn_gemm_h2_mean_workspace_bytes(G, M, N) > ws_bytes) return FRCNN_E_WS;
+  GemmH2Params p;
+  p.x = (const unsigned short*)x_planes_d; p.x_inv = x_inv_d; p.w = (const unsigned short*)w_planes_d; p.w_inv = w_inv_d;
+  p.bias = bias_d; p.res = res_d; p.resp = (const unsigned short*)res_planes_d; p.resp_inv = res_inv_d; p.y = nullptr; p.yp = nullptr; p.y_inv = nullptr;
+  p.M = M; p.N = N; p.K = K; p.batch = G; p.act = act; p.Mtot = Mtot;
+  p.nsteps = p.mtiles = p.ntiles = 0;
+#ifdef FRCNN_H2_TRACE
+  p.trace = g_h2_trace;
+#endif
+  p.mean_part = (float*)ws; p.mean_rows = rows;
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = run_h2(p, cfg, st);
+  if (rc) return rc;
+  const long long tot = (long long)G * (M / rows) * (N / 4);
+  hipLaunchKernelGGL(k_h2_mean_finish, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)ws, G, M, N / 4, rows, (float4*)mean_out_d);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
 }

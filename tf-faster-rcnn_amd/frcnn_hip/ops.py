@@ -359,22 +359,6 @@ def conv2d(x, w_packed, bias, KH, KW, stride=1, pad=(0, 0, 0, 0), act=ACT_NONE, 
     return out
 
 
-def conv1x1_mean(x, w_packed, bias, group_rows, act=ACT_NONE, residual=None, out=None):
-    """mean over consecutive `group_rows` rows of act(x W^T + bias + residual) without writing the [M,Cout] tensor:
-    x [..., Cin] (M rows), w_packed [Cout,1,1,Cin] -> [M/group_rows, Cout] (frcnn_conv1x1_mean)."""
-    _chk(x), _chk(w_packed)
-    Cin = x.shape[-1]
-    M = x.numel() // Cin
-    Cout = w_packed.shape[0]
-    out = torch.empty((M // group_rows, Cout), dtype=torch.float32, device=x.device) if out is None else out
-    if residual is not None:
-        _chk(residual)
-    ws = workspace(lib().frcnn_conv1x1_mean_workspace_bytes(M, Cout), x.device, "conv_mean")
-    call("frcnn_conv1x1_mean", _ptr(x), M, Cin, _ptr(w_packed), _ptr(bias), _ptr(residual), Cout, int(act), int(group_rows), _ptr(out),
-         _ptr(ws), ws.numel(), _stream())
-    return out
-
-
 def prep_image_shape(h, w, target_size, max_size):
     """HOST: (im_scale, OH, OW) of _get_image_blob / prep_im_for_blob for an h x w image."""
     sc, oh, ow = ctypes.c_double(), ctypes.c_int(), ctypes.c_int()
@@ -820,6 +804,20 @@ def gemm_h2(x, wp, G, M, N, K, bias=None, residual=None, act=ACT_NONE, out=None,
          _ptr(None if out_planes is None else out_planes.planes), _ptr(None if out_planes is None else out_planes.inv),
          int(G), int(M), int(N), int(K), int(act), int(cfg), _stream())
     return out, out_planes
+
+
+def gemm_h2_mean(x, wp, G, M, N, K, bias, residual, act, rows, out=None, cfg=-1):
+    """frcnn_gemm_h2_mean: [G * M / rows, N] = mean over each group of `rows` consecutive rows of act(x[g] W^T + bias + residual[g]); one
+    batch entry per image (the reduction order is then independent of the batch slot).  residual: f32 [G*M, N], an H2, or None."""
+    assert isinstance(x, H2) and x.rows == G * M and x.K == K and M % rows == 0
+    if out is None:
+        out = torch.empty((G * (M // rows), N), dtype=torch.float32, device=x.planes.device)
+    rp = residual if isinstance(residual, H2) else None
+    ws = workspace(lib().frcnn_gemm_h2_mean_workspace_bytes(int(G), int(M), int(N)), x.planes.device, "h2_mean")
+    call("frcnn_gemm_h2_mean", _ptr(x.planes), _ptr(x.inv), _ptr(wp[0]), _ptr(wp[1]), _ptr(bias), _ptr(None if rp is not None else residual),
+         _ptr(None if rp is None else rp.planes), _ptr(None if rp is None else rp.inv), int(G), int(M), int(N), int(K), int(act), int(rows),
+         _ptr(out), _ptr(ws), ws.numel() * ws.element_size(), int(cfg), _stream())
+    return out
 
 
 def winograd_input_transform_h2(x, v, m):

@@ -252,17 +252,32 @@ class Network(object):
         return out
 
     def _conv1x1_mean(self, x, scope, group_rows, act=ACT_RELU, bn_eps=None, residual=None, name="fc7"):
-        """The tail's last 1x1 convolution fused with reduce_mean over the P*P positions of every RoI (resnet_v1.py:115-125,
-        mobilenet_v1.py:240-250), TEST mode: the [R*P*P, Cout] tensor is never written (frcnn_conv1x1_mean)."""
+        """The tail's last 1x1 convolution fused with reduce_mean over the P*P positions of every RoI (resnet_v1.py:115-125), TEST mode,
+        cfg.HIP.FUSE_TAIL_MEAN: frcnn_gemm_h2_mean -- the [R*P*P, Cout] tensor is never written or re-read.  One batch entry per IMAGE:
+        a RoI's rows are added in an order that depends on its index inside its image only, so batch slots and batch sizes do not
+        change a bit of fc7 (the caller checks _mean_fusable first: the layer must be h2-eligible and x must exist as operand planes)."""
         sess = self._sess
         w, b = sess.conv_params(scope, bn_eps=bn_eps)
         Cin, Cout = x.shape[-1], w.shape[0]
-        M = x.numel() // Cin
-        out = sess.buf(self._tag + "/" + name, (M // group_rows, Cout))
-        self._need_f32(x), self._need_f32(residual)
-        sess.mark("conv:" + scope, 2 * M * Cout * Cin, lambda: ops.conv1x1_mean(x, w, b, group_rows, act, residual, out=out),
-                  nbytes=4 * (x.numel() + w.numel() + out.numel() + (M * Cout if residual is not None else 0)))
+        rows = x.numel() // Cin
+        G = max(1, getattr(self, "_plan_batch", 0))
+        assert rows % G == 0 and (rows // G) % group_rows == 0
+        M = rows // G
+        out = sess.buf(self._tag + "/" + name, (rows // group_rows, Cout))
+        xp, wp = self._h2_of[x.data_ptr()], sess.h2_planes(w)
+        res = residual
+        if residual is not None and residual.data_ptr() in self._f32_missing:
+            res = self._h2_of[residual.data_ptr()]
+        tcfg = int(cfg.HIP.H2_TILE_CFG)
+        sess.mark("conv:h2:" + scope, 2 * rows * Cout * Cin, lambda: ops.gemm_h2_mean(xp, wp, G, M, Cout, Cin, b, res, act, group_rows, out=out, cfg=tcfg),
+                  nbytes=4 * (rows * Cin + w.numel() + out.numel() + (rows * Cout if residual is not None else 0)))
         return self._wrote(out)
+
+    def _mean_fusable(self, rows, cout, cin, scope):
+        """cfg.HIP.FUSE_TAIL_MEAN applies where the tail's last convolution runs in frcnn_gemm_h2 (TEST mode, h2-eligible shape and filter)
+        and the RoI rows split evenly over the images of the batch."""
+        G = max(1, getattr(self, "_plan_batch", 0))
+        return (bool(cfg.HIP.FUSE_TAIL_MEAN) and self._mode == "TEST" and rows % G == 0 and self._h2_eligible(rows, cout, cin, 1, scope))
 
     # ------------------------------------------------------------------ ImageNet-pretrained weights (train_val.py:177-202)
     _rgb_first_conv = None                   # scope tail of the stem conv whose input channels are RGB in the released weights

@@ -86,11 +86,13 @@ class resnetv1(Network):
             shortcut, res_stride = x, stride                # slim `subsample`: fused into conv3's epilogue
         r = self._conv(x, prefix + "/conv1", 1, 1, act=ACT_RELU, bn_eps=BN_EPS)
         pad = (1, 1, 1, 1) if stride == 1 else _same_pad(3, stride)
-        if mean_rows and res_stride == 1 and cfg.HIP.FUSE_TAIL_MEAN:
-            r = self._conv(r, prefix + "/conv2", 3, stride, pad, act=ACT_RELU, bn_eps=BN_EPS)
-            return self._conv1x1_mean(r, prefix + "/conv3", mean_rows, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut)
         N, H, W, _ = r.shape
         M3 = N * ops.conv_out_size(H, 3, stride, pad[0], pad[1]) * ops.conv_out_size(W, 3, stride, pad[2], pad[3])
+        if mean_rows and res_stride == 1 and stride == 1 and self._mean_fusable(M3, depth, base, prefix + "/conv3"):
+            r = self._conv(r, prefix + "/conv2", 3, stride, pad, act=ACT_RELU, bn_eps=BN_EPS, emit_h2=True, want_f32=False)
+            if r.data_ptr() in self._h2_of:        # conv2 really emitted planes (Winograd + h2): conv3 + reduce_mean in one launch
+                return self._conv1x1_mean(r, prefix + "/conv3", mean_rows, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut)
+            raise RuntimeError("graph construction error: FUSE_TAIL_MEAN expected operand planes from " + prefix + "/conv2")
         c3_h2 = res_stride == 1 and self._h2_eligible(M3, depth, base, 1, prefix + "/conv3")
         r = self._conv(r, prefix + "/conv2", 3, stride, pad, act=ACT_RELU, bn_eps=BN_EPS, emit_h2=c3_h2, want_f32=not c3_h2)
         return self._conv(r, prefix + "/conv3", 1, 1, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut, res_stride=res_stride,
@@ -101,7 +103,7 @@ class resnetv1(Network):
         planes only?  Yes when that unit's conv1 reads planes (h2-eligible), its conv3 takes the residual from planes (h2-eligible,
         stride 1) -- then nothing reads the float32 tensor.  The planes carry >= 22 significant bits (csrc/gemm_h2.hip)."""
         depth = 4 * base
-        return (bool(cfg.HIP.H2_TRUNK_PLANES) and not cfg.HIP.FUSE_TAIL_MEAN and next_stride == 1
+        return (bool(cfg.HIP.H2_TRUNK_PLANES) and next_stride == 1
                 and self._h2_eligible(rows, base, depth, 1, None if next_prefix is None else next_prefix + "/conv1")
                 and self._h2_eligible(rows, depth, base, 1, None if next_prefix is None else next_prefix + "/conv3"))
 
@@ -169,7 +171,7 @@ class resnetv1(Network):
         x = self._conv(r, prefix + "/conv3", 1, 1, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut, res_stride=1, emit_h2=n_units >= 2,
                        want_f32=not (n_units >= 2 and self._trunk_planes_only(R * P * P, base, stride if n_units == 2 else 1,
                                                                               "%s/%s/unit_2/bottleneck_v1" % (self._scope, name))))
-        fused = bool(cfg.HIP.FUSE_TAIL_MEAN) and stride == 1 and n_units >= 2
+        fused = stride == 1 and n_units >= 2 and self._mean_fusable(R * P * P, 4 * base, base, "%s/%s/unit_%d/bottleneck_v1/conv3" % (self._scope, name, n_units))
         for u in range(2, n_units + 1):
             x = self._bottleneck(x, "%s/%s/unit_%d/bottleneck_v1" % (self._scope, name, u), base, stride if u == n_units else 1,
                                  mean_rows=P * P if (fused and u == n_units) else 0, emit_out=u < n_units,
@@ -182,7 +184,8 @@ class resnetv1(Network):
 
     def _head_to_tail(self, pool5, is_training, reuse=None):
         name, base, n_units, stride = self._blocks[-1]
-        if self._mode == "TEST" and cfg.HIP.FUSE_TAIL_MEAN and stride == 1:
+        if stride == 1 and self._mean_fusable(pool5.shape[0] * pool5.shape[1] * pool5.shape[2], 4 * base, base,
+                                              "%s/%s/unit_%d/bottleneck_v1/conv3" % (self._scope, name, n_units)):
             x = pool5
             hw = pool5.shape[1] * pool5.shape[2]
             for u in range(1, n_units + 1):
