@@ -460,7 +460,7 @@ def main():
     ap.add_argument("--stagger", type=int, default=0, help="A/B knob: frcnn_set_tuning key 5 (second-slot workgroups of the big GEMM launches "
                     "start n/8 of a tile late)")
     ap.add_argument("--crop-slabs", type=int, default=-1, help="A/B knob: channel-slab count of the crop kernels (frcnn_detect_set_tuning key 4)")
-    ap.add_argument("--fused-mean", action="store_true", help="A/B knob: the tail's last conv3 + reduce_mean in one kernel (cfg.HIP.FUSE_TAIL_MEAN)")
+    ap.add_argument("--no-fused-mean", action="store_true", help="A/B knob: cfg.HIP.FUSE_TAIL_MEAN False: the tail's last conv3 writes its tensor and a separate kernel takes the mean")
     ap.add_argument("--dp-constrained", action="store_true", help="c5: ONE replica under the data-parallel rules -- at most one filter-gradient side "
                     "stream, the bucketed all-reduce issued from inside the reverse sweep over a one-rank RCCL group, no captured sweep: the step "
                     "every GPU of an N-GPU run executes, timed at N = 1")
@@ -532,8 +532,8 @@ def main():
         frcnn_hip.lib().frcnn_set_tuning(6, 0)
     if args.crop_slabs > 0:
         frcnn_hip.lib().frcnn_detect_set_tuning(4, args.crop_slabs)
-    if args.fused_mean:
-        cfg.HIP.FUSE_TAIL_MEAN = True
+    if args.no_fused_mean:
+        cfg.HIP.FUSE_TAIL_MEAN = False
     cfg.USE_GPU_NMS = False           # the reference's CPU/Cython suppression rule (cpu_nms.pyx:65): the path BASELINE.json pins
     cfg.TEST.RPN_POST_NMS_TOP_N = c["post"]
     B = args.batch or c["batch"]

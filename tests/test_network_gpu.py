@@ -407,22 +407,21 @@ def test_tools_test_net_on_a_voc_devkit_and_checkpoint(dev, tmp_path, capsys):
     assert "Applying NMS to all detections" in capsys.readouterr().out
 
 
-def test_optional_fused_tail_mean_matches_the_default_path(small_net):
-    """cfg.HIP.FUSE_TAIL_MEAN (last conv3 + reduce_mean in one kernel) is off by default (config.py says why); when switched on it must
-    give the default path's tensors up to f32 summation order."""
+def test_fused_tail_mean_matches_the_unfused_path(small_net):
+    """cfg.HIP.FUSE_TAIL_MEAN (default: the last conv3 + reduce_mean in one frcnn_gemm_h2_mean launch) against the unfused path (conv3
+    writes its tensor, frcnn_spatial_mean reads it): the same tensors up to f32 summation order."""
     from model.config import cfg
     sess, net, image, im_info = small_net
-    base = [a.copy() for a in net.test_image(sess, image, im_info)]
-    for key in ("FUSE_TAIL_MEAN",):
-        old = cfg.HIP[key]
-        try:
-            cfg.HIP[key] = True
-            got = net.test_image(sess, image, im_info)
-        finally:
-            cfg.HIP[key] = old
-        assert np.array_equal(got[3], base[3])                                   # same proposals
-        for a, b in ((got[0], base[0]), (got[2], base[2])):                      # cls_score, bbox_pred (this fixture's logits are O(1e3))
-            assert rel_err(a, b) <= 2e-5, key
+    assert cfg.HIP.FUSE_TAIL_MEAN
+    fused = [a.copy() for a in net.test_image(sess, image, im_info)]
+    try:
+        cfg.HIP.FUSE_TAIL_MEAN = False
+        base = net.test_image(sess, image, im_info)
+    finally:
+        cfg.HIP.FUSE_TAIL_MEAN = True
+    assert np.array_equal(fused[3], base[3])                                     # same proposals
+    for a, b in ((fused[0], base[0]), (fused[2], base[2])):                      # cls_score, bbox_pred (this fixture's logits are O(1e3))
+        assert rel_err(a, b) <= 2e-5
 
 
 def test_h2_static_filter_criterion_falls_back_to_x3(dev):

@@ -50,6 +50,7 @@ struct GemmH2Params {
   const float* bias; const float* res; const unsigned short* resp; const float* resp_inv; float* y; unsigned short* yp; float* y_inv;
   int M, N, K, batch, act, nsteps, mtiles, ntiles;
   long long Mtot;                     // rows of x / res / y / yp over all batch entries (= batch * M)
+  int wshare;                         // 1: every batch entry multiplies by W[0] (frcnn_gemm_h2_mean: entries = images); 0: entry g by W[g]
   float* mean_part; int mean_rows;    // frcnn_gemm_h2_mean: the result is not stored; column sums of row groups go to mean_part [batch][ceil(M / 32)][2][N]
 #ifdef FRCNN_H2_TRACE
   unsigned long long* trace;          // measurement builds only (scratch/h2_trace.py): s_memtime stamps of the first slabs of a few workgroups
@@ -172,7 +173,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
 #ifdef FRCNN_ABLATION     // TUNE & 64: every tile reads the FIRST tile's X rows (cache-resident operands: what does the HBM latency cost?)
     if (TUNE & 64) i_xb = (const char*)p.x;
 #endif
-    i_wb = (const char*)p.w + ((size_t)g * 2 * p.N + bn0) * p.K * 2;
+    i_wb = (const char*)p.w + ((size_t)(p.wshare ? 0 : g) * 2 * p.N + bn0) * p.K * 2;
     i_sb = (const char*)(p.x_inv + row0);
 #pragma unroll
     for (int t = 0; t < LA; ++t) {
@@ -319,7 +320,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
       const int nc = c_bn0 + wn0 + j * 32;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 wi = *(const float4*)(p.w_inv + (size_t)c_g * p.N + n0 + 8 * q);
+        const float4 wi = *(const float4*)(p.w_inv + (size_t)(p.wshare ? 0 : c_g) * p.N + n0 + 8 * q);
         // 1 / w_inv, exact: both are powers of two (frcnn_h2_pack_w keeps e_w <= 54, so (bias + res) * 2^e_w cannot overflow)
         const float s0 = __uint_as_float(0x7f000000u - __float_as_uint(wi.x)), s1 = __uint_as_float(0x7f000000u - __float_as_uint(wi.y));
         const float s2 = __uint_as_float(0x7f000000u - __float_as_uint(wi.z)), s3 = __uint_as_float(0x7f000000u - __float_as_uint(wi.w));
@@ -366,7 +367,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
       const int n0 = c_bn0 + wn0 + j * 32 + 4 * khalf;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 wi = *(const float4*)(p.w_inv + (size_t)c_g * p.N + n0 + 8 * q);
+        const float4 wi = *(const float4*)(p.w_inv + (size_t)(p.wshare ? 0 : c_g) * p.N + n0 + 8 * q);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           tot[i][j][4 * q + 0] = act_clamp(tot[i][j][4 * q + 0] * wi.x, act_lo, act_hi);
@@ -886,7 +887,7 @@ extern "C" int frcnn_gemm_h2(const void* x_planes_d, const float* x_inv_d, const
 #ifdef FRCNN_H2_TRACE
   p.trace = g_h2_trace;
 #endif
-  p.mean_part = nullptr; p.mean_rows = 0;
+  p.mean_part = nullptr; p.mean_rows = 0; p.wshare = 0;
   return run_h2(p, cfg, (hipStream_t)stream);
 }
 
@@ -975,7 +976,7 @@ extern "C" int frcnn_gemm_h2_mean(const void* x_planes_d, const float* x_inv_d, 
 #ifdef FRCNN_H2_TRACE
   p.trace = g_h2_trace;
 #endif
-  p.mean_part = (float*)ws; p.mean_rows = rows;
+  p.mean_part = (float*)ws; p.mean_rows = rows; p.wshare = 1;
   hipStream_t st = (hipStream_t)stream;
   const int rc = run_h2(p, cfg, st);
   if (rc) return rc;

@@ -73,11 +73,11 @@ __C = AttrDict(
     # large common mean, are where the F(4x4,3x3) transforms lose digits (full-size head error 1.8x the float32 control with F(4,3)
     # everywhere, 1.0x with this policy, for 1.2 % of throughput); F(4x4,3x3) in block3 / RPN / block4 (7x7 scheme).
     # WINOGRAD_DIRECT_SCOPES: scopes containing one of these tokens keep the direct implicit-GEMM kernel.
-    # FUSE_TAIL_MEAN: TEST mode, the tail's last 1x1 convolution + reduce_mean in one kernel (frcnn_conv1x1_mean): +0.7 % images/s
-    # (profiles/r02_c_sweep.txt), but the 49 rows of a RoI are then added in an order that depends on where the RoI falls inside the
-    # 128-row GEMM tiles, i.e. on its slot in the batch: fc7 moves by an ulp between slots and tie-breaks between equal scores can
-    # change.  Off by default: the same image gives bit-identical detections in every batch slot
-    # (tests/test_network_gpu.py::test_batched_forward_equals_single_image_forward).
+    # FUSE_TAIL_MEAN: TEST mode, the tail's last 1x1 convolution + reduce_mean in ONE launch (frcnn_gemm_h2_mean: the [R*49, 2048] tensor is
+    # neither written nor re-read: 964 MB less per 4-image batch, one launch less; +0.3 % images/s, profiles/r04_q_ab_fused_mean.txt) where
+    # that convolution runs in frcnn_gemm_h2.  One batch entry per image: the 49 rows of a RoI are added in an order that depends on the
+    # RoI's index inside its image only, so the same image gives bit-identical fc7 in every batch slot and at every batch size (round 3's
+    # f32 version added them in tile order, i.e. slot-dependent, and was off for that reason; it is gone).
     # WINOGRAD_7X7: 7x7 maps (per-RoI crops) use the mixed F(4,3)+F(3,3) scheme (121 instead of 144 products per RoI)
     # MFMA_X3: TEST mode, the large pointwise convolutions and Winograd products (plain GEMMs with Cout % 64 == 0, Cin % 32 == 0, >= 150 tiles) run on the bf16
     # matrix pipe with EXACTLY split f32 operands (csrc/gemm_x3.hip: x = h + m + l, six bf16 MFMAs per f32 product, f32 accumulation,
@@ -110,7 +110,7 @@ __C = AttrDict(
     # H2_TILE_CFG: -1 = tile shape by launch size (csrc/gemm_h2.hip), else a frcnn_gemm_h2 configuration id for every launch (A/B runs).
     HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=64, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=("block1", "block2"), WINOGRAD_DIRECT_SCOPES=(),
              WINOGRAD_TRAIN=True,
-             WINOGRAD_7X7=True, FUSE_TAIL_MEAN=False, MFMA_X3=True,
+             WINOGRAD_7X7=True, FUSE_TAIL_MEAN=True, MFMA_X3=True,
              MFMA_H2=True, H2_LAZY_SPLIT=True, H2_MIN_TILES=150, H2_TRUNK_PLANES=False, H2_TILE_CFG=-1,
              X3_TILE_CFG=-1, H2_TRAIN=True, WGRAD_STREAM=2, WGRAD_TN=True, WGRAD_H2=True, PREP_STREAM=True))
 __C.DATA_DIR = osp.abspath(osp.join(__C.ROOT_DIR, 'data'))
