@@ -270,9 +270,11 @@ def train_bench(args, c, dev, world, rank, dist):
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    ar_host0 = (getattr(ar, "host_s", 0.0), getattr(ar, "sends", 0))
     t0 = time.perf_counter()
     sw.train_model(args.steps, verbose=False)
     sess.host_enqueue_s = time.perf_counter() - t0          # the host's share: launches enqueued, GPU not yet waited for
+    sess.all_reduce_host = None if ar is None else (getattr(ar, "host_s", 0.0) - ar_host0[0], getattr(ar, "sends", 0) - ar_host0[1])
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -565,6 +567,9 @@ def main():
                        roofline=train_roofline(sess.step_flops_by_pipe, elapsed / args.steps, c["gflop_ref"]))
             if sess.dp_note:
                 out["config"]["data_parallel_rules"] = sess.dp_note
+            if sess.all_reduce_host is not None:
+                out["config"]["all_reduce_host_ms_per_step"] = round(1000.0 * sess.all_reduce_host[0] / args.steps, 3)
+                out["config"]["all_reduce_calls_per_step"] = round(sess.all_reduce_host[1] / float(args.steps), 2)
             print(json.dumps(out), flush=True)
         if dist is not None:
             dist.barrier()

@@ -115,19 +115,26 @@ class BucketedAllReduce(object):
         self.group, self.bucket = group, max(1, int(bucket_bytes) // 4)
         self.reset()
 
+    host_s = 0.0                       # host seconds spent inside torch.distributed calls (sends + waits), cumulative: bench.py reports it
+    sends = 0
+
     def reset(self):
         self.sent_from = None          # element index: [sent_from, numel) is already in flight / done
         self.final_from = None
         self.handles = []
 
     def _send(self, flat, lo, hi, stream=None):
+        import time
         import torch.distributed as dist
         if hi > lo:
+            t0 = time.perf_counter()
+            self.sends += 1
             if stream is None:
                 self.handles.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             else:                      # the collective orders itself after torch's CURRENT stream: make `stream` current for this call only
                 with torch.cuda.stream(stream):
                     self.handles.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.host_s += time.perf_counter() - t0
 
     def ready(self, flat, data_ptr, stream=None):
         """stream: the stream the gradient kernels up to this parameter were enqueued on (the reverse sweep's filter-gradient side
@@ -156,8 +163,11 @@ class BucketedAllReduce(object):
             lo = max(0, hi - step)
             self._send(flat, lo, hi)
             hi = lo
+        import time
+        t0 = time.perf_counter()
         for h in self.handles:
             h.wait()
+        self.host_s += time.perf_counter() - t0
         self.reset()
         return flat
 

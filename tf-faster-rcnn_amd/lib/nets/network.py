@@ -277,7 +277,8 @@ class Network(object):
         """cfg.HIP.FUSE_TAIL_MEAN applies where the tail's last convolution runs in frcnn_gemm_h2 (TEST mode, h2-eligible shape and filter)
         and the RoI rows split evenly over the images of the batch."""
         G = max(1, getattr(self, "_plan_batch", 0))
-        return (bool(cfg.HIP.FUSE_TAIL_MEAN) and self._mode == "TEST" and rows % G == 0 and self._h2_eligible(rows, cout, cin, 1, scope))
+        return (bool(cfg.HIP.FUSE_TAIL_MEAN) and self._mode == "TEST" and rows % G == 0 and self._h2_eligible(rows, cout, cin, 1, scope)
+                and bool(cfg.HIP.H2_LAZY_SPLIT or cfg.HIP.WINOGRAD))         # its input must exist as planes: emitted by the Winograd conv2, or split lazily
 
     # ------------------------------------------------------------------ ImageNet-pretrained weights (train_val.py:177-202)
     _rgb_first_conv = None                   # scope tail of the stem conv whose input channels are RGB in the released weights

@@ -90,7 +90,7 @@ class resnetv1(Network):
         M3 = N * ops.conv_out_size(H, 3, stride, pad[0], pad[1]) * ops.conv_out_size(W, 3, stride, pad[2], pad[3])
         if mean_rows and res_stride == 1 and stride == 1 and self._mean_fusable(M3, depth, base, prefix + "/conv3"):
             r = self._conv(r, prefix + "/conv2", 3, stride, pad, act=ACT_RELU, bn_eps=BN_EPS, emit_h2=True, want_f32=False)
-            if r.data_ptr() in self._h2_of:        # conv2 really emitted planes (Winograd + h2): conv3 + reduce_mean in one launch
+            if self._h2_input(r) is not None:      # planes from conv2's output transform, or (direct conv2) a lazy split of its f32 result
                 return self._conv1x1_mean(r, prefix + "/conv3", mean_rows, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut)
             raise RuntimeError("graph construction error: FUSE_TAIL_MEAN expected operand planes from " + prefix + "/conv2")
         c3_h2 = res_stride == 1 and self._h2_eligible(M3, depth, base, 1, prefix + "/conv3")
