@@ -899,7 +899,10 @@ static int run_h2(GemmH2Params& p, int cfg, hipStream_t st) {
     // the 1 400 W socket limit, so time follows energy) but owns a whole CU per 256 x 128 tile: it pays on long-K launches whose tile
     // epilogues are a small part (K >= 1024: 64 slabs per tile), with at least one tile per CU and 256-row tiles that waste < 4 % of M.
     const long long mt256 = (M + 255) / 256;
-    const bool pp = K >= 1024 && mt256 * 256 * 100 <= (long long)M * 104 && mt256 * (N / 128) * G >= 256;
+#ifndef FRCNN_H2_PP_MIN_K
+#define FRCNN_H2_PP_MIN_K 1024          // (scratch/bench_ablation.py rebuilds with other values: 512 measured in the pipeline, profiles/r04_u)
+#endif
+    const bool pp = K >= FRCNN_H2_PP_MIN_K && mt256 * 256 * 100 <= (long long)M * 104 && mt256 * (N / 128) * G >= 256;
     // fewer than 150 tiles of 128 x 128 (a single image's launches: batch-1 latency mode): 64-row tiles, three workgroups per CU
     // (profiles/r03_g_h2_sweep.txt: 21.8 vs 30.9 us on one image's block3 conv1); in the 4-image pipeline these lose (r03_l_ab.txt)
     const bool tiny = (long long)((M + 127) / 128) * (N / 128) * G < 150;
