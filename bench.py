@@ -395,7 +395,7 @@ def other_configs(budget_s, t_start):
         rf = d.get("roofline") or {}
         rec = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "workload": d["config"]["workload"],
                "images_per_step": d["config"].get("images_per_gpu_per_step", 1), "chains": d["config"].get("chains_in_flight_per_gpu", 1),
-               "roofline_frac": rf.get("frac"), "roofline_peak_f32_equivalent": rf.get("peak"),
+               "roofline_bound": rf.get("bound"), "roofline_frac": rf.get("frac"), "mfma_frac": rf.get("mfma_frac", rf.get("frac")), "hbm_frac": rf.get("hbm_frac"),
                "pipes": {k: (v.get("frac_of_pipe_peak") if "frac_of_pipe_peak" in v else v.get("share_of_launched_flops")) for k, v in (rf.get("pipes") or {}).items()},
                "wall_s": d["wall_s"]}
         if "data_parallel_rules" in d["config"]:
@@ -744,22 +744,30 @@ def main():
             bound_by_pipe = {k: ("hbm" if t_hbm[k] > t_mfma[k] else "mfma") for k, pp in pipes.items() if pp[2]}
             all_bytes_step = sum(v[3] for v in per_layer.values()) / steps_p            # every launch group of a step: GEMMs, transforms, crop, ...
             step_s = elapsed / args.steps
+            hbm_bound = sum(t_hbm.values()) > t_at_peak
+            hbm_ach = conv[3] / (conv[0] * 1e-3) / 1e9                                     # algorithmic GB/s over the GEMM launches
+            mfma_frac = t_at_peak / (conv[0] * 1e-3)
             out["roofline"] = {
-                "bound": "hbm" if sum(t_hbm.values()) > t_at_peak else "mfma", "achieved": round(ach, 2), "peak": round(ceiling, 1), "unit": "TFLOP/s",
+                # the contract's five fields describe the resource that BINDS the dominant kernel family (the GEMM launches): the one
+                # whose time at peak is the larger (seconds_at_peak_per_step).  Both views are always carried below: `mfma_frac` /
+                # `achieved_f32_equivalent` / `pipes` (the figure rounds 1-3 quoted as `frac`) and `hbm`.
+                "bound": "hbm" if hbm_bound else "mfma",
+                "achieved": round(hbm_ach, 1) if hbm_bound else round(ach, 2), "peak": HBM_PEAK_GBS if hbm_bound else round(ceiling, 1),
+                "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round(hbm_ach / HBM_PEAK_GBS, 4) if hbm_bound else round(mfma_frac, 4),
+                "mfma_frac": round(mfma_frac, 4), "mfma_peak_f32_equivalent": round(ceiling, 1), "hbm_frac": round(hbm_ach / HBM_PEAK_GBS, 4),
                 "bound_by_pipe": bound_by_pipe,
                 "seconds_at_peak_per_step": {"mfma": round(t_at_peak / steps_p, 6), "hbm_8TBs_gemm_launches": round(sum(t_hbm.values()) / steps_p, 6),
                                              "hbm_8TBs_all_launches": round(all_bytes_step / (HBM_PEAK_GBS * 1e9), 6), "timed_step": round(step_s, 6)},
-                # achieved / peak / frac below are the MATRIX-PIPE figures of the GEMM launches whichever resource `bound` names; the HBM
-                # side of the same launches and of the whole step:
+                # the HBM side of the GEMM launches and of the whole step:
                 "hbm": {"gemm_achieved_GBs": round(conv[3] / (conv[0] * 1e-3) / 1e9, 1), "peak_GBs": HBM_PEAK_GBS,
                         "gemm_frac": round(conv[3] / (conv[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "algorithmic_GB_per_step_all_launches": round(all_bytes_step / 1e9, 3),
                         "hbm_frac_timed_region": round(all_bytes_step / step_s / 1e9 / HBM_PEAK_GBS, 4),
                         "gemm_arithmetic_intensity_flop_per_byte": round(conv[1] / max(conv[3], 1), 1)},
-                # frac = sum_launch (FLOPs_i / peak of the pipe launch i issues on) / sum_launch time_i  (event pass, one chain):
-                # the fraction of the matrix pipes' dense peak the issued instruction mix achieves.  `achieved` / `peak` are the same
-                # ratio in f32-equivalent TFLOP/s (peak = what this mix of 3-MFMA / 6-MFMA / f32-MFMA products could reach)
-                "frac": round(t_at_peak / (conv[0] * 1e-3), 4),
+                # mfma_frac = sum_launch (FLOPs_i / peak of the pipe launch i issues on) / sum_launch time_i  (event pass, one chain):
+                # the fraction of the matrix pipes' dense peak the issued instruction mix achieves; achieved_f32_equivalent /
+                # mfma_peak_f32_equivalent are the same ratio in f32-equivalent TFLOP/s (peak = what this mix of 3-MFMA / 6-MFMA /
+                # f32-MFMA products could reach)
                 "achieved_f32_equivalent": round(ach, 2),
                 "pipe_peaks_f32_equivalent": {"h2 (3 x v_mfma_f32_32x32x16_f16 per product, 2500 / 3)": H2_PEAK_TFLOPS,
                                               "x3 (6 x v_mfma_f32_32x32x16_bf16, 2500 / 6)": X3_PEAK_TFLOPS,
@@ -774,7 +782,7 @@ def main():
                 # the dense peaks above are quoted at the 2.4 GHz boost clock; every configuration of this pipeline runs at the socket
                 # power limit (1 400 W) with the firmware picking the clock (profiles/r04_e_h2_power.txt), so the same fraction against
                 # the peak AT THE CLOCK THE RUN HELD is reported too
-                "frac_at_running_clock": None if (telemetry is None or not telemetry["sclk_mhz"]) else round(t_at_peak / (conv[0] * 1e-3) * 2400.0 / telemetry["sclk_mhz"], 4),
+                "mfma_frac_at_running_clock": None if (telemetry is None or not telemetry["sclk_mhz"]) else round(mfma_frac * 2400.0 / telemetry["sclk_mhz"], 4),
                 "kernel": "k_gemm_h2 (fp16 pipe, block-scaled two-piece operands) + k_gemm_x3 (bf16 pipe, exact 3-way split) + k_conv_igemm / "
                           "k_gemm_stream (f32 MFMA 32x32x2), all tile shapes; Winograd GEMMs included",
                 "algorithmic_bytes_per_launch": conv[3] // max(conv[2], 1), "launches_per_step": conv[2] // steps_p,
