@@ -128,3 +128,17 @@ def test_unsupported_modes_and_values_raise_instead_of_being_ignored():
     finally:
         C.cfg.TEST.BBOX_REG, C.cfg.TRAIN.RPN_POSITIVE_WEIGHT, C.cfg.RESNET.MAX_POOL = old
         C.cfg.TRAIN.USE_GT, C.cfg.TRAIN.RPN_CLOBBER_POSITIVES, C.cfg.TRAIN.TRUNCATED, C.cfg.POOLING_MODE = old_t
+
+
+def test_launch_size_rules_see_the_per_image_shape():
+    """Network._plan_rows: every TEST-mode rule that picks a matrix pipe sees the rows a launch would have in a 4-image batch, whatever
+    the batch is (results must not depend on the batch: lib/model/test.py:88 is batch-1)."""
+    from nets.network import Network
+    n = object.__new__(Network)
+    n._plan_batch = 0
+    assert n._plan_rows(2394) == 2394                       # TRAIN / no context: the launch as it is
+    for B in (1, 2, 4, 8, 12):
+        n._plan_batch = B
+        assert n._plan_rows(B * 2394) == 4 * 2394 and n._plan_rows(B * 300 * 49) == 4 * 300 * 49
+    n._plan_batch = 3
+    assert n._plan_rows(100) == 100                         # rows that do not split evenly over the images: left alone
