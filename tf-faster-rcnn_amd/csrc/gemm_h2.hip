@@ -313,50 +313,98 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
   // final  tot * w_inv  = products + bias + res  is one f32 sum evaluated in the scaled domain -- and the residual is fetched when the
   // tile starts (its latency hides under the first 128-k block; it is first touched by that block's fold) instead of after the last MFMA.
   auto init_tot = [&]() {
+    // Every load of the tile start is issued before the first one is used: the filter scales and the bias of the tile's columns
+    // (TN x 4 float4 each) and the residual straight into `tot`.  (Round 3 interleaved load, wait and arithmetic per 4 columns inside
+    // runtime `if (p.res)` branches: ~30 dependent memory round trips per tile, as long as the whole K loop of a K = 256 tile.)
     const size_t row_base = (size_t)c_g * p.M;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    if (p.res) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n0 = c_bn0 + wn0 + j * 32 + 4 * khalf;
-      const int nc = c_bn0 + wn0 + j * 32;
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int m0 = c_bm0 + wm0 + i * 32, nc = c_bn0 + wn0 + j * 32;
+          const auto rr = rsrc_f(p.res + (long long)(row_base + m0) * p.N + nc, (long long)(p.M - m0) * p.N - nc, 4);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const u32x4 ld = __builtin_amdgcn_raw_buffer_load_b128(rr, (frow * p.N + 4 * khalf) * 4 + 32 * q, 0, 0);
+            tot[i][j][4 * q + 0] = __uint_as_float(ld[0]); tot[i][j][4 * q + 1] = __uint_as_float(ld[1]);
+            tot[i][j][4 * q + 2] = __uint_as_float(ld[2]); tot[i][j][4 * q + 3] = __uint_as_float(ld[3]);
+          }
+        }
+    } else if (p.resp) {
+      // the residual as operand planes (the trunk of a bottleneck chain kept as planes only): (h + l) is exact in f32 (<= 23
+      // significant bits), times the block's power-of-two scale; the tile's 128 columns are one scale block (BN == 128)
+      float ri[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        ri[i] = p.resp_inv[(size_t)(c_bn0 / H2_KB) * p.Mtot + row_base + min(c_bm0 + wm0 + i * 32 + frow, p.M - 1)];
+      h4 hv[TM][TN][4], lv[TM][TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int m0 = c_bm0 + wm0 + i * 32, nc = c_bn0 + wn0 + j * 32;
+          const long long sbase = (long long)(row_base + m0) * p.N + nc, left_e = (long long)(p.M - m0) * p.N - nc;
+          const auto rh = rsrc_f(p.resp + sbase, left_e, 2), rl = rsrc_f(p.resp + (size_t)p.Mtot * p.N + sbase, left_e, 2);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int lo2 = (frow * p.N + 4 * khalf) * 2 + 16 * q;
+            hv[i][j][q] = __builtin_bit_cast(h4, __builtin_amdgcn_raw_buffer_load_b64(rh, lo2, 0, 0));
+            lv[i][j][q] = __builtin_bit_cast(h4, __builtin_amdgcn_raw_buffer_load_b64(rl, lo2, 0, 0));
+          }
+        }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tot[i][j][4 * q + e] = ((float)hv[i][j][q][e] + (float)lv[i][j][q][e]) * ri[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+    }
+    // the filter scales and the bias of the tile's columns (issued behind the residual's loads: all of them are in flight together)
+    float4 wi[TN][4], bv[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        wi[j][q] = *(const float4*)(p.w_inv + (size_t)(p.wshare ? 0 : c_g) * p.N + c_bn0 + wn0 + j * 32 + 4 * khalf + 8 * q);
+    if (p.bias) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[j][q] = *(const float4*)(p.bias + c_bn0 + wn0 + j * 32 + 4 * khalf + 8 * q);
+    } else {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // The accumulators of a tile START at (bias + res) * 2^e_w: the filter row's scale w_inv = 2^-e_w is an exact power of two, so the
+    // final  tot * w_inv  = products + bias + res  is one f32 sum evaluated in the scaled domain (frcnn_h2_pack_w keeps e_w <= 54, so
+    // (bias + res) * 2^e_w cannot overflow; 1 / w_inv is formed exactly from its exponent field).
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 wi = *(const float4*)(p.w_inv + (size_t)(p.wshare ? 0 : c_g) * p.N + n0 + 8 * q);
-        // 1 / w_inv, exact: both are powers of two (frcnn_h2_pack_w keeps e_w <= 54, so (bias + res) * 2^e_w cannot overflow)
-        const float s0 = __uint_as_float(0x7f000000u - __float_as_uint(wi.x)), s1 = __uint_as_float(0x7f000000u - __float_as_uint(wi.y));
-        const float s2 = __uint_as_float(0x7f000000u - __float_as_uint(wi.z)), s3 = __uint_as_float(0x7f000000u - __float_as_uint(wi.w));
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) bv = *(const float4*)(p.bias + n0 + 8 * q);
+        const float s0 = __uint_as_float(0x7f000000u - __float_as_uint(wi[j][q].x)), s1 = __uint_as_float(0x7f000000u - __float_as_uint(wi[j][q].y));
+        const float s2 = __uint_as_float(0x7f000000u - __float_as_uint(wi[j][q].z)), s3 = __uint_as_float(0x7f000000u - __float_as_uint(wi[j][q].w));
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (p.res) {
-            const int m0 = c_bm0 + wm0 + i * 32;
-            const long long sbase = (long long)(row_base + m0) * p.N + nc;
-            const long long left_e = (long long)(p.M - m0) * p.N - nc;
-            const auto rr = rsrc_f(p.res + sbase, left_e, 4);
-            const auto ld = __builtin_amdgcn_raw_buffer_load_b128(rr, (frow * p.N + 4 * khalf) * 4 + 32 * q, 0, 0);
-            rv = make_float4(__uint_as_float(ld[0]), __uint_as_float(ld[1]), __uint_as_float(ld[2]), __uint_as_float(ld[3]));
-          } else if (p.resp) {
-            // the residual as operand planes (the trunk of a bottleneck chain kept as planes only): (h + l) is exact in f32 (<= 23
-            // significant bits), times the block's power-of-two scale; the tile's 128 columns are one scale block (BN == 128)
-            const int m0 = c_bm0 + wm0 + i * 32;
-            const long long sbase = (long long)(row_base + m0) * p.N + nc;
-            const long long left_e = (long long)(p.M - m0) * p.N - nc;
-            const auto rh = rsrc_f(p.resp + sbase, left_e, 2), rl = rsrc_f(p.resp + (size_t)p.Mtot * p.N + sbase, left_e, 2);
-            const int lo2 = (frow * p.N + 4 * khalf) * 2 + 16 * q;
-            const auto hv = __builtin_bit_cast(h4, __builtin_amdgcn_raw_buffer_load_b64(rh, lo2, 0, 0));
-            const auto lv = __builtin_bit_cast(h4, __builtin_amdgcn_raw_buffer_load_b64(rl, lo2, 0, 0));
-            const float ri = p.resp_inv[(size_t)(c_bn0 / H2_KB) * p.Mtot + row_base + min(m0 + frow, p.M - 1)];
-            rv = make_float4(((float)hv[0] + (float)lv[0]) * ri, ((float)hv[1] + (float)lv[1]) * ri, ((float)hv[2] + (float)lv[2]) * ri,
-                             ((float)hv[3] + (float)lv[3]) * ri);
-          }
-          tot[i][j][4 * q + 0] = (rv.x + bv.x) * s0;
-          tot[i][j][4 * q + 1] = (rv.y + bv.y) * s1;
-          tot[i][j][4 * q + 2] = (rv.z + bv.z) * s2;
-          tot[i][j][4 * q + 3] = (rv.w + bv.w) * s3;
+          tot[i][j][4 * q + 0] = (tot[i][j][4 * q + 0] + bv[j][q].x) * s0;
+          tot[i][j][4 * q + 1] = (tot[i][j][4 * q + 1] + bv[j][q].y) * s1;
+          tot[i][j][4 * q + 2] = (tot[i][j][4 * q + 2] + bv[j][q].z) * s2;
+          tot[i][j][4 * q + 3] = (tot[i][j][4 * q + 3] + bv[j][q].w) * s3;
         }
       }
-    }
   };
 
   auto epilogue = [&]() {
@@ -420,6 +468,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
       }
       return;
     }
+    // (Measured and not kept, profiles/r04_y_*: the same stores ROW-MAJOR through a wave-private LDS block -- 8 rows x one full 128-byte
+    // line per instruction instead of 32 rows x 32 bytes -- double the tile boundary (30.8 -> 57.8 thousand cycles for residual + float32 +
+    // planes): the extra LDS round trips and the registers they hold cost more than the request count saves.)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int m0 = c_bm0 + wm0 + i * 32;                                  // first row of the sub-tile inside the batch entry
@@ -459,12 +510,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
         if (BN / WN > 1 && khalf == 0) red[wni * BM + wm0 + i * 32 + frow] = m;
       }
       if (BN / WN > 1) {
-        if constexpr (PP) {          // raw barrier: __syncthreads() would also drain the slabs in flight (vmcnt(0))
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-        } else {
-          __syncthreads();
-        }
+        // raw barrier + lgkmcnt(0): the exchange goes through LDS only.  __syncthreads() would add vmcnt(0), i.e. wait until the float32
+        // stores just issued (and the slabs in flight) have COMPLETED -- 7-9 thousand cycles per drain under a write burst
+        // (profiles/r04_w_h2_tile_boundary.txt)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -496,12 +546,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
         }
       }
       if (BN / WN > 1) {                                                         // red[] is reused by the next tile
-        if constexpr (PP) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-        } else {
-          __syncthreads();
-        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
       }
     }
   };
