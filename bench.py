@@ -41,11 +41,11 @@ CONFIGS = {
     "c2": dict(label="configs[1]: ResNet-101 VOC 600x1000, 300 proposals, 21 classes, A=9, TEST.MODE nms", net="res101", H=600, W=1000,
                scales=(8, 16, 32), classes=21, post=300, gflop_ref=622.29, batch=8, streams=3),
     "c3": dict(label="configs[2]: ResNet-101 COCO 800x1333, 1000 proposals, 81 classes, A=15, TEST.MODE nms", net="res101", H=800, W=1333,
-               scales=(2, 4, 8, 16, 32), classes=81, post=1000, gflop_ref=1787.9, batch=2, streams=3),
+               scales=(2, 4, 8, 16, 32), classes=81, post=1000, gflop_ref=1787.9, batch=4, streams=3),
     "c4": dict(label="configs[3]: MobileNet-V1 1.0 COCO 600x1000, 300 proposals, 81 classes, A=12", net="mobile", H=600, W=1000,
-               scales=(4, 8, 16, 32), classes=81, post=300, gflop_ref=70.2, batch=4, streams=3),
+               scales=(4, 8, 16, 32), classes=81, post=300, gflop_ref=70.2, batch=8, streams=3),
     "c1": dict(label="configs[0] shape on the device chain: VGG16 VOC 600x1000, 300 proposals, 21 classes, A=9", net="vgg16", H=600, W=1000,
-               scales=(8, 16, 32), classes=21, post=300, gflop_ref=451.1, batch=2, streams=3),
+               scales=(8, 16, 32), classes=21, post=300, gflop_ref=451.1, batch=4, streams=3),
     "c5": dict(label="configs[4]: ResNet-152 COCO trainval step 600x1000 (anchor_target + proposal_target + losses + backward + "
                      "Momentum SGD), 81 classes, A=12, 256 RoIs", net="res152", H=600, W=1000, scales=(4, 8, 16, 32), classes=81, post=2000,
                gflop_ref=1910.0, batch=1, streams=1),
