@@ -377,7 +377,8 @@ def other_configs(budget_s, t_start):
     training step once more under the data-parallel rules, and configs[1] with one image on one chain (latency) -- each a child run of
     this script, value / ms per step / per-pipe roofline fraction copied from its line.  Stops adding runs once `budget_s` seconds of
     wall clock have passed since t_start (the skipped ones are named)."""
-    runs = [("latency_batch1", ["--config", "c2", "--batch", "1", "--streams", "1", "--steps", "20", "--warmup", "5", "--profile-steps", "0"]),
+    runs = [("latency_batch1", ["--config", "c2", "--batch", "1", "--streams", "1", "--steps", "40", "--warmup", "40", "--profile-steps", "0"]),   # (a 0.1 s run on an idle GPU
+            # is timed before the clock has ramped: 5.1 vs 4.3 ms with 5 warm-up steps on two boxes)
             ("c3", ["--config", "c3", "--steps", "5", "--warmup", "3", "--profile-steps", "1"]),
             ("c5", ["--config", "c5", "--steps", "5", "--warmup", "3"]),
             ("c5_dp_constrained", ["--config", "c5", "--steps", "5", "--warmup", "3", "--dp-constrained"]),

@@ -194,19 +194,35 @@ extern "C" int frcnn_spatial_mean_bwd(const float* dy_d, int N, int HW, int C, f
   return FRCNN_OK;
 }
 
-// bias gradient: db[c] = sum_m dy[m][c]  (one wave-column sweep per 64 channels, f64 accumulation, deterministic)
-__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dy, int M, int C, float* __restrict__ db) {
-  __shared__ double sh[4][64];
+// bias gradient: db[c] = sum_m dy[m][c]  (f64 accumulation, deterministic: a fixed partition of the rows and a fixed order of the adds).
+// 1024 threads = 16 row parts x 64 channels, every part walks its rows four at a time with four independent accumulators (round 3: 4
+// parts, one dependent load + add per iteration -- 226 us for the 2 394 rows of an RPN head, profiles/r03_aj_train_kernels_by_shape.txt).
+__global__ __launch_bounds__(1024) void k_colsum(const float* __restrict__ dy, int M, int C, float* __restrict__ db) {
+  __shared__ double sh[16][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
-  double s = 0.0;
-  if (c < C) for (int m = part; m < M; m += 4) s += (double)dy[(size_t)m * C + c];
-  sh[part][threadIdx.x & 63] = s;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (c < C) {
+    int m = part;
+    for (; m + 48 < M; m += 64) {
+      s0 += (double)dy[(size_t)m * C + c];
+      s1 += (double)dy[(size_t)(m + 16) * C + c];
+      s2 += (double)dy[(size_t)(m + 32) * C + c];
+      s3 += (double)dy[(size_t)(m + 48) * C + c];
+    }
+    for (; m < M; m += 16) s0 += (double)dy[(size_t)m * C + c];
+  }
+  sh[part][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (part == 0 && c < C) db[c] = (float)(sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+  if (part == 0 && c < C) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sh[q][threadIdx.x];
+    db[c] = (float)t;
+  }
 }
 extern "C" int frcnn_colsum(const float* dy_d, int M, int C, float* db_d, void* stream) {
   if (!dy_d || !db_d || M <= 0 || C <= 0) return FRCNN_E_ARG;
-  hipLaunchKernelGGL(k_colsum, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, dy_d, M, C, db_d);
+  hipLaunchKernelGGL(k_colsum, dim3(cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, dy_d, M, C, db_d);
   LAUNCH_CHECK();
   return FRCNN_OK;
 }
