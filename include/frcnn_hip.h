@@ -39,9 +39,10 @@ extern "C" {
 /* ---- library ------------------------------------------------------------------------------- */
 /* Bumps when an exported signature changes.  2: batched detection stages, NMS rule.  3: `opts` argument of the target-layer entries,
  * per-call cfg / terms of frcnn_gemm_x3 (frcnn_gemm_x3_set_* removed), frcnn_gemm_h2 + operand planes.  4: frcnn_gemm_h2_mean replaces
- * frcnn_conv1x1_mean (whose reduction order depended on the batch slot).  A caller compiled against
+ * frcnn_conv1x1_mean (whose reduction order depended on the batch slot).  5: the *_masked entries of the training step's data-gradient
+ * chain (a library without them must not be loaded by a caller that expects them).  A caller compiled against
  * this header compares frcnn_abi_version() with FRCNN_ABI_VERSION before its first call (the ctypes binding does, on load). */
-#define FRCNN_ABI_VERSION 4
+#define FRCNN_ABI_VERSION 5
 int frcnn_abi_version(void);
 const char* frcnn_build_info(void);          /* "gfx950 ..." */
 
@@ -446,6 +447,27 @@ int frcnn_conv2d_wgrad_h2(const float* dy_d, const float* x_d, int N, int H, int
                           int stride, int pad_top, int pad_left, float* dw_d, void* ws, size_t ws_bytes, void* stream);
 void frcnn_conv2d_wgrad_h2_set_plan(int tile, int min_workgroups);      /* as above; 0 = 256 workgroups */
 int frcnn_relu_bwd(float* grad_d, const float* y_d, long long n, void* stream);              /* grad *= (y > 0) */
+/* The data-gradient chain with that ReLU gradient INSIDE the producing launch (the reverse sweep of lib/nets/resnet_v1.py's bottlenecks:
+ * every convolution input of the trunk is a ReLU output, so the gradient a data-gradient launch produces is masked by the launch's own
+ * forward input): y = mask > 0 ? y : 0, mask = the forward activation, float32, same shape as y.  The select is exact -- the float32
+ * result of each entry equals its unmasked counterpart followed by frcnn_relu_bwd bit for bit; operand planes, where emitted, are those
+ * of the MASKED tensor (the GEMM's: frcnn_h2_split's bits; the Winograd transforms': one scale per group of rows written together, like
+ * their unmasked _h2 forms) -- tests/test_chain_fusion_gpu.py.
+ *   frcnn_conv2d_nhwc_masked_ws:            frcnn_conv2d_nhwc_ws (f32 matrix pipe; split-K plans mask in their finishing pass)
+ *   frcnn_gemm_h2_masked:                   frcnn_gemm_h2 (float32 residual only)
+ *   frcnn_winograd_output_transform_masked: F(4x4,3x3) output transform without bias / activation; float32 (y_d) and / or operand planes
+ *   frcnn_winograd7_output_transform_masked: the 7x7-map transform likewise */
+int frcnn_conv2d_nhwc_masked_ws(const float* x_d, int N, int H, int W, int Cin, const float* w_d, const float* bias_d,
+                                const float* residual_d, int RH, int RW, int res_stride, float* y_d, int OH, int OW,
+                                int Cout, int KH, int KW, int stride, int pad_top, int pad_left, int act, const float* mask_d,
+                                void* ws, size_t ws_bytes, void* stream);
+int frcnn_gemm_h2_masked(const void* x_planes_d, const float* x_inv_d, const void* w_planes_d, const float* w_inv_d, const float* bias_d,
+                         const float* res_d, const float* mask_d, float* y_d, void* y_planes_d, float* y_inv_d, int G, int M, int N, int K,
+                         int act, int cfg, void* stream);
+int frcnn_winograd_output_transform_masked(const float* m_d, int N, int H, int W, int C, int m, const float* mask_d, float* y_d,
+                                           void* y_planes_d, float* y_inv_d, void* stream);
+int frcnn_winograd7_output_transform_masked(const float* m_d, int R, int C, const float* mask_d, float* y_d, void* y_planes_d,
+                                            float* y_inv_d, void* stream);
 int frcnn_relu6_bwd(float* grad_d, const float* y_d, long long n, void* stream);             /* grad *= (0 < y < 6) */
 /* Reverse-sweep pieces of the VGG16 / MobileNet-v1 TRAIN graphs (lib/nets/vgg16.py:26-60, mobilenet_v1.py:114-172):
  *   frcnn_maxpool_bwd:      gradient of slim.max_pool2d (padding at the bottom / right only): a window's gradient goes to its first

@@ -36,6 +36,7 @@ __device__ float4 g_zero_page[4];     // 64 zero bytes (static device memory, ze
 
 struct ConvParams {
   const float* x; const float* w; const float* bias; const float* res; float* y;
+  const float* mask;               // training: y = mask[m][n] > 0 ? y : 0 after the activation (the ReLU gradient of the tensor y is the gradient OF)
   int N, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad_top, pad_left, act;
   int RH, RW, res_stride;
   int M, Ktot, nsteps;             // M = N*OH*OW, Ktot = KH*KW*Cin (fold_w: KH*32)
@@ -340,6 +341,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
       if (p.act == FRCNN_ACT_RELU) v = act_relu(v);
       else if (p.act == FRCNN_ACT_RELU6)
         v = act_relu6(v);
+      if (p.mask) {
+        const float4 k = *(const float4*)(p.mask + (size_t)m * p.Cout + n);
+        v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+      }
       *(float4*)(py + (size_t)m * p.Cout + n) = v;
     }
   } else {          // Cout not a multiple of 4 (RPN / fc heads): scalar path
@@ -359,6 +364,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_conv_igemm(const
       }
       if (p.act == FRCNN_ACT_RELU) v = act_relu(v);
       else if (p.act == FRCNN_ACT_RELU6) v = act_relu6(v);
+      if (p.mask) v = p.mask[(size_t)m * p.Cout + n] > 0.f ? v : 0.f;
       py[(size_t)m * p.Cout + n] = v;
     }
   }
@@ -621,7 +627,7 @@ static int launch_stream(const ConvParams& c, hipStream_t st) {
   int slots = 0;                            // resident workgroups on the CURRENT device
   HIP_TRY(kernel_once(once, (const void*)kern, NT, lds, &slots));
   const bool plain = c.KH == 1 && c.KW == 1 && c.stride == 1 && c.pad_top == 0 && c.pad_left == 0 && c.OH == c.H && c.OW == c.W;
-  if (slots < 8 || !plain || c.Cout % BN || c.splits != 1 || (c.res && c.res_stride != 1) || (long long)c.M * c.Cout >= (1ll << 31) ||
+  if (slots < 8 || !plain || c.mask || c.Cout % BN || c.splits != 1 || (c.res && c.res_stride != 1) || (long long)c.M * c.Cout >= (1ll << 31) ||
       (long long)c.M * c.Cin >= (1ll << 31) || (long long)c.Cout * c.Cin >= (1ll << 31))
     return FRCNN_E_UNSUPPORTED;
   GemmParams p;
@@ -742,7 +748,7 @@ extern "C" size_t frcnn_conv2d_workspace_bytes(int N, int OH, int OW, int Cout, 
 }
 
 __global__ void k_splitk_finish(const float* __restrict__ part, int S, int M, int Cout, const float* __restrict__ bias,
-                                const float* res, int res_stride, int OH, int OW, int RH, int RW, int act,
+                                const float* res, int res_stride, int OH, int OW, int RH, int RW, int act, const float* __restrict__ mask,
                                 float* y) {      // res may alias y (in-place gradient accumulation): no __restrict__ on the pair
   const long long total = (long long)M * Cout;
   const int ohow = OH * OW;
@@ -762,20 +768,22 @@ __global__ void k_splitk_finish(const float* __restrict__ part, int S, int M, in
     }
     if (act == FRCNN_ACT_RELU) v = act_relu(v);
     else if (act == FRCNN_ACT_RELU6) v = act_relu6(v);
+    if (mask) v = mask[i] > 0.f ? v : 0.f;
     y[i] = v;
   }
 }
 
 static int conv2d_impl(const float* x_d, int N, int H, int W, int Cin, const float* w_d, const float* bias_d,
                        const float* residual_d, int RH, int RW, int res_stride, float* y_d, int OH, int OW, int Cout, int KH, int KW,
-                       int stride, int pad_top, int pad_left, int act, int fold_w, void* ws, size_t ws_bytes, void* stream);
+                       int stride, int pad_top, int pad_left, int act, int fold_w, void* ws, size_t ws_bytes, const float* mask_d,
+                       void* stream);
 
 extern "C" int frcnn_conv2d_nhwc(const float* x_d, int N, int H, int W, int Cin, const float* w_d, const float* bias_d,
                                  const float* residual_d, int RH, int RW, int res_stride, float* y_d, int OH, int OW,
                                  int Cout, int KH, int KW, int stride, int pad_top, int pad_left, int act, int fold_w,
                                  void* stream) {
   return conv2d_impl(x_d, N, H, W, Cin, w_d, bias_d, residual_d, RH, RW, res_stride, y_d, OH, OW, Cout, KH, KW, stride, pad_top,
-                     pad_left, act, fold_w, nullptr, 0, stream);
+                     pad_left, act, fold_w, nullptr, 0, nullptr, stream);
 }
 
 // Same convolution with a scratch buffer of frcnn_conv2d_workspace_bytes(...) bytes: under-filled launches run split-K.
@@ -784,12 +792,26 @@ extern "C" int frcnn_conv2d_nhwc_ws(const float* x_d, int N, int H, int W, int C
                                     int Cout, int KH, int KW, int stride, int pad_top, int pad_left, int act, int fold_w,
                                     void* ws, size_t ws_bytes, void* stream) {
   return conv2d_impl(x_d, N, H, W, Cin, w_d, bias_d, residual_d, RH, RW, res_stride, y_d, OH, OW, Cout, KH, KW, stride, pad_top,
-                     pad_left, act, fold_w, ws, ws_bytes, stream);
+                     pad_left, act, fold_w, ws, ws_bytes, nullptr, stream);
+}
+
+// Training (the data-gradient chain): the same convolution followed by the ReLU gradient of the tensor the result is the gradient OF,
+//   y = mask > 0 ? y : 0   (mask: float32 [N, OH, OW, Cout], the forward activation; lib/nets/resnet_v1.py's bottleneck: every
+// convolution input of the trunk is a ReLU output) -- in the kernel's / the split-K finish's epilogue instead of a frcnn_relu_bwd pass
+// over the result.  The select is exact, so the result equals frcnn_conv2d_nhwc_ws + frcnn_relu_bwd bit for bit.
+extern "C" int frcnn_conv2d_nhwc_masked_ws(const float* x_d, int N, int H, int W, int Cin, const float* w_d, const float* bias_d,
+                                           const float* residual_d, int RH, int RW, int res_stride, float* y_d, int OH, int OW,
+                                           int Cout, int KH, int KW, int stride, int pad_top, int pad_left, int act, const float* mask_d,
+                                           void* ws, size_t ws_bytes, void* stream) {
+  if (!mask_d) return FRCNN_E_ARG;
+  return conv2d_impl(x_d, N, H, W, Cin, w_d, bias_d, residual_d, RH, RW, res_stride, y_d, OH, OW, Cout, KH, KW, stride, pad_top,
+                     pad_left, act, 0, ws, ws_bytes, mask_d, stream);
 }
 
 static int conv2d_impl(const float* x_d, int N, int H, int W, int Cin, const float* w_d, const float* bias_d,
                        const float* residual_d, int RH, int RW, int res_stride, float* y_d, int OH, int OW, int Cout, int KH, int KW,
-                       int stride, int pad_top, int pad_left, int act, int fold_w, void* ws, size_t ws_bytes, void* stream) {
+                       int stride, int pad_top, int pad_left, int act, int fold_w, void* ws, size_t ws_bytes, const float* mask_d,
+                       void* stream) {
   if (!x_d || !w_d || !y_d) return FRCNN_E_ARG;
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || OH <= 0 || OW <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0)
     return FRCNN_E_ARG;
@@ -802,7 +824,7 @@ static int conv2d_impl(const float* x_d, int N, int H, int W, int Cin, const flo
   }
   if ((long long)N * H * W * Cin >= (1ll << 31) || (long long)N * OH * OW >= (1ll << 31) / 4) return FRCNN_E_UNSUPPORTED;
   ConvParams p;
-  p.x = x_d; p.w = w_d; p.bias = bias_d; p.res = residual_d; p.y = y_d;
+  p.x = x_d; p.w = w_d; p.bias = bias_d; p.res = residual_d; p.y = y_d; p.mask = mask_d;
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.Cout = Cout; p.KH = KH; p.KW = fold_w ? 1 : KW;
   p.stride = stride; p.pad_top = pad_top; p.pad_left = pad_left; p.act = act;
   p.RH = RH; p.RW = RW; p.res_stride = residual_d ? res_stride : 1;
@@ -823,13 +845,13 @@ static int conv2d_impl(const float* x_d, int N, int H, int W, int Cin, const flo
     const int S = plan_splits(p.M, Cout, p.nsteps);
     if (S > 1 && (size_t)S * p.M * Cout * sizeof(float) <= ws_bytes) {
       ConvParams q = p;
-      q.bias = nullptr; q.res = nullptr; q.act = FRCNN_ACT_NONE; q.y = (float*)ws;
+      q.bias = nullptr; q.res = nullptr; q.act = FRCNN_ACT_NONE; q.y = (float*)ws; q.mask = nullptr;
       q.kchunk = cdiv(p.nsteps, S); q.splits = S; q.gz = (long long)p.M * Cout;
       const int rc = launch_cfg(Cout > 32 ? 15 : 4, q, st);
       if (rc) return rc;
       const long long total = (long long)p.M * Cout;
       hipLaunchKernelGGL(k_splitk_finish, dim3((unsigned)min((long long)2048, (total + 255) / 256)), dim3(256), 0, st, (const float*)ws, S,
-                         p.M, Cout, bias_d, residual_d, p.res_stride, OH, OW, RH, RW, act, y_d);
+                         p.M, Cout, bias_d, residual_d, p.res_stride, OH, OW, RH, RW, act, mask_d, y_d);
       LAUNCH_CHECK();
       return FRCNN_OK;
     }
@@ -877,7 +899,7 @@ extern "C" int frcnn_gemm_batched_nt(const float* x_d, const float* w_d, float* 
   if (!x_d || !w_d || !y_d || G <= 0 || M <= 0 || N <= 0 || K <= 0) return FRCNN_E_ARG;
   if (K % 32 || G > 65535) return FRCNN_E_UNSUPPORTED;
   ConvParams p;
-  p.x = x_d; p.w = w_d; p.bias = nullptr; p.res = nullptr; p.y = y_d;
+  p.x = x_d; p.w = w_d; p.bias = nullptr; p.res = nullptr; p.y = y_d; p.mask = nullptr;
   p.N = 1; p.H = 1; p.W = M; p.Cin = K; p.OH = 1; p.OW = M; p.Cout = N; p.KH = 1; p.KW = 1;
   p.stride = 1; p.pad_top = 0; p.pad_left = 0; p.act = FRCNN_ACT_NONE;
   p.RH = p.RW = 0; p.res_stride = 1;

@@ -3,7 +3,7 @@
 #include "h2_common.h"
 
 extern "C" int frcnn_abi_version(void) { return FRCNN_ABI_VERSION; }
-extern "C" const char* frcnn_build_info(void) { return "libfrcnn_hip gfx950 (CDNA4, wave64, f32 / f16 / bf16 MFMA) abi 4"; }
+extern "C" const char* frcnn_build_info(void) { return "libfrcnn_hip gfx950 (CDNA4, wave64, f32 / f16 / bf16 MFMA) abi 5"; }
 
 // ---- max pool (nets/resnet_v1.py:83-84 pool1: pad 1 + 3x3/2 VALID; nets/vgg16.py:30-39 2x2/2 SAME;
 //      nets/network.py:157).  Out-of-image taps are skipped, which equals TF's SAME behaviour and,

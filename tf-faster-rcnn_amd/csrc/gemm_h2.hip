@@ -51,6 +51,7 @@ struct GemmH2Params {
   int M, N, K, batch, act, nsteps, mtiles, ntiles;
   long long Mtot;                     // rows of x / res / y / yp over all batch entries (= batch * M)
   int wshare;                         // 1: every batch entry multiplies by W[0] (frcnn_gemm_h2_mean: entries = images); 0: entry g by W[g]
+  const float* mask;                  // frcnn_gemm_h2_masked (training): result = mask > 0 ? result : 0, mask [batch * M][N] float32
   float* mean_part; int mean_rows;    // frcnn_gemm_h2_mean: the result is not stored; column sums of row groups go to mean_part [batch][ceil(M / 32)][2][N]
 #ifdef FRCNN_H2_TRACE
   unsigned long long* trace;          // measurement builds only (scratch/h2_trace.py): s_memtime stamps of the first slabs of a few workgroups
@@ -424,6 +425,25 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
           tot[i][j][4 * q + 3] = act_clamp(tot[i][j][4 * q + 3] * wi.w, act_lo, act_hi);
         }
       }
+    }
+    // ---- frcnn_gemm_h2_masked: the ReLU gradient of the tensor this result is the gradient of (an exact select; NaN / inf of the result
+    //      pass where the mask is positive, like frcnn_relu_bwd) -------------------------------------------------------------------------
+    if ((TUNE & 128) && p.mask) {       // TUNE & 128: the training instantiations (the inference kernels do not carry this code)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int m0 = c_bm0 + wm0 + i * 32, nc = c_bn0 + wn0 + j * 32;
+          const auto rk = rsrc_f(p.mask + (long long)(row_base + m0) * p.N + nc, (long long)(p.M - m0) * p.N - nc, 4);
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          u32x4 k[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) k[q] = __builtin_amdgcn_raw_buffer_load_b128(rk, (frow * p.N + 4 * khalf) * 4 + 32 * q, 0, 0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tot[i][j][4 * q + e] = __uint_as_float(k[q][e]) > 0.f ? tot[i][j][4 * q + e] : 0.f;
+        }
     }
     // ---- frcnn_gemm_h2_mean: reduce_mean over row groups instead of a result tensor (the tail's last convolution feeds only the spatial
     //      mean, lib/nets/resnet_v1.py:115-125).  A 32-row accumulator block (lanes = rows) meets at most two groups (mean_rows >= 32):
@@ -933,7 +953,31 @@ extern "C" int frcnn_gemm_h2(const void* x_planes_d, const float* x_inv_d, const
 #ifdef FRCNN_H2_TRACE
   p.trace = g_h2_trace;
 #endif
-  p.mean_part = nullptr; p.mean_rows = 0; p.wshare = 0;
+  p.mean_part = nullptr; p.mean_rows = 0; p.wshare = 0; p.mask = nullptr;
+  return run_h2(p, cfg, (hipStream_t)stream);
+}
+
+// Training (the data-gradient chain, dX = dY W): frcnn_gemm_h2 followed by the ReLU gradient of the tensor the result is the gradient OF --
+//   y = mask > 0 ? act(x W^T + bias + res) : 0,  mask [G*M][N] float32 (the forward activation X) -- inside the tile epilogue instead of a
+// frcnn_relu_bwd pass over y.  The select is exact: bit for bit frcnn_gemm_h2 + frcnn_relu_bwd.  The operand planes of the result
+// (y_planes) are those of the masked tensor.
+extern "C" int frcnn_gemm_h2_masked(const void* x_planes_d, const float* x_inv_d, const void* w_planes_d, const float* w_inv_d, const float* bias_d,
+                                    const float* res_d, const float* mask_d, float* y_d, void* y_planes_d, float* y_inv_d, int G, int M, int N, int K,
+                                    int act, int cfg, void* stream) {
+  if (!x_planes_d || !x_inv_d || !w_planes_d || !w_inv_d || !mask_d || (!y_d && !y_planes_d) || (y_planes_d && !y_inv_d) || G <= 0 || M <= 0 ||
+      N <= 0 || K <= 0 || act < 0 || act > 2)
+    return FRCNN_E_ARG;
+  const long long Mtot = (long long)G * M;
+  if (K % H2_KB || N % 128 || 4ll * Mtot * K >= (1ll << 32) || 4ll * N * K >= (1ll << 32) || (long long)M * N >= (1ll << 29)) return FRCNN_E_UNSUPPORTED;
+  GemmH2Params p;
+  p.x = (const unsigned short*)x_planes_d; p.x_inv = x_inv_d; p.w = (const unsigned short*)w_planes_d; p.w_inv = w_inv_d;
+  p.bias = bias_d; p.res = res_d; p.resp = nullptr; p.resp_inv = nullptr; p.y = y_d; p.yp = (unsigned short*)y_planes_d; p.y_inv = y_inv_d;
+  p.M = M; p.N = N; p.K = K; p.batch = G; p.act = act; p.Mtot = Mtot;
+  p.nsteps = p.mtiles = p.ntiles = 0;
+#ifdef FRCNN_H2_TRACE
+  p.trace = g_h2_trace;
+#endif
+  p.mean_part = nullptr; p.mean_rows = 0; p.wshare = 0; p.mask = mask_d;
   return run_h2(p, cfg, (hipStream_t)stream);
 }
 
@@ -953,6 +997,12 @@ static int run_h2(GemmH2Params& p, int cfg, hipStream_t st) {
     // (profiles/r03_g_h2_sweep.txt: 21.8 vs 30.9 us on one image's block3 conv1); in the 4-image pipeline these lose (r03_l_ab.txt)
     const bool tiny = (long long)((M + 127) / 128) * (N / 128) * G < 150;
     cfg = pp ? 21 : tiny ? 12 : 9;       // 9: 128 x 128 tiles, two workgroups per CU, one barrier per slab (profiles/r03_l_ab.txt)
+  }
+  if (p.mask) switch (cfg) {            // frcnn_gemm_h2_masked: the same three configurations with the mask in the epilogue
+    case 9: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 128>(p, st);
+    case 12: return launch_h2<64, 128, 32, 64, 2, 2, 128>(p, st);
+    case 21: return launch_h2<256, 128, 64, 64, 3, 2, 34 + 128>(p, st);
+    default: return FRCNN_E_ARG;
   }
   switch (cfg) {
     case 9: return launch_h2<128, 128, 64, 64, 2, 2, 2>(p, st);  // 67 KB: 2 workgroups / CU, one barrier per slab, scales once per 128-k block
@@ -1025,7 +1075,7 @@ extern "C" int frcnn_gemm_h2_mean(const void* x_planes_d, const float* x_inv_d, 
 #ifdef FRCNN_H2_TRACE
   p.trace = g_h2_trace;
 #endif
-  p.mean_part = (float*)ws; p.mean_rows = rows; p.wshare = 1;
+  p.mean_part = (float*)ws; p.mean_rows = rows; p.wshare = 1; p.mask = nullptr;
   hipStream_t st = (hipStream_t)stream;
   const int rc = run_h2(p, cfg, st);
   if (rc) return rc;

@@ -168,9 +168,11 @@ __global__ void __launch_bounds__(256) k_wino4_input(const float4* __restrict__ 
     o3 = f4add(f4mad(8.f, u, q), v5);                                                  \
   }
 
-template <bool H2>
+// MASK (training, frcnn_winograd_output_transform_masked): y = mask > 0 ? y : 0 -- the ReLU gradient of the tensor y is the gradient of
+template <bool H2, bool MASK = false>
 __global__ void __launch_bounds__(256) k_wino4_output(const float4* __restrict__ Mx, int N, int H, int W, int C4, int TH, int TW,
-                                                       const float4* __restrict__ bias, int act, const WinoSink<H2> y) {
+                                                       const float4* __restrict__ bias, int act, const float4* __restrict__ mask,
+                                                       const WinoSink<H2> y) {
   const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long T = (long long)N * TH * TW;
   if (id >= T * C4) return;
@@ -203,6 +205,10 @@ __global__ void __launch_bounds__(256) k_wino4_output(const float4* __restrict__
       valid |= (ow < W ? 1u : 0u) << b;
       float4 v = f4add(o[b], bv);
       if (act == FRCNN_ACT_RELU) v = act_relu(v);
+      if (MASK && ow < W) {
+        const float4 k = mask[r[b] * C4 + c4];
+        v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+      }
       o[b] = v;
     }
     y.template putn<4>(r, o, valid, c4, C4);
@@ -281,12 +287,17 @@ __global__ void k_wino_output(const float4* __restrict__ Mx, int N, int H, int W
 
 template <bool H2>
 static int wino_output_launch(const float* m_d, int N, int H, int W, int C, int m, const float* bias_d, int act, const WinoSink<H2>& sink,
-                              hipStream_t st) {
+                              hipStream_t st, const float* mask_d = nullptr) {
   const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
   const long long tot = (long long)N * TH * TW * (C / 4);
-  if (m == 4)
-    hipLaunchKernelGGL(k_wino4_output<H2>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float4*)m_d, N, H, W, C / 4, TH, TW,
-                       (const float4*)bias_d, act, sink);
+  if (m == 4 && mask_d)
+    hipLaunchKernelGGL((k_wino4_output<H2, true>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float4*)m_d, N, H, W, C / 4, TH,
+                       TW, (const float4*)bias_d, act, (const float4*)mask_d, sink);
+  else if (mask_d)
+    return FRCNN_E_UNSUPPORTED;
+  else if (m == 4)
+    hipLaunchKernelGGL((k_wino4_output<H2, false>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float4*)m_d, N, H, W, C / 4, TH,
+                       TW, (const float4*)bias_d, act, (const float4*)nullptr, sink);
   else
     hipLaunchKernelGGL(k_wino_output<H2>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float4*)m_d, N, H, W, C / 4, TH, TW,
                        (const float4*)bias_d, act, sink);
@@ -310,6 +321,22 @@ extern "C" int frcnn_winograd_output_transform_h2(const float* m_d, int N, int H
   if (C % H2_KB || (m != 2 && m != 4) || (act != FRCNN_ACT_NONE && act != FRCNN_ACT_RELU)) return FRCNN_E_UNSUPPORTED;
   const WinoSink<true> sink{(float4*)y_d, (unsigned short*)y_planes_d, y_inv_d, (size_t)N * H * W};
   return wino_output_launch<true>(m_d, N, H, W, C, m, bias_d, act, sink, (hipStream_t)stream);
+}
+
+// Training (the data-gradient chain of a 3x3 convolution): the output transform followed by the ReLU gradient of the tensor the result
+// is the gradient OF, y = mask > 0 ? A^T M A : 0 (mask [N,H,W,C] float32, the forward activation), as float32 (y_d) and / or as the
+// operand planes of the next data-gradient GEMM (y_planes_d + y_inv_d, C % 128 == 0) -- instead of frcnn_relu_bwd (+ frcnn_h2_split)
+// passes over the result.  m = 4 only.  The float32 result is bit for bit the unfused sequence (exact select).
+extern "C" int frcnn_winograd_output_transform_masked(const float* m_d, int N, int H, int W, int C, int m, const float* mask_d, float* y_d,
+                                                      void* y_planes_d, float* y_inv_d, void* stream) {
+  if (!m_d || !mask_d || (!y_d && !y_planes_d) || (y_planes_d && !y_inv_d) || N <= 0 || H <= 0 || W <= 0 || C <= 0) return FRCNN_E_ARG;
+  if (C % 4 || m != 4 || (y_planes_d && C % H2_KB)) return FRCNN_E_UNSUPPORTED;
+  if (y_planes_d) {
+    const WinoSink<true> sink{(float4*)y_d, (unsigned short*)y_planes_d, y_inv_d, (size_t)N * H * W};
+    return wino_output_launch<true>(m_d, N, H, W, C, m, nullptr, FRCNN_ACT_NONE, sink, (hipStream_t)stream, mask_d);
+  }
+  const WinoSink<false> sink{(float4*)y_d, nullptr, nullptr, 0};
+  return wino_output_launch<false>(m_d, N, H, W, C, m, nullptr, FRCNN_ACT_NONE, sink, (hipStream_t)stream, mask_d);
 }
 
 // ---------------------------------------------------------------------------------------------------- filter transform on device

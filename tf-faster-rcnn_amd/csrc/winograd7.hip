@@ -109,9 +109,9 @@ __global__ void __launch_bounds__(256) k_wino7_input(const float2* __restrict__ 
 
 // y[r][i][j][o] = act( (A^T M A)[i][j] + bias[o] ), M[(xi*11+nu)][r][o]; the two row segments (xi 0..5 -> rows 0..3, xi 6..10 ->
 // rows 4..6) are processed one after the other to bound the register footprint
-template <int XI0, int NXI, int I0, int NI, bool H2>
+template <int XI0, int NXI, int I0, int NI, bool H2, bool MASK>
 __device__ __forceinline__ void wino7_out_segment(const float2* __restrict__ in, size_t plane, float2 bv, int act, const Wino7Sink<H2>& y,
-                                                  size_t row0, int c2, int C2) {
+                                                  size_t row0, int c2, int C2, const float2* __restrict__ mask) {
   float2 m[NXI][11];
 #pragma unroll
   for (int a = 0; a < NXI; ++a)
@@ -137,16 +137,21 @@ __device__ __forceinline__ void wino7_out_segment(const float2* __restrict__ in,
       for (int nu = 0; nu < 11; ++nu) acc_term(v, first, w7::AT[j][nu], s[nu]);
       v = make_float2(v.x + bv.x, v.y + bv.y);
       if (act == FRCNN_ACT_RELU) v = act_relu(v);
-      o[j] = v;
       rw[j] = row0 + (I0 + i) * 7 + j;
+      if (MASK) {
+        const float2 k = mask[rw[j] * C2 + c2];
+        v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f;
+      }
+      o[j] = v;
     }
     y.template putn<7>(rw, o, c2, C2);
   }
 }
 
-template <bool H2>
+// MASK (training, frcnn_winograd7_output_transform_masked): y = mask > 0 ? y : 0
+template <bool H2, bool MASK = false>
 __global__ void __launch_bounds__(256) k_wino7_output(const float2* __restrict__ Mx, int R, int C2, const float2* __restrict__ bias, int act,
-                                                       const Wino7Sink<H2> y) {
+                                                       const float2* __restrict__ mask, const Wino7Sink<H2> y) {
   const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= (long long)R * C2) return;
   const int c2 = (int)(id % C2);
@@ -154,8 +159,8 @@ __global__ void __launch_bounds__(256) k_wino7_output(const float2* __restrict__
   const size_t plane = (size_t)R * C2;
   const float2* in = Mx + (size_t)r * C2 + c2;
   const float2 bv = bias ? bias[c2] : make_float2(0.f, 0.f);
-  wino7_out_segment<0, 6, 0, 4, H2>(in, plane, bv, act, y, (size_t)r * 49, c2, C2);
-  wino7_out_segment<6, 5, 4, 3, H2>(in, plane, bv, act, y, (size_t)r * 49, c2, C2);
+  wino7_out_segment<0, 6, 0, 4, H2, MASK>(in, plane, bv, act, y, (size_t)r * 49, c2, C2, mask);
+  wino7_out_segment<6, 5, 4, 3, H2, MASK>(in, plane, bv, act, y, (size_t)r * 49, c2, C2, mask);
 }
 
 // U[(xi*11+nu)][o][c] = (G g G^T)[xi][nu] on the device from the packed filter [Cout][3][3][Cin] (training); transpose_flip as in
@@ -244,8 +249,8 @@ extern "C" int frcnn_winograd7_output_transform(const float* m_d, int R, int C, 
   if (C % 2 || (act != FRCNN_ACT_NONE && act != FRCNN_ACT_RELU)) return FRCNN_E_UNSUPPORTED;
   const long long tot = (long long)R * (C / 2);
   const Wino7Sink<false> sink{(float2*)y_d, nullptr, nullptr, 0};
-  hipLaunchKernelGGL(k_wino7_output<false>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float2*)m_d, R, C / 2,
-                     (const float2*)bias_d, act, sink);
+  hipLaunchKernelGGL((k_wino7_output<false, false>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float2*)m_d, R,
+                     C / 2, (const float2*)bias_d, act, (const float2*)nullptr, sink);
   LAUNCH_CHECK();
   return FRCNN_OK;
 }
@@ -257,8 +262,28 @@ extern "C" int frcnn_winograd7_output_transform_h2(const float* m_d, int R, int 
   if (C % H2_KB || (act != FRCNN_ACT_NONE && act != FRCNN_ACT_RELU)) return FRCNN_E_UNSUPPORTED;
   const long long tot = (long long)R * (C / 2);
   const Wino7Sink<true> sink{(float2*)y_d, (unsigned short*)y_planes_d, y_inv_d, (size_t)R * 49};
-  hipLaunchKernelGGL(k_wino7_output<true>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float2*)m_d, R, C / 2,
-                     (const float2*)bias_d, act, sink);
+  hipLaunchKernelGGL((k_wino7_output<true, false>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float2*)m_d, R,
+                     C / 2, (const float2*)bias_d, act, (const float2*)nullptr, sink);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+
+// Training: the output transform followed by the ReLU gradient of the tensor the result is the gradient OF (see
+// frcnn_winograd_output_transform_masked): y = mask > 0 ? A^T M A : 0, mask [R][7][7][C] float32; float32 (y_d) and / or operand planes.
+extern "C" int frcnn_winograd7_output_transform_masked(const float* m_d, int R, int C, const float* mask_d, float* y_d, void* y_planes_d,
+                                                       float* y_inv_d, void* stream) {
+  if (!m_d || !mask_d || (!y_d && !y_planes_d) || (y_planes_d && !y_inv_d) || R <= 0 || C <= 0) return FRCNN_E_ARG;
+  if (C % 2 || (y_planes_d && C % H2_KB)) return FRCNN_E_UNSUPPORTED;
+  const long long tot = (long long)R * (C / 2);
+  if (y_planes_d) {
+    const Wino7Sink<true> sink{(float2*)y_d, (unsigned short*)y_planes_d, y_inv_d, (size_t)R * 49};
+    hipLaunchKernelGGL((k_wino7_output<true, true>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float2*)m_d, R,
+                       C / 2, (const float2*)nullptr, FRCNN_ACT_NONE, (const float2*)mask_d, sink);
+  } else {
+    const Wino7Sink<false> sink{(float2*)y_d, nullptr, nullptr, 0};
+    hipLaunchKernelGGL((k_wino7_output<false, true>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float2*)m_d, R,
+                       C / 2, (const float2*)nullptr, FRCNN_ACT_NONE, (const float2*)mask_d, sink);
+  }
   LAUNCH_CHECK();
   return FRCNN_OK;
 }

@@ -12,7 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libfrcnn_hip.so")
 _lib = None
 
-ABI_VERSION = 4                          # include/frcnn_hip.h FRCNN_ABI_VERSION: the signatures below are this version's
+ABI_VERSION = 5                          # include/frcnn_hip.h FRCNN_ABI_VERSION: the signatures below are this version's
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 NMS_RULE_CPU, NMS_RULE_GPU = 0, 1        # FRCNN_NMS_RULE_*: `(double)ovr >= thresh` (cpu_nms.pyx:65) / `ovr > (float)thresh` (nms_kernel.cu:71)
 
@@ -63,6 +63,11 @@ SIGNATURES = {
     "frcnn_conv2d_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "frcnn_conv2d_nhwc_ws": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "frcnn_conv2d_nhwc_masked_ws": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, _P, c_int, c_int,
+                                            c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
+    "frcnn_gemm_h2_masked": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "frcnn_winograd_output_transform_masked": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "frcnn_winograd7_output_transform_masked": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P]),
     "frcnn_crc32c": (ctypes.c_uint32, [_P, c_size_t, ctypes.c_uint32]),
     "frcnn_snappy_uncompress": (c_longlong, [_P, c_size_t, _P, c_size_t]),
     "frcnn_prep_image_shape": (c_int, [c_int, c_int, c_int, c_int, _P, _P, _P]),

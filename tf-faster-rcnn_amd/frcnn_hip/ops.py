@@ -334,8 +334,9 @@ split_k = True      # module switch: allow split-K launches (frcnn_conv2d_nhwc_w
 
 
 def conv2d(x, w_packed, bias, KH, KW, stride=1, pad=(0, 0, 0, 0), act=ACT_NONE, residual=None, res_stride=1,
-           fold_w=False, out=None):
-    """x [N,H,W,Cin]; w_packed [Cout,KH,KW,Cin] (fold_w: [Cout,KH,8,4]); pad = (top, bottom, left, right)."""
+           fold_w=False, out=None, mask=None):
+    """x [N,H,W,Cin]; w_packed [Cout,KH,KW,Cin] (fold_w: [Cout,KH,8,4]); pad = (top, bottom, left, right).
+    mask (training, a float32 tensor of the result's shape): out = mask > 0 ? out : 0 inside the launch (frcnn_conv2d_nhwc_masked_ws)."""
     _chk(x), _chk(w_packed)
     N, H, W, Cin = x.shape
     Cout = w_packed.shape[0]
@@ -347,6 +348,14 @@ def conv2d(x, w_packed, bias, KH, KW, stride=1, pad=(0, 0, 0, 0), act=ACT_NONE, 
         _chk(residual)
         RH, RW = residual.shape[1], residual.shape[2]
     nb = lib().frcnn_conv2d_workspace_bytes(N, OH, OW, Cout, KH, KW, Cin, 1 if fold_w else 0) if split_k else 0
+    if mask is not None:
+        _chk(mask)
+        assert not fold_w and mask.numel() == out.numel()
+        ws = workspace(nb, x.device, "conv_splitk") if nb else None
+        call("frcnn_conv2d_nhwc_masked_ws", _ptr(x), N, H, W, Cin, _ptr(w_packed), _ptr(bias), _ptr(residual), RH, RW,
+             int(res_stride), _ptr(out), OH, OW, Cout, KH, KW, int(stride), int(pad[0]), int(pad[2]), int(act), _ptr(mask),
+             _ptr(ws), ws.numel() if nb else 0, _stream())
+        return out
     if nb:                                  # under-filled launch: split-K through a per-chain scratch buffer
         ws = workspace(nb, x.device, "conv_splitk")
         call("frcnn_conv2d_nhwc_ws", _ptr(x), N, H, W, Cin, _ptr(w_packed), _ptr(bias), _ptr(residual), RH, RW,
@@ -458,10 +467,27 @@ def winograd_output_transform(mm, bias, act, out, m=2):
     return out
 
 
-def conv3x3_winograd(x, u, bias, act=ACT_NONE, out=None, v_buf=None, m_buf=None, u_planes=None, v_planes=None):
+def winograd_output_transform_masked(mm, mask, out, m, out_planes=None):
+    """Training: out = mask > 0 ? A^T M A : 0 (no bias, no activation) as float32 `out` [N,H,W,C] and, with `out_planes` (an H2 of
+    [N*H*W, C]), as the operand planes of the next data-gradient GEMM too.  m in (4, 7)."""
+    _chk(mm), _chk(mask), _chk(out)
+    N, H, W, C = out.shape
+    assert mm.numel() == winograd_points(m) * winograd_tiles(N, H, W, m) * C and mask.numel() == out.numel()
+    if out_planes is not None:
+        assert isinstance(out_planes, H2) and out_planes.rows == N * H * W and out_planes.K == C
+    pl, inv = (None, None) if out_planes is None else (out_planes.planes, out_planes.inv)
+    if m == 7:
+        call("frcnn_winograd7_output_transform_masked", _ptr(mm), N, C, _ptr(mask), _ptr(out), _ptr(pl), _ptr(inv), _stream())
+    else:
+        call("frcnn_winograd_output_transform_masked", _ptr(mm), N, H, W, C, int(m), _ptr(mask), _ptr(out), _ptr(pl), _ptr(inv), _stream())
+    return out
+
+
+def conv3x3_winograd(x, u, bias, act=ACT_NONE, out=None, v_buf=None, m_buf=None, u_planes=None, v_planes=None, mask=None, out_planes=None):
     """3x3 / stride 1 / pad 1 convolution as Winograd F(m x m,3x3): x [N,H,W,Cin], u [(m+2)^2,Cout,Cin] -> [N,H,W,Cout].
     u_planes = h2_pack_w(u) and v_planes (an H2 of [points * tiles, Cin]): the input transform emits V as operand planes and the
-    products run in frcnn_gemm_h2 instead of the f32-MFMA batched GEMM."""
+    products run in frcnn_gemm_h2 instead of the f32-MFMA batched GEMM.
+    mask / out_planes (training, m in (4, 7), no bias / activation): winograd_output_transform_masked."""
     N, H, W, Cin = x.shape
     G, Cout = u.shape[0], u.shape[1]
     m = {16: 2, 36: 4, 121: 7}[G]
@@ -477,6 +503,12 @@ def conv3x3_winograd(x, u, bias, act=ACT_NONE, out=None, v_buf=None, m_buf=None,
         v = torch.empty((G, T, Cin), dtype=torch.float32, device=dev) if v_buf is None else v_buf
         winograd_input_transform(x, v, m)
         gemm_batched_nt(v, u, mm)
+    if mask is not None:
+        assert bias is None and act == ACT_NONE
+        return winograd_output_transform_masked(mm, mask, out, m, out_planes)
+    if out_planes is not None:              # float32 result + the operand planes of the convolution that follows (training forward)
+        winograd_output_transform_h2(mm, bias, act, tuple(out.shape), m, out_planes, out)
+        return out
     return winograd_output_transform(mm, bias, act, out, m)
 
 
@@ -786,10 +818,11 @@ def h2_pack_w(w, out=None):
     return out
 
 
-def gemm_h2(x, wp, G, M, N, K, bias=None, residual=None, act=ACT_NONE, out=None, out_planes=None, want_f32=True, cfg=-1):
+def gemm_h2(x, wp, G, M, N, K, bias=None, residual=None, act=ACT_NONE, out=None, out_planes=None, want_f32=True, cfg=-1, mask=None):
     """out[g] = act(x[g] W[g]^T + bias + residual[g]) through frcnn_gemm_h2.  x: H2 of [G*M, K]; wp = h2_pack_w(W [G,N,K]).
     residual: f32 [G*M, N] or an H2 of [G*M, N] (read as (h + l) * 2^-e).  out: f32 [G*M, N] (allocated when want_f32 and out is None);
     out_planes: an H2 of [G*M, N] to ALSO receive the result as the next GEMM's operand (emitted from the epilogue).
+    mask (training; float32 [G*M, N]): result = mask > 0 ? result : 0 in the tile epilogue (frcnn_gemm_h2_masked; float32 residual only).
     Returns (out or None, out_planes or None)."""
     assert isinstance(x, H2) and x.rows == G * M and x.K == K
     if out is None and want_f32:
@@ -799,6 +832,13 @@ def gemm_h2(x, wp, G, M, N, K, bias=None, residual=None, act=ACT_NONE, out=None,
     rp = residual if isinstance(residual, H2) else None
     if rp is not None:
         assert rp.rows == G * M and rp.K == N
+    if mask is not None:
+        _chk(mask)
+        assert rp is None and mask.numel() == G * M * N
+        call("frcnn_gemm_h2_masked", _ptr(x.planes), _ptr(x.inv), _ptr(wp[0]), _ptr(wp[1]), _ptr(bias), _ptr(residual), _ptr(mask), _ptr(out),
+             _ptr(None if out_planes is None else out_planes.planes), _ptr(None if out_planes is None else out_planes.inv),
+             int(G), int(M), int(N), int(K), int(act), int(cfg), _stream())
+        return out, out_planes
     call("frcnn_gemm_h2", _ptr(x.planes), _ptr(x.inv), _ptr(wp[0]), _ptr(wp[1]), _ptr(bias), _ptr(None if rp is not None else residual),
          _ptr(None if rp is None else rp.planes), _ptr(None if rp is None else rp.inv), _ptr(out),
          _ptr(None if out_planes is None else out_planes.planes), _ptr(None if out_planes is None else out_planes.inv),

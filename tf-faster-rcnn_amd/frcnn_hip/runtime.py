@@ -126,11 +126,13 @@ class VariableStore(object):
 
 class PreparedFilters(object):
     """Weight-only launches of a TRAINING step -- the Winograd transforms of the 3x3 filters (forward and gradient filter), the flipped /
-    transposed filters of the data gradients and their h2 split: ~150 tiny kernels that depend on nothing but the filters, yet sit on
-    the chain every activation waits for.  Each call site hands its launches over as `get(key, fn)`; fn() enqueues them into buffers
-    of its own and returns those.  The first time (and whenever the filters changed behind the solver's back) fn runs inline; the
-    solver calls weights_changed() + refresh() right after its update, which re-runs every remembered fn on a side stream -- beside
-    the next forward pass -- and the next get() finds the buffers done (one event wait per step, at the first use)."""
+    transposed filters of the data gradients and their h2 split, the operand planes of the forward pass's filters: ~200 tiny kernels that
+    depend on nothing but the filters, yet sit on the chain every activation waits for.  Each call site hands its launches over as
+    `get(key, fn)`; fn() enqueues them into buffers of its own and returns those.  The first time (and whenever the filters changed
+    behind the solver's back) fn runs inline; the solver calls weights_changed() + refresh() right after its update, which re-runs every
+    remembered fn on a side stream -- beside the next forward pass -- and the next get() finds the buffers done.  Three tiers, one event
+    each, waited for once per step at the first use: 0 = the session's cached filter images (refresh(pre=...): operand planes, TEST-mode
+    Winograd U; readers call wait_planes()), 1 = the forward pass's entries (keys ("fwd", ...)), 2 = the reverse sweep's."""
 
     def __init__(self, device):
         self.device = device
@@ -139,45 +141,63 @@ class PreparedFilters(object):
         self.ready = frozenset()
         self.version, self.ready_version = 0, -1
         self.stream = None
-        self.events = None                      # [after the forward pass's entries (keys ("fwd", ...)), after all of them]
-        self.waited = [True, True]
+        self.events = None                      # one per tier
+        self.waited = [True, True, True]
+
+    def _wait(self, tier):
+        if not self.waited[tier]:               # tiers complete in order on one stream: waiting for one covers the earlier ones
+            torch.cuda.current_stream(self.device).wait_event(self.events[tier])
+            for t in range(tier + 1):
+                self.waited[t] = True
 
     def get(self, key, fn):
         if self.enabled and self.ready_version == self.version and key in self.ready:
-            tier = 0 if key[0] == "fwd" else 1
-            if not self.waited[tier]:           # one wait per step and tier, at the first use: the forward pass does not wait for the
-                torch.cuda.current_stream(self.device).wait_event(self.events[tier])      # gradient filters queued behind its own
-                self.waited[tier] = True
-                if tier == 1:
-                    self.waited[0] = True
+            self._wait(1 if key[0] == "fwd" else 2)     # the forward pass does not wait for the gradient filters queued behind its own
             return self.plan[key][1]
         out = fn()
         if self.enabled:
             self.plan[key] = (fn, out)
         return out
 
+    def wait_planes(self):
+        """Before a launch reads a cached filter image of the session (Session.h2_planes / x3_planes / winograd_params, and a TEST-mode
+        graph replay, whose launches read them without passing through those accessors)."""
+        if self.events is not None:
+            self._wait(0)
+
+    def join(self):
+        """Before the filters are written again (the solver's update): everything the last refresh() enqueued has read them."""
+        if self.events is not None:
+            self._wait(2)
+
     def weights_changed(self):
         self.version += 1
 
-    def refresh(self):
-        if not self.enabled or not self.plan:
+    def refresh(self, pre=None):
+        """pre: launches that re-derive the session's cached filter images from the updated filters (tier 0)."""
+        if not self.enabled:
             self.ready = frozenset()
+            if pre is not None:
+                pre()
             return
         from . import ops
         main = torch.cuda.current_stream(self.device)
         if self.stream is None:
-            self.stream, self.events = torch.cuda.Stream(device=self.device), [torch.cuda.Event(), torch.cuda.Event()]
+            self.stream, self.events = torch.cuda.Stream(device=self.device), [torch.cuda.Event() for _ in range(3)]
         self.stream.wait_stream(main)           # the update itself, and the last step's reads of these buffers
         with ops.pinned_stream(self.stream):
+            if pre is not None:
+                pre()
+            self.events[0].record(self.stream)
             for key, (fn, _) in self.plan.items():
                 if key[0] == "fwd":
                     fn()
-            self.events[0].record(self.stream)
+            self.events[1].record(self.stream)
             for key, (fn, _) in self.plan.items():
                 if key[0] != "fwd":
                     fn()
-        self.events[1].record(self.stream)
-        self.ready, self.ready_version, self.waited = frozenset(self.plan), self.version, [False, False]
+        self.events[2].record(self.stream)
+        self.ready, self.ready_version, self.waited = frozenset(self.plan), self.version, [False, False, False]
 
     def invalidate(self):
         """The filter tensors were replaced or rewritten by somebody else than the solver (restore, initialise): forget the plan (its
@@ -240,6 +260,7 @@ class Session(VariableStore):
         """(U_d [(m+2)^2,Cout,Cin], bias_d) for a 3x3 stride-1 scope run as Winograd F(m x m,3x3); m = 7: the mixed 7x7 scheme,
         U_d [121,Cout,Cin] (TEST mode; training transforms the live filter on the device)."""
         key = ("wino", scope, bn_eps, m)
+        self.prepared.wait_planes()
         if key in self.packed:
             return self.packed[key]
         w = self.variables[scope + "/weights"]
@@ -265,6 +286,7 @@ class Session(VariableStore):
         """Pre-split bf16 planes of a static device filter for frcnn_gemm_x3 (cfg.HIP.MFMA_X3), split once and cached for the
         life of the session (the entry keeps the filter alive: its address is the key)."""
         key = (w.data_ptr(), tuple(w.shape))
+        self.prepared.wait_planes()
         ent = self.x3.get(key)
         if ent is None:
             ent = (ops.gemm_x3_pack(w), w)
@@ -315,6 +337,7 @@ class Session(VariableStore):
         """Pre-split fp16 planes + per-row scales of a static device filter [N, ...K] / [G, N, K] for frcnn_gemm_h2 (cfg.HIP.MFMA_H2),
         split once and cached like x3_planes."""
         key = (w.data_ptr(), tuple(w.shape))
+        self.prepared.wait_planes()                 # (training: the solver re-splits the cached filters on its side stream)
         ent = self.h2.get(key)
         if ent is None:
             ent = (ops.h2_pack_w(w), w)

@@ -70,6 +70,7 @@ class TrainState(object):
         self.flat = None
         self.reg_scopes = []
         self._wgrad_events = None
+        self.fuse_chain = True                                  # see _sweep (False: separate relu_bwd / copy / h2_split passes; tests)
         self.prep_stream = True                                 # sess.prepared: weight-only launches re-run by the solver on a side stream
 
     def build(self):
@@ -173,13 +174,52 @@ class TrainState(object):
         prep.enabled = bool(getattr(self, "prep_stream", True)) and not getattr(self, "graph", False)      # (a captured sweep prepares inline)
         prepared = prep.get
 
+        # Elementwise passes of the chain rule folded into the launches on either side of them (cfg-free; `fuse_chain = False` keeps the
+        # separate passes, for the bit-equality test):
+        #  * ReLU gradient: the input x of a trunk convolution is a ReLU output, so the data gradient a record produces is masked by
+        #    (x > 0) in the producing launch's epilogue (ops.*(mask=x)); `masked` = tensors whose gradient buffer holds ONLY masked
+        #    contributions -- their producer record skips its relu_bwd pass (the select is idempotent and distributes over the sum, so a
+        #    buffer that also received an unmasked contribution is simply masked again by the pass);
+        #  * identity shortcut: the residual's gradient IS the masked dY of the unit's last convolution -- `borrowed` maps it to that
+        #    buffer instead of copying it; the convolution that later adds its own data gradient reads it as the launch's residual and
+        #    writes a fresh buffer (the borrowed one is still being read by the filter gradient on a side stream);
+        #  * operand planes of dY for a following frcnn_gemm_h2 data gradient come out of the Winograd output transform (`emitted`).
+        fuse = bool(getattr(self, "fuse_chain", True))
+        producer = {}
+        if fuse:
+            for r in net._tape:
+                if r["kind"] not in ("mean", "crop", "maxpool", "dropout", "dwconv"):
+                    producer[r["y"].data_ptr()] = r
+        masked, borrowed, emitted = set(), set(), {}
+
+        def relu_mask(t):
+            r = producer.get(t.data_ptr())
+            return r["y"] if (r is not None and r["act"] == ACT_RELU) else None
+
         def accumulate_into(target, shape, name):
             key = target.data_ptr()
             if key in grads:
+                emitted.pop(key, None)                       # (planes emitted with the first contribution would be stale)
+                if key in borrowed:                          # an in-place accumulation is about to write it: take a private copy
+                    g = sess.buf("grad/" + name + "/own", shape)
+                    g.copy_(grads[key].view(shape))
+                    grads[key] = g
+                    borrowed.discard(key)
+                masked.discard(key)                          # (callers that mask the whole sum add it again)
                 return grads[key], True
             g = sess.buf("grad/" + name, shape)
             grads[key] = g
+            masked.discard(key)
             return g, False
+
+        def h2_dgrad(r):
+            """Does the record's data gradient run as frcnn_gemm_h2 (dX = dY W, K = Cout)?  (cfg.HIP.H2_TRAIN)"""
+            if r["k"] != 1 or r["stride"] != 1 or tuple(r["pad"]) != (0, 0, 0, 0) or getattr(self, "h2_train", None) is None:
+                return False
+            yy, wf = r["y"], sess.conv_info[r["scope"]]["w"]
+            Mr, Co, Ci = yy.numel() // yy.shape[-1], yy.shape[-1], wf.shape[3]
+            return (Co % 128 == 0 and Ci % 128 == 0 and ((Mr + 127) // 128) * (Ci // 128) >= self.h2_train
+                    and 4 * Mr * Co < (1 << 32) and Mr * Ci < (1 << 29))
 
         for rec in reversed(net._tape):
             kind = rec["kind"]
@@ -245,19 +285,30 @@ class TrainState(object):
             if gy is None:
                 continue
             gy = gy.view(y.shape)
+            if rec["act"] != ACT_NONE and y.data_ptr() in borrowed:      # the activation gradient is applied in place
+                gy = sess.buf("grad/" + sc + "/own", y.shape)
+                gy.copy_(grads[y.data_ptr()].view(y.shape))
+                grads[y.data_ptr()] = gy
+                borrowed.discard(y.data_ptr())
             if rec["act"] == ACT_RELU:
-                ops.relu_bwd(gy, y)
+                if y.data_ptr() not in masked:
+                    ops.relu_bwd(gy, y)
             elif rec["act"] == ACT_RELU6:
                 ops.relu6_bwd(gy, y)
             res = rec["residual"]
             if res is not None and res.data_ptr() in needs:
-                gr, had = accumulate_into(res, res.shape, sc + "/res")
-                if rec["res_stride"] == 1 and not had:
-                    gr.copy_(gy)
+                if fuse and rec["res_stride"] == 1 and res.data_ptr() not in grads:
+                    grads[res.data_ptr()] = gy                   # identity shortcut: no copy (see `borrowed` above)
+                    borrowed.add(res.data_ptr())
+                    masked.discard(res.data_ptr())
                 else:
-                    if not had:
-                        gr.zero_()
-                    ops.add_strided(gy, gr, rec["res_stride"], True)
+                    gr, had = accumulate_into(res, res.shape, sc + "/res")
+                    if rec["res_stride"] == 1 and not had:
+                        gr.copy_(gy)
+                    else:
+                        if not had:
+                            gr.zero_()
+                        ops.add_strided(gy, gr, rec["res_stride"], True)
             k, stride, pad = rec["k"], rec["stride"], rec["pad"]
             N, OH, OW, Cout = y.shape
             M = N * OH * OW
@@ -293,42 +344,69 @@ class TrainState(object):
                         ar.ready(self.flat, p.grad_w.data_ptr(), side)
                 on_side(wgrad)
             if x.data_ptr() in needs:
-                gx, had = accumulate_into(x, x.shape, sc + "/in")
+                key = x.data_ptr()
+                mk = relu_mask(x) if fuse else None             # x itself when it is a ReLU output: the gradient's mask
+                lent = key in borrowed                          # an identity shortcut's gradient waits there, in somebody else's buffer
                 wf = sess.conv_info[sc]["w"]
                 wino = getattr(self, "winograd", None)          # (m, min channels) set by the Network from cfg.HIP, or None
-                if (wino is not None and not had and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1)
-                        and Cout % 32 == 0 and Cout >= wino[1] and wf.shape[3] % 4 == 0):
+                Cin = wf.shape[3]
+                flipped = stride == 1 and Cout % 32 == 0
+                use_wino = (wino is not None and key not in grads and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1)
+                            and Cout % 32 == 0 and Cout >= wino[1] and Cin % 4 == 0)
+                if lent and (use_wino or not flipped):
+                    lent = False                                # (accumulate_into below takes the private copy)
+                if lent:
+                    # out-of-place: residual = the borrowed buffer (read only), result = this record's own buffer
+                    gres, had = grads[key], True
+                    emitted.pop(key, None)
+                    gx = sess.buf("grad/" + sc + "/in", x.shape)
+                    grads[key] = gx
+                    borrowed.discard(key)
+                    masked.discard(key)
+                else:
+                    gx, had = accumulate_into(x, x.shape, sc + "/in")
+                    gres = gx
+                if use_wino:
                     # dX = conv(dY, flipped / transposed filter) is itself a 3x3 stride-1 SAME convolution: Winograd, with the
                     # gradient filter transformed straight from the packed forward filter
                     m = 7 if (wino[0] == 4 and len(wino) > 2 and wino[2] and OH == 7 and OW == 7) else wino[0]
-                    G, Cin = ops.winograd_points(m), wf.shape[3]
+                    G = ops.winograd_points(m)
                     T = ops.winograd_tiles(N, OH, OW, m)
                     u = prepared(("wino_u", sc, m), lambda wf=wf, m=m, sc=sc, G=G, Cin=Cin, Cout=Cout: ops.winograd_filter_transform_device(
                         wf, m, True, out=sess.buf("bwd/wino_u/" + sc, (G, Cin, Cout))))
+                    fused = mk is not None and m in (4, 7)
+                    gxp = None
+                    if fused and Cin % 128 == 0 and h2_dgrad(producer[key]):
+                        gxp = emitted[key] = sess.h2_buf("bwd/gyp/" + sc, x.numel() // Cin, Cin)      # dY planes of the producer's dgrad GEMM
                     ops.conv3x3_winograd(gy, u, None, ACT_NONE, out=gx, v_buf=sess.buf("bwd/wino_v", (G, T, Cout)),
-                                         m_buf=sess.buf("bwd/wino_m", (G, T, Cin)))
+                                         m_buf=sess.buf("bwd/wino_m", (G, T, Cin)), mask=mk if fused else None, out_planes=gxp)
+                    if fused:
+                        masked.add(key)
                     self.count_flops("f32", 2 * G * T * Cin * Cout)
-                elif stride == 1 and Cout % 32 == 0:
+                elif flipped:
                     wd = prepared(("wflip", sc), lambda wf=wf, sc=sc, k=k, Cout=Cout: ops.flip_transpose_filter(
                         wf, out=sess.buf("bwd/wflip/" + sc, (wf.shape[3], k, k, Cout))))
-                    Cin = wf.shape[3]
-                    if (k == 1 and tuple(pad) == (0, 0, 0, 0) and getattr(self, "h2_train", None) is not None
-                            and Cout % 128 == 0 and Cin % 128 == 0 and ((M + 127) // 128) * (Cin // 128) >= self.h2_train
-                            and 4 * M * Cout < (1 << 32) and M * Cin < (1 << 29)):
+                    if h2_dgrad(rec):
                         # dX = dY W: a plain GEMM with K = Cout -- frcnn_gemm_h2 on the split of dY and of the transposed filter
                         # (cfg.HIP.H2_TRAIN; both change every step, so both are split here: 8 B per element of dY, a few MB of filter)
-                        gp = ops.h2_split(gy.view(M, Cout), out=sess.h2_buf("bwd/gy", M, Cout))
+                        gp = emitted.pop(y.data_ptr(), None)
+                        if gp is None:
+                            gp = ops.h2_split(gy.view(M, Cout), out=sess.h2_buf("bwd/gy", M, Cout))
                         wq = prepared(("wflip_h2", sc), lambda wd=wd, sc=sc, Cin=Cin, Cout=Cout: ops.h2_pack_w(
                             wd.view(Cin, Cout), out=sess.buf_pair("bwd/wflip_h2/" + sc, Cin, Cout)))
-                        ops.gemm_h2(gp, wq, 1, M, Cin, Cout, None, gx.view(M, Cin) if had else None, ACT_NONE, out=gx.view(M, Cin))
+                        ops.gemm_h2(gp, wq, 1, M, Cin, Cout, None, gres.view(M, Cin) if had else None, ACT_NONE, out=gx.view(M, Cin),
+                                    mask=None if mk is None else mk.view(M, Cin))
                         self.count_flops("h2", 2 * M * Cin * Cout)
                     else:
                         dpad = (k - 1 - pad[0], k - 1 - pad[1], k - 1 - pad[2], k - 1 - pad[3])
-                        ops.conv2d(gy, wd, None, k, k, 1, dpad, ACT_NONE, gx if had else None, 1, out=gx)
+                        ops.conv2d(gy, wd, None, k, k, 1, dpad, ACT_NONE, gres if had else None, 1, out=gx, mask=mk)
                         self.count_flops("f32", 2 * M * Cin * Cout * k * k)
+                    if mk is not None:
+                        masked.add(key)                          # mask * (dX + what was there): the whole buffer is masked
                 else:
                     ops.conv2d_dgrad_strided(gy, wf, stride, pad, x.shape[1], x.shape[2], gx, had)
                     self.count_flops("f32", 2 * M * Cout * k * k * wf.shape[3])
+            emitted.pop(y.data_ptr(), None)
         for side in sides:
             main.wait_stream(side)               # the solver (and the next forward pass, which overwrites x) come after every wgrad
         return grads
@@ -353,6 +431,7 @@ class TrainState(object):
             else:
                 all_reduce(self.flat)
         gs = 1.0 / float(world_size)
+        self.sess.prepared.join()                    # (a step that used none of the side stream's buffers has not waited for it yet)
         if getattr(self, "_sgd_table", None) is None:
             entries = []
             for p in self.params.values():
@@ -370,15 +449,18 @@ class TrainState(object):
         for p in self.params.values():
             if getattr(p, "dw", False):
                 ops.dwconv3x3_refold(p.w, p.scale, p.wf)
-        # a TEST-mode network on the same session reads derived filter images: Winograd U of the 3x3 filters first (also with x3 / h2
-        # off: a no-op when no ('wino', ...) entry is cached), then the pre-split planes of everything (x3 / h2)
-        self.sess.wino_refresh()
-        if self.sess.x3:
-            self.sess.x3_refresh()
-        if self.sess.h2:                             # the same for cfg.HIP.MFMA_H2
-            self.sess.h2_refresh()
+        # Derived filter images -- the operand planes of the forward pass's frcnn_gemm_h2 launches, and what a TEST-mode network on the same
+        # session reads: Winograd U of the 3x3 filters first (also with x3 / h2 off: a no-op when no ('wino', ...) entry is cached), then the
+        # pre-split planes of everything (x3 / h2).  Weight-only launches: with cfg.HIP.PREP_STREAM they run on the side stream, beside the
+        # next forward pass (Session.h2_planes & co. wait for them at their first use: PreparedFilters.wait_planes).
+        def derived():
+            self.sess.wino_refresh()
+            if self.sess.x3:
+                self.sess.x3_refresh()
+            if self.sess.h2:                         # the same for cfg.HIP.MFMA_H2
+                self.sess.h2_refresh()
         self.sess.prepared.weights_changed()
-        self.sess.prepared.refresh()
+        self.sess.prepared.refresh(pre=derived)
 
     def invalidate_prepared(self):
         self.sess.prepared.invalidate()

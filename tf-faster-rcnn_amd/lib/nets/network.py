@@ -112,9 +112,12 @@ class Network(object):
                 w, m, False, out=sess.buf(self._tag + "/wino_u/" + scope, (G, Cout, Cin))))
             mm = sess.buf(self._tag + "/wino_m", (G, T, Cout))
             v = sess.buf(self._tag + "/wino_v", (G, T, Cin))
-            sess.mark("conv:" + scope, 2 * G * T * Cout * Cin, lambda: ops.conv3x3_winograd(x, u, b, act, out=out, v_buf=v, m_buf=mm),
+            # emit_h2: the output transform writes the float32 tensor (the tape needs it) AND the operand planes of the 1x1 that follows
+            yp = sess.h2_buf(self._tag + "/" + scope, M, Cout) if (emit_h2 and cfg.HIP.MFMA_H2 and Cout % 128 == 0) else None
+            sess.mark("conv:" + scope, 2 * G * T * Cout * Cin,
+                      lambda: ops.conv3x3_winograd(x, u, b, act, out=out, v_buf=v, m_buf=mm, out_planes=yp),
                       nbytes=4 * (v.numel() + u.numel() + mm.numel()))
-            self._wrote(out)
+            self._wrote(out, yp, True) if yp is not None else self._wrote(out)
         elif plain and self._h2_eligible(M, Cout, Cin, 1, scope) and self._h2_input(x) is not None:
             # a plain GEMM with a static filter on the fp16 matrix pipe, block-scaled two-piece operands (cfg.HIP.MFMA_H2)
             xp, wp = self._h2_input(x), sess.h2_planes(w)
@@ -633,6 +636,7 @@ class Network(object):
         self._sess = sess
         self._image = image_d
         self._im_info = (float(im_info[0]), float(im_info[1]), float(im_info[2]))
+        sess.prepared.wait_planes()                    # a solver sharing the session re-derives filter planes on a side stream (a replay reads them)
         ops.ws_scope = self._tag                       # scratch buffers are per network tag (= per stream)
         c = cfg[self._mode]
         key = (self._tag, self._scope, self._num_classes, self._anchor_scales, self._anchor_ratios, bool(cfg.RESNET.MAX_POOL),
@@ -664,6 +668,7 @@ class Network(object):
     # only useful during testing mode
     def extract_head(self, sess, image):
         self._sess = sess
+        sess.prepared.wait_planes()
         self._image = self._stage_image(sess, image)
         self._h2_of, self._f32_missing = {}, set()
         feat = self._image_to_head(False)
