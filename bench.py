@@ -265,6 +265,7 @@ def train_bench(args, c, dev, world, rank, dist):
         ar = parallel.make_grad_all_reduce()
     sw = SolverWrapper(sess, net, resident_blobs(synthetic_data_layer(c["classes"], seed=cfg.RNG_SEED + rank, image_gain=1 / 256.0), dev),
                        all_reduce=ar, world_size=world, force_dp=args.dp_constrained)
+    sw.state.solver_in_sweep, sw.state.fuse_chain, sw.state.pipe_dgrads = not args.no_solver_in_sweep, not args.no_fuse_chain, not args.no_fuse_chain
     sw.train_model(max(args.warmup, 1), verbose=False)
     torch.cuda.synchronize()
     if dist is not None:
@@ -449,6 +450,8 @@ def main():
     ap.add_argument("--h2-min-tiles", type=int, default=-1, help="cfg.HIP.H2_MIN_TILES (A/B)")
     ap.add_argument("--no-wgrad-tn", action="store_true", help="cfg.HIP.WGRAD_TN False: filter gradients by transposes + the forward GEMM kernel (c5 A/B)")
     ap.add_argument("--no-wgrad-h2", action="store_true", help="cfg.HIP.WGRAD_H2 False: filter gradients on the f32 matrix pipe (c5 A/B)")
+    ap.add_argument("--no-solver-in-sweep", action="store_true", help="c5 A/B: the solver updates every parameter after the sweep, in one launch on the main stream")
+    ap.add_argument("--no-fuse-chain", action="store_true", help="c5 A/B: separate relu_bwd / residual-copy / h2_split passes in the reverse sweep, gather-form strided / odd-width data gradients")
     ap.add_argument("--no-prep-stream", action="store_true", help="cfg.HIP.PREP_STREAM False: gradient filters prepared inside the sweep (c5 A/B)")
     ap.add_argument("--wgrad-plan", default=None, help="tile,workgroups override of frcnn_conv2d_wgrad_h2's slicing plan (c5 A/B), e.g. 0,256")
     ap.add_argument("--splitk-target", type=int, default=0, help="frcnn_set_tuning(7, N): workgroups a split-K convolution launch aims at (A/B; default 640)")

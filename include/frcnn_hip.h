@@ -506,6 +506,9 @@ int frcnn_sgd_momentum(float* w_d, float* acc_d, float* w_folded_d, const float*
  * (lib/model/train_val.py:132-141), 1 otherwise.  Element-wise identical to frcnn_sgd_momentum. */
 size_t frcnn_sgd_desc_bytes(void);
 int frcnn_sgd_momentum_multi(const void* desc_table_d, int count, float lr, float momentum, float grad_scale, void* stream);
+/* ... for the descriptors [first, first + count) of the table: the solver updates the tensors of a finished part of the reverse sweep
+ * on its own stream while the sweep goes on (single-GPU runs; a data-parallel step updates after the all-reduce, in one launch). */
+int frcnn_sgd_momentum_range(const void* desc_table_d, int first, int count, float lr, float momentum, float grad_scale, void* stream);
 /* out (+)= scale * sum(w^2)   (slim l2_regularizer value); ws >= 2 KiB. */
 int frcnn_sumsq(const float* w_d, long long n, double scale, float* out_d, int accumulate, void* ws, size_t ws_bytes, void* stream);
 /* The same over `count` tensors in two launches: ptr_table_d = device array of `count` float pointers, sizes_d = their

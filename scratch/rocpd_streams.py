@@ -8,12 +8,13 @@ c = sqlite3.connect(db)
 cols = [d[0] for d in c.execute("select * from kernels limit 1").description]
 sid = "stream_id" if "stream_id" in cols else "queue_id"
 rows = c.execute("select name, start, end, %s, grid_x, grid_y, grid_z from kernels order by start" % sid).fetchall()
-sgd = [i for i, r in enumerate(rows) if r[0].startswith("k_sgd_multi")]
-lo, hi = sgd[-2] + 1, sgd[-1] + 1
+# one step = from the start of one k_nms_reduce (once per step, in the proposal layer of the forward pass) to the start of the next
+sgd = [i for i, r in enumerate(rows) if r[0].startswith("void k_nms_reduce") or r[0].startswith("k_nms_reduce")]
+lo, hi = sgd[-2], sgd[-1]
 step = rows[lo:hi]
-t0, t1 = rows[sgd[-2]][2], rows[sgd[-1]][2]
+t0, t1 = rows[sgd[-2]][1], rows[sgd[-1]][1]
 f = open(out, "w")
-f.write("# last full training step: %d launches, %.1f us from the end of one k_sgd_multi to the end of the next\n" % (len(step), (t1 - t0) / 1e3))
+f.write("# last full training step: %d launches, %.1f us from one k_nms_reduce to the next\n" % (len(step), (t1 - t0) / 1e3))
 by = {}
 for r in step: by.setdefault(r[3], []).append(r)
 main = max(by, key=lambda s: len(by[s]))
@@ -39,25 +40,28 @@ for t, d in ev:
 f.write("# kernels running at once -> us of the step: " + ", ".join("%d: %.0f" % (k, v / 1e3) for k, v in sorted(hist.items())) + "\n")
 # phases on the main stream
 ms = sorted(by[main], key=lambda r: r[1])
+# the step as cut above: [proposal layer .. losses] [reverse sweep, solver] [next forward pass up to its proposal layer]
 marks = [i for i, r in enumerate(ms) if r[0].startswith("k_softmax_ce")]
 fw_end = marks[-1] if marks else 0
+sg = [i for i, r in enumerate(ms) if r[0].startswith("k_sgd_multi")]
+bw_end = sg[-1] if sg else len(ms) - 1
 def seg(name, a, b):
     rs = ms[a:b]
     if not rs: return
     dur = sum(r[2] - r[1] for r in rs)
     f.write("# main stream %-10s %5d launches, kernel time %9.1f us, span %9.1f us\n" % (name, len(rs), dur / 1e3, (rs[-1][2] - rs[0][1]) / 1e3))
-seg("forward", 0, fw_end + 1); seg("backward", fw_end + 1, len(ms))
+seg("fwd tail", 0, fw_end + 1); seg("backward", fw_end + 1, bw_end + 1); seg("fwd head", bw_end + 1, len(ms))
 # side streams: when do they finish relative to the main stream's last kernel before the solver
 f.write("# main stream last kernel ends at %.1f us; per stream last end: %s\n" % ((ms[-1][2] - t0) / 1e3, ", ".join("%s %.1f" % (s, (max(r[2] for r in rs) - t0) / 1e3) for s, rs in by.items())))
 # the main stream's kernels of the backward phase by name
 agg = {}
-for r in ms[fw_end + 1:]:
+for r in ms[fw_end + 1:bw_end + 1]:
     k = (r[0][:44], "%dx%dx%d" % (r[4], r[5], r[6])); a = agg.setdefault(k, [0, 0]); a[0] += 1; a[1] += r[2] - r[1]
 f.write("# backward phase of the main stream by kernel / grid\n")
 for k, (n, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
     f.write("%-46s %18s %5d %10.1f us\n" % (k[0], k[1], n, d / 1e3))
 agg = {}
-for r in ms[:fw_end + 1]:
+for r in ms[:fw_end + 1] + ms[bw_end + 1:]:
     k = (r[0][:44], "%dx%dx%d" % (r[4], r[5], r[6])); a = agg.setdefault(k, [0, 0]); a[0] += 1; a[1] += r[2] - r[1]
 f.write("# forward phase of the main stream by kernel / grid\n")
 for k, (n, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:

@@ -291,9 +291,12 @@ extern "C" int frcnn_sgd_momentum(float* w_d, float* acc_d, float* w_folded_d, c
 // table of descriptors, grid = (SGD_BLOCKS, count), block (b, t) walks tensor t with a grid stride.  lr and the mean-over-replicas
 // factor are launch arguments (they change per step); per-tensor lr multiplier (DOUBLE_BIAS) and weight decay sit in the table.
 struct SgdDesc { float* w; float* acc; float* wf; const float* grad; const float* scale; long long n; int K; float lr_mult; float wd; int pad; };
-#define SGD_BLOCKS 32
+// (128 blocks per tensor: with 32 the launch took as long as the 32 workgroups of the largest filter -- 2.4 M elements, 290 dependent
+// iterations each -- needed, 440 of the 487 us; blocks past a small tensor's end leave at once)
+#define SGD_BLOCKS 128
 __global__ __launch_bounds__(256) void k_sgd_multi(const SgdDesc* __restrict__ table, float lr, float mom, float grad_scale) {
   const SgdDesc d = table[blockIdx.y];
+  if ((long long)blockIdx.x * 256 >= d.n) return;
   const float lr_t = lr * d.lr_mult;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (long long)SGD_BLOCKS * 256) {
     const float s = d.scale ? d.scale[i / d.K] : 1.f;
@@ -303,6 +306,15 @@ __global__ __launch_bounds__(256) void k_sgd_multi(const SgdDesc* __restrict__ t
     d.acc[i] = a; d.w[i] = nw;
     if (d.wf) d.wf[i] = nw * s;
   }
+}
+// `first`: the launch covers table[first .. first + count) -- the solver updates the tensors of a finished part of the reverse sweep while
+// the sweep goes on (frcnn_hip/train.py)
+extern "C" int frcnn_sgd_momentum_range(const void* desc_table_d, int first, int count, float lr, float momentum, float grad_scale, void* stream) {
+  if (!desc_table_d || first < 0 || count <= 0 || count > 65535) return FRCNN_E_ARG;
+  hipLaunchKernelGGL(k_sgd_multi, dim3(SGD_BLOCKS, count), dim3(256), 0, (hipStream_t)stream, (const SgdDesc*)desc_table_d + first, lr, momentum,
+                     grad_scale);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
 }
 extern "C" size_t frcnn_sgd_desc_bytes(void) { return sizeof(SgdDesc); }
 extern "C" int frcnn_sgd_momentum_multi(const void* desc_table_d, int count, float lr, float momentum, float grad_scale, void* stream) {

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void k_nms_mask(const float4* __restrict__ box
 //
 // resolve_chunk: the 64 in-chunk decisions from the chunk's diagonal words, scalar bit operations.
 // k_nms_reduce<WPL>: one 1024-thread workgroup per image walks the boxes in 64-box chunks.  The 64 mask rows of chunk c+1
-// (every word >= c+1: 4 rows per wave, WPL words per lane) are loaded into registers WHILE chunk c is being decided, so no
+// and c+2 (every word >= c+1: 4 rows per wave, WPL words per lane) are loaded into registers WHILE chunk c is being decided, so no
 // decision waits for HBM/L2 latency: per chunk the cost is one diagonal resolve on wave 0 plus an LDS atomic-OR of the kept
 // rows into the removed-bit words.  The scan stops as soon as max_keep boxes are kept (== truncating the keep list,
 // proposal_layer.py:44-45).  K <= 4096 * WPL.
@@ -396,6 +396,7 @@ __device__ __forceinline__ void reduce_finish(const ReduceOut& o, int b, int max
   if (threadIdx.x == 0) o.num[b] = n;
 }
 
+#define NMS_KEEP_LDS 4096
 template <int WPL>
 __global__ __launch_bounds__(1024) void k_nms_reduce(const u64* __restrict__ mask_all, int K, int cb, int max_keep,
                                                      const ReduceOut o, size_t img) {
@@ -403,6 +404,11 @@ __global__ __launch_bounds__(1024) void k_nms_reduce(const u64* __restrict__ mas
   __shared__ u64 diag[64];
   __shared__ u64 kept_s;
   __shared__ int total_s;
+  // The kept boxes' indices wait in LDS and the output rows (box gather -> roi / keep entry: a dependent global load per kept box) are
+  // written by all 1024 threads AFTER the scan: inside the scan that load sat on wave 0's in-order vmcnt queue behind the prefetched mask
+  // rows, one memory round trip per chunk of the serial loop (650 us for 12 000 -> 2 000 boxes, profiles/r04_ac_train_kernels_by_shape.txt).
+  __shared__ int kidx[NMS_KEEP_LDS];
+  const bool defer = max_keep <= NMS_KEEP_LDS;
   const int b = blockIdx.x;
   const u64* mask = img_ptr(mask_all, img, b);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;       // 16 waves x 4 rows = the 64 rows of a chunk
@@ -410,7 +416,10 @@ __global__ __launch_bounds__(1024) void k_nms_reduce(const u64* __restrict__ mas
   if (tid == 0) total_s = 0;
   int total = 0;                                                        // wave 0's running count (uniform)
 
-  u64 bufA[4][WPL], bufB[4][WPL];
+  // the rows of chunks c+1 and (WPL <= 2: 16 instead of 32 registers per chunk) c+2 are in flight while chunk c is decided; 1024 threads
+  // leave 128 registers each, a third buffer of the 4-word form spills
+  constexpr bool DEEP = WPL <= 2;
+  u64 bufA[4][WPL], bufB[4][WPL], bufC[DEEP ? 4 : 1][DEEP ? WPL : 1];
   auto load_chunk = [&](int c, u64 (&buf)[4][WPL]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -442,7 +451,10 @@ __global__ __launch_bounds__(1024) void k_nms_reduce(const u64* __restrict__ mas
       const u64 kept = resolve_chunk(d, ((u64)cur_hi << 32) | (u64)cur_lo);
       if ((kept >> lane) & 1ull) {
         const int pos = total + __popcll(kept & ((1ull << lane) - 1ull));
-        if (pos < max_keep) reduce_emit(o, img, b, max_keep, pos, c * 64 + lane);
+        if (pos < max_keep) {
+          if (defer) kidx[pos] = c * 64 + lane;
+          else reduce_emit(o, img, b, max_keep, pos, c * 64 + lane);
+        }
       }
       total += __popcll(kept);
       if (lane == 0) { kept_s = kept; total_s = total; }
@@ -463,15 +475,32 @@ __global__ __launch_bounds__(1024) void k_nms_reduce(const u64* __restrict__ mas
   };
   __syncthreads();
   load_chunk(0, bufA);
-  for (int c = 0; c < cb; c += 2) {
-    if (c + 1 < cb) load_chunk(c + 1, bufB);
-    if (process(c, bufA)) break;
-    if (c + 1 >= cb) break;
-    if (c + 2 < cb) load_chunk(c + 2, bufA);
-    if (process(c + 1, bufB)) break;
+  if constexpr (DEEP) {
+    if (1 < cb) load_chunk(1, bufB);
+    for (int c = 0; c < cb; c += 3) {
+      if (c + 2 < cb) load_chunk(c + 2, bufC);
+      if (process(c, bufA)) break;
+      if (c + 1 >= cb) break;
+      if (c + 3 < cb) load_chunk(c + 3, bufA);
+      if (process(c + 1, bufB)) break;
+      if (c + 2 >= cb) break;
+      if (c + 4 < cb) load_chunk(c + 4, bufB);
+      if (process(c + 2, bufC)) break;
+    }
+  } else {
+    for (int c = 0; c < cb; c += 2) {
+      if (c + 1 < cb) load_chunk(c + 1, bufB);
+      if (process(c, bufA)) break;
+      if (c + 1 >= cb) break;
+      if (c + 2 < cb) load_chunk(c + 2, bufA);
+      if (process(c + 1, bufB)) break;
+    }
   }
   __syncthreads();
-  reduce_finish(o, b, max_keep, min(total_s, max_keep), 1024);
+  const int n = min(total_s, max_keep);
+  if (defer)
+    for (int p = tid; p < n; p += 1024) reduce_emit(o, img, b, max_keep, p, kidx[p]);
+  reduce_finish(o, b, max_keep, n, 1024);
 }
 
 // Same scan for K up to 65536 boxes (tf.image.non_max_suppression sees ALL H*W*A anchors, proposal_layer.py:56-72; also

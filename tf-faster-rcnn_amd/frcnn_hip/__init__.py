@@ -145,6 +145,7 @@ SIGNATURES = {
     "frcnn_sgd_momentum": (c_int, [_P, _P, _P, _P, _P, c_longlong, c_int, c_float, c_float, c_float, c_float, _P]),
     "frcnn_sgd_desc_bytes": (c_size_t, []),
     "frcnn_sgd_momentum_multi": (c_int, [_P, c_int, c_float, c_float, c_float, _P]),
+    "frcnn_sgd_momentum_range": (c_int, [_P, c_int, c_int, c_float, c_float, c_float, _P]),
     "frcnn_sumsq": (c_int, [_P, c_longlong, c_double, _P, c_int, _P, c_size_t, _P]),
     "frcnn_sumsq_multi": (c_int, [_P, _P, c_int, c_double, _P, c_int, _P, c_size_t, _P]),
     "frcnn_graph_begin": (c_int, [_P]),

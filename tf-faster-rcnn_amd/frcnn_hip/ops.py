@@ -985,6 +985,11 @@ def sgd_momentum_multi(table, count, lr, momentum, grad_scale=1.0):
     call("frcnn_sgd_momentum_multi", _ptr(table), int(count), float(lr), float(momentum), float(grad_scale), _stream())
 
 
+def sgd_momentum_range(table, first, count, lr, momentum, grad_scale=1.0):
+    """frcnn_sgd_momentum_multi for the descriptors [first, first + count) of `table`."""
+    call("frcnn_sgd_momentum_range", _ptr(table), int(first), int(count), float(lr), float(momentum), float(grad_scale), _stream())
+
+
 def sumsq(w, scale, out, accumulate):
     ws = workspace(4096, w.device, "sumsq")
     call("frcnn_sumsq", _ptr(w), w.numel(), float(scale), _ptr(out), 1 if accumulate else 0, _ptr(ws), ws.numel(), _stream())

@@ -71,6 +71,7 @@ class TrainState(object):
         self.reg_scopes = []
         self._wgrad_events = None
         self.fuse_chain = True                                  # see _sweep (False: separate relu_bwd / copy / h2_split passes; tests)
+        self.pipe_dgrads = True                                 # see _sweep (False: frcnn_conv2d_dgrad_strided for every strided / odd-width layer; tests)
         self.prep_stream = True                                 # sess.prepared: weight-only launches re-run by the solver on a side stream
 
     def build(self):
@@ -151,6 +152,35 @@ class TrainState(object):
         pins = [ops.pinned_stream(st) for st in sides]
         events = self._wgrad_events
 
+        # The solver inside the sweep (single-GPU runs with side streams; from the second step on, when apply() has built its descriptor
+        # table): the reverse sweep finishes the parameters from the END of the flat gradient backwards, so every SOLVER_CHUNK filter
+        # gradients the solver stream updates that range -- frcnn_sgd_momentum_range -- behind (a) the side streams' filter gradients
+        # enqueued so far and (b) the main stream's data gradients enqueued so far (the last readers of those filters in this step).
+        # ~0.5 ms of memory-bound update leaves the tail of the step; apply() updates what is left (the first layers).  The L2
+        # regulariser value reads the filters BEFORE any update: it opens the solver stream's step.
+        self._sgd_done_from = None
+        solver = None
+        if (sides and not self.data_parallel() and getattr(self, "_sgd_table", None) is not None and getattr(self, "lr", None) is not None
+                and getattr(self, "solver_in_sweep", True) and not any(getattr(p, "dw", False) for p in self.params.values())):
+            solver = self._solver_stream_obj()
+            solver.wait_stream(main)                             # (the previous step's apply() -- nothing else of this step matters to it)
+            with ops.pinned_stream(solver):
+                self.regularization_loss(self._reg_total())
+            self._reg_in_sweep = True
+            self._sgd_done_from = self._sgd_count
+        pending = [0]                                            # filter gradients enqueued since the last solver launch
+
+        def solver_step(first):
+            """update table[first, done_from) on the solver stream"""
+            for i, st in enumerate([main] + list(sides)):
+                ev = self._solver_events[i]
+                ev.record(st)
+                solver.wait_event(ev)
+            with ops.pinned_stream(solver):
+                ops.sgd_momentum_range(self._sgd_table, first, self._sgd_done_from - first, self.lr, self.momentum, 1.0)
+            self._sgd_done_from = first
+            pending[0] = 0
+
         def on_side(fn):
             if not sides:
                 return fn("", None)
@@ -185,6 +215,7 @@ class TrainState(object):
         #    writes a fresh buffer (the borrowed one is still being read by the filter gradient on a side stream);
         #  * operand planes of dY for a following frcnn_gemm_h2 data gradient come out of the Winograd output transform (`emitted`).
         fuse = bool(getattr(self, "fuse_chain", True))
+        pipe = bool(getattr(self, "pipe_dgrads", True))         # strided 3x3 / odd-width 1x1 data gradients on the matrix pipe (False: gather kernel)
         producer = {}
         if fuse:
             for r in net._tape:
@@ -351,9 +382,13 @@ class TrainState(object):
                 wino = getattr(self, "winograd", None)          # (m, min channels) set by the Network from cfg.HIP, or None
                 Cin = wf.shape[3]
                 flipped = stride == 1 and Cout % 32 == 0
+                up_h, up_w = (OH - 1) * stride + 1, (OW - 1) * stride + 1
+                up_pad = (k - 1 - pad[0], x.shape[1] - up_h - (k - 1 - pad[0]) + k - 1, k - 1 - pad[2], x.shape[2] - up_w - (k - 1 - pad[2]) + k - 1)
+                upsampled = pipe and stride > 1 and k > 1 and Cout % 32 == 0 and Cin % 32 == 0 and min(up_pad) >= 0
+                padded = pipe and k == 1 and stride == 1 and tuple(pad) == (0, 0, 0, 0) and Cout % 32 != 0 and Cin % 4 == 0 and y.dim() == 4
                 use_wino = (wino is not None and key not in grads and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1)
                             and Cout % 32 == 0 and Cout >= wino[1] and Cin % 4 == 0)
-                if lent and (use_wino or not flipped):
+                if lent and (use_wino or not (flipped or upsampled or padded)):
                     lent = False                                # (accumulate_into below takes the private copy)
                 if lent:
                     # out-of-place: residual = the borrowed buffer (read only), result = this record's own buffer
@@ -394,8 +429,11 @@ class TrainState(object):
                             gp = ops.h2_split(gy.view(M, Cout), out=sess.h2_buf("bwd/gy", M, Cout))
                         wq = prepared(("wflip_h2", sc), lambda wd=wd, sc=sc, Cin=Cin, Cout=Cout: ops.h2_pack_w(
                             wd.view(Cin, Cout), out=sess.buf_pair("bwd/wflip_h2/" + sc, Cin, Cout)))
+                        gxp = None
+                        if mk is not None and h2_dgrad(producer[key]):     # the producer's own data gradient reads this result as planes
+                            gxp = emitted[key] = sess.h2_buf("bwd/gyp/" + sc, M, Cin)
                         ops.gemm_h2(gp, wq, 1, M, Cin, Cout, None, gres.view(M, Cin) if had else None, ACT_NONE, out=gx.view(M, Cin),
-                                    mask=None if mk is None else mk.view(M, Cin))
+                                    mask=None if mk is None else mk.view(M, Cin), out_planes=gxp)
                         self.count_flops("h2", 2 * M * Cin * Cout)
                     else:
                         dpad = (k - 1 - pad[0], k - 1 - pad[1], k - 1 - pad[2], k - 1 - pad[3])
@@ -403,13 +441,66 @@ class TrainState(object):
                         self.count_flops("f32", 2 * M * Cin * Cout * k * k)
                     if mk is not None:
                         masked.add(key)                          # mask * (dX + what was there): the whole buffer is masked
+                elif padded:
+                    # 1x1 heads whose output width is no multiple of 32 (cls_score 81, bbox_pred 324, the RPN's 2A / 4A): dX = dY W on the
+                    # matrix pipe with dY and the transposed filter zero-padded to the next multiple (the gather kernel: 60-120 us each)
+                    Cp = (Cout + 31) // 32 * 32
+                    wdp = prepared(("wflip_pad", sc), lambda wf=wf, sc=sc, Cin=Cin, Cout=Cout, Cp=Cp: ops.transpose_pad(
+                        wf.view(Cout, Cin), Cp, out=sess.buf("bwd/wflip_pad/" + sc, (Cin, Cp))))
+                    gyp = sess.buf("bwd/gypad/" + sc, (N, OH, OW, Cp), zero=True)      # columns >= Cout stay zero
+                    gyp[..., :Cout].copy_(gy)
+                    ops.conv2d(gyp, wdp.view(Cin, 1, 1, Cp), None, 1, 1, 1, (0, 0, 0, 0), ACT_NONE, gres if had else None, 1, out=gx, mask=mk)
+                    self.count_flops("f32", 2 * M * Cin * Cp)
+                    if mk is not None:
+                        masked.add(key)
+                elif upsampled:
+                    # A strided 3x3 (the last unit of a block, resnet_v1.py:80-113): dX = the stride-1 convolution of dY spread out on the
+                    # input grid (zeros between its pixels) with the flipped / transposed filter -- the matrix pipe on a 75 % empty operand
+                    # (~45 us) instead of the gather kernel's scalar FMAs (246 us, profiles/r04_ac_train_kernels_by_shape.txt).  The
+                    # buffer is zeroed once: only the pixels (oh * stride, ow * stride) are ever written.
+                    wd = prepared(("wflip", sc), lambda wf=wf, sc=sc, k=k, Cout=Cout: ops.flip_transpose_filter(
+                        wf, out=sess.buf("bwd/wflip/" + sc, (wf.shape[3], k, k, Cout))))
+                    up = sess.buf("bwd/up/" + sc, (N, up_h, up_w, Cout), zero=True)
+                    ops.add_strided(gy, up, stride, False)
+                    ops.conv2d(up, wd, None, k, k, 1, up_pad, ACT_NONE, gres if had else None, 1, out=gx, mask=mk)
+                    self.count_flops("f32", 2 * x.shape[0] * x.shape[1] * x.shape[2] * Cin * Cout * k * k)
+                    if mk is not None:
+                        masked.add(key)
                 else:
                     ops.conv2d_dgrad_strided(gy, wf, stride, pad, x.shape[1], x.shape[2], gx, had)
                     self.count_flops("f32", 2 * M * Cout * k * k * wf.shape[3])
             emitted.pop(y.data_ptr(), None)
+            if solver is not None and p is not None:
+                pending[0] += 1
+                first = self._sgd_entry.get(sc)
+                if pending[0] >= self.SOLVER_CHUNK and first is not None and first < self._sgd_done_from:
+                    solver_step(first)                           # this record's data gradient is enqueued: its filter has no reader left
         for side in sides:
             main.wait_stream(side)               # the solver (and the next forward pass, which overwrites x) come after every wgrad
+        if solver is not None:
+            main.wait_stream(solver)
         return grads
+
+    SOLVER_CHUNK = 32
+
+    def _solver_stream_obj(self):
+        if getattr(self, "_solver_stream", None) is None:
+            self._solver_stream = torch.cuda.Stream(device=self.sess.device)
+            self._solver_events = [torch.cuda.Event() for _ in range(8)]
+        return self._solver_stream
+
+    def _reg_total(self):
+        if getattr(self, "_reg_buf", None) is None:
+            self._reg_buf = torch.zeros((1,), dtype=torch.float32, device=self.sess.device)
+        return self._reg_buf
+
+    def regularization_value(self):
+        """Device tensor [1]: the slim L2 term of this step's weights (network.py:315-317) -- computed by the sweep on the solver stream
+        when that is active (before its first update), else here."""
+        if not getattr(self, "_reg_in_sweep", False):
+            self.regularization_loss(self._reg_total())
+        self._reg_in_sweep = False
+        return self._reg_total()
 
     def _wgrad_side_streams(self, n):
         have = getattr(self, "_wgrad_stream_objs", None)
@@ -445,7 +536,14 @@ class TrainState(object):
                                     wd if self.bias_decay else 0.0))
             self._sgd_count = len(entries)
             self._sgd_table = ops.sgd_desc_table(entries, self.sess.device)
-        ops.sgd_momentum_multi(self._sgd_table, self._sgd_count, lr, self.momentum, gs)
+            self._sgd_entry, i = {}, 0                 # scope -> index of its first descriptor (filter, then bias)
+            for p in self.params.values():
+                self._sgd_entry[p.scope] = i
+                i += 1 if (getattr(p, "dw", False) or p.bias is None) else 2
+        left = self._sgd_count if getattr(self, "_sgd_done_from", None) is None else self._sgd_done_from      # (the sweep updated the rest)
+        self._sgd_done_from = None
+        if left > 0:
+            ops.sgd_momentum_range(self._sgd_table, 0, left, lr, self.momentum, gs)
         for p in self.params.values():
             if getattr(p, "dw", False):
                 ops.dwconv3x3_refold(p.w, p.scale, p.wf)

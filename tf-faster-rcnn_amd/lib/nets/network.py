@@ -717,8 +717,7 @@ class Network(object):
                 train_op.pending_slots = None
         self.configure_train_op(train_op)
         train_op.backward(self._loss_seeds)
-        total = torch.empty((1,), dtype=torch.float32, device=sess.device)
-        train_op.regularization_loss(total)
+        total = train_op.regularization_value()
         parts = [losses[k].view(1) for k in ("rpn_cross_entropy", "rpn_loss_box", "cross_entropy", "loss_box")]
         total = total + parts[0] + parts[1] + parts[2] + parts[3]
         out = torch.cat(parts + [total])
