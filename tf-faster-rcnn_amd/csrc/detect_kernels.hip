@@ -416,9 +416,10 @@ __global__ __launch_bounds__(1024) void k_nms_reduce(const u64* __restrict__ mas
   if (tid == 0) total_s = 0;
   int total = 0;                                                        // wave 0's running count (uniform)
 
-  // the rows of chunks c+1 and (WPL <= 2: 16 instead of 32 registers per chunk) c+2 are in flight while chunk c is decided; 1024 threads
-  // leave 128 registers each, a third buffer of the 4-word form spills
-  constexpr bool DEEP = WPL <= 2;
+  // the rows of chunks c+1 and (WPL <= 3: at most 24 registers per chunk) c+2 are in flight while chunk c is decided -- deciding a chunk
+  // takes less than a memory round trip, so with one chunk in flight every chunk of the serial scan waited for its rows (3.2 us each).
+  // 1024 threads leave 128 registers each: a third buffer of the 4-word form spills, so 12 000 boxes (188 words) run the 3-word form
+  constexpr bool DEEP = WPL <= 3;
   u64 bufA[4][WPL], bufB[4][WPL], bufC[DEEP ? 4 : 1][DEEP ? WPL : 1];
   auto load_chunk = [&](int c, u64 (&buf)[4][WPL]) {
 #pragma unroll
@@ -666,6 +667,7 @@ static int launch_mask(const SortWs& s, int K, int B, float thr, int rule, hipSt
 static int launch_reduce(const SortWs& s, int K, int B, int max_keep, const ReduceOut& o, hipStream_t st) {
   const int cb = cdiv(K, 64);
   if (cb <= 128) hipLaunchKernelGGL(k_nms_reduce<2>, dim3(B), dim3(1024), 0, st, s.mask, K, cb, max_keep, o, s.bytes);
+  else if (cb <= 192) hipLaunchKernelGGL(k_nms_reduce<3>, dim3(B), dim3(1024), 0, st, s.mask, K, cb, max_keep, o, s.bytes);
   else if (cb <= 256) hipLaunchKernelGGL(k_nms_reduce<4>, dim3(B), dim3(1024), 0, st, s.mask, K, cb, max_keep, o, s.bytes);
   else if (cb <= NMS_WIDE_WORDS) hipLaunchKernelGGL(k_nms_reduce_wide, dim3(B), dim3(64), 0, st, s.mask, K, cb, max_keep, o, s.bytes);
   else return FRCNN_E_UNSUPPORTED;

@@ -386,7 +386,9 @@ class TrainState(object):
                 up_pad = (k - 1 - pad[0], x.shape[1] - up_h - (k - 1 - pad[0]) + k - 1, k - 1 - pad[2], x.shape[2] - up_w - (k - 1 - pad[2]) + k - 1)
                 upsampled = pipe and stride > 1 and k > 1 and Cout % 32 == 0 and Cin % 32 == 0 and min(up_pad) >= 0
                 padded = pipe and k == 1 and stride == 1 and tuple(pad) == (0, 0, 0, 0) and Cout % 32 != 0 and Cin % 4 == 0 and y.dim() == 4
-                use_wino = (wino is not None and key not in grads and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1)
+                # (a tensor that already holds a gradient -- the RPN's 3x3 behind the crop's: Winograd into a scratch tensor + one add pass
+                # instead of the direct kernel with its residual epilogue: 4608-deep float32 products, 490 us, r04_aj_train_streams.txt)
+                use_wino = (wino is not None and (key not in grads or pipe) and k == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1)
                             and Cout % 32 == 0 and Cout >= wino[1] and Cin % 4 == 0)
                 if lent and (use_wino or not (flipped or upsampled or padded)):
                     lent = False                                # (accumulate_into below takes the private copy)
@@ -409,12 +411,15 @@ class TrainState(object):
                     T = ops.winograd_tiles(N, OH, OW, m)
                     u = prepared(("wino_u", sc, m), lambda wf=wf, m=m, sc=sc, G=G, Cin=Cin, Cout=Cout: ops.winograd_filter_transform_device(
                         wf, m, True, out=sess.buf("bwd/wino_u/" + sc, (G, Cin, Cout))))
-                    fused = mk is not None and m in (4, 7)
+                    fused = mk is not None and m in (4, 7) and not had
                     gxp = None
                     if fused and Cin % 128 == 0 and h2_dgrad(producer[key]):
                         gxp = emitted[key] = sess.h2_buf("bwd/gyp/" + sc, x.numel() // Cin, Cin)      # dY planes of the producer's dgrad GEMM
-                    ops.conv3x3_winograd(gy, u, None, ACT_NONE, out=gx, v_buf=sess.buf("bwd/wino_v", (G, T, Cout)),
+                    dst = sess.buf("bwd/wino_sum", x.shape) if had else gx
+                    ops.conv3x3_winograd(gy, u, None, ACT_NONE, out=dst, v_buf=sess.buf("bwd/wino_v", (G, T, Cout)),
                                          m_buf=sess.buf("bwd/wino_m", (G, T, Cin)), mask=mk if fused else None, out_planes=gxp)
+                    if had:
+                        ops.add_strided(dst, gx, 1, True)
                     if fused:
                         masked.add(key)
                     self.count_flops("f32", 2 * G * T * Cin * Cout)
