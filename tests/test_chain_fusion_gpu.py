@@ -194,3 +194,42 @@ def test_fused_chain_rule_passes_change_nothing(dev, min_tiles):
     assert n(c1, "frcnn_conv2d_nhwc_masked_ws") > 0 and n(c1, "frcnn_winograd_output_transform_masked") + n(c1, "frcnn_winograd7_output_transform_masked") > 10
     for k in ("frcnn_conv2d_wgrad_h2", "frcnn_conv2d_wgrad", "frcnn_gemm_batched_nt"):
         assert n(c0, k) == n(c1, k), k
+
+
+@pytest.mark.parametrize("C", [256, 128, 64])
+def test_winograd_row_per_thread_form_gives_the_bits_of_the_tile_per_thread_form(dev, C):
+    """Launches of fewer than 256 workgroups (one 38 x 63 image: the training step, batch-1 inference) run F(4x4,3x3)'s transforms with one
+    row of the tile per thread (csrc/winograd.hip k_wino4_input_rows / k_wino4_output_rows); a batch of 8 runs a tile per thread.  Same
+    expressions -> the single image's result IS slot 3 of the batch's, bit for bit: V, planes of V, the output tensor, its planes, and
+    the masked output of the reverse sweep."""
+    from frcnn_hip import ops
+    H, W, m, B = 38, 63, 4, 8
+    G = ops.winograd_points(m)
+    xb = _rand((B, H, W, C), dev, 21)
+    x1 = xb[3:4].contiguous()
+    T1, TB = ops.winograd_tiles(1, H, W, m), ops.winograd_tiles(B, H, W, m)
+    v1 = ops.winograd_input_transform(x1, torch.empty((G, T1, C), device=dev), m)
+    vb = ops.winograd_input_transform(xb, torch.empty((G, TB, C), device=dev), m)
+    assert torch.equal(v1, vb[:, 3 * T1:4 * T1])
+    if C % 128 == 0:
+        p1 = ops.winograd_input_transform_h2(x1, ops.H2.empty(G * T1, C, dev), m)
+        pb = ops.winograd_input_transform_h2(xb, ops.H2.empty(G * TB, C, dev), m)
+        f1, fb = p1.to_float().view(G, T1, C), pb.to_float().view(G, TB, C)
+        assert torch.equal(f1, fb[:, 3 * T1:4 * T1])
+        assert torch.equal(p1.inv.view(C // 128, G, T1), pb.inv.view(C // 128, G, TB)[:, :, 3 * T1:4 * T1])
+    mb = _rand((G, TB, C), dev, 22)
+    m1 = mb[:, 3 * T1:4 * T1].contiguous()
+    bias = _rand((C,), dev, 23)
+    fwd = _rand((B, H, W, C), dev, 24)
+    y1 = ops.winograd_output_transform(m1, bias, 1, torch.empty((1, H, W, C), device=dev), m)
+    yb = ops.winograd_output_transform(mb, bias, 1, torch.empty((B, H, W, C), device=dev), m)
+    assert torch.equal(y1[0], yb[3])
+    k1 = ops.winograd_output_transform_masked(m1, fwd[3:4].contiguous(), torch.empty((1, H, W, C), device=dev), m)
+    kb = ops.winograd_output_transform_masked(mb, fwd, torch.empty((B, H, W, C), device=dev), m)
+    assert torch.equal(k1[0], kb[3])
+    if C % 128 == 0:
+        q1, qb = ops.H2.empty(H * W, C, dev), ops.H2.empty(B * H * W, C, dev)
+        ops.winograd_output_transform_h2(m1, bias, 1, (1, H, W, C), m, q1)
+        ops.winograd_output_transform_h2(mb, bias, 1, (B, H, W, C), m, qb)
+        assert torch.equal(q1.to_float(), qb.to_float()[3 * H * W:4 * H * W])
+        assert torch.equal(q1.inv, qb.inv[:, 3 * H * W:4 * H * W])

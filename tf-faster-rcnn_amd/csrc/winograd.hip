@@ -158,6 +158,62 @@ __global__ void __launch_bounds__(256) k_wino4_input(const float4* __restrict__ 
   }
 }
 
+// The same transform with ONE row xi of V per thread (6 x the threads) for launches that do not fill the chip in the tile-per-thread
+// form: a single 38 x 63 image is 160 tiles x C/4 threads = 40 workgroups of 36 dependent loads + 36 stores per thread, i.e. a
+// latency chain on a sixth of the CUs (12-19 us per launch, 2 x 36 launches per ResNet-152 training step).  Row xi needs the input rows
+// B^T[xi] touches (3 or 4 of the 6); every value is formed by the SAME macro expressions as in k_wino4_input -- unused results of the
+// column pass are dead code -- so both forms give the same bits (tests/test_dense_gpu.py: small launch == slot of a big one).
+template <int I, bool H2>
+__device__ __forceinline__ void wino4_input_row(const float4* __restrict__ x, int H, int W, int C4, int img, int ty, int tx, int c4, long long t,
+                                                long long T, const WinoSink<H2>& V) {
+  // rows of d that B^T row I reads: 0 -> (0, 2, 4); 5 -> (1, 3, 5); 1..4 -> (1, 2, 3, 4)
+  constexpr unsigned need = I == 0 ? 0x15u : I == 5 ? 0x2au : 0x1eu;
+  float4 d[6][6];
+#pragma unroll
+  for (int r = 0; r < 6; ++r) {
+    const int ih = 4 * ty - 1 + r;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int iw = 4 * tx - 1 + j;
+      d[r][j] = (((need >> r) & 1u) && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) ? x[((size_t)(img * H + ih) * W + iw) * C4 + c4]
+                                                                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  float4 b[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float4 c[6];
+    WINO4_BT(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], c[0], c[1], c[2], c[3], c[4], c[5]);
+    b[j] = c[I];
+  }
+  float4 o[6];
+  WINO4_BT(b[0], b[1], b[2], b[3], b[4], b[5], o[0], o[1], o[2], o[3], o[4], o[5]);
+  size_t r[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) r[j] = (size_t)(I * 6 + j) * T + t;
+  V.template putn<6>(r, o, 0x3fu, c4, C4);
+}
+
+template <bool H2>
+__global__ void __launch_bounds__(256) k_wino4_input_rows(const float4* __restrict__ x, int N, int H, int W, int C4, int TH, int TW,
+                                                           const WinoSink<H2> V) {
+  const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long T = (long long)N * TH * TW;
+  if (id >= T * C4 * 6) return;
+  const int c4 = (int)(id % C4);
+  const int i = (int)((id / C4) % 6);              // (wave-uniform for C >= 256; with H2 the 32 lanes of a scale group always share it)
+  const long long t = id / ((long long)C4 * 6);
+  const int tx = (int)(t % TW), ty = (int)((t / TW) % TH), img = (int)(t / ((long long)TW * TH));
+  switch (i) {
+    case 0: wino4_input_row<0, H2>(x, H, W, C4, img, ty, tx, c4, t, T, V); break;
+    case 1: wino4_input_row<1, H2>(x, H, W, C4, img, ty, tx, c4, t, T, V); break;
+    case 2: wino4_input_row<2, H2>(x, H, W, C4, img, ty, tx, c4, t, T, V); break;
+    case 3: wino4_input_row<3, H2>(x, H, W, C4, img, ty, tx, c4, t, T, V); break;
+    case 4: wino4_input_row<4, H2>(x, H, W, C4, img, ty, tx, c4, t, T, V); break;
+    default: wino4_input_row<5, H2>(x, H, W, C4, img, ty, tx, c4, t, T, V); break;
+  }
+}
+
 // A^T (6 -> 4): rows (1 1 1 1 1 0), (0 1 -1 2 -2 0), (0 1 1 4 4 0), (0 1 -1 8 -8 1)
 #define WINO4_AT(v0, v1, v2, v3, v4, v5, o0, o1, o2, o3)                               \
   {                                                                                    \
@@ -215,11 +271,78 @@ __global__ void __launch_bounds__(256) k_wino4_output(const float4* __restrict__
   }
 }
 
+// One output row a (of the tile's 4) per thread, for launches that do not fill the chip tile-per-thread (see k_wino4_input_rows): the same
+// macro expressions, the same 4 pixels written together (one shared plane scale per group of rows, as in k_wino4_output) -> the same bits.
+template <int A, bool H2, bool MASK>
+__device__ __forceinline__ void wino4_output_row(const float4* __restrict__ in, size_t plane, int H, int W, int C4, int img, int ty, int tx, int c4,
+                                                 const float4* __restrict__ bias, int act, const float4* __restrict__ mask,
+                                                 const WinoSink<H2>& y) {
+  const int oh = 4 * ty + A;
+  if (oh >= H) return;                 // (the 32 lanes of a plane-scale group share (t, A): they leave together)
+  float4 sa[6];                        // row A of A^T m, one column j at a time; A^T row 0 reads m0..m4, rows 1 / 2 m1..m4, row 3 m1..m5
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 m0 = A == 0 ? in[(size_t)(0 * 6 + j) * plane] : z, m1 = in[(size_t)(1 * 6 + j) * plane], m2 = in[(size_t)(2 * 6 + j) * plane];
+    const float4 m3 = in[(size_t)(3 * 6 + j) * plane], m4 = in[(size_t)(4 * 6 + j) * plane], m5 = A == 3 ? in[(size_t)(5 * 6 + j) * plane] : z;
+    float4 sv[4];
+    WINO4_AT(m0, m1, m2, m3, m4, m5, sv[0], sv[1], sv[2], sv[3]);
+    sa[j] = sv[A];
+  }
+  const float4 bv = bias ? bias[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 o[4];
+  WINO4_AT(sa[0], sa[1], sa[2], sa[3], sa[4], sa[5], o[0], o[1], o[2], o[3]);
+  const size_t row = (size_t)(img * H + oh) * W;
+  size_t r[4];
+  unsigned valid = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int ow = 4 * tx + b;
+    r[b] = row + ow;
+    valid |= (ow < W ? 1u : 0u) << b;
+    float4 v = f4add(o[b], bv);
+    if (act == FRCNN_ACT_RELU) v = act_relu(v);
+    if (MASK && ow < W) {
+      const float4 k = mask[r[b] * C4 + c4];
+      v.x = k.x > 0.f ? v.x : 0.f; v.y = k.y > 0.f ? v.y : 0.f; v.z = k.z > 0.f ? v.z : 0.f; v.w = k.w > 0.f ? v.w : 0.f;
+    }
+    o[b] = v;
+  }
+  y.template putn<4>(r, o, valid, c4, C4);
+}
+
+template <bool H2, bool MASK = false>
+__global__ void __launch_bounds__(256) k_wino4_output_rows(const float4* __restrict__ Mx, int N, int H, int W, int C4, int TH, int TW,
+                                                            const float4* __restrict__ bias, int act, const float4* __restrict__ mask,
+                                                            const WinoSink<H2> y) {
+  const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long T = (long long)N * TH * TW;
+  if (id >= T * C4 * 4) return;
+  const int c4 = (int)(id % C4);
+  const int a = (int)((id / C4) & 3);
+  const long long t = id / ((long long)C4 * 4);
+  const int tx = (int)(t % TW), ty = (int)((t / TW) % TH), img = (int)(t / ((long long)TW * TH));
+  const size_t plane = (size_t)T * C4;
+  const float4* in = Mx + (size_t)t * C4 + c4;
+  switch (a) {
+    case 0: wino4_output_row<0, H2, MASK>(in, plane, H, W, C4, img, ty, tx, c4, bias, act, mask, y); break;
+    case 1: wino4_output_row<1, H2, MASK>(in, plane, H, W, C4, img, ty, tx, c4, bias, act, mask, y); break;
+    case 2: wino4_output_row<2, H2, MASK>(in, plane, H, W, C4, img, ty, tx, c4, bias, act, mask, y); break;
+    default: wino4_output_row<3, H2, MASK>(in, plane, H, W, C4, img, ty, tx, c4, bias, act, mask, y); break;
+  }
+}
+
+// launches below this many workgroups of the tile-per-thread form run the row-per-thread form (256 CUs)
+#define WINO_ROWS_BELOW 256
+
 template <bool H2>
 static int wino_input_launch(const float* x_d, int N, int H, int W, int C, int m, const WinoSink<H2>& sink, hipStream_t st) {
   const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
   const long long tot = (long long)N * TH * TW * (C / 4);
-  if (m == 4)
+  if (m == 4 && (tot + 255) / 256 < WINO_ROWS_BELOW)
+    hipLaunchKernelGGL(k_wino4_input_rows<H2>, dim3((unsigned)((tot * 6 + 255) / 256)), dim3(256), 0, st, (const float4*)x_d, N, H, W, C / 4, TH, TW,
+                       sink);
+  else if (m == 4)
     hipLaunchKernelGGL(k_wino4_input<H2>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float4*)x_d, N, H, W, C / 4, TH, TW, sink);
   else
     hipLaunchKernelGGL(k_wino_input<H2>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float4*)x_d, N, H, W, C / 4, TH, TW, sink);
@@ -290,11 +413,18 @@ static int wino_output_launch(const float* m_d, int N, int H, int W, int C, int 
                               hipStream_t st, const float* mask_d = nullptr) {
   const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
   const long long tot = (long long)N * TH * TW * (C / 4);
-  if (m == 4 && mask_d)
+  const bool rows = (tot + 255) / 256 < WINO_ROWS_BELOW;
+  if (m == 4 && mask_d && rows)
+    hipLaunchKernelGGL((k_wino4_output_rows<H2, true>), dim3((unsigned)((tot * 4 + 255) / 256)), dim3(256), 0, st, (const float4*)m_d, N, H, W,
+                       C / 4, TH, TW, (const float4*)bias_d, act, (const float4*)mask_d, sink);
+  else if (m == 4 && mask_d)
     hipLaunchKernelGGL((k_wino4_output<H2, true>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float4*)m_d, N, H, W, C / 4, TH,
                        TW, (const float4*)bias_d, act, (const float4*)mask_d, sink);
   else if (mask_d)
     return FRCNN_E_UNSUPPORTED;
+  else if (m == 4 && rows)
+    hipLaunchKernelGGL((k_wino4_output_rows<H2, false>), dim3((unsigned)((tot * 4 + 255) / 256)), dim3(256), 0, st, (const float4*)m_d, N, H, W,
+                       C / 4, TH, TW, (const float4*)bias_d, act, (const float4*)nullptr, sink);
   else if (m == 4)
     hipLaunchKernelGGL((k_wino4_output<H2, false>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float4*)m_d, N, H, W, C / 4, TH,
                        TW, (const float4*)bias_d, act, (const float4*)nullptr, sink);
