@@ -917,8 +917,11 @@ extern "C" int frcnn_gemm_batched_nt(const float* x_d, const float* w_d, float* 
     const int rc = launch_stream_cfg(108, p, (hipStream_t)stream);
     if (rc != FRCNN_E_UNSUPPORTED) return rc;
   }
-  return (N >= 96 && big >= 384 && p.nsteps >= 8) ? launch_cfg(N >= 1024 ? 21 : 20, p, (hipStream_t)stream)
-                                                 : launch_cfg(N > 32 ? 15 : 4, p, (hipStream_t)stream);
+  // 128-row tiles only when they waste at most a quarter of their rows: 160 Winograd tiles of one 38 x 63 image would be 2 x 128 (the RPN
+  // 3x3's data gradient, N = 1024: 350 us in 128 x 128 tiles, profiles/r04_ak_*), 64-row tiles cover them with 3 x 64
+  const bool waste = (Mp + 127) / 128 * 128 * 4 > Mp * 5;
+  return (N >= 96 && big >= 384 && p.nsteps >= 8 && !waste) ? launch_cfg(N >= 1024 ? 21 : 20, p, (hipStream_t)stream)
+                                                           : launch_cfg(N > 32 ? 15 : 4, p, (hipStream_t)stream);
 }
 
 // HOST: HWIO -> [Cout][KH][KW][Cin] with optional per-output-channel scale (folded frozen BN).
