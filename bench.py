@@ -256,13 +256,15 @@ def train_bench(args, c, dev, world, rank, dist):
     ar = None
     if world > 1 or args.dp_constrained:
         from frcnn_hip import parallel
-        if world == 1:                                    # a one-rank RCCL group: the same torch.distributed / RCCL calls an N-GPU run makes
+        if world == 1 and args.dp_probe != "noop-nogroup":  # a one-rank RCCL group: the same torch.distributed / RCCL calls an N-GPU run makes
             import torch.distributed as dist1
             import datetime
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
             dist1.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=120))
-        ar = parallel.make_grad_all_reduce()
+        ar = parallel.make_grad_all_reduce() if args.dp_probe != "noop-nogroup" else parallel.BucketedAllReduce()
+        if args.dp_probe:                                 # diagnosis only: the data-parallel rules without a single collective
+            ar._send = lambda flat, lo, hi, stream=None: None
     sw = SolverWrapper(sess, net, resident_blobs(synthetic_data_layer(c["classes"], seed=cfg.RNG_SEED + rank, image_gain=1 / 256.0), dev),
                        all_reduce=ar, world_size=world, force_dp=args.dp_constrained)
     sw.state.solver_in_sweep, sw.state.fuse_chain, sw.state.pipe_dgrads = not args.no_solver_in_sweep, not args.no_fuse_chain, not args.no_fuse_chain
@@ -289,7 +291,9 @@ def train_bench(args, c, dev, world, rank, dist):
     sess.step_flops_by_pipe = {k: sess.flops_by_pipe.get(k, 0) + sw.state.flop_ledger.get(k, 0) for k in ("h2", "x3", "f32")}
     sess.flops_by_pipe, sw.state.flop_ledger = None, None
     sess.dp_note = None
-    if args.dp_constrained and world == 1:
+    if args.dp_constrained and world == 1 and args.dp_probe == "noop-nogroup":
+        sess.dp_note = "diagnosis: the data-parallel rules with no RCCL group and no collective"
+    elif args.dp_constrained and world == 1:
         import torch.distributed as dist1
         sess.dp_note = "one replica under the data-parallel rules: <= 1 filter-gradient side stream, bucketed all-reduce (64 MiB) issued from " \
                        "inside the sweep over a one-rank RCCL group (backend %s), eager sweep" % dist1.get_backend()
@@ -450,6 +454,8 @@ def main():
     ap.add_argument("--h2-min-tiles", type=int, default=-1, help="cfg.HIP.H2_MIN_TILES (A/B)")
     ap.add_argument("--no-wgrad-tn", action="store_true", help="cfg.HIP.WGRAD_TN False: filter gradients by transposes + the forward GEMM kernel (c5 A/B)")
     ap.add_argument("--no-wgrad-h2", action="store_true", help="cfg.HIP.WGRAD_H2 False: filter gradients on the f32 matrix pipe (c5 A/B)")
+    ap.add_argument("--dp-probe", choices=["noop", "noop-nogroup"], default=None,
+                    help="c5 --dp-constrained A/B (diagnosis): the bucketed all-reduce object sends nothing (noop), and no RCCL group is created (noop-nogroup)")
     ap.add_argument("--no-solver-in-sweep", action="store_true", help="c5 A/B: the solver updates every parameter after the sweep, in one launch on the main stream")
     ap.add_argument("--no-fuse-chain", action="store_true", help="c5 A/B: separate relu_bwd / residual-copy / h2_split passes in the reverse sweep, gather-form strided / odd-width data gradients")
     ap.add_argument("--no-prep-stream", action="store_true", help="cfg.HIP.PREP_STREAM False: gradient filters prepared inside the sweep (c5 A/B)")
