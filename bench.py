@@ -454,6 +454,9 @@ def main():
     ap.add_argument("--h2-min-tiles", type=int, default=-1, help="cfg.HIP.H2_MIN_TILES (A/B)")
     ap.add_argument("--no-wgrad-tn", action="store_true", help="cfg.HIP.WGRAD_TN False: filter gradients by transposes + the forward GEMM kernel (c5 A/B)")
     ap.add_argument("--no-wgrad-h2", action="store_true", help="cfg.HIP.WGRAD_H2 False: filter gradients on the f32 matrix pipe (c5 A/B)")
+    ap.add_argument("--one-rank-group", action="store_true",
+                    help="A/B (diagnosis, N = 1): create a one-rank RCCL process group before the run and issue no collective -- what the EXISTENCE "
+                         "of the group every rank of an N-GPU run has costs the per-GPU rate (its streams come out of torch's stream pool first)")
     ap.add_argument("--dp-probe", choices=["noop", "noop-nogroup"], default=None,
                     help="c5 --dp-constrained A/B (diagnosis): the bucketed all-reduce object sends nothing (noop), and no RCCL group is created (noop-nogroup)")
     ap.add_argument("--no-solver-in-sweep", action="store_true", help="c5 A/B: the solver updates every parameter after the sweep, in one launch on the main stream")
@@ -504,6 +507,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")      # a failed / stuck collective tears the process down instead of hanging
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=300))
+
+    if args.one_rank_group and world == 1 and args.config != "c5":
+        import torch.distributed as dist1
+        import datetime
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        dist1.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=120))
 
     import frcnn_hip
     frcnn_hip.lib()
