@@ -1,0 +1,317 @@
+"""CPU: the bookkeeping of the reverse sweep (frcnn_hip/train.py TrainState._sweep) -- which gradient buffer is masked in the producing
+launch, which identity-shortcut gradient is borrowed instead of copied, where operand planes of dY are emitted, when a tensor that
+received an unmasked contribution still gets its relu_bwd pass -- run against plain torch-CPU stand-ins for the C-ABI entries and for
+the stream / event objects.  The stand-ins compute the same functions the entries document (a convolution, y = mask > 0 ? y : 0, ...),
+so the sweep with the folded passes must give the SAME bits as the sweep with the separate passes, and both must agree with torch
+autograd of the same small network (two bottleneck units with identity / projection shortcuts, a strided 3x3, odd-width heads, a tensor
+with two consumers).  No GPU, no library: this is the host logic only; the kernels themselves are checked in tests/test_chain_fusion_gpu.py."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tf-faster-rcnn_amd"))
+
+ACT_NONE, ACT_RELU = 0, 1
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2)
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def w_oihw(w):                      # packed [Cout, KH, KW, Cin] -> torch [Cout, Cin, KH, KW]
+    return w.permute(0, 3, 1, 2)
+
+
+class FakeStream(object):
+    cuda_stream = 0
+
+    def wait_event(self, ev):
+        pass
+
+    def wait_stream(self, other):
+        pass
+
+
+class FakeEvent(object):
+    def record(self, stream=None):
+        pass
+
+
+class Planes(object):
+    """stand-in for ops.H2: the tensor itself"""
+
+    def __init__(self, rows, K):
+        self.rows, self.K, self.t = rows, K, torch.zeros((rows, K))
+
+
+class FakeOps(types.SimpleNamespace):
+    """torch-CPU versions of the entries the sweep calls; `log` counts the calls per entry"""
+
+    def __init__(self):
+        types.SimpleNamespace.__init__(self)
+        self.log, self.ws_scope, self.filters = {}, "", {}
+
+    def _n(self, name):
+        self.log[name] = self.log.get(name, 0) + 1
+
+    class pinned_stream(object):
+        def __init__(self, stream):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    # ---- elementwise
+    def relu_bwd(self, g, y):
+        self._n("relu_bwd")
+        g.copy_(torch.where(y > 0, g, torch.zeros_like(g)))
+        return g
+
+    def add_strided(self, src, dst, stride, accumulate):
+        self._n("add_strided")
+        view = dst[:, ::stride, ::stride, :][:, :src.shape[1], :src.shape[2], :]
+        view.copy_(view + src if accumulate else src)
+        return dst
+
+    def spatial_mean_bwd(self, dy, HW, out):
+        self._n("spatial_mean_bwd")
+        out.copy_((dy / float(HW)).view(dy.shape[0], 1, 1, dy.shape[1]).expand_as(out))
+        return out
+
+    def colsum(self, gy2d, out):
+        out.copy_(gy2d.double().sum(0).float())
+
+    def transpose_pad(self, x2d, Mp, out=None):
+        out.zero_()
+        out[:, :x2d.shape[0]] = x2d.t()
+        return out
+
+    # ---- convolutions
+    @staticmethod
+    def _mask(v, mask):
+        return v if mask is None else torch.where(mask.reshape(v.shape) > 0, v, torch.zeros_like(v))
+
+    def conv2d(self, x, w, bias, KH, KW, stride=1, pad=(0, 0, 0, 0), act=0, residual=None, res_stride=1, fold_w=False, out=None, mask=None):
+        self._n("conv2d_masked" if mask is not None else "conv2d")
+        xp = F.pad(nchw(x), (pad[2], pad[3], pad[0], pad[1]))
+        v = nhwc(F.conv2d(xp, w_oihw(w.view(w.shape[0], KH, KW, -1)), stride=stride))
+        if residual is not None:
+            v = v + residual.reshape(v.shape)
+        out.copy_(self._mask(v, mask).reshape(out.shape))
+        return out
+
+    def flip_transpose_filter(self, wf, out=None):
+        out.copy_(wf.flip(1, 2).permute(3, 1, 2, 0))          # [Cout,k,k,Cin] -> [Cin,k,k,Cout], taps reversed
+        return out
+
+    def conv2d_dgrad_strided(self, gy, wf, stride, pad, H, W, gx, accumulate):
+        self._n("dgrad_strided")
+        full = F.conv_transpose2d(nchw(gy), w_oihw(wf), stride=stride)
+        full = F.pad(full, (0, max(0, W + pad[2] - full.shape[3]), 0, max(0, H + pad[0] - full.shape[2])))
+        v = nhwc(full[:, :, pad[0]:pad[0] + H, pad[2]:pad[2] + W])
+        gx.copy_(gx + v if accumulate else v)
+        return gx
+
+    def conv2d_wgrad_supported(self, Cin, Cout):
+        return True
+
+    def conv2d_wgrad(self, gy, x, KH, KW, stride, pad, out, h2=False):
+        self._n("wgrad")
+        xp = F.pad(nchw(x), (pad[2], pad[3], pad[0], pad[1])).double()
+        g = torch.nn.grad.conv2d_weight(xp, (gy.shape[3], x.shape[3], KH, KW), nchw(gy).double(), stride=stride)
+        out.copy_(g.permute(0, 2, 3, 1).float().reshape(out.shape))
+        return out
+
+    # ---- Winograd path: the "transform" remembers the filter, the "convolution" is the plain one
+    def winograd_points(self, m):
+        return 121 if m == 7 else (m + 2) ** 2
+
+    def winograd_tiles(self, N, H, W, m):
+        return N if m == 7 else N * ((H + m - 1) // m) * ((W + m - 1) // m)
+
+    def winograd_filter_transform_device(self, wf, m, transpose_flip, out=None):
+        assert transpose_flip
+        self.filters[out.data_ptr()] = wf
+        return out
+
+    def conv3x3_winograd(self, x, u, bias, act=0, out=None, v_buf=None, m_buf=None, u_planes=None, v_planes=None, mask=None, out_planes=None):
+        self._n("wino_masked" if mask is not None else "wino")
+        wf = self.filters[u.data_ptr()]
+        v = nhwc(F.conv_transpose2d(nchw(x), w_oihw(wf), padding=1))
+        v = self._mask(v, mask)
+        out.copy_(v)
+        if out_planes is not None:
+            self._n("planes_from_wino")
+            out_planes.t.copy_(v.reshape(out_planes.rows, out_planes.K))
+        return out
+
+    # ---- the fp16-pipe GEMM
+    def h2_split(self, x2d, out=None):
+        self._n("h2_split")
+        out.t.copy_(x2d)
+        return out
+
+    def h2_pack_w(self, w2d, out=None):
+        out.copy_(w2d)
+        return out
+
+    def gemm_h2(self, x, wp, G, M, N, K, bias=None, residual=None, act=0, out=None, out_planes=None, want_f32=True, cfg=-1, mask=None):
+        self._n("gemm_h2_masked" if mask is not None else "gemm_h2")
+        v = x.t @ wp.t()
+        if residual is not None:
+            v = v + residual.reshape(v.shape)
+        v = self._mask(v, mask)
+        out.copy_(v.reshape(out.shape))
+        if out_planes is not None:
+            self._n("planes_from_gemm")
+            out_planes.t.copy_(v)
+        return out, out_planes
+
+
+class FakeSession(object):
+    device = "cpu"
+
+    def __init__(self):
+        self.buffers, self.conv_info = {}, {}
+        self.prepared = types.SimpleNamespace(enabled=False, get=lambda key, fn: fn())
+
+    def buf(self, name, shape, dtype=torch.float32, zero=False):
+        key = (name, tuple(shape))
+        if key not in self.buffers:
+            self.buffers[key] = torch.zeros(tuple(shape), dtype=dtype)
+        return self.buffers[key]
+
+    def h2_buf(self, name, rows, K):
+        key = ("h2", name, rows, K)
+        if key not in self.buffers:
+            self.buffers[key] = Planes(rows, K)
+        return self.buffers[key]
+
+    def buf_pair(self, name, N, K):
+        return self.buf("pair/" + name, (N, K))
+
+
+class Net(object):
+    """A small TRAIN graph in the reference's bottleneck shape (resnet_v1.py:80-113), forward values from torch, as a tape."""
+
+    def __init__(self, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        self.g = g
+        self.params, self._tape, self._requires_grad = {}, [], set()
+        self.autograd_w = {}
+
+    def conv(self, sess, x, scope, cout, k, stride=1, act=ACT_RELU, residual=None, res_stride=1, x_ref=None, res_ref=None):
+        cin = x.shape[3]
+        w = (torch.randn((cout, k, k, cin), generator=self.g) * (1.5 / (k * np.sqrt(cin)))).float()
+        sess.conv_info[scope] = {"w": w}
+        pad = (k // 2,) * 4
+        wr = w.clone().double().requires_grad_(True)
+        self.autograd_w[scope] = wr
+
+        def fwd(xx, ww, rr):
+            v = F.conv2d(F.pad(nchw(xx), (pad[2], pad[3], pad[0], pad[1])), w_oihw(ww), stride=stride).permute(0, 2, 3, 1)
+            if rr is not None:
+                v = v + rr[:, ::res_stride, ::res_stride, :][:, :v.shape[1], :v.shape[2], :]
+            return torch.relu(v) if act == ACT_RELU else v
+        y = fwd(x, w, residual).contiguous()
+        y_ref = fwd(x_ref, wr, res_ref)
+        self._tape.append(dict(kind="conv", scope=scope, x=x, y=y, k=k, stride=stride, pad=pad, act=act, residual=residual, res_stride=res_stride))
+        self._requires_grad.add(y.data_ptr())
+        grad_w = torch.zeros_like(w)
+        self.params[scope] = types.SimpleNamespace(scope=scope, K=w[0].numel(), bias=None, grad_w=grad_w, grad_b=None)
+        return y, y_ref
+
+
+def build(sess, seed):
+    net = Net(seed)
+    g = torch.Generator().manual_seed(100 + seed)
+    image = torch.randn((1, 8, 8, 32), generator=g)
+    img_ref = image.double()
+    x0, r0 = net.conv(sess, image, "conv0", 128, 3, x_ref=img_ref)                               # input of the trunk: a ReLU output
+    # unit A: identity shortcut
+    a1, ra1 = net.conv(sess, x0, "A/conv1", 128, 1, x_ref=r0)
+    a2, ra2 = net.conv(sess, a1, "A/conv2", 128, 3, x_ref=ra1)
+    xa, rxa = net.conv(sess, a2, "A/conv3", 128, 1, residual=x0, x_ref=ra2, res_ref=r0)
+    # unit B: projection shortcut (no activation) + a strided 3x3; x of B has TWO consumers (conv1 and the shortcut)
+    sb, rsb = net.conv(sess, xa, "B/shortcut", 256, 1, stride=1, act=ACT_NONE, x_ref=rxa)
+    b1, rb1 = net.conv(sess, xa, "B/conv1", 128, 1, x_ref=rxa)
+    b2, rb2 = net.conv(sess, b1, "B/conv2", 128, 3, stride=2, x_ref=rb1)
+    xb, rxb = net.conv(sess, b2, "B/conv3", 256, 1, residual=sb, res_stride=2, x_ref=rb2, res_ref=rsb)
+    # unit C: identity shortcut on 256 channels (the GEMM data gradients: Cin, Cout % 128 == 0)
+    c1, rc1 = net.conv(sess, xb, "C/conv1", 128, 1, x_ref=rxb)
+    c2, rc2 = net.conv(sess, c1, "C/conv2", 128, 3, x_ref=rc1)
+    xc, rxc = net.conv(sess, c2, "C/conv3", 256, 1, residual=xb, x_ref=rc2, res_ref=rxb)
+    # heads of odd width on the trunk output (two consumers of xc), like rpn_cls_score / rpn_bbox_pred
+    h1, rh1 = net.conv(sess, xc, "head5", 5, 1, act=ACT_NONE, x_ref=rxc)
+    h2, rh2 = net.conv(sess, xc, "head12", 12, 1, act=ACT_NONE, x_ref=rxc)
+    g1 = torch.randn(h1.shape, generator=g)
+    g2 = torch.randn(h2.shape, generator=g)
+    loss = (rh1 * g1.double()).sum() + (rh2 * g2.double()).sum()
+    loss.backward()
+    return net, [(h1, g1.clone()), (h2, g2.clone())]
+
+
+def run_sweep(monkeypatch, fuse, pipe, wino, h2_train, seed=0):
+    from frcnn_hip import train
+    ops = FakeOps()
+    monkeypatch.setattr(train, "ops", ops)
+    monkeypatch.setattr(torch.cuda, "Stream", lambda device=None: FakeStream())
+    monkeypatch.setattr(torch.cuda, "Event", FakeEvent)
+    sess = FakeSession()
+    net, seeds = build(sess, seed)
+    ts = train.TrainState.__new__(train.TrainState)
+    ts.sess, ts.net, ts.params, ts.flat = sess, net, net.params, None
+    ts._wgrad_events = None
+    ts.fuse_chain, ts.pipe_dgrads = fuse, pipe
+    ts.winograd = (4, 64, True) if wino else None
+    ts.h2_train = h2_train
+    ts.wgrad_stream, ts.wgrad_tn, ts.wgrad_h2, ts.prep_stream = 2, True, True, False
+    ts._sweep(seeds, FakeStream())
+    return net, ops.log
+
+
+@pytest.mark.parametrize("wino", [False, True])
+@pytest.mark.parametrize("h2_train", [None, 1])
+def test_folded_passes_give_the_bits_of_the_separate_passes_and_the_gradients_of_autograd(monkeypatch, wino, h2_train):
+    n0, log0 = run_sweep(monkeypatch, False, False, wino, h2_train)
+    n1, log1 = run_sweep(monkeypatch, True, False, wino, h2_train)
+    n2, log2 = run_sweep(monkeypatch, True, True, wino, h2_train)
+    assert set(n0.params) == set(n1.params) and len(n0.params) == 13
+    for sc in n0.params:
+        ref = n0.autograd_w[sc].grad.float()
+        scale = float(ref.abs().max())
+        assert scale > 0
+        assert float((n0.params[sc].grad_w - ref).abs().max()) <= 2e-5 * scale, sc        # the sweep itself (separate passes)
+        assert torch.equal(n0.params[sc].grad_w, n1.params[sc].grad_w), sc                # folding changes no bit
+        assert float((n2.params[sc].grad_w - ref).abs().max()) <= 2e-5 * scale, sc        # other data-gradient forms: rounding only
+    # what the folded sweep no longer launches
+    assert log0["relu_bwd"] == 10                                                        # one per ReLU record
+    assert log1.get("relu_bwd", 0) <= 3 and log1.get("conv2d_masked", 0) + log1.get("gemm_h2_masked", 0) + log1.get("wino_masked", 0) >= 7
+    if h2_train:
+        assert log1.get("h2_split", 0) < log0["h2_split"] and log1.get("planes_from_gemm", 0) + log1.get("planes_from_wino", 0) >= 1
+    assert log2.get("dgrad_strided", 0) < log1["dgrad_strided"]                           # strided 3x3 + odd-width heads left the gather form
+    assert log0["wgrad"] == log1["wgrad"] == log2["wgrad"] == 13
+
+
+def test_a_tensor_with_an_unmasked_contribution_keeps_its_relu_pass(monkeypatch):
+    """B's input feeds conv1 (masked data gradient) AND the projection shortcut; whichever lands second accumulates -- the sum must end up
+    masked exactly once more or already be masked; the heads' two data gradients into the trunk output likewise.  Checked through the
+    gradients of the layers BELOW those tensors (A/*, conv0) in the test above; here: the call pattern."""
+    n1, log1 = run_sweep(monkeypatch, True, True, True, 1, seed=3)
+    n0, log0 = run_sweep(monkeypatch, False, True, True, 1, seed=3)
+    for sc in n0.params:
+        assert torch.equal(n0.params[sc].grad_w, n1.params[sc].grad_w), sc
+    assert log1.get("relu_bwd", 0) <= 1 < log0["relu_bwd"]          # every contribution came masked out of its launch
