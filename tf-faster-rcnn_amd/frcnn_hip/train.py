@@ -546,6 +546,9 @@ class TrainState(object):
                 self._sgd_entry[p.scope] = i
                 i += 1 if (getattr(p, "dw", False) or p.bias is None) else 2
         left = self._sgd_count if getattr(self, "_sgd_done_from", None) is None else self._sgd_done_from      # (the sweep updated the rest)
+        if left != self._sgd_count and float(lr) != float(self.lr):
+            raise RuntimeError("TrainState.apply(lr=%r): the reverse sweep already updated part of the parameters with TrainState.lr = %r"
+                               % (lr, self.lr))
         self._sgd_done_from = None
         if left > 0:
             ops.sgd_momentum_range(self._sgd_table, 0, left, lr, self.momentum, gs)
