@@ -158,6 +158,24 @@ class FakeOps(types.SimpleNamespace):
             out_planes.t.copy_(v.reshape(out_planes.rows, out_planes.K))
         return out
 
+    # ---- solver (train_val.py:128-145 semantics, as csrc/backward_kernels.hip k_sgd_multi states them)
+    def sgd_desc_table(self, entries, device):
+        return list(entries)
+
+    def sgd_momentum_range(self, table, first, count, lr, momentum, grad_scale=1.0):
+        self._n("sgd_range")
+        assert 0 <= first and first + count <= len(table) and count > 0
+        for w, acc, wf, grad, scale, K, lr_mult, wd in table[first:first + count]:
+            sc = 1.0 if scale is None else scale.view(-1, 1, 1, 1)
+            g = grad_scale * grad * sc + wd * w
+            acc.copy_(momentum * acc + g)
+            w.copy_(w - lr * lr_mult * acc)
+            self.updated = getattr(self, "updated", [])
+            self.updated.append(w.data_ptr())
+
+    def sumsq_multi(self, ptrs, sizes, scale, out, accumulate=False):
+        return out
+
     # ---- the fp16-pipe GEMM
     def h2_split(self, x2d, out=None):
         self._n("h2_split")
@@ -186,7 +204,9 @@ class FakeSession(object):
 
     def __init__(self):
         self.buffers, self.conv_info = {}, {}
-        self.prepared = types.SimpleNamespace(enabled=False, get=lambda key, fn: fn())
+        self.prepared = types.SimpleNamespace(enabled=False, get=lambda key, fn: fn(), join=lambda: None, weights_changed=lambda: None,
+                                              refresh=lambda pre=None: pre() if pre else None)
+        self.x3, self.h2, self.wino_refresh = {}, {}, (lambda: 0)
 
     def buf(self, name, shape, dtype=torch.float32, zero=False):
         key = (name, tuple(shape))
@@ -231,7 +251,8 @@ class Net(object):
         self._tape.append(dict(kind="conv", scope=scope, x=x, y=y, k=k, stride=stride, pad=pad, act=act, residual=residual, res_stride=res_stride))
         self._requires_grad.add(y.data_ptr())
         grad_w = torch.zeros_like(w)
-        self.params[scope] = types.SimpleNamespace(scope=scope, K=w[0].numel(), bias=None, grad_w=grad_w, grad_b=None)
+        self.params[scope] = types.SimpleNamespace(scope=scope, K=w[0].numel(), bias=None, grad_w=grad_w, grad_b=None, w=w, wf=w, scale=None,
+                                                   acc_w=torch.zeros_like(w), acc_b=None)
         return y, y_ref
 
 
@@ -315,3 +336,50 @@ def test_a_tensor_with_an_unmasked_contribution_keeps_its_relu_pass(monkeypatch)
     for sc in n0.params:
         assert torch.equal(n0.params[sc].grad_w, n1.params[sc].grad_w), sc
     assert log1.get("relu_bwd", 0) <= 1 < log0["relu_bwd"]          # every contribution came masked out of its launch
+
+
+def run_steps(monkeypatch, in_sweep, steps=3, chunk=3):
+    """`steps` x (reverse sweep + solver) on one tape: the in-sweep solver updates ranges of the descriptor table while the sweep goes on"""
+    from frcnn_hip import train
+    ops = FakeOps()
+    monkeypatch.setattr(train, "ops", ops)
+    monkeypatch.setattr(torch.cuda, "Stream", lambda device=None: FakeStream())
+    monkeypatch.setattr(torch.cuda, "Event", FakeEvent)
+    sess = FakeSession()
+    net, seeds = build(sess, 5)
+    ts = train.TrainState.__new__(train.TrainState)
+    ts.sess, ts.net, ts.params, ts.flat = sess, net, net.params, None
+    ts._wgrad_events, ts.reg_scopes = None, []
+    ts.momentum, ts.weight_decay, ts.double_bias, ts.bias_decay = 0.9, 1e-4, False, False
+    ts.fuse_chain, ts.pipe_dgrads, ts.winograd, ts.h2_train = True, True, (4, 64, True), 1
+    ts.wgrad_stream, ts.wgrad_tn, ts.wgrad_h2, ts.prep_stream = 2, True, True, False
+    ts.solver_in_sweep, ts.SOLVER_CHUNK, ts.lr = in_sweep, chunk, 1e-4
+    order = []
+    for _ in range(steps):
+        ops.updated = []
+        ts._sweep([(t, g.clone()) for t, g in seeds], FakeStream())
+        ts.apply(ts.lr)
+        order.append(list(ops.updated))
+    return net, ops.log, order
+
+
+def test_the_solver_inside_the_sweep_updates_every_tensor_exactly_once_with_the_same_result(monkeypatch):
+    """TrainState: from the second step on the solver updates ranges of its descriptor table on a side stream while the sweep goes on
+    (frcnn_sgd_momentum_range), always behind the data gradient that last reads those filters; apply() updates the rest.  Three steps with
+    and without it on the same tape: every master filter and momentum slot bit-identical, every tensor updated exactly once per step, the
+    first step (no descriptor table yet) in one launch."""
+    n0, log0, order0 = run_steps(monkeypatch, False)
+    n1, log1, order1 = run_steps(monkeypatch, True)
+    for sc in n0.params:
+        assert torch.equal(n0.params[sc].w, n1.params[sc].w), sc
+        assert torch.equal(n0.params[sc].acc_w, n1.params[sc].acc_w), sc
+        assert float(n0.params[sc].acc_w.abs().max()) > 0
+    assert log0["sgd_range"] == 3                                        # one launch per step
+    assert log1["sgd_range"] == 1 + 2 * 5                                # step 1: one; then 13 tensors in chunks of 3 + the rest in apply()
+    for net, order in ((n0, order0), (n1, order1)):
+        every = sorted(p.w.data_ptr() for p in net.params.values())
+        for upd in order:
+            assert sorted(upd) == every                                  # each tensor once per step, none skipped, none twice
+    # in-sweep order: the END of the table (the layers the sweep visits first) is updated first
+    table_order = [p.w.data_ptr() for p in n1.params.values()]
+    assert order1[1][:3] == table_order[-3:] or set(order1[1][:3]) <= set(table_order[-4:])
