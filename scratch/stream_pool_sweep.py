@@ -6,7 +6,7 @@ This script measures the step for `skip` = 0 .. 11 pool streams burnt before the
 created, with and without a one-rank RCCL group, so that the assignment can be chosen by measurement (and then made deliberate in
 frcnn_hip/train.py: e.g. a start-up autotune over a few skips, 2 steps each).
 
-    python scratch/stream_pool_sweep.py [out.txt]        # ~12 s per line on an MI355X
+    python scratch/stream_pool_sweep.py [out.txt [skip,skip,...]]        # ~12 s per line on an MI355X
 """
 import os
 import subprocess
@@ -56,8 +56,9 @@ print("RESULT skip %%d group %%d: %%.2f ms per step" %% (skip, group, 1e3 * (tim
 
 def main():
     out = open(sys.argv[1], "w") if len(sys.argv) > 1 else sys.stdout
+    skips = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else list(range(12))
     for group in (0, 1):
-        for skip in range(12):
+        for skip in skips:
             t0 = time.time()
             p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, str(skip), str(group)], capture_output=True, text=True, timeout=300)
             line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")]

@@ -126,10 +126,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
   constexpr int SL = BM / 64;
   constexpr int XP = BM * 64, WP = BN * 64;       // bytes of one plane of a stage
   constexpr bool PP = (TUNE & 32) != 0;           // the ping-pong schedule (below): 8 waves in two groups, one barrier apart
+  constexpr bool LTB = (TUNE & 256) != 0;         // the light tile boundary (round 5, below): no dependent memory round trip, no store drain
+  constexpr bool W21 = (TUNE & 512) != 0;         // plane stores widened to 16 B per lane by v_permlane32_swap pairs (half the instructions)
   constexpr int S_OFF = 2 * XP + 2 * WP, STAGE = S_OFF + (PP ? 0 : 1024);
   constexpr int RED_OFF = NS * STAGE;             // row-maximum exchange of the plane-emitting epilogue: [BN / WN][BM] floats
   constexpr int S2_OFF = RED_OFF + (BN / WN) * BM * 4;      // TUNE & 2: two 1 KB block-scale regions, alternating per 128-k block
                                                             // PP: [wave][parity] 256 B: each wave's own 64 row scales
+  constexpr int CB_OFF = S2_OFF + (PP ? NW * 512 : (TUNE & 2) ? 2048 : 0);   // LTB: [tile parity][filter scales BN | bias BN] floats
+  static_assert(!LTB || (!PP && NS == 2 && NW >= 3 && BN % 64 == 0), "light boundary: the two-slot one-barrier-per-slab schedule");
   static_assert(!PP || (NW == 8 && NS == 3 && (TUNE & 2) && ((BM == 256 && WM == 64) || (BM == 128 && WM == 32)) && BN == 128 && WN == 64),
                 "ping-pong geometry: 8 waves as 4 (M) x 2 (N), waves 0-3 = the upper half of the rows");
   static_assert((2 * BM / 16) % NW == 0 && (2 * BN / 16) % NW == 0, "tile/wave mismatch");
@@ -157,6 +161,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
   unsigned a_off[LA], b_off[LB], s_off[SL];
   const char* i_xb = nullptr; const char* i_wb = nullptr; const char* i_sb = nullptr;  // wave-uniform bases, advanced per slab
   int i_tile = tile0, i_step = 0, i_par = 0, c_par = 0;       // *_par: parity of the running 128-k block count (issue / compute side)
+  int i_g = 0, i_bn0 = 0, i_cpar = 0, c_cpar = 0;             // LTB: batch entry / first column of the tile being issued; tile parities
+  int pend = 0;                                               // LTB: vector-memory instructions this wave issued AFTER its last slab load
 #pragma unroll
   for (int t = 0; t < LB; ++t) {
     const int u = wave * LB + t, plane = u / (BN / 16), row = (u % (BN / 16)) * 16 + (lane >> 2), pos = lane & 3;
@@ -170,6 +176,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
     const int mt = rem / p.ntiles, nt = rem - mt * p.ntiles;
     const int bm0 = mt * BM, bn0 = nt * BN;
     const size_t row0 = (size_t)g * p.M + bm0;
+    i_g = g; i_bn0 = bn0;
     i_xb = (const char*)p.x + row0 * p.K * 2;
 #ifdef FRCNN_ABLATION     // TUNE & 64: every tile reads the FIRST tile's X rows (cache-resident operands: what does the HBM latency cost?)
     if (TUNE & 64) i_xb = (const char*)p.x;
@@ -233,6 +240,35 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
       i_xb += 64; i_wb += 64;
       if ((i_step & 3) == 0) i_sb += (size_t)p.Mtot * 4;       // next 128-k block: next row of x_inv [K/128][Mtot]
     }
+  };
+
+  // LTB: the column-block constants of the tile whose FIRST slab has just been issued -- the filter scales and the bias of its BN columns --
+  // travel to LDS with that slab (waves 1 and 2, BN / 64 four-byte direct-to-LDS loads each), into the parity region of the tile.  The
+  // tile start and the epilogue then read them with ds_read: no global load whose wait would drain the stores / slabs in flight.
+  auto issue_cb = [&]() {
+    const unsigned cb = lds0 + CB_OFF + i_cpar * (2 * BN * 4);
+    if (wave == 1) {
+#pragma unroll
+      for (int j = 0; j < BN / 64; ++j)
+        h2_glds4((unsigned)(lane * 4 + j * 256), uniform_ptr((const char*)(p.w_inv + (size_t)(p.wshare ? 0 : i_g) * p.N + i_bn0)),
+                 __builtin_amdgcn_readfirstlane(cb + j * 256));
+    }
+    if (wave == 2 && p.bias) {
+#pragma unroll
+      for (int j = 0; j < BN / 64; ++j)
+        h2_glds4((unsigned)(lane * 4 + j * 256), uniform_ptr((const char*)(p.bias + i_bn0)), __builtin_amdgcn_readfirstlane(cb + BN * 4 + j * 256));
+    }
+    i_cpar ^= 1;
+  };
+  // LTB: wait until at most `n` (rounded down to a template value) of this wave's vector-memory instructions are outstanding.  vmcnt
+  // retires in issue order, loads and stores alike (gfx9), so with n = the instructions issued AFTER the slab loads the wave needs, the
+  // epilogue's stores and the next tile's residual loads stay in flight across the wait.
+  auto wait_pending = [&](int n) {
+    if (n >= 63) h2_wait_vmcnt<63>();
+    else if (n >= 48) h2_wait_vmcnt<48>();
+    else if (n >= 32) h2_wait_vmcnt<32>();
+    else if (n >= 16) h2_wait_vmcnt<16>();
+    else h2_wait_vmcnt<0>();
   };
 
   // ---- compute side -------------------------------------------------------------------------------------------------------------
@@ -310,6 +346,22 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)max(0ll, min(bytes, 0x7fffffffll)), 0x00020000);
   };
 
+#ifdef FRCNN_H2_TRACE
+  int tr_slab = 0;
+  auto stamp = [&](int point) {       // [workgroup < 16][wave][slab < 64][point < 8]
+    if (p.trace && blockIdx.x < 16 && tr_slab < 64 && lane == 0)
+      p.trace[(((size_t)blockIdx.x * NW + wave) * 64 + tr_slab) * 8 + point] = __builtin_amdgcn_s_memtime();
+  };
+  // tile-boundary stamps (scratch/h2_trace_boundary.py): a second region behind the slab stamps, [workgroup < 16][wave][tile < 32][point < 8]
+  int tr_tile = 0;
+  auto bstamp = [&](int point) {
+    if (p.trace && blockIdx.x < 16 && tr_tile < 32 && lane == 0)
+      p.trace[(size_t)16 * 8 * 64 * 8 + (((size_t)blockIdx.x * NW + wave) * 32 + tr_tile) * 8 + point] = __builtin_amdgcn_s_memtime();
+  };
+#else
+  auto stamp = [](int) {};
+  auto bstamp = [](int) {};
+#endif
   // The accumulators of a tile START at (bias + res) * 2^e_w: the filter row's scale w_inv = 2^-e_w is an exact power of two, so the
   // final  tot * w_inv  = products + bias + res  is one f32 sum evaluated in the scaled domain -- and the residual is fetched when the
   // tile starts (its latency hides under the first 128-k block; it is first touched by that block's fold) instead of after the last MFMA.
@@ -333,6 +385,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
             tot[i][j][4 * q + 2] = __uint_as_float(ld[2]); tot[i][j][4 * q + 3] = __uint_as_float(ld[3]);
           }
         }
+      pend += TM * TN * 4;
     } else if (p.resp) {
       // the residual as operand planes (the trunk of a bottleneck chain kept as planes only): (h + l) is exact in f32 (<= 23
       // significant bits), times the block's power-of-two scale; the tile's 128 columns are one scale block (BN == 128)
@@ -371,6 +424,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
 #pragma unroll
           for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
     }
+    // LTB: that is all -- the residual stays RAW in `tot` (its loads in flight behind the previous tile's stores) until the first fold of the
+    // tile, four slabs from here, turns it into the scaled start value with the filter scales and the bias read from LDS (fold_first).
+    if constexpr (LTB) return;
     // the filter scales and the bias of the tile's columns (issued behind the residual's loads: all of them are in flight together)
     float4 wi[TN][4], bv[TN][4];
 #pragma unroll
@@ -410,13 +466,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
 
   auto epilogue = [&]() {
     const size_t row_base = (size_t)c_g * p.M;
+    bstamp(0);
     // ---- v = act(tot * w_inv), kept in tot (bias and residual went in with init_tot) ----------------------------------------------
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n0 = c_bn0 + wn0 + j * 32 + 4 * khalf;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 wi = *(const float4*)(p.w_inv + (size_t)(p.wshare ? 0 : c_g) * p.N + n0 + 8 * q);
+        const float4 wi = LTB ? *(const float4*)(smem + CB_OFF + c_cpar * (2 * BN * 4) + (wn0 + j * 32 + 4 * khalf + 8 * q) * 4)
+                             : *(const float4*)(p.w_inv + (size_t)(p.wshare ? 0 : c_g) * p.N + n0 + 8 * q);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           tot[i][j][4 * q + 0] = act_clamp(tot[i][j][4 * q + 0] * wi.x, act_lo, act_hi);
@@ -426,6 +484,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
         }
       }
     }
+    bstamp(1);
     // ---- frcnn_gemm_h2_masked: the ReLU gradient of the tensor this result is the gradient of (an exact select; NaN / inf of the result
     //      pass where the mask is positive, like frcnn_relu_bwd) -------------------------------------------------------------------------
     if ((TUNE & 128) && p.mask) {       // TUNE & 128: the training instantiations (the inference kernels do not carry this code)
@@ -483,9 +542,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
               *(float4*)(dst + n0 + 8 * q) = make_float4(a[0], a[1], a[2], a[3]);
               *(float4*)(dst + p.N + n0 + 8 * q) = make_float4(b[0], b[1], b[2], b[3]);
             }
+            pend += 2;
           }
         }
       }
+      c_cpar ^= 1;
       return;
     }
     // (Measured and not kept, profiles/r04_y_*: the same stores ROW-MAJOR through a wave-private LDS block -- 8 rows x one full 128-byte
@@ -511,9 +572,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
             o[2] = __float_as_uint(tot[i][j][4 * q + 2]); o[3] = __float_as_uint(tot[i][j][4 * q + 3]);
             __builtin_amdgcn_raw_buffer_store_b128(o, ry, lo + 32 * q, 0, 0);
           }
+          pend += 4;
         }
       }
     }
+    bstamp(2);
     // ---- the next layer's operand planes: block scale over this workgroup's 128 columns, per row ------------------------------------
     if (p.yp) {
       float* red = (float*)(smem + RED_OFF);
@@ -540,6 +603,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
 #pragma unroll
           for (int o = 0; o < BN / WN; ++o) mx[i] = fmaxf(mx[i], red[o * BM + wm0 + i * 32 + frow]);
       }
+      bstamp(3);
       const size_t yplane = (size_t)p.Mtot * p.N;                                 // elements
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -554,38 +618,58 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
           const long long sbase = (long long)(row_base + m0) * p.N + nc;
           const long long left_e = (long long)(p.M - m0) * p.N - nc;
           const auto rh = rsrc_f(p.yp + sbase, left_e, 2), rl = rsrc_f(p.yp + yplane + sbase, left_e, 2);
-          const int lo = (frow * p.N + 4 * khalf) * 2;
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          if constexpr (W21) {
+            // The accumulator layout gives a lane 4 consecutive columns (8 bytes of a plane) per register quad q and puts the next 4 in lane + 32.
+            // v_permlane32_swap(vdst = quad 2p, src = quad 2p + 1) exchanges the upper half of vdst with the lower half of src: afterwards a
+            // lower lane holds columns 16p .. 16p+7 of its row as [own 2p | upper's 2p], an upper lane columns 16p+8 .. 16p+15 as
+            // [lower's 2p+1 | own 2p+1] -- ONE 16-byte store per pair and plane instead of two 8-byte stores: the same bytes at the same
+            // addresses from half the store instructions (the epilogue is bound by store ISSUE, not by bytes).
+            const int lo = (frow * p.N + 8 * khalf) * 2;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            h4 hh, ll;
-            h2_split4(make_float4(tot[i][j][4 * q + 0], tot[i][j][4 * q + 1], tot[i][j][4 * q + 2], tot[i][j][4 * q + 3]), scale, hh, ll);
-            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), rh, lo + 16 * q, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), rl, lo + 16 * q, 0, 0);
+            for (int pq = 0; pq < 2; ++pq) {
+              h4 ha, la, hb, lb;
+              h2_split4(make_float4(tot[i][j][8 * pq + 0], tot[i][j][8 * pq + 1], tot[i][j][8 * pq + 2], tot[i][j][8 * pq + 3]), scale, ha, la);
+              h2_split4(make_float4(tot[i][j][8 * pq + 4], tot[i][j][8 * pq + 5], tot[i][j][8 * pq + 6], tot[i][j][8 * pq + 7]), scale, hb, lb);
+              const u32x2 uha = __builtin_bit_cast(u32x2, ha), uhb = __builtin_bit_cast(u32x2, hb);
+              const u32x2 ula = __builtin_bit_cast(u32x2, la), ulb = __builtin_bit_cast(u32x2, lb);
+              typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+              const auto h0 = __builtin_amdgcn_permlane32_swap(uha[0], uhb[0], false, false), h1 = __builtin_amdgcn_permlane32_swap(uha[1], uhb[1], false, false);
+              const auto l0 = __builtin_amdgcn_permlane32_swap(ula[0], ulb[0], false, false), l1 = __builtin_amdgcn_permlane32_swap(ula[1], ulb[1], false, false);
+              __builtin_amdgcn_raw_buffer_store_b128(u32x4{h0[0], h1[0], h0[1], h1[1]}, rh, lo + 32 * pq, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b128(u32x4{l0[0], l1[0], l0[1], l1[1]}, rl, lo + 32 * pq, 0, 0);
+            }
+            pend += 4;
+          } else {
+            const int lo = (frow * p.N + 4 * khalf) * 2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              h4 hh, ll;
+              h2_split4(make_float4(tot[i][j][4 * q + 0], tot[i][j][4 * q + 1], tot[i][j][4 * q + 2], tot[i][j][4 * q + 3]), scale, hh, ll);
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), rh, lo + 16 * q, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), rl, lo + 16 * q, 0, 0);
+            }
+            pend += 8;
           }
         }
       }
+      bstamp(4);
       if (BN / WN > 1) {                                                         // red[] is reused by the next tile
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       }
     }
+    bstamp(5);
+    c_cpar ^= 1;
   };
 
-#ifdef FRCNN_H2_TRACE
-  int tr_slab = 0;
-  auto stamp = [&](int point) {       // [workgroup < 16][wave][slab < 64][point < 8]
-    if (p.trace && blockIdx.x < 16 && tr_slab < 64 && lane == 0)
-      p.trace[(((size_t)blockIdx.x * NW + wave) * 64 + tr_slab) * 8 + point] = __builtin_amdgcn_s_memtime();
-  };
-#else
-  auto stamp = [](int) {};
-#endif
   // one slab of the stream: wait for it, let the ring slot it frees be refilled (loads spread over nothing here: they are issued
   // right after the barrier, G + SL instructions, and land under the 24 * TM * TN / 4 MFMAs of this slab and the next NS - 2)
-  auto slab = [&](auto first_c, bool fold) {
+  auto slab = [&](auto first_c, bool fold, bool first_block) {
     stamp(0);
-    if (left >= 1) {                                   // steady state: NS - 2 younger slabs may stay in flight
+    if constexpr (LTB) {
+      wait_pending(pend);                              // the slab's loads are older than the `pend` instructions that may stay in flight
+    } else if (left >= 1) {                            // steady state: NS - 2 younger slabs may stay in flight
       if (wave == 0) h2_wait_vmcnt<(NS - 2) * (G + SL)>(); else h2_wait_vmcnt<(NS - 2) * G>();
     } else {
       h2_wait_vmcnt<0>();                              // tail of the stream: nothing more will be issued
@@ -595,9 +679,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
     stamp(2);
     const bool more = left > 0;
     constexpr int HALF = (TUNE & 4) ? 0 : (TUNE & 1) ? (G + SL) / 2 : G + SL;
+    static_assert(!LTB || HALF == G + SL, "light boundary: the slab's loads are issued in one burst");
     if (more) {
 #pragma unroll
       for (int t = 0; t < HALF; ++t) issue_one(nxt, t);
+      if constexpr (LTB) {
+        if (i_step == 0) issue_cb();                   // first slab of a tile: its filter scales and bias travel with it
+        pend = 0;
+      }
     }
     stamp(3);
     float ainv[TM];
@@ -630,12 +719,34 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
       nxt = nxt + 1 == NS ? 0 : nxt + 1;
     }
     if (fold) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
+      if (LTB && first_block) {
+        // The tile's first fold: `tot` holds the raw residual (or zeros); the start value (bias + res) * 2^e_w is formed here, from the
+        // filter scales and the bias in LDS -- the same add, multiply and fma as init_tot's, bit for bit.
+        const float* cbp = (const float*)(smem + CB_OFF + c_cpar * (2 * BN * 4));
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) tot[i][j][r] = __builtin_fmaf(tmp[i][j][r], ainv[i], tot[i][j][r]);
+          for (int q = 0; q < 4; ++q) {
+            const float4 wi = *(const float4*)(cbp + wn0 + j * 32 + 4 * khalf + 8 * q);
+            const float4 bv = p.bias ? *(const float4*)(cbp + BN + wn0 + j * 32 + 4 * khalf + 8 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float s0 = __uint_as_float(0x7f000000u - __float_as_uint(wi.x)), s1 = __uint_as_float(0x7f000000u - __float_as_uint(wi.y));
+            const float s2 = __uint_as_float(0x7f000000u - __float_as_uint(wi.z)), s3 = __uint_as_float(0x7f000000u - __float_as_uint(wi.w));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+              tot[i][j][4 * q + 0] = __builtin_fmaf(tmp[i][j][4 * q + 0], ainv[i], (tot[i][j][4 * q + 0] + bv.x) * s0);
+              tot[i][j][4 * q + 1] = __builtin_fmaf(tmp[i][j][4 * q + 1], ainv[i], (tot[i][j][4 * q + 1] + bv.y) * s1);
+              tot[i][j][4 * q + 2] = __builtin_fmaf(tmp[i][j][4 * q + 2], ainv[i], (tot[i][j][4 * q + 2] + bv.z) * s2);
+              tot[i][j][4 * q + 3] = __builtin_fmaf(tmp[i][j][4 * q + 3], ainv[i], (tot[i][j][4 * q + 3] + bv.w) * s3);
+            }
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tot[i][j][r] = __builtin_fmaf(tmp[i][j][r], ainv[i], tot[i][j][r]);
+      }
     }
     cur = cur + 1 == NS ? 0 : cur + 1;
     stamp(6);
@@ -798,6 +909,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
     if (left > 0) {
 #pragma unroll
       for (int t = 0; t < G + SL; ++t) issue_one(nxt, t);
+      if constexpr (LTB) {
+        if (i_step == 0) issue_cb();
+        pend = 0;
+      }
       issue_advance();
       nxt = nxt + 1 == NS ? 0 : nxt + 1;
     }
@@ -805,11 +920,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
   const int nkb = p.nsteps >> 2;
   for (int tl = 0; tl < my_tiles; ++tl) {
     init_tot();
+    bstamp(6);
+#ifdef FRCNN_H2_TRACE
+    ++tr_tile;                                         // (stamps 0-5 of tile t's epilogue and stamp 6 of tile t + 1's start share an index)
+#endif
     for (int kb = 0; kb < nkb; ++kb) {
-      slab(std::true_type{}, false);
-      slab(std::false_type{}, false);
-      slab(std::false_type{}, false);
-      slab(std::false_type{}, true);
+      slab(std::true_type{}, false, kb == 0);
+      slab(std::false_type{}, false, kb == 0);
+      slab(std::false_type{}, false, kb == 0);
+      slab(std::false_type{}, true, kb == 0);
     }
     epilogue();
     c_tile += W8;
@@ -909,8 +1028,9 @@ extern "C" int frcnn_h2_split(const float* x_d, long long M, int K, void* planes
 template <int BM, int BN, int WM, int WN, int NS, int WPE = 2, int TUNE = 0>
 static int launch_h2(const GemmH2Params& q, hipStream_t st) {
   constexpr int NT = (BM / WM) * (BN / WN) * 64;
-  constexpr size_t lds = (TUNE & 32) ? (size_t)NS * (2 * BM * 64 + 2 * BN * 64) + (size_t)(BN / WN) * BM * 4 + (size_t)(NT / 64) * 512
-                                     : (size_t)NS * (2 * BM * 64 + 2 * BN * 64 + 1024) + (size_t)(BN / WN) * BM * 4 + ((TUNE & 2) ? 2048 : 0);
+  constexpr size_t lds = ((TUNE & 32) ? (size_t)NS * (2 * BM * 64 + 2 * BN * 64) + (size_t)(BN / WN) * BM * 4 + (size_t)(NT / 64) * 512
+                                      : (size_t)NS * (2 * BM * 64 + 2 * BN * 64 + 1024) + (size_t)(BN / WN) * BM * 4 + ((TUNE & 2) ? 2048 : 0)) +
+                         ((TUNE & 256) ? (size_t)2 * 2 * BN * 4 : 0);
   auto kern = k_gemm_h2<BM, BN, WM, WN, NS, WPE, TUNE>;
   static KernelOnce once;
   int slots = 0;                            // resident workgroups on the CURRENT device
@@ -996,7 +1116,9 @@ static int run_h2(GemmH2Params& p, int cfg, hipStream_t st) {
     // fewer than 150 tiles of 128 x 128 (a single image's launches: batch-1 latency mode): 64-row tiles, three workgroups per CU
     // (profiles/r03_g_h2_sweep.txt: 21.8 vs 30.9 us on one image's block3 conv1); in the 4-image pipeline these lose (r03_l_ab.txt)
     const bool tiny = (long long)((M + 127) / 128) * (N / 128) * G < 150;
-    cfg = pp ? 21 : tiny ? 12 : 9;       // 9: 128 x 128 tiles, two workgroups per CU, one barrier per slab (profiles/r03_l_ab.txt)
+    // cfg == -2: round 4's choice (A/B runs).  Round 5: the same tiles with the light tile boundary and 16-byte plane stores (31, 33):
+    // bit-identical, 5-16 % faster on the short-K launches, indifferent elsewhere (profiles/r05_b_h2_conv3.txt)
+    cfg = pp ? 21 : tiny ? (cfg == -2 ? 12 : 33) : (cfg == -2 ? 9 : 31);
   }
   if (p.mask) switch (cfg) {            // frcnn_gemm_h2_masked: the same three configurations with the mask in the epilogue
     case 9: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 128>(p, st);
@@ -1008,6 +1130,10 @@ static int run_h2(GemmH2Params& p, int cfg, hipStream_t st) {
     case 9: return launch_h2<128, 128, 64, 64, 2, 2, 2>(p, st);  // 67 KB: 2 workgroups / CU, one barrier per slab, scales once per 128-k block
     case 12: return launch_h2<64, 128, 32, 64, 2>(p, st);        // 64-row tiles, 4 waves of 32 x 64, 51 KB: 3 workgroups / CU (single-image launches)
     case 21: return launch_h2<256, 128, 64, 64, 3, 2, 34>(p, st); // ping-pong: 256 x 128, 8 waves in two groups a segment apart, 3-slot ring
+    case 30: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 256>(p, st);        // cfg 9 with the light tile boundary
+    case 31: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 256 + 512>(p, st);  // ... and 16-byte plane stores
+    case 32: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 512>(p, st);        // cfg 9 with 16-byte plane stores only
+    case 33: return launch_h2<64, 128, 32, 64, 2, 2, 256 + 512>(p, st);       // cfg 12 with both
 #ifdef FRCNN_ABLATION
     // measurement builds only (scratch/ablation_lib.py): the configurations the sweeps under profiles/r03_*, r04_* compare.  All of
     // them multiply and fold in the same order as the three above (bit-identical results; measured, not shipped).
