@@ -276,7 +276,8 @@ def train_bench(args, c, dev, world, rank, dist):
     ar_host0 = (getattr(ar, "host_s", 0.0), getattr(ar, "sends", 0))
     t0 = time.perf_counter()
     sw.train_model(args.steps, verbose=False)
-    sess.host_enqueue_s = time.perf_counter() - t0          # the host's share: launches enqueued, GPU not yet waited for
+    sess.host_enqueue_s = sw.enqueue_s                      # the host's share: launches enqueued, GPU not yet waited for (rounds 3-4 stopped
+    # this clock after train_model's final loss read-back, i.e. after a device synchronisation: it read the step time)
     sess.all_reduce_host = None if ar is None else (getattr(ar, "host_s", 0.0) - ar_host0[0], getattr(ar, "sends", 0) - ar_host0[1])
     torch.cuda.synchronize()
     if dist is not None:
@@ -286,7 +287,10 @@ def train_bench(args, c, dev, world, rank, dist):
     # matrix work of ONE step per matrix pipe (an extra, untimed step with the host-side ledgers on): forward pass from the launch tags
     # (Session.mark), reverse sweep from TrainState.count_flops
     sess.flops_by_pipe, sw.state.flop_ledger = {}, {}
+    sess.replay_stats = dict(net.replay_stats)
+    replay_on, cfg.HIP.TRAIN_REPLAY = cfg.HIP.TRAIN_REPLAY, False          # (the ledgers are host bookkeeping of the Python step: a replayed step runs none)
     sw.train_model(1, verbose=False)
+    cfg.HIP.TRAIN_REPLAY = replay_on
     torch.cuda.synchronize()
     sess.step_flops_by_pipe = {k: sess.flops_by_pipe.get(k, 0) + sw.state.flop_ledger.get(k, 0) for k in ("h2", "x3", "f32")}
     sess.flops_by_pipe, sw.state.flop_ledger = None, None
@@ -404,8 +408,9 @@ def other_configs(budget_s, t_start):
                "roofline_bound": rf.get("bound"), "roofline_frac": rf.get("frac"), "mfma_frac": rf.get("mfma_frac", rf.get("frac")), "hbm_frac": rf.get("hbm_frac"),
                "pipes": {k: (v.get("frac_of_pipe_peak") if "frac_of_pipe_peak" in v else v.get("share_of_launched_flops")) for k, v in (rf.get("pipes") or {}).items()},
                "wall_s": d["wall_s"]}
-        if "data_parallel_rules" in d["config"]:
-            rec["data_parallel_rules"] = d["config"]["data_parallel_rules"]
+        for k in ("data_parallel_rules", "host_enqueue_ms_per_step", "launch", "all_reduce_host_ms_per_step"):
+            if k in d["config"]:
+                rec[k] = d["config"][k]
         out[name] = rec
     return out
 
@@ -459,6 +464,7 @@ def main():
                          "of the group every rank of an N-GPU run has costs the per-GPU rate (its streams come out of torch's stream pool first)")
     ap.add_argument("--dp-probe", choices=["noop", "noop-nogroup"], default=None,
                     help="c5 --dp-constrained A/B (diagnosis): the bucketed all-reduce object sends nothing (noop), and no RCCL group is created (noop-nogroup)")
+    ap.add_argument("--no-train-replay", action="store_true", help="cfg.HIP.TRAIN_REPLAY False: every training step enqueued by the Python code (c5 A/B)")
     ap.add_argument("--no-solver-in-sweep", action="store_true", help="c5 A/B: the solver updates every parameter after the sweep, in one launch on the main stream")
     ap.add_argument("--no-fuse-chain", action="store_true", help="c5 A/B: separate relu_bwd / residual-copy / h2_split passes in the reverse sweep, gather-form strided / odd-width data gradients")
     ap.add_argument("--no-prep-stream", action="store_true", help="cfg.HIP.PREP_STREAM False: gradient filters prepared inside the sweep (c5 A/B)")
@@ -528,6 +534,8 @@ def main():
         cfg.HIP.WGRAD_TN = False
     if args.no_wgrad_h2:
         cfg.HIP.WGRAD_H2 = False
+    if args.no_train_replay:
+        cfg.HIP.TRAIN_REPLAY = False
     if args.no_prep_stream:
         cfg.HIP.PREP_STREAM = False
     if args.wgrad_plan:
@@ -580,7 +588,9 @@ def main():
             value = world * args.steps / elapsed
             out = dict(common, value=round(value, 3), ms_per_step=round(1000.0 * elapsed / args.steps, 4),
                        config={"workload": c["label"] + "; one image per GPU per step", "parallelism": "dp%d (RCCL gradient all-reduce)" % world,
-                               "launch": "eager (forward, reverse sweep, solver), filter gradients on %d side stream(s)" % (
+                               "launch": "%s (forward, reverse sweep, solver), filter gradients on %d side stream(s)" % (
+                                   "one recorded launch list per step, replayed (cfg.HIP.TRAIN_REPLAY: %r)" % (sess.replay_stats,)
+                                   if cfg.HIP.TRAIN_REPLAY else "eager: every step enqueued by the Python code",
                                    min(int(cfg.HIP.WGRAD_STREAM), 1 if (world > 1 or args.dp_constrained) else 99)),
                                "host_enqueue_ms_per_step": round(1000.0 * sess.host_enqueue_s / args.steps, 3),
                                "gflop_per_step_reference_graph": c["gflop_ref"]},

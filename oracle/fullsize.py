@@ -267,7 +267,7 @@ GRAD_TOL = 2e-4              # of the tensor's largest entry; or GRAD_CTRL_FACTO
 GRAD_CTRL_FACTOR = 4.0
 GATE_EPS = 2e-5              # relative to the layer's largest pre-activation: what a Winograd F(4x4,3x3) forward may move a gate by
 EPS_SCORE, EPS_IOU, TOL = 1e-4, 1e-3, 1e-4        # BASELINE.json north_star: 1e-4 on scores / box coordinates
-CTRL_FACTOR = {"direct": 1.5, "shipped": 1.5, "shipped_trunk_planes": 1.5, "shipped_x3": 1.5, "shipped_f32": 1.5}     # allowed multiple of the float32 control's own loss (exploratory policies: 2.5)
+CTRL_FACTOR = {"direct": 1.5, "shipped": 1.5, "shipped_f32trunk": 1.5, "shipped_x3": 1.5, "shipped_f32": 1.5}     # allowed multiple of the float32 control's own loss (exploratory policies: 2.5)
 
 
 def tolerance(fx, key, policy):

@@ -29,7 +29,7 @@ SHIPPED = "shipped"
 
 SHIPPED_F32 = "shipped_f32"
 SHIPPED_X3 = "shipped_x3"
-SHIPPED_TP = "shipped_trunk_planes"
+SHIPPED_TP = "shipped_f32trunk"
 
 
 def _shipped_policy():
@@ -38,7 +38,7 @@ def _shipped_policy():
     from model.config import cfg
     fs.POLICIES[SHIPPED] = {k: cfg.HIP[k] for k in ("WINOGRAD", "WINOGRAD_M", "WINOGRAD_F2_SCOPES", "WINOGRAD_DIRECT_SCOPES", "WINOGRAD_7X7",
                                                     "WINOGRAD_MIN_CIN", "MFMA_X3", "MFMA_H2", "H2_LAZY_SPLIT", "H2_MIN_TILES", "H2_TRUNK_PLANES", "FUSE_TAIL_MEAN")}
-    fs.POLICIES[SHIPPED_TP] = dict(fs.POLICIES[SHIPPED], H2_TRUNK_PLANES=True)        # the identity-shortcut trunk as operand planes only (conv3: 8 instead of 12 B / element)
+    fs.POLICIES[SHIPPED_TP] = dict(fs.POLICIES[SHIPPED], H2_TRUNK_PLANES=False)       # the identity-shortcut trunk ALSO written as float32 (rounds 3 / 4's shipped form; conv3: 12 instead of 8 B / element)
     fs.POLICIES[SHIPPED_X3] = dict(fs.POLICIES[SHIPPED], MFMA_H2=False)               # round 2's configuration (bench.py `x3_variant`)
     fs.POLICIES[SHIPPED_F32] = dict(fs.POLICIES[SHIPPED], MFMA_X3=False, MFMA_H2=False)
     return SHIPPED

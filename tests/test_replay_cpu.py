@@ -1,0 +1,167 @@
+"""CPU: the launch-list form of a training step (frcnn_hip/replay.py) against stand-ins for the C-ABI entries, streams and events:
+a recording replays the same calls with the same arguments in the same order; streams are slots that can be bound to other physical
+streams; the per-step arguments (sampling seeds, gt-box count) are rewritten at replay; a failing entry raises; the recording hooks in
+frcnn_hip.call / frcnn_hip.ops append to the recorder only while one is installed; the arena hands out the same tensors every step."""
+import ctypes
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tf-faster-rcnn_amd"))
+
+import frcnn_hip                              # noqa: E402
+from frcnn_hip import ops, replay             # noqa: E402
+
+
+class FakeFn(object):
+    """a C-ABI entry: logs (name, argument values) and returns a status code"""
+
+    def __init__(self, name, argtypes, log, rc=0):
+        self.__name__, self.argtypes, self.log, self.rc = name, argtypes, log, rc
+
+    def __call__(self, *args):
+        assert all(isinstance(a, t) for a, t in zip(args, self.argtypes)), "replayed arguments must arrive as the ctypes of the signature"
+        self.log.append((self.__name__,) + tuple(a.value for a in args))
+        return self.rc
+
+
+class FakeStream(object):
+    def __init__(self, name, handle, log):
+        self.name, self.cuda_stream, self.log = name, handle, log
+
+    def wait_event(self, ev):
+        self.log.append(("wait", self.name, ev.name))
+
+
+class FakeEvent(object):
+    def __init__(self, name, log):
+        self.name, self.log = name, log
+
+    def record(self, stream):
+        self.log.append(("record", self.name, stream.name))
+
+
+P, I, LL, D = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_double
+
+
+def record_a_step(log):
+    main, side = FakeStream("main", 0x1000, log), FakeStream("side", 0x2000, log)
+    ev = FakeEvent("e0", log)
+    conv = FakeFn("frcnn_conv", [P, I, P], log)
+    target = FakeFn("frcnn_target", [P, I, D, LL, P], log)
+    plan = FakeFn("frcnn_conv2d_wgrad_set_plan", [I, I], log)
+    rec = replay.Recording(main)
+    rec.vars = dict(seed=10, gt=3)
+    rec.slot(side)
+    frcnn_hip.recorder = rec
+    try:
+        rec.add_call(conv, "frcnn_conv", (P(0xA0), 7, P(0x1000)))                 # a launch on main
+        rec.add_call(target, "frcnn_target", (P(0xB0), 3, 0.5, 10 + 1, P(0x1000)))
+        rec.patch_last(1, var="gt")
+        rec.patch_last(3)
+        ops.ev_record(ev, main)
+        ops.st_wait_event(side, ev)
+        rec.add_call(plan, "frcnn_conv2d_wgrad_set_plan", (0, 256))               # no stream argument although the last one is an int
+        rec.add_call(conv, "frcnn_conv", (P(0xC0), 9, P(0x2000)))                 # a launch on the side stream
+    finally:
+        frcnn_hip.recorder = None
+    return rec, main, side
+
+
+def test_replay_repeats_the_recorded_step_and_rewrites_the_per_step_arguments():
+    log = []
+    rec, main, side = record_a_step(log)
+    eager = list(log)
+    assert eager == [("record", "e0", "main"), ("wait", "side", "e0")]            # (add_call does not execute; the ops helpers do)
+    del log[:]
+    rec.bind(rec.default_binding(main))
+    rec.replay(dict(seed=10, gt=3))
+    assert log == [("frcnn_conv", 0xA0, 7, 0x1000), ("frcnn_target", 0xB0, 3, 0.5, 11, 0x1000), ("record", "e0", "main"),
+                   ("wait", "side", "e0"), ("frcnn_conv2d_wgrad_set_plan", 0, 256), ("frcnn_conv", 0xC0, 9, 0x2000)]
+    del log[:]
+    rec.replay(dict(seed=16, gt=40))                                              # three steps later, an image with 40 boxes
+    assert log[1] == ("frcnn_target", 0xB0, 40, 0.5, 17, 0x1000)
+    assert [e for i, e in enumerate(log) if i != 1] == [("frcnn_conv", 0xA0, 7, 0x1000), ("record", "e0", "main"), ("wait", "side", "e0"),
+                                                        ("frcnn_conv2d_wgrad_set_plan", 0, 256), ("frcnn_conv", 0xC0, 9, 0x2000)]
+
+
+def test_streams_are_slots_that_can_be_bound_to_other_streams():
+    log = []
+    rec, main, side = record_a_step(log)
+    other_main, other_side = FakeStream("main2", 0x3000, log), FakeStream("side2", 0x4000, log)
+    assert not rec.bound_to(other_main)
+    rec.bind([other_main, other_side])
+    assert rec.bound_to(other_main) and not rec.bound_to(main)
+    del log[:]
+    rec.replay(dict(seed=10, gt=3))
+    assert log == [("frcnn_conv", 0xA0, 7, 0x3000), ("frcnn_target", 0xB0, 3, 0.5, 11, 0x3000), ("record", "e0", "main2"),
+                   ("wait", "side2", "e0"), ("frcnn_conv2d_wgrad_set_plan", 0, 256), ("frcnn_conv", 0xC0, 9, 0x4000)]
+
+
+def test_a_failing_entry_raises_at_replay():
+    log = []
+    main = FakeStream("main", 0x1000, log)
+    rec = replay.Recording(main)
+    rec.add_call(FakeFn("frcnn_bad", [P], log, rc=-2), "frcnn_bad", (P(0x1000),))
+    rec.bind([main])
+    with pytest.raises(frcnn_hip.FrcnnHipError, match="workspace too small"):
+        rec.replay(dict(seed=0, gt=0))
+
+
+def test_host_ops_run_now_and_at_every_replay_and_see_the_bound_streams():
+    log = []
+    main, side = FakeStream("main", 0x1000, log), FakeStream("side", 0x2000, log)
+    rec = replay.Recording(main)
+    frcnn_hip.recorder = rec
+    try:
+        slot = rec.slot(side)
+        ops.host_op(lambda: log.append("plain"))
+        ops.host_op(lambda r: log.append(("send on", side.name if r is None else r.bound[slot].name)))
+    finally:
+        frcnn_hip.recorder = None
+    assert log == ["plain", ("send on", "side")]
+    ops.host_op(lambda: log.append("not recorded"))                               # no recorder installed: runs, is not kept
+    del log[:]
+    rec.bind([main, FakeStream("side2", 0x5000, log)])
+    rec.replay(dict(seed=0, gt=0))
+    assert log == ["plain", ("send on", "side2")]
+
+
+def test_arena_hands_out_the_same_tensors_every_step_and_only_while_active():
+    class Sess(object):
+        buffers, device = {}, torch.device("cpu")
+    a = replay.Arena(Sess(), "t")
+    ops.arena = a
+    try:
+        x1, y1, z1 = ops._empty((2, 3)), ops._empty((2, 3)), ops._zeros((4,), dtype=torch.int32)
+        a.reset()
+        x2, y2, z2 = ops._empty((2, 3)), ops._empty((2, 3)), ops._zeros((4,), dtype=torch.int32)
+    finally:
+        ops.arena = None
+    assert x1.data_ptr() == x2.data_ptr() and y1.data_ptr() == y2.data_ptr() and z1.data_ptr() == z2.data_ptr()
+    assert x1.data_ptr() != y1.data_ptr() and z1.dtype == torch.int32 and int(z1.abs().sum()) == 0
+    w = ops._empty((2, 3))
+    assert w.data_ptr() not in (x1.data_ptr(), y1.data_ptr())                     # outside the arena: an ordinary allocation
+
+
+def test_every_entry_without_a_stream_argument_is_classified():
+    """A recording treats the LAST pointer argument of a launch as its stream.  Entries of include/frcnn_hip.h that do not end in
+    `void* stream` must therefore be known: launch-context setters (recorded as they are), host-only functions (never recorded) or
+    size queries (never called through frcnn_hip.call)."""
+    import re
+    h = open(os.path.join(ROOT, "include", "frcnn_hip.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    h = re.sub(r"//.*", "", h)
+    decls = re.findall(r"\b(?:int|size_t|void|unsigned int|long long|const char\*)\s+\*?\s*(_nms|frcnn_\w+)\s*\(([^;{]*)\)\s*;", h)
+    assert len(decls) > 100
+    without = {n for n, a in decls if not re.search(r"void\s*\*\s*stream\s*$", a.strip())}
+    queries = {n for n in without if n.endswith("_bytes") or n.endswith("_supported")}
+    assert without - queries <= (replay.NO_STREAM_ARG | replay.HOST_ONLY), sorted(without - queries - replay.NO_STREAM_ARG - replay.HOST_ONLY)
+    assert not (replay.NO_STREAM_ARG & replay.HOST_ONLY)
+    log = []
+    rec = replay.Recording(FakeStream("main", 0x1000, log))
+    rec.add_call(FakeFn("frcnn_generate_anchors", [I, P, I, P, I, P], log), "frcnn_generate_anchors", (16, P(1), 3, P(2), 3, P(3)))
+    assert rec.cmds == []

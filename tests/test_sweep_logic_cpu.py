@@ -64,6 +64,27 @@ class FakeOps(types.SimpleNamespace):
     def _n(self, name):
         self.log[name] = self.log.get(name, 0) + 1
 
+    # the stream-level helpers of frcnn_hip.ops (recorded when a step is being recorded; here: the plain operations)
+    @staticmethod
+    def ev_record(ev, stream):
+        ev.record(stream)
+
+    @staticmethod
+    def st_wait_event(stream, ev):
+        stream.wait_event(ev)
+
+    @staticmethod
+    def st_wait_stream(stream, other):
+        stream.wait_stream(other)
+
+    @staticmethod
+    def t_copy(dst, src):
+        return dst.copy_(src)
+
+    @staticmethod
+    def t_zero(t):
+        return t.zero_()
+
     class pinned_stream(object):
         def __init__(self, stream):
             pass
@@ -357,7 +378,7 @@ def run_steps(monkeypatch, in_sweep, steps=3, chunk=3):
     order = []
     for _ in range(steps):
         ops.updated = []
-        ts._sweep([(t, g.clone()) for t, g in seeds], FakeStream())
+        ts._sweep([(t, g.clone()) for t, g in seeds], FakeStream(), in_sweep)
         ts.apply(ts.lr)
         order.append(list(ops.updated))
     return net, ops.log, order

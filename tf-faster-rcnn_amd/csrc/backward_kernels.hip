@@ -227,39 +227,94 @@ extern "C" int frcnn_colsum(const float* dy_d, int M, int C, float* db_d, void* 
   return FRCNN_OK;
 }
 
-// ---- crop_and_resize backward w.r.t. the feature map (TF CropAndResizeGradImage semantics): every
-//      output sample scatters its gradient to its four bilinear taps; out-of-range samples contribute 0.
-__global__ __launch_bounds__(256) void k_crop_bwd(const float* __restrict__ dout, int H, int W, int C, const float* __restrict__ rois,
-                                                  float stride, int pool, float* __restrict__ dfeat) {
-  const int r = blockIdx.x / pool, py = blockIdx.x % pool;
+// ---- crop_and_resize backward w.r.t. the feature map (TF CropAndResizeGradImage semantics): every output sample hands its
+//      gradient to its four bilinear taps; out-of-range samples contribute 0.  GATHER form, deterministic: TensorFlow's kernel (and
+//      rounds 1-4 here) scatters with float atomics, so the sum a feature pixel receives depended on the order the hardware happened to
+//      retire ~100 overlapping RoIs in, and two runs of the same training step differed in the last bits of every gradient upstream of
+//      the crop.  Here one workgroup owns ONE feature row h and 256 channels: (1) all threads scan the R * pool sample rows and compact,
+//      in ascending (roi, py) order, those whose top or bottom tap row is h (wave ballots + a running prefix: the list order is a
+//      function of the inputs only); (2) thread = channel walks the list and adds the samples' taps into its own column of an LDS row
+//      buffer [W][256] in (roi, py, px, tap) order; (3) the row buffer is added to dfeat.  No atomics, a fixed order per element, and
+//      the 2 x 7 x 256 RoI rows that touch a feature row are read once, coalesced over the channels.
+__global__ __launch_bounds__(256) void k_crop_bwd_rows(const float* __restrict__ dout, int H, int W, int C, const float* __restrict__ rois,
+                                                       int R, float stride, int pool, float* __restrict__ dfeat) {
+  extern __shared__ float crop_lds[];
+  float* acc = crop_lds;                                   // [W][256]
+  int* list = (int*)(crop_lds + (size_t)W * 256);          // [R * pool] hits, ascending
+  __shared__ int wcnt[4];
+  __shared__ int total_s;
+  const int h = blockIdx.x, tid = threadIdx.x, c = blockIdx.y * 256 + tid;
+  const int lane = tid & 63, wave = tid >> 6;
   const float height = ((float)H - 1.0f) * stride, width = ((float)W - 1.0f) * stride;
-  const float* roi = rois + 5 * (size_t)r;
-  const float x1 = roi[1] / width, y1 = roi[2] / height, x2 = roi[3] / width, y2 = roi[4] / height;
-  const float hs = (y2 - y1) * (float)(H - 1) / (float)(pool - 1);
-  const float ws = (x2 - x1) * (float)(W - 1) / (float)(pool - 1);
-  const float in_y = y1 * (float)(H - 1) + (float)py * hs;
-  if (in_y < 0 || in_y > (float)(H - 1)) return;
-  const int top = (int)floorf(in_y), bot = (int)ceilf(in_y);
-  const float ly = in_y - (float)top;
-  const float* drow = dout + ((size_t)r * pool + py) * pool * C;
-  for (int t = threadIdx.x; t < pool * C; t += 256) {
-    const int px = t / C, c = t % C;
-    const float in_x = x1 * (float)(W - 1) + (float)px * ws;
-    if (in_x < 0 || in_x > (float)(W - 1)) continue;
-    const int left = (int)floorf(in_x), right = (int)ceilf(in_x);
-    const float lx = in_x - (float)left;
-    const float g = drow[(size_t)px * C + c];
-    atomicAdd(dfeat + ((size_t)top * W + left) * C + c, g * (1.f - ly) * (1.f - lx));
-    atomicAdd(dfeat + ((size_t)top * W + right) * C + c, g * (1.f - ly) * lx);
-    atomicAdd(dfeat + ((size_t)bot * W + left) * C + c, g * ly * (1.f - lx));
-    atomicAdd(dfeat + ((size_t)bot * W + right) * C + c, g * ly * lx);
+  for (int w = 0; w < W; ++w) acc[w * 256 + tid] = 0.f;
+  if (tid == 0) total_s = 0;
+  __syncthreads();
+  const int n = R * pool;
+  for (int base = 0; base < n; base += 256) {
+    const int i = base + tid;
+    bool hit = false;
+    if (i < n) {
+      const int r = i / pool, py = i - r * pool;
+      const float* roi = rois + 5 * (size_t)r;
+      const float y1 = roi[2] / height, y2 = roi[4] / height;
+      const float hs = (y2 - y1) * (float)(H - 1) / (float)(pool - 1);
+      const float in_y = y1 * (float)(H - 1) + (float)py * hs;
+      if (!(in_y < 0 || in_y > (float)(H - 1))) hit = ((int)floorf(in_y) == h) || ((int)ceilf(in_y) == h);
+    }
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) wcnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = total_s;
+    for (int q = 0; q < wave; ++q) off += wcnt[q];
+    if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    __syncthreads();
+    if (tid == 0) total_s += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+  }
+  const int hits = total_s;
+  const bool live = c < C;
+  for (int k = 0; k < hits; ++k) {
+    const int i = list[k];
+    const int r = i / pool, py = i - r * pool;
+    const float* roi = rois + 5 * (size_t)r;
+    const float x1 = roi[1] / width, y1 = roi[2] / height, x2 = roi[3] / width, y2 = roi[4] / height;
+    const float hs = (y2 - y1) * (float)(H - 1) / (float)(pool - 1);
+    const float ws = (x2 - x1) * (float)(W - 1) / (float)(pool - 1);
+    const float in_y = y1 * (float)(H - 1) + (float)py * hs;
+    const int top = (int)floorf(in_y), bot = (int)ceilf(in_y);
+    const float ly = in_y - (float)top;
+    const float* drow = dout + ((size_t)r * pool + py) * pool * C;
+    for (int px = 0; px < pool; ++px) {
+      const float in_x = x1 * (float)(W - 1) + (float)px * ws;
+      if (in_x < 0 || in_x > (float)(W - 1)) continue;
+      const int left = (int)floorf(in_x), right = (int)ceilf(in_x);
+      const float lx = in_x - (float)left;
+      const float g = live ? drow[(size_t)px * C + c] : 0.f;
+      if (top == h) {
+        acc[left * 256 + tid] += g * (1.f - ly) * (1.f - lx);
+        acc[right * 256 + tid] += g * (1.f - ly) * lx;
+      }
+      if (bot == h) {
+        acc[left * 256 + tid] += g * ly * (1.f - lx);
+        acc[right * 256 + tid] += g * ly * lx;
+      }
+    }
+  }
+  if (live) {
+    float* drow = dfeat + (size_t)h * W * C + c;
+    for (int w = 0; w < W; ++w) drow[(size_t)w * C] += acc[w * 256 + tid];
   }
 }
 extern "C" int frcnn_crop_and_resize_bwd(const float* dout_d, int H, int W, int C, const float* rois_d, int R, float feat_stride,
                                          int pool, float* dfeat_d, void* stream) {
   if (!dout_d || !rois_d || !dfeat_d || H < 2 || W < 2 || C <= 0 || R < 0 || pool < 2) return FRCNN_E_ARG;
   if (R == 0) return FRCNN_OK;
-  hipLaunchKernelGGL(k_crop_bwd, dim3(R * pool), dim3(256), 0, (hipStream_t)stream, dout_d, H, W, C, rois_d, feat_stride, pool, dfeat_d);
+  const size_t lds = (size_t)W * 256 * 4 + (size_t)R * pool * 4;
+  if (lds > 160 * 1024 - 64) return FRCNN_E_UNSUPPORTED;  // W <= ~140 feature columns at 256 RoIs x 14 rows (a 2 240-pixel image side)
+  static KernelOnce once;
+  HIP_TRY(kernel_once(once, (const void*)k_crop_bwd_rows, 256, 160 * 1024 - 64));
+  hipLaunchKernelGGL(k_crop_bwd_rows, dim3(H, cdiv(C, 256)), dim3(256), lds, (hipStream_t)stream, dout_d, H, W, C, rois_d, R, feat_stride,
+                     pool, dfeat_d);
   LAUNCH_CHECK();
   return FRCNN_OK;
 }

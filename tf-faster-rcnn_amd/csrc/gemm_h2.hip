@@ -1120,9 +1120,10 @@ static int run_h2(GemmH2Params& p, int cfg, hipStream_t st) {
     // bit-identical, 5-16 % faster on the short-K launches, indifferent elsewhere (profiles/r05_b_h2_conv3.txt)
     cfg = pp ? 21 : tiny ? (cfg == -2 ? 12 : 33) : (cfg == -2 ? 9 : 31);
   }
-  if (p.mask) switch (cfg) {            // frcnn_gemm_h2_masked: the same three configurations with the mask in the epilogue
-    case 9: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 128>(p, st);
-    case 12: return launch_h2<64, 128, 32, 64, 2, 2, 128>(p, st);
+  if (p.mask) switch (cfg) {            // frcnn_gemm_h2_masked: round 4's three configurations with the mask in the epilogue (the light tile
+    case 9: case 30: case 31: case 32:  // boundary of cfgs 30-33 has no masked instantiation: those ids take the schedule they derive from)
+      return launch_h2<128, 128, 64, 64, 2, 2, 2 + 128>(p, st);
+    case 12: case 33: return launch_h2<64, 128, 32, 64, 2, 2, 128>(p, st);
     case 21: return launch_h2<256, 128, 64, 64, 3, 2, 34 + 128>(p, st);
     default: return FRCNN_E_ARG;
   }

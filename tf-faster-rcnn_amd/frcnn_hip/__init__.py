@@ -186,5 +186,11 @@ def check(rc, what):
                                                -3: "shape not supported by the kernels"}.get(rc, "error %d" % rc)))
 
 
+recorder = None                          # a replay.Recording while ONE eager training step is being recorded (frcnn_hip/replay.py), else None
+
+
 def call(name, *args):
-    check(getattr(lib(), name)(*args), name)
+    fn = getattr(lib(), name)
+    check(fn(*args), name)
+    if recorder is not None:
+        recorder.add_call(fn, name, args)

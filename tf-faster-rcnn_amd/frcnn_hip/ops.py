@@ -9,6 +9,7 @@ import ctypes
 import numpy as np
 import torch
 
+import frcnn_hip as _binding
 from . import ACT_NONE, NMS_RULE_CPU, call, lib
 
 _ws_cache = {}
@@ -46,11 +47,81 @@ def _ptr(t):
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
-def _chk(t, dtype=torch.float32):
-    if not (t.is_cuda and t.is_contiguous() and t.dtype == dtype):
-        raise ValueError("expected a contiguous CUDA %s tensor, got %s %s contiguous=%s" %
-                         (dtype, t.device, t.dtype, t.is_contiguous()))
+# ---- a training step as a replayable launch list (frcnn_hip/replay.py) ------------------------------------------------------------------
+# `arena`: while set, the result tensors these wrappers allocate themselves are static session buffers (same address every step).
+# `_binding.recorder`: while set, every call() and every stream-level operation below is appended to the recording of the step.
+arena = None
+
+
+def _empty(shape, dtype=torch.float32, device=None):
+    if arena is not None:
+        return arena.take(shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,), dtype, device)
+    return torch.empty(shape, dtype=dtype, device=device)
+
+
+def _zeros(shape, dtype=torch.float32, device=None):
+    if arena is not None:
+        return t_zero(arena.take(shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,), dtype, device))
+    return torch.zeros(shape, dtype=dtype, device=device)
+
+
+def t_zero(t):
+    """t.zero_() on torch's current stream (recorded as an operation of the step)"""
+    t.zero_()
+    R = _binding.recorder
+    if R is not None:
+        R.add_op(lambda rec, t=t: t.zero_())
     return t
+
+
+def t_copy(dst, src):
+    """dst.copy_(src) on torch's current stream"""
+    dst.copy_(src)
+    R = _binding.recorder
+    if R is not None:
+        R.add_op(lambda rec, dst=dst, src=src: dst.copy_(src))
+    return dst
+
+
+def ev_record(ev, stream):
+    ev.record(stream)
+    R = _binding.recorder
+    if R is not None:
+        s = R.slot(stream)
+        R.add_op(lambda rec, ev=ev, s=s: ev.record(rec.bound[s]))
+
+
+def st_wait_event(stream, ev):
+    stream.wait_event(ev)
+    R = _binding.recorder
+    if R is not None:
+        s = R.slot(stream)
+        R.add_op(lambda rec, ev=ev, s=s: rec.bound[s].wait_event(ev))
+
+
+def st_wait_stream(stream, other):
+    """stream.wait_stream(other)"""
+    R = _binding.recorder
+    if R is None:
+        stream.wait_stream(other)
+        return
+    ev = torch.cuda.Event()                     # (torch's wait_stream makes a fresh event per call; a recording owns one per site)
+    R.keep.append(ev)
+    ev_record(ev, other)
+    st_wait_event(stream, ev)
+
+
+def host_op(fn):
+    """fn(): host code that enqueues work through torch (a collective, a tensor expression): run now and, while a step is being
+    recorded, again at every replay.  fn may take one argument -- None now, the Recording at replay (rec.bound[slot] is the stream
+    bound to a slot that was looked up with recorder.slot(stream) at record time)."""
+    import inspect
+    takes = len(inspect.signature(fn).parameters) > 0
+    out = fn(None) if takes else fn()
+    R = _binding.recorder
+    if R is not None:
+        R.add_op(fn if takes else (lambda rec, fn=fn: fn()))
+    return out
 
 
 def workspace(nbytes, device, tag="default"):
@@ -82,7 +153,7 @@ def generate_anchors_pre(height, width, feat_stride, base_d, out=None):
     A = base_d.shape[0]
     _chk(base_d, torch.float64)
     if out is None:
-        out = torch.empty((height * width * A, 4), dtype=torch.float32, device=base_d.device)
+        out = _empty((height * width * A, 4), dtype=torch.float32, device=base_d.device)
     call("frcnn_generate_anchors_pre", height, width, int(feat_stride), _ptr(base_d), A, _ptr(out), _stream())
     return out
 
@@ -95,8 +166,8 @@ def nms(dets, thresh, max_keep=None, keep=None, num=None, rule=NMS_RULE_CPU):
     k = dets.shape[0]
     max_keep = k if max_keep is None else min(max_keep, k)
     dev = dets.device
-    keep = torch.empty((max(max_keep, 1),), dtype=torch.int32, device=dev) if keep is None else keep
-    num = torch.zeros((1,), dtype=torch.int32, device=dev) if num is None else num
+    keep = _empty((max(max_keep, 1),), dtype=torch.int32, device=dev) if keep is None else keep
+    num = _zeros((1,), dtype=torch.int32, device=dev) if num is None else num
     nb = lib().frcnn_nms_workspace_bytes(max(k, 1))
     ws = workspace(nb, dev, "nms")
     call("frcnn_nms_rule", _ptr(dets), k, float(thresh), int(rule), max_keep, _ptr(keep), _ptr(num), _ptr(ws), ws.numel(), _stream())
@@ -109,8 +180,8 @@ def nms_sorted(boxes, thresh, max_keep=None, rule=NMS_RULE_CPU):
     k, stride = boxes.shape
     max_keep = k if max_keep is None else min(max_keep, k)
     dev = boxes.device
-    keep = torch.empty((max(max_keep, 1),), dtype=torch.int32, device=dev)
-    num = torch.zeros((1,), dtype=torch.int32, device=dev)
+    keep = _empty((max(max_keep, 1),), dtype=torch.int32, device=dev)
+    num = _zeros((1,), dtype=torch.int32, device=dev)
     nb = lib().frcnn_nms_workspace_bytes(max(k, 1))
     ws = workspace(nb, dev, "nms")
     call("frcnn_nms_sorted_rule", _ptr(boxes), k, stride, float(thresh), int(rule), max_keep, _ptr(keep), _ptr(num), _ptr(ws),
@@ -126,8 +197,8 @@ def non_max_suppression(boxes, scores, max_output_size, iou_threshold, selected=
     assert boxes.shape == (k, 4) and scores.numel() == k
     m = min(int(max_output_size), k)
     dev = boxes.device
-    selected = torch.empty((max(m, 1),), dtype=torch.int32, device=dev) if selected is None else selected
-    num = torch.zeros((1,), dtype=torch.int32, device=dev) if num is None else num
+    selected = _empty((max(m, 1),), dtype=torch.int32, device=dev) if selected is None else selected
+    num = _zeros((1,), dtype=torch.int32, device=dev) if num is None else num
     nb = lib().frcnn_nms_workspace_bytes(max(k, 1))
     ws = workspace(nb, dev, "nms")
     call("frcnn_non_max_suppression", _ptr(boxes), _ptr(scores), k, m, float(iou_threshold), _ptr(selected), _ptr(num),
@@ -137,7 +208,7 @@ def non_max_suppression(boxes, scores, max_output_size, iou_threshold, selected=
 
 def bbox_overlaps(boxes, query):
     _chk(boxes, torch.float64), _chk(query, torch.float64)
-    out = torch.empty((boxes.shape[0], query.shape[0]), dtype=torch.float64, device=boxes.device)
+    out = _empty((boxes.shape[0], query.shape[0]), dtype=torch.float64, device=boxes.device)
     call("frcnn_bbox_overlaps", _ptr(boxes), boxes.shape[0], _ptr(query), query.shape[0], _ptr(out), _stream())
     return out
 
@@ -146,7 +217,7 @@ def bbox_transform_inv(boxes, deltas, out=None):
     """lib/model/bbox_transform.py:35-65 on device: boxes [N,4], deltas [N,4k] -> [N,4k]."""
     _chk(boxes), _chk(deltas)
     N, k = boxes.shape[0], deltas.shape[1] // 4
-    out = torch.empty((N, 4 * k), dtype=torch.float32, device=boxes.device) if out is None else out
+    out = _empty((N, 4 * k), dtype=torch.float32, device=boxes.device) if out is None else out
     call("frcnn_bbox_transform_inv", _ptr(boxes), _ptr(deltas), N, k, _ptr(out), _stream())
     return out
 
@@ -161,7 +232,7 @@ def clip_boxes(boxes, im_h, im_w):
 def bbox_transform(ex_rois, gt_rois):
     """lib/model/bbox_transform.py:14-32 on device: [N,4] x [N,4] -> targets [N,4]."""
     _chk(ex_rois), _chk(gt_rois)
-    out = torch.empty((ex_rois.shape[0], 4), dtype=torch.float32, device=ex_rois.device)
+    out = _empty((ex_rois.shape[0], 4), dtype=torch.float32, device=ex_rois.device)
     call("frcnn_bbox_transform", _ptr(ex_rois), _ptr(gt_rois), ex_rois.shape[0], _ptr(out), _stream())
     return out
 
@@ -175,9 +246,9 @@ def proposal_layer(rpn_cls_prob, rpn_bbox_pred, im_h, im_w, feat_stride, base_d,
     B, H, W, A2 = rpn_cls_prob.shape
     A = A2 // 2
     dev = rpn_cls_prob.device
-    rois = torch.empty((B * post_nms_topn, 5), dtype=torch.float32, device=dev) if rois is None else rois
-    scores = torch.empty((B * post_nms_topn, 1), dtype=torch.float32, device=dev) if scores is None else scores
-    num = torch.zeros((B,), dtype=torch.int32, device=dev) if num is None else num
+    rois = _empty((B * post_nms_topn, 5), dtype=torch.float32, device=dev) if rois is None else rois
+    scores = _empty((B * post_nms_topn, 1), dtype=torch.float32, device=dev) if scores is None else scores
+    num = _zeros((B,), dtype=torch.int32, device=dev) if num is None else num
     nb = lib().frcnn_proposal_batched_workspace_bytes(B, H, W, A, int(pre_nms_topn))
     ws = workspace(nb, dev, "proposal")
     call("frcnn_proposal_layer_batched", _ptr(rpn_cls_prob), _ptr(rpn_bbox_pred), B, float(im_h), float(im_w), H, W, A,
@@ -194,9 +265,9 @@ def proposal_layer_tf(rpn_cls_prob, rpn_bbox_pred, im_h, im_w, feat_stride, base
     B, H, W, A2 = rpn_cls_prob.shape
     A = A2 // 2
     dev = rpn_cls_prob.device
-    rois = torch.empty((B * post_nms_topn, 5), dtype=torch.float32, device=dev) if rois is None else rois
-    scores = torch.empty((B * post_nms_topn, 1), dtype=torch.float32, device=dev) if scores is None else scores
-    num = torch.zeros((B,), dtype=torch.int32, device=dev) if num is None else num
+    rois = _empty((B * post_nms_topn, 5), dtype=torch.float32, device=dev) if rois is None else rois
+    scores = _empty((B * post_nms_topn, 1), dtype=torch.float32, device=dev) if scores is None else scores
+    num = _zeros((B,), dtype=torch.int32, device=dev) if num is None else num
     nb = lib().frcnn_proposal_batched_workspace_bytes(B, H, W, A, 0)
     ws = workspace(nb, dev, "proposal")
     call("frcnn_proposal_layer_tf_batched", _ptr(rpn_cls_prob), _ptr(rpn_bbox_pred), B, float(im_h), float(im_w), H, W, A,
@@ -211,8 +282,8 @@ def proposal_top_layer_inds(rpn_cls_prob, rpn_bbox_pred, im_h, im_w, feat_stride
     _, H, W, A2 = rpn_cls_prob.shape
     n = top_inds.numel()
     dev = rpn_cls_prob.device
-    rois = torch.empty((n, 5), dtype=torch.float32, device=dev) if rois is None else rois
-    scores = torch.empty((n, 1), dtype=torch.float32, device=dev) if scores is None else scores
+    rois = _empty((n, 5), dtype=torch.float32, device=dev) if rois is None else rois
+    scores = _empty((n, 1), dtype=torch.float32, device=dev) if scores is None else scores
     call("frcnn_proposal_top_layer_inds", _ptr(rpn_cls_prob), _ptr(rpn_bbox_pred), float(im_h), float(im_w), H, W, A2 // 2,
          int(feat_stride), _ptr(base_d), _ptr(top_inds), n, _ptr(rois), _ptr(scores), _stream())
     return rois, scores
@@ -223,8 +294,8 @@ def proposal_top_layer(rpn_cls_prob, rpn_bbox_pred, im_h, im_w, feat_stride, bas
     _, H, W, A2 = rpn_cls_prob.shape
     A = A2 // 2
     dev = rpn_cls_prob.device
-    rois = torch.empty((rpn_top_n, 5), dtype=torch.float32, device=dev) if rois is None else rois
-    scores = torch.empty((rpn_top_n, 1), dtype=torch.float32, device=dev) if scores is None else scores
+    rois = _empty((rpn_top_n, 5), dtype=torch.float32, device=dev) if rois is None else rois
+    scores = _empty((rpn_top_n, 1), dtype=torch.float32, device=dev) if scores is None else scores
     nb = lib().frcnn_proposal_workspace_bytes(H, W, A, int(rpn_top_n))
     ws = workspace(nb, dev, "proposal")
     call("frcnn_proposal_top_layer", _ptr(rpn_cls_prob), _ptr(rpn_bbox_pred), float(im_h), float(im_w), H, W, A,
@@ -239,7 +310,7 @@ def crop_and_resize(feat, rois, feat_stride, pool, max_pool=False, out=None):
     H, W, C = feat.shape[-3:]
     N = feat.shape[0] if feat.dim() == 4 else 1
     R = rois.shape[0]
-    out = torch.empty((R, pool, pool, C), dtype=torch.float32, device=feat.device) if out is None else out
+    out = _empty((R, pool, pool, C), dtype=torch.float32, device=feat.device) if out is None else out
     call("frcnn_crop_and_resize_batched", _ptr(feat), N, H, W, C, _ptr(rois), R, float(feat_stride), int(pool),
          1 if max_pool else 0, _ptr(out), _stream())
     return out
@@ -251,7 +322,7 @@ def crop_and_resize_bias_act(feat, rois, feat_stride, pool, bias, act, out=None)
     H, W, C = feat.shape[-3:]
     N = feat.shape[0] if feat.dim() == 4 else 1
     R = rois.shape[0]
-    out = torch.empty((R, pool, pool, C), dtype=torch.float32, device=feat.device) if out is None else out
+    out = _empty((R, pool, pool, C), dtype=torch.float32, device=feat.device) if out is None else out
     call("frcnn_crop_and_resize_bias_act", _ptr(feat), N, H, W, C, _ptr(rois), R, float(feat_stride), int(pool), _ptr(bias),
          int(act), _ptr(out), _stream())
     return out
@@ -272,8 +343,8 @@ def detect_post(cls_prob, bbox_pred, rois, num_rois, im_scale, im_h, im_w, nms_t
     dev = cls_prob.device
     max_out = (max_per_image + 28 if max_per_image > 0 else R * (C - 1)) if max_out is None else max_out
     shape = (max_out, 6) if B == 1 else (B, max_out, 6)
-    out = torch.empty(shape, dtype=torch.float32, device=dev) if out is None else out
-    count = torch.zeros((B,), dtype=torch.int32, device=dev) if count is None else count
+    out = _empty(shape, dtype=torch.float32, device=dev) if out is None else out
+    count = _zeros((B,), dtype=torch.int32, device=dev) if count is None else count
     # a batched record may be a strided view (per-image slices contiguous, frcnn_hip.parallel.new_record)
     if out.dtype != torch.float32 or out.shape[-1] != 6 or out.stride(-1) != 1 or out.stride(-2) != 6 or out.shape[-2] < max_out:
         raise ValueError("detect_post: `out` must be float32 [.., >=max_out, 6] with contiguous images")
@@ -294,7 +365,7 @@ def im_detect_boxes(rois, bbox_pred, im_scale, im_h, im_w, num_classes=None):
     else:
         _chk(bbox_pred)
         R, C4 = bbox_pred.shape
-    out = torch.empty((R, C4), dtype=torch.float32, device=rois.device)
+    out = _empty((R, C4), dtype=torch.float32, device=rois.device)
     call("frcnn_im_detect_boxes", _ptr(rois), _ptr(bbox_pred), R, C4 // 4, float(im_scale), int(im_h), int(im_w), _ptr(out),
          _stream())
     return out
@@ -342,7 +413,7 @@ def conv2d(x, w_packed, bias, KH, KW, stride=1, pad=(0, 0, 0, 0), act=ACT_NONE, 
     Cout = w_packed.shape[0]
     OH = conv_out_size(H, KH, stride, pad[0], pad[1])
     OW = conv_out_size(W, KW, stride, pad[2], pad[3])
-    out = torch.empty((N, OH, OW, Cout), dtype=torch.float32, device=x.device) if out is None else out
+    out = _empty((N, OH, OW, Cout), dtype=torch.float32, device=x.device) if out is None else out
     RH = RW = 0
     if residual is not None:
         _chk(residual)
@@ -382,7 +453,7 @@ def prep_image(im_d, pixel_means, im_scale, out_hw, out=None, out_c=4):
     assert im_d.dtype in (torch.uint8, torch.float32)
     h, w = im_d.shape[:2]
     OH, OW = out_hw
-    out = torch.empty((1, OH, OW, out_c), dtype=torch.float32, device=im_d.device) if out is None else out
+    out = _empty((1, OH, OW, out_c), dtype=torch.float32, device=im_d.device) if out is None else out
     assert out.shape == (1, OH, OW, out_c)
     means = (ctypes.c_double * 3)(*[float(v) for v in np.asarray(pixel_means, dtype=np.float64).reshape(-1)[:3]])
     call("frcnn_prep_image", _ptr(im_d), 1 if im_d.dtype == torch.float32 else 0, h, w, means, float(im_scale), _ptr(out), OH, OW,
@@ -414,7 +485,7 @@ def winograd_filter_transform_device(w_packed, m=4, transpose_flip=False, out=No
     assert kh == 3 and kw == 3
     G = winograd_points(m)
     shape = (G, C, O) if transpose_flip else (G, O, C)
-    out = torch.empty(shape, dtype=torch.float32, device=w_packed.device) if out is None else out
+    out = _empty(shape, dtype=torch.float32, device=w_packed.device) if out is None else out
     assert out.numel() == G * O * C
     if m == 7:
         call("frcnn_winograd7_filter_transform_device", _ptr(w_packed), O, C, 1 if transpose_flip else 0, _ptr(out), _stream())
@@ -493,14 +564,14 @@ def conv3x3_winograd(x, u, bias, act=ACT_NONE, out=None, v_buf=None, m_buf=None,
     m = {16: 2, 36: 4, 121: 7}[G]
     T = winograd_tiles(N, H, W, m)
     dev = x.device
-    mm = torch.empty((G, T, Cout), dtype=torch.float32, device=dev) if m_buf is None else m_buf
-    out = torch.empty((N, H, W, Cout), dtype=torch.float32, device=dev) if out is None else out
+    mm = _empty((G, T, Cout), dtype=torch.float32, device=dev) if m_buf is None else m_buf
+    out = _empty((N, H, W, Cout), dtype=torch.float32, device=dev) if out is None else out
     if u_planes is not None:
         v_planes = H2.empty(G * T, Cin, dev) if v_planes is None else v_planes
         winograd_input_transform_h2(x, v_planes, m)
         gemm_h2(v_planes, u_planes, G, T, Cout, Cin, out=mm.view(G * T, Cout))
     else:
-        v = torch.empty((G, T, Cin), dtype=torch.float32, device=dev) if v_buf is None else v_buf
+        v = _empty((G, T, Cin), dtype=torch.float32, device=dev) if v_buf is None else v_buf
         winograd_input_transform(x, v, m)
         gemm_batched_nt(v, u, mm)
     if mask is not None:
@@ -517,7 +588,7 @@ def maxpool(x, k, stride, pad=(0, 0, 0, 0), out=None):
     N, H, W, C = x.shape
     OH = conv_out_size(H, k, stride, pad[0], pad[1])
     OW = conv_out_size(W, k, stride, pad[2], pad[3])
-    out = torch.empty((N, OH, OW, C), dtype=torch.float32, device=x.device) if out is None else out
+    out = _empty((N, OH, OW, C), dtype=torch.float32, device=x.device) if out is None else out
     call("frcnn_maxpool_nhwc", _ptr(x), N, H, W, C, int(k), int(stride), int(pad[0]), int(pad[2]), _ptr(out), OH, OW,
          _stream())
     return out
@@ -531,13 +602,13 @@ def dwconv3x3(x, w, bias, stride=1, pad=(1, 1, 1, 1), act=ACT_NONE, out=None, ou
     OH = conv_out_size(H, 3, stride, pad[0], pad[1])
     OW = conv_out_size(W, 3, stride, pad[2], pad[3])
     if out_planes is None:
-        out = torch.empty((N, OH, OW, C), dtype=torch.float32, device=x.device) if out is None else out
+        out = _empty((N, OH, OW, C), dtype=torch.float32, device=x.device) if out is None else out
         call("frcnn_dwconv3x3_nhwc", _ptr(x), N, H, W, C, _ptr(w), _ptr(bias), _ptr(out), OH, OW, int(stride),
              int(pad[0]), int(pad[2]), int(act), _stream())
         return out
     assert isinstance(out_planes, H2) and out_planes.rows == N * OH * OW and out_planes.K == C
     if want_f32 and out is None:
-        out = torch.empty((N, OH, OW, C), dtype=torch.float32, device=x.device)
+        out = _empty((N, OH, OW, C), dtype=torch.float32, device=x.device)
     call("frcnn_dwconv3x3_nhwc_h2", _ptr(x), N, H, W, C, _ptr(w), _ptr(bias), _ptr(out if want_f32 else None), _ptr(out_planes.planes),
          _ptr(out_planes.inv), OH, OW, int(stride), int(pad[0]), int(pad[2]), int(act), _stream())
     return out if want_f32 else None
@@ -547,7 +618,7 @@ def spatial_mean(x, out=None):
     _chk(x)
     N, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (N * C)
-    out = torch.empty((N, C), dtype=torch.float32, device=x.device) if out is None else out
+    out = _empty((N, C), dtype=torch.float32, device=x.device) if out is None else out
     call("frcnn_spatial_mean", _ptr(x), N, HW, C, _ptr(out), _stream())
     return out
 
@@ -556,7 +627,7 @@ def softmax_rows(x, C=None, out=None):
     _chk(x)
     R, ld = x.shape
     C = ld if C is None else C
-    out = torch.empty((R, C), dtype=torch.float32, device=x.device) if out is None else out
+    out = _empty((R, C), dtype=torch.float32, device=x.device) if out is None else out
     call("frcnn_softmax_rows", _ptr(x), R, C, ld, _ptr(out), _stream())
     return out
 
@@ -565,7 +636,7 @@ def rpn_softmax(score, A, out=None):
     """score [1,H,W,ld] (first 2A channels = bg|fg scores) -> prob [1,H,W,2A]."""
     _chk(score)
     N, H, W, ld = score.shape
-    out = torch.empty((N, H, W, 2 * A), dtype=torch.float32, device=score.device) if out is None else out
+    out = _empty((N, H, W, 2 * A), dtype=torch.float32, device=score.device) if out is None else out
     call("frcnn_rpn_softmax", _ptr(score), N * H * W, A, ld, _ptr(out), _stream())
     return out
 
@@ -574,7 +645,7 @@ def copy_cols(src, col0, cols, out=None):
     _chk(src)
     ld = src.shape[-1]
     R = src.numel() // ld
-    out = torch.empty(tuple(src.shape[:-1]) + (cols,), dtype=torch.float32, device=src.device) if out is None else out
+    out = _empty(tuple(src.shape[:-1]) + (cols,), dtype=torch.float32, device=src.device) if out is None else out
     call("frcnn_copy_cols", _ptr(src), R, ld, int(col0), int(cols), _ptr(out), cols, _stream())
     return out
 
@@ -582,6 +653,8 @@ def copy_cols(src, col0, cols, out=None):
 # ------------------------------------------------------------------------------------------ training
 def _host_doubles(values):
     a = np.ascontiguousarray(values, dtype=np.float64)
+    if _binding.recorder is not None:
+        _binding.recorder.keep.append(a)         # (a recorded launch keeps the pointer)
     return a, a.ctypes.data_as(ctypes.c_void_p)
 
 
@@ -601,13 +674,19 @@ def anchor_target_layer(gt_boxes, im_h, im_w, H, W, base_d, feat_stride=16, rpn_
     opts: rpn_target_opts(...) or None (reference defaults)."""
     _chk(gt_boxes), _chk(base_d, torch.float64)
     A, G, dev = base_d.shape[0], gt_boxes.shape[0], gt_boxes.device
-    labels = torch.empty((1, 1, A * H, W), dtype=torch.float32, device=dev)
-    tg, iw, ow = (torch.empty((1, H, W, 4 * A), dtype=torch.float32, device=dev) for _ in range(3))
-    ws = workspace(lib().frcnn_anchor_target_workspace_bytes(H, W, A, G), dev, "anchor_target")
+    labels = _empty((1, 1, A * H, W), dtype=torch.float32, device=dev)
+    tg, iw, ow = (_empty((1, H, W, 4 * A), dtype=torch.float32, device=dev) for _ in range(3))
+    # (sized for every box count the tensor's storage can hold: a recorded step is replayed with the next image's G)
+    Gcap = max(G, (gt_boxes.untyped_storage().nbytes() - 4 * gt_boxes.storage_offset()) // 20)
+    ws = workspace(lib().frcnn_anchor_target_workspace_bytes(H, W, A, Gcap), dev, "anchor_target")
     o = _host_doubles(opts) if opts is not None else (None, None)
     call("frcnn_anchor_target_layer", _ptr(gt_boxes), G, float(im_h), float(im_w), H, W, A, int(feat_stride), _ptr(base_d),
          int(rpn_batchsize), float(fg_fraction), float(pos_overlap), float(neg_overlap), int(seed), o[1], _ptr(labels), _ptr(tg),
          _ptr(iw), _ptr(ow), _ptr(ws), ws.numel(), _stream())
+    if _binding.recorder is not None:
+        _binding.recorder.patch_last(1, var="gt")    # the image's box count (gt_boxes: the first G rows of a static buffer)
+        if int(seed) >= 0:
+            _binding.recorder.patch_last(13)         # the sampling seed advances with the step (Network._sample_seed)
     return labels, tg, iw, ow
 
 
@@ -617,8 +696,8 @@ def anchor_target_layer_inject(gt_boxes, im_h, im_w, H, W, base_d, disable, feat
     empty): see frcnn_anchor_target_layer_inject."""
     _chk(gt_boxes), _chk(base_d, torch.float64), _chk(disable, torch.int32)
     A, G, dev = base_d.shape[0], gt_boxes.shape[0], gt_boxes.device
-    labels = torch.empty((1, 1, A * H, W), dtype=torch.float32, device=dev)
-    tg, iw, ow = (torch.empty((1, H, W, 4 * A), dtype=torch.float32, device=dev) for _ in range(3))
+    labels = _empty((1, 1, A * H, W), dtype=torch.float32, device=dev)
+    tg, iw, ow = (_empty((1, H, W, 4 * A), dtype=torch.float32, device=dev) for _ in range(3))
     ws = workspace(lib().frcnn_anchor_target_workspace_bytes(H, W, A, G), dev, "anchor_target")
     o = _host_doubles(opts) if opts is not None else (None, None)
     call("frcnn_anchor_target_layer_inject", _ptr(gt_boxes), G, float(im_h), float(im_w), H, W, A, int(feat_stride), _ptr(base_d),
@@ -633,10 +712,10 @@ def proposal_target_layer_inject(rpn_rois, rpn_scores, gt_boxes, num_classes, ke
     opts: roi_target_opts(...) or None."""
     _chk(rpn_rois), _chk(rpn_scores), _chk(gt_boxes), _chk(keep_inds, torch.int32)
     dev, N, G, B, C = rpn_rois.device, rpn_rois.shape[0], gt_boxes.shape[0], keep_inds.numel(), int(num_classes)
-    rois = torch.empty((B, 5), dtype=torch.float32, device=dev)
-    sc = torch.empty((B,), dtype=torch.float32, device=dev)
-    labels = torch.empty((B, 1), dtype=torch.float32, device=dev)
-    tg, iw, ow = (torch.empty((B, 4 * C), dtype=torch.float32, device=dev) for _ in range(3))
+    rois = _empty((B, 5), dtype=torch.float32, device=dev)
+    sc = _empty((B,), dtype=torch.float32, device=dev)
+    labels = _empty((B, 1), dtype=torch.float32, device=dev)
+    tg, iw, ow = (_empty((B, 4 * C), dtype=torch.float32, device=dev) for _ in range(3))
     m, s, o = _host_doubles(means), _host_doubles(stds), (_host_doubles(opts) if opts is not None else (None, None))
     call("frcnn_proposal_target_layer_inject", _ptr(rpn_rois), _ptr(rpn_scores), N, _ptr(gt_boxes), G, C, B, _ptr(keep_inds), int(n_fg),
          m[1], s[1], o[1], _ptr(rois), _ptr(sc), _ptr(labels), _ptr(tg), _ptr(iw), _ptr(ow), _stream())
@@ -649,20 +728,26 @@ def proposal_target_layer(rpn_rois, rpn_scores, gt_boxes, num_classes, batch_siz
     (the proposal layer's count); without it every row is a proposal.  opts: roi_target_opts(...) or None."""
     _chk(rpn_rois), _chk(rpn_scores), _chk(gt_boxes)
     dev, N, G, B, C = rpn_rois.device, rpn_rois.shape[0], gt_boxes.shape[0], int(batch_size), int(num_classes)
-    rois = torch.empty((B, 5), dtype=torch.float32, device=dev)
-    sc = torch.empty((B,), dtype=torch.float32, device=dev)
-    labels = torch.empty((B, 1), dtype=torch.float32, device=dev)
-    tg, iw, ow = (torch.empty((B, 4 * C), dtype=torch.float32, device=dev) for _ in range(3))
-    counts = torch.zeros((4,), dtype=torch.int32, device=dev)
+    rois = _empty((B, 5), dtype=torch.float32, device=dev)
+    sc = _empty((B,), dtype=torch.float32, device=dev)
+    labels = _empty((B, 1), dtype=torch.float32, device=dev)
+    tg, iw, ow = (_empty((B, 4 * C), dtype=torch.float32, device=dev) for _ in range(3))
+    counts = _zeros((4,), dtype=torch.int32, device=dev)
     m, s, o = _host_doubles(means), _host_doubles(stds), (_host_doubles(opts) if opts is not None else (None, None))
     if num is not None:
         call("frcnn_proposal_target_layer_dn", _ptr(rpn_rois), _ptr(rpn_scores), N, _ptr(num), _ptr(gt_boxes), G, C, B,
              float(fg_fraction), float(fg_thresh), float(bg_hi), float(bg_lo), m[1], s[1], int(seed), o[1], _ptr(rois), _ptr(sc),
              _ptr(labels), _ptr(tg), _ptr(iw), _ptr(ow), _ptr(counts), _stream())
+        if _binding.recorder is not None:
+            _binding.recorder.patch_last(5, var="gt")
+            _binding.recorder.patch_last(14)
         return rois, sc, labels, tg, iw, ow, counts
     call("frcnn_proposal_target_layer", _ptr(rpn_rois), _ptr(rpn_scores), N, _ptr(gt_boxes), G, C, B, float(fg_fraction),
          float(fg_thresh), float(bg_hi), float(bg_lo), m[1], s[1], int(seed), o[1], _ptr(rois), _ptr(sc), _ptr(labels), _ptr(tg),
          _ptr(iw), _ptr(ow), _ptr(counts), _stream())
+    if _binding.recorder is not None:
+        _binding.recorder.patch_last(4, var="gt")
+        _binding.recorder.patch_last(13)
     return rois, sc, labels, tg, iw, ow, counts
 
 
@@ -675,8 +760,8 @@ def softmax_ce_loss(logits, labels, rpn_shape=None):
     else:
         A, H, W = rpn_shape
         R, C = A * H * W, 2
-    loss = torch.zeros((1,), dtype=torch.float32, device=dev)
-    grad = torch.zeros_like(logits)
+    loss = _zeros((1,), dtype=torch.float32, device=dev)
+    grad = _zeros(tuple(logits.shape), dtype=logits.dtype, device=logits.device)
     ws = workspace(lib().frcnn_loss_workspace_bytes(R), dev, "loss")
     call("frcnn_softmax_ce_loss", _ptr(logits), _ptr(labels), R, C, A, H, W, _ptr(loss), _ptr(grad), _ptr(ws), ws.numel(), _stream())
     return loss, grad
@@ -685,8 +770,8 @@ def softmax_ce_loss(logits, labels, rpn_shape=None):
 def smooth_l1_loss(pred, targets, inside_w, outside_w, sigma, mean_divisor):
     _chk(pred), _chk(targets), _chk(inside_w), _chk(outside_w)
     dev, n = pred.device, pred.numel()
-    loss = torch.zeros((1,), dtype=torch.float32, device=dev)
-    grad = torch.empty_like(pred)
+    loss = _zeros((1,), dtype=torch.float32, device=dev)
+    grad = _empty(tuple(pred.shape), dtype=pred.dtype, device=pred.device)
     ws = workspace(lib().frcnn_loss_workspace_bytes(n), dev, "loss")
     call("frcnn_smooth_l1_loss", _ptr(pred), _ptr(targets), _ptr(inside_w), _ptr(outside_w), n, float(sigma), float(mean_divisor),
          _ptr(loss), _ptr(grad), _ptr(ws), ws.numel(), _stream())
@@ -698,7 +783,7 @@ def transpose_pad(x2d, Mp, out=None):
     """x2d [M,C] -> [C,Mp] (zero padded)."""
     _chk(x2d)
     M, C = x2d.shape
-    out = torch.empty((C, Mp), dtype=torch.float32, device=x2d.device) if out is None else out
+    out = _empty((C, Mp), dtype=torch.float32, device=x2d.device) if out is None else out
     call("frcnn_transpose_pad", _ptr(x2d), M, C, _ptr(out), int(Mp), _stream())
     return out
 
@@ -706,7 +791,7 @@ def transpose_pad(x2d, Mp, out=None):
 def im2col_t(x, KH, KW, stride, pad, OH, OW, Mp, out=None):
     _chk(x)
     N, H, W, Cin = x.shape
-    out = torch.empty((KH * KW * Cin, Mp), dtype=torch.float32, device=x.device) if out is None else out
+    out = _empty((KH * KW * Cin, Mp), dtype=torch.float32, device=x.device) if out is None else out
     call("frcnn_im2col_t", _ptr(x), N, H, W, Cin, OH, OW, KH, KW, int(stride), int(pad[0]), int(pad[2]), _ptr(out), int(Mp), _stream())
     return out
 
@@ -714,7 +799,7 @@ def im2col_t(x, KH, KW, stride, pad, OH, OW, Mp, out=None):
 def flip_transpose_filter(w_packed, out=None):
     _chk(w_packed)
     Cout, KH, KW, Cin = w_packed.shape
-    out = torch.empty((Cin, KH, KW, Cout), dtype=torch.float32, device=w_packed.device) if out is None else out
+    out = _empty((Cin, KH, KW, Cout), dtype=torch.float32, device=w_packed.device) if out is None else out
     call("frcnn_flip_transpose_filter", _ptr(w_packed), Cout, KH, KW, Cin, _ptr(out), _stream())
     return out
 
@@ -769,7 +854,7 @@ def gemm_x3(x, planes, G, M, N, K, bias=None, residual=None, act=ACT_NONE, out=N
     """out[g] = act(x[g] W[g]^T + bias + residual[g]) through frcnn_gemm_x3 (products on the bf16 pipe as exact 3-way splits).
     cfg: -1 = tiles by shape; terms: 6 (default) or 9 (all cross terms: every f32 product exact)."""
     _chk(x)
-    out = torch.empty((G, M, N) if G > 1 else (M, N), dtype=torch.float32, device=x.device) if out is None else out
+    out = _empty((G, M, N) if G > 1 else (M, N), dtype=torch.float32, device=x.device) if out is None else out
     call("frcnn_gemm_x3", _ptr(x), _ptr(planes), _ptr(bias), _ptr(residual), _ptr(out), int(G), int(M), int(N), int(K), int(act),
          int(cfg), int(terms), _stream())
     return out
@@ -826,7 +911,7 @@ def gemm_h2(x, wp, G, M, N, K, bias=None, residual=None, act=ACT_NONE, out=None,
     Returns (out or None, out_planes or None)."""
     assert isinstance(x, H2) and x.rows == G * M and x.K == K
     if out is None and want_f32:
-        out = torch.empty((G * M, N), dtype=torch.float32, device=x.planes.device)
+        out = _empty((G * M, N), dtype=torch.float32, device=x.planes.device)
     if out_planes is not None:
         assert out_planes.rows == G * M and out_planes.K == N
     rp = residual if isinstance(residual, H2) else None
@@ -851,7 +936,7 @@ def gemm_h2_mean(x, wp, G, M, N, K, bias, residual, act, rows, out=None, cfg=-1)
     batch entry per image (the reduction order is then independent of the batch slot).  residual: f32 [G*M, N], an H2, or None."""
     assert isinstance(x, H2) and x.rows == G * M and x.K == K and M % rows == 0
     if out is None:
-        out = torch.empty((G * (M // rows), N), dtype=torch.float32, device=x.planes.device)
+        out = _empty((G * (M // rows), N), dtype=torch.float32, device=x.planes.device)
     rp = residual if isinstance(residual, H2) else None
     ws = workspace(lib().frcnn_gemm_h2_mean_workspace_bytes(int(G), int(M), int(N)), x.planes.device, "h2_mean")
     call("frcnn_gemm_h2_mean", _ptr(x.planes), _ptr(x.inv), _ptr(wp[0]), _ptr(wp[1]), _ptr(bias), _ptr(None if rp is not None else residual),
@@ -905,11 +990,14 @@ def maxpool_bwd(x, y, dy, k, stride, dx):
     return dx
 
 
-def dropout(x, seed, keep_prob, out=None):
-    """tf.nn.dropout with a counter-based mask of (seed, element index); the same call on a gradient is the backward pass."""
+def dropout(x, seed, keep_prob, out=None, step_mult=0):
+    """tf.nn.dropout with a counter-based mask of (seed, element index); the same call on a gradient is the backward pass.
+    step_mult: seed = step_mult * (the step's sampling seed) + const -- tells a recorded training step how to advance it."""
     _chk(x)
-    out = torch.empty_like(x) if out is None else out
+    out = _empty(tuple(x.shape), dtype=x.dtype, device=x.device) if out is None else out
     call("frcnn_dropout", _ptr(x), x.numel(), int(seed) & 0xFFFFFFFFFFFFFFFF, float(keep_prob), _ptr(out), _stream())
+    if _binding.recorder is not None and step_mult:
+        _binding.recorder.patch_last(2, step_mult)
     return out
 
 

@@ -124,17 +124,28 @@ class BucketedAllReduce(object):
         self.handles = []
 
     def _send(self, flat, lo, hi, stream=None):
+        """One asynchronous all-reduce over flat[lo:hi].  A step that is being recorded (frcnn_hip/replay.py) keeps the call as a host
+        operation of the step: a replayed step issues the same collectives at the same points of its launch list."""
         import time
         import torch.distributed as dist
-        if hi > lo:
+        from . import ops
+        import frcnn_hip as _binding
+        if hi <= lo:
+            return
+        R = _binding.recorder
+        slot = None if (stream is None or R is None) else R.slot(stream)
+
+        def send(rec):
             t0 = time.perf_counter()
             self.sends += 1
-            if stream is None:
+            st = stream if (rec is None or slot is None) else rec.bound[slot]
+            if st is None:
                 self.handles.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             else:                      # the collective orders itself after torch's CURRENT stream: make `stream` current for this call only
-                with torch.cuda.stream(stream):
+                with torch.cuda.stream(st):
                     self.handles.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
             self.host_s += time.perf_counter() - t0
+        ops.host_op(send)
 
     def ready(self, flat, data_ptr, stream=None):
         """stream: the stream the gradient kernels up to this parameter were enqueued on (the reverse sweep's filter-gradient side
@@ -163,13 +174,17 @@ class BucketedAllReduce(object):
             lo = max(0, hi - step)
             self._send(flat, lo, hi)
             hi = lo
+        from . import ops
+        ops.host_op(self._wait_all)
+        return flat
+
+    def _wait_all(self):
         import time
         t0 = time.perf_counter()
         for h in self.handles:
             h.wait()
         self.host_s += time.perf_counter() - t0
         self.reset()
-        return flat
 
     def __call__(self, flat):                            # plain callable form (no overlap)
         return self.finish(flat)

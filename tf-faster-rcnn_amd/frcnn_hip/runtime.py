@@ -146,7 +146,7 @@ class PreparedFilters(object):
 
     def _wait(self, tier):
         if not self.waited[tier]:               # tiers complete in order on one stream: waiting for one covers the earlier ones
-            torch.cuda.current_stream(self.device).wait_event(self.events[tier])
+            ops.st_wait_event(torch.cuda.current_stream(self.device), self.events[tier])
             for t in range(tier + 1):
                 self.waited[t] = True
 
@@ -184,19 +184,19 @@ class PreparedFilters(object):
         main = torch.cuda.current_stream(self.device)
         if self.stream is None:
             self.stream, self.events = torch.cuda.Stream(device=self.device), [torch.cuda.Event() for _ in range(3)]
-        self.stream.wait_stream(main)           # the update itself, and the last step's reads of these buffers
+        ops.st_wait_stream(self.stream, main)   # the update itself, and the last step's reads of these buffers
         with ops.pinned_stream(self.stream):
             if pre is not None:
                 pre()
-            self.events[0].record(self.stream)
+            ops.ev_record(self.events[0], self.stream)
             for key, (fn, _) in self.plan.items():
                 if key[0] == "fwd":
                     fn()
-            self.events[1].record(self.stream)
+            ops.ev_record(self.events[1], self.stream)
             for key, (fn, _) in self.plan.items():
                 if key[0] != "fwd":
                     fn()
-        self.events[2].record(self.stream)
+        ops.ev_record(self.events[2], self.stream)
         self.ready, self.ready_version, self.waited = frozenset(self.plan), self.version, [False, False, False]
 
     def invalidate(self):

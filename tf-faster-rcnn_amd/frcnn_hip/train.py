@@ -124,13 +124,29 @@ class TrainState(object):
         if led is not None:
             led[pipe] = led.get(pipe, 0) + int(flops)
 
-    def backward(self, seeds):
-        """seeds: list of (tensor, grad) for network outputs.  Fills every Param.grad_*."""
+    def backward(self, seeds, fuse_solver=False):
+        """seeds: list of (tensor, grad) for network outputs.  Fills every Param.grad_*.
+
+        fuse_solver = True (what Network.train_step_async passes, and nobody else should): the sweep ALSO runs the solver for the tail of
+        the parameter table on its own stream as the filter gradients finish (frcnn_sgd_momentum_range with TrainState.lr) -- weights and
+        momentum of those parameters are updated when this returns, and the caller MUST complete the step with apply(self.lr, ...), which
+        updates the rest.  With the default, backward() only computes gradients: calling it twice, inspecting gradients, accumulating
+        them or skipping a step leaves the parameters alone."""
+        if getattr(self, "_sgd_done_from", None) is not None:
+            raise RuntimeError("TrainState.backward: the previous sweep updated part of the parameters inside the sweep (fuse_solver=True) "
+                               "and apply() never completed that step")
         main = torch.cuda.current_stream()
         with ops.pinned_stream(main):                 # ~1000 launches: one stream lookup instead of one per launch
-            return self._sweep(seeds, main)
+            return self._sweep(seeds, main, bool(fuse_solver))
 
-    def _sweep(self, seeds, main):
+    def replay_signature(self):
+        """Everything about this solver handle that decides WHICH launches a step makes (a recorded step is valid for one signature)."""
+        ar = getattr(self, "all_reduce", None)
+        return (float(self.momentum), float(self.weight_decay), bool(self.double_bias), bool(self.bias_decay), bool(self.fuse_chain),
+                bool(self.pipe_dgrads), bool(self.prep_stream), bool(getattr(self, "solver_in_sweep", True)), int(getattr(self, "world_size", 1)),
+                bool(getattr(self, "force_dp", False)), None if ar is None else id(ar), len(self.params))
+
+    def _sweep(self, seeds, main, fuse_solver=False):
         sess, net = self.sess, self.net
         grads = {}
         for t, g in seeds:
@@ -160,10 +176,10 @@ class TrainState(object):
         # regulariser value reads the filters BEFORE any update: it opens the solver stream's step.
         self._sgd_done_from = None
         solver = None
-        if (sides and not self.data_parallel() and getattr(self, "_sgd_table", None) is not None and getattr(self, "lr", None) is not None
+        if (fuse_solver and sides and not self.data_parallel() and getattr(self, "_sgd_table", None) is not None and getattr(self, "lr", None) is not None
                 and getattr(self, "solver_in_sweep", True) and not any(getattr(p, "dw", False) for p in self.params.values())):
             solver = self._solver_stream_obj()
-            solver.wait_stream(main)                             # (the previous step's apply() -- nothing else of this step matters to it)
+            ops.st_wait_stream(solver, main)                     # (the previous step's apply() -- nothing else of this step matters to it)
             with ops.pinned_stream(solver):
                 self.regularization_loss(self._reg_total())
             self._reg_in_sweep = True
@@ -172,10 +188,12 @@ class TrainState(object):
 
         def solver_step(first):
             """update table[first, done_from) on the solver stream"""
+            while len(self._solver_events) < 1 + len(sides):     # (cfg.HIP.WGRAD_STREAM is not bounded)
+                self._solver_events.append(torch.cuda.Event())
             for i, st in enumerate([main] + list(sides)):
                 ev = self._solver_events[i]
-                ev.record(st)
-                solver.wait_event(ev)
+                ops.ev_record(ev, st)
+                ops.st_wait_event(solver, ev)
             with ops.pinned_stream(solver):
                 ops.sgd_momentum_range(self._sgd_table, first, self._sgd_done_from - first, self.lr, self.momentum, 1.0)
             self._sgd_done_from = first
@@ -188,8 +206,8 @@ class TrainState(object):
             ev = events[turn[0] % len(events)]                   # a small ring: a wait captures the record that precedes it
             turn[0] += 1
             side = sides[i]
-            ev.record(main)
-            side.wait_event(ev)
+            ops.ev_record(ev, main)
+            ops.st_wait_event(side, ev)
             scope, ops.ws_scope = ops.ws_scope, ops.ws_scope + "/wgrad%d" % i
             try:
                 with pins[i]:                                    # this module's launches go to `side` without a torch stream switch; a
@@ -233,7 +251,7 @@ class TrainState(object):
                 emitted.pop(key, None)                       # (planes emitted with the first contribution would be stale)
                 if key in borrowed:                          # an in-place accumulation is about to write it: take a private copy
                     g = sess.buf("grad/" + name + "/own", shape)
-                    g.copy_(grads[key].view(shape))
+                    ops.t_copy(g, grads[key].view(shape))
                     grads[key] = g
                     borrowed.discard(key)
                 masked.discard(key)                          # (callers that mask the whole sum add it again)
@@ -270,7 +288,7 @@ class TrainState(object):
                 feat = rec["feat"]
                 gx, had = accumulate_into(feat, feat.shape, "feat")
                 if not had:
-                    gx.zero_()
+                    ops.t_zero(gx)
                 ops.crop_and_resize_bwd(gy.view(rec["y"].shape), rec["rois"], rec["stride"], gx)
                 continue
             if kind == "maxpool":
@@ -289,7 +307,7 @@ class TrainState(object):
                     continue
                 gx, had = accumulate_into(x, x.shape, rec["name"] + "/in")
                 assert not had
-                ops.dropout(gy.view(x.shape), rec["seed"], rec["keep"], out=gx)      # same mask, same 1 / keep_prob
+                ops.dropout(gy.view(x.shape), rec["seed"], rec["keep"], out=gx, step_mult=256)      # same mask, same 1 / keep_prob
                 continue
             if kind == "dwconv":
                 y, x, sc = rec["y"], rec["x"], rec["scope"]
@@ -318,7 +336,7 @@ class TrainState(object):
             gy = gy.view(y.shape)
             if rec["act"] != ACT_NONE and y.data_ptr() in borrowed:      # the activation gradient is applied in place
                 gy = sess.buf("grad/" + sc + "/own", y.shape)
-                gy.copy_(grads[y.data_ptr()].view(y.shape))
+                ops.t_copy(gy, grads[y.data_ptr()].view(y.shape))
                 grads[y.data_ptr()] = gy
                 borrowed.discard(y.data_ptr())
             if rec["act"] == ACT_RELU:
@@ -335,10 +353,10 @@ class TrainState(object):
                 else:
                     gr, had = accumulate_into(res, res.shape, sc + "/res")
                     if rec["res_stride"] == 1 and not had:
-                        gr.copy_(gy)
+                        ops.t_copy(gr, gy)
                     else:
                         if not had:
-                            gr.zero_()
+                            ops.t_zero(gr)
                         ops.add_strided(gy, gr, rec["res_stride"], True)
             k, stride, pad = rec["k"], rec["stride"], rec["pad"]
             N, OH, OW, Cout = y.shape
@@ -453,7 +471,7 @@ class TrainState(object):
                     wdp = prepared(("wflip_pad", sc), lambda wf=wf, sc=sc, Cin=Cin, Cout=Cout, Cp=Cp: ops.transpose_pad(
                         wf.view(Cout, Cin), Cp, out=sess.buf("bwd/wflip_pad/" + sc, (Cin, Cp))))
                     gyp = sess.buf("bwd/gypad/" + sc, (N, OH, OW, Cp), zero=True)      # columns >= Cout stay zero
-                    gyp[..., :Cout].copy_(gy)
+                    ops.t_copy(gyp[..., :Cout], gy)
                     ops.conv2d(gyp, wdp.view(Cin, 1, 1, Cp), None, 1, 1, 1, (0, 0, 0, 0), ACT_NONE, gres if had else None, 1, out=gx, mask=mk)
                     self.count_flops("f32", 2 * M * Cin * Cp)
                     if mk is not None:
@@ -481,9 +499,9 @@ class TrainState(object):
                 if pending[0] >= self.SOLVER_CHUNK and first is not None and first < self._sgd_done_from:
                     solver_step(first)                           # this record's data gradient is enqueued: its filter has no reader left
         for side in sides:
-            main.wait_stream(side)               # the solver (and the next forward pass, which overwrites x) come after every wgrad
+            ops.st_wait_stream(main, side)       # the solver (and the next forward pass, which overwrites x) come after every wgrad
         if solver is not None:
-            main.wait_stream(solver)
+            ops.st_wait_stream(main, solver)
         return grads
 
     SOLVER_CHUNK = 32
@@ -552,13 +570,19 @@ class TrainState(object):
         self._sgd_done_from = None
         if left > 0:
             ops.sgd_momentum_range(self._sgd_table, 0, left, lr, self.momentum, gs)
+        self.refresh_derived()
+
+    def refresh_derived(self):
+        """Everything computed FROM the trainable filters, after they changed (the solver's update; a caller that wrote Param.w / .wf
+        itself): folded depthwise copies, then the derived filter images -- the operand planes of the forward pass's frcnn_gemm_h2
+        launches and what a TEST-mode network on the same session reads: Winograd U of the 3x3 filters first (also with x3 / h2 off: a
+        no-op when no ('wino', ...) entry is cached), then the pre-split planes of everything (x3 / h2) -- and the prepared gradient
+        filters.  Weight-only launches: with cfg.HIP.PREP_STREAM they run on the side stream, beside the next forward pass
+        (Session.h2_planes & co. wait for them at their first use: PreparedFilters.wait_planes)."""
         for p in self.params.values():
             if getattr(p, "dw", False):
                 ops.dwconv3x3_refold(p.w, p.scale, p.wf)
-        # Derived filter images -- the operand planes of the forward pass's frcnn_gemm_h2 launches, and what a TEST-mode network on the same
-        # session reads: Winograd U of the 3x3 filters first (also with x3 / h2 off: a no-op when no ('wino', ...) entry is cached), then the
-        # pre-split planes of everything (x3 / h2).  Weight-only launches: with cfg.HIP.PREP_STREAM they run on the side stream, beside the
-        # next forward pass (Session.h2_planes & co. wait for them at their first use: PreparedFilters.wait_planes).
+
         def derived():
             self.sess.wino_refresh()
             if self.sess.x3:

@@ -91,8 +91,10 @@ __C = AttrDict(
     # H2_TRUNK_PLANES: inside a run of h2 bottleneck units with identity shortcuts the unit output (the residual trunk) is kept as operand
     # planes ONLY -- the next unit's conv1 reads them as its input and its conv3 reads them as the residual ((h + l) * 2^-e, >= 22
     # significant bits: the stored trunk rounds at 2^-23 relative instead of 2^-24); the float32 tensor is written only where a
-    # non-GEMM consumer follows (block ends, RPN / crop, the spatial mean).  Saves a third of conv3's HBM traffic; measured +0.6 %
-    # images/s (profiles/r03_h_ab.txt), so it is OFF by default: the trunk stays exact float32.
+    # non-GEMM consumer follows (block ends, RPN / crop, the spatial mean).  Saves a third of conv3's HBM traffic.  Rounds 3 / 4 measured
+    # +0.6 % / -0.2 % images/s (the epilogue was bound by its serial tile boundary, not by bytes) and kept it off; with round 5's light tile
+    # boundary the bytes show: +3.0 % (515.1 / 516.4 -> 533.0 / 529.7 images/s, interleaved on one box, profiles/r05_f_ab_trunk_planes.txt),
+    # every config of the full-size harness inside the float32 control's own loss (policy `shipped`; `shipped_f32trunk` is the old form): ON.
     # H2_TRAIN: TRAIN mode too -- the pointwise convolutions of the forward pass and their data gradients (>= H2_MIN_TILES tiles, i.e. the
     # RoI tail) run in frcnn_gemm_h2; filters are re-split after every solver step, float32 activations are kept for the tape.
     # WGRAD_STREAM: the reverse sweep enqueues the filter gradients (operand transposes, split-K GEMM, bias column sum) round-robin on this
@@ -107,12 +109,16 @@ __C = AttrDict(
     # Round-3 switches that measured no gain were removed in round 4 (OVERLAP_TAIL_ENTRY, TRAIN_GRAPH, H2_TRAIN_WINO, X3_TERMS = 9): the
     # code is kept as scratch/r04_pruned_switches.patch (git apply -R restores it), the measurements in profiles/r02_c_sweep.txt,
     # r03_ab_c5_streams_graph.txt, r02_r_x3_9terms.txt.
+    # TRAIN_REPLAY: the training step as ONE recorded launch list (frcnn_hip/replay.py; the reference's step is one sess.run of a graph
+    # built once, network.py:488-498): the second step of an image shape is recorded while it runs eagerly, later steps of that shape
+    # replay the list (same launches, arguments, streams, order -> same bits) without the Python a step costs the host (~14 ms for ~1 300
+    # launches).  False: every step is enqueued by the Python code (the form rounds 1-4 measured).
     # H2_TILE_CFG: -1 = tile shape by launch size (csrc/gemm_h2.hip), else a frcnn_gemm_h2 configuration id for every launch (A/B runs).
     HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=64, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=("block1", "block2"), WINOGRAD_DIRECT_SCOPES=(),
              WINOGRAD_TRAIN=True,
              WINOGRAD_7X7=True, FUSE_TAIL_MEAN=True, MFMA_X3=True,
-             MFMA_H2=True, H2_LAZY_SPLIT=True, H2_MIN_TILES=150, H2_TRUNK_PLANES=False, H2_TILE_CFG=-1,
-             X3_TILE_CFG=-1, H2_TRAIN=True, WGRAD_STREAM=2, WGRAD_TN=True, WGRAD_H2=True, PREP_STREAM=True))
+             MFMA_H2=True, H2_LAZY_SPLIT=True, H2_MIN_TILES=150, H2_TRUNK_PLANES=True, H2_TILE_CFG=-1,
+             X3_TILE_CFG=-1, H2_TRAIN=True, WGRAD_STREAM=2, WGRAD_TN=True, WGRAD_H2=True, PREP_STREAM=True, TRAIN_REPLAY=True))
 __C.DATA_DIR = osp.abspath(osp.join(__C.ROOT_DIR, 'data'))
 cfg = __C
 

@@ -142,6 +142,7 @@ class SolverWrapper(object):
                 print('speed: {:.3f}s / iter'.format((time.time() - t0) / (it - start_iter)))
             if snapshot_dir is not None and self.write_snapshots and it % cfg.TRAIN.SNAPSHOT_ITERS == 0:
                 self.snapshot(it, snapshot_dir)
+        self.enqueue_s = time.time() - t0          # the host's share: every step enqueued, the GPU not yet waited for (the read-back below waits)
         if history:
             import torch
             history = [float(v) for v in torch.stack(history)[:, 4].cpu().tolist()]

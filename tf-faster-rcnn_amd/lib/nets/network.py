@@ -43,6 +43,7 @@ class Network(object):
         self._requires_grad = set()
         self._gt_boxes = None
         self._sample_seed = 0
+        self.replay_stats = dict(eager=0, recorded=0, replayed=0)      # train_step_async under cfg.HIP.TRAIN_REPLAY
         self._train_state = None
         self._fuse_tail_entry = False          # TEST-only graph restructuring, see resnetv1._fused_tail_entry
         self._h2_of = {}                       # activation address -> ops.H2 operand planes of that tensor (cfg.HIP.MFMA_H2)
@@ -416,7 +417,7 @@ class Network(object):
         rois, roi_scores, labels, tg, iw, ow, counts = out
         # the sampled RoIs live at ONE address for the life of the session: the tape's crop record names them, and a captured reverse
         # sweep (cfg.HIP.TRAIN_GRAPH) is only valid for the tensors it was recorded with
-        rois = self._sess.buf(self._tag + "/" + name + "/rois", tuple(rois.shape)).copy_(rois)
+        rois = ops.t_copy(self._sess.buf(self._tag + "/" + name + "/rois", tuple(rois.shape)), rois)
         self._proposal_targets = dict(rois=rois, labels=labels, bbox_targets=tg, bbox_inside_weights=iw, bbox_outside_weights=ow,
                                       counts=counts)
         self._num_rois = None
@@ -686,15 +687,31 @@ class Network(object):
                 p["rois"][:n].cpu().numpy())
 
     # ------------------------------------------------------------------ training (network.py:488-516)
-    def train_forward(self, sess, blobs):
-        """TRAIN-mode forward + losses on the device (eager; the tape for the reverse sweep is recorded)."""
-        assert self._mode == "TRAIN"
+    def _stage_train_inputs(self, sess, blobs):
+        """blobs -> the step's static input buffers: image [1,H,W,4] (like _stage_image), gt boxes in a [TRAIN_MAX_GT,5] buffer whose
+        first G rows are valid (G is a launch argument of the two target layers, the only consumers), im_info as host floats (launch
+        arguments; part of a recorded step's key)."""
         self._sess = sess
         self._image = self._stage_image(sess, blobs["data"])
         info = blobs["im_info"]
         self._im_info = (float(info[0]), float(info[1]), float(info[2]))
         gt = blobs["gt_boxes"]
-        self._gt_boxes = gt if torch.is_tensor(gt) else sess.to_device(np.ascontiguousarray(gt, dtype=np.float32))
+        gt = gt if torch.is_tensor(gt) else torch.from_numpy(np.ascontiguousarray(gt, dtype=np.float32))
+        G = int(gt.shape[0])
+        cap = max(self.TRAIN_MAX_GT, (G + 63) // 64 * 64)
+        buf = sess.buf(self._tag + "/gt_boxes", (cap, 5), zero=True)
+        buf[:G].copy_(gt, non_blocking=True)
+        self._gt_boxes = buf[:G]
+
+    TRAIN_MAX_GT = 128          # rows of the static gt buffer (grows in steps of 64 for an image with more boxes: a new recorded-step key)
+
+    def train_forward(self, sess, blobs):
+        """TRAIN-mode forward + losses on the device (eager; the tape for the reverse sweep is recorded)."""
+        assert self._mode == "TRAIN"
+        self._stage_train_inputs(sess, blobs)
+        return self._train_forward_staged(sess)
+
+    def _train_forward_staged(self, sess):
         ops.ws_scope = self._tag
         sess.flops_last_forward = 0
         sess.prepared.enabled = bool(cfg.HIP.PREP_STREAM)
@@ -708,22 +725,99 @@ class Network(object):
 
     def train_step_async(self, sess, blobs, train_op):
         """train_step without the host read-back: returns a DEVICE tensor [5] = (rpn_loss_cls, rpn_loss_box, loss_cls, loss_box,
-        total_loss).  Nothing in the step synchronises with the host, so the launch queue stays ahead of the GPU across steps."""
-        losses = self.train_forward(sess, blobs)
+        total_loss).  Nothing in the step synchronises with the host, so the launch queue stays ahead of the GPU across steps.
+
+        cfg.HIP.TRAIN_REPLAY (default): the reference runs a step as ONE `sess.run` of a graph built once (network.py:488-498); here the
+        second step of an image shape is recorded while it runs eagerly (frcnn_hip/replay.py: every C-ABI launch, event record / wait,
+        tensor copy and collective of the step, streams as slots) and every later step of that shape replays the list -- the same
+        launches, arguments, streams and order, hence the same bits, without the ~14 ms of Python a step costs the host."""
+        assert self._mode == "TRAIN"
+        self._stage_train_inputs(sess, blobs)
+        if not cfg.HIP.TRAIN_REPLAY:
+            return self._train_step_body(sess, train_op, sess.buf(self._tag + "/train/losses", (5,))).clone()
+        return self._train_step_replayed(sess, train_op)
+
+    def _train_step_body(self, sess, train_op, out):
+        """forward + losses + reverse sweep + solver, enqueued eagerly; the five losses into the static tensor `out`"""
+        losses = self._train_forward_staged(sess)
         if not train_op.params:
             train_op.build()
             if getattr(train_op, "pending_slots", None) is not None:          # resumed run: momentum before the first update
                 train_op.import_slots(train_op.pending_slots)
                 train_op.pending_slots = None
         self.configure_train_op(train_op)
-        train_op.backward(self._loss_seeds)
-        total = train_op.regularization_value()
+        train_op.backward(self._loss_seeds, fuse_solver=True)
+        reg = train_op.regularization_value()
         parts = [losses[k].view(1) for k in ("rpn_cross_entropy", "rpn_loss_box", "cross_entropy", "loss_box")]
-        total = total + parts[0] + parts[1] + parts[2] + parts[3]
-        out = torch.cat(parts + [total])
+
+        def assemble():
+            torch.cat(parts + [reg + parts[0] + parts[1] + parts[2] + parts[3]], out=out)
+        ops.host_op(assemble)
         train_op.apply(train_op.lr, getattr(train_op, "world_size", 1), getattr(train_op, "all_reduce", None))
         self._sample_seed += 2
         return out
+
+    REPLAY_CAP = 16             # recorded steps kept per session (one per image shape; least recently used goes first)
+
+    def _train_step_replayed(self, sess, train_op):
+        import frcnn_hip
+        from frcnn_hip import replay
+        main = torch.cuda.current_stream(sess.device)
+        hip = tuple((k, tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in sorted(cfg.HIP.items()))
+        t = cfg.TRAIN
+        key = ("train_replay", self._tag, tuple(self._image.shape), self._im_info, int(self._gt_boxes.data_ptr()), float(train_op.lr),
+               train_op.replay_signature(), hip, self._num_classes, self._anchor_scales, self._anchor_ratios, bool(cfg.RESNET.MAX_POOL),
+               bool(cfg.USE_GPU_NMS), bool(cfg.USE_E2E_TF), cfg.POOLING_SIZE,
+               (t.RPN_PRE_NMS_TOP_N, t.RPN_POST_NMS_TOP_N, t.RPN_NMS_THRESH, t.BATCH_SIZE, t.FG_FRACTION, t.FG_THRESH, t.BG_THRESH_HI, t.BG_THRESH_LO,
+                t.RPN_BATCHSIZE, t.RPN_FG_FRACTION, t.RPN_POSITIVE_OVERLAP, t.RPN_NEGATIVE_OVERLAP, bool(t.RPN_CLOBBER_POSITIVES),
+                float(t.RPN_POSITIVE_WEIGHT), tuple(t.RPN_BBOX_INSIDE_WEIGHTS), tuple(t.BBOX_INSIDE_WEIGHTS), bool(t.USE_GT),
+                tuple(float(v) for v in t.BBOX_NORMALIZE_MEANS), tuple(float(v) for v in t.BBOX_NORMALIZE_STDS)))
+        ent = sess.graphs.get(key)
+        if ent is None:
+            live = [k for k in sess.graphs if isinstance(k, tuple) and k and k[0] == "train_replay"]
+            if len(live) >= self.REPLAY_CAP:
+                del sess.graphs[min(live, key=lambda k: sess.graphs[k]["used"])]
+            ent = sess.graphs[key] = dict(seen=0, rec=None, used=0)
+        self._replay_clock = getattr(self, "_replay_clock", 0) + 1
+        ent["used"] = self._replay_clock
+        out = sess.buf(self._tag + "/train/losses", (5,))
+        rec = ent["rec"]
+        if rec is not None:
+            if not rec.bound_to(main):
+                rec.bind(rec.default_binding(main))
+            rec.replay(dict(seed=self._sample_seed, gt=int(self._gt_boxes.shape[0])))
+            sess.prepared.waited = [False, False, False]      # (the replayed refresh re-recorded the tier events: every reader waits again)
+            self._predictions, self._losses, self._proposal_targets, self._anchor_targets = ent["views"]
+            self._sample_seed += 2
+            self.replay_stats["replayed"] += 1
+            return out.clone()
+        arena = getattr(self, "_train_arena", None)
+        if arena is None or arena.sess is not sess:
+            arena = self._train_arena = replay.Arena(sess, self._tag + "/train")
+        arena.reset()
+        prep = sess.prepared
+        steady = (ent["seen"] >= 1 and bool(train_op.params) and getattr(train_op, "_sgd_table", None) is not None
+                  and frcnn_hip.recorder is None
+                  and (not cfg.HIP.PREP_STREAM or (prep.ready_version == prep.version and len(prep.plan) > 0 and len(prep.ready) == len(prep.plan))))
+        plan_before = len(prep.plan)
+        ops.arena = arena
+        try:
+            if steady:
+                rec = replay.Recording(main)
+                rec.vars = dict(seed=self._sample_seed, gt=int(self._gt_boxes.shape[0]))
+                frcnn_hip.recorder = rec
+            self._train_step_body(sess, train_op, out)
+        finally:
+            ops.arena = None
+            frcnn_hip.recorder = None
+        ent["seen"] += 1
+        if steady and len(prep.plan) == plan_before:          # (a filter prepared inline during the step = not the steady state yet)
+            ent["rec"] = rec
+            ent["views"] = (dict(self._predictions), dict(self._losses), dict(self._proposal_targets), dict(self._anchor_targets))
+            self.replay_stats["recorded"] += 1
+        else:
+            self.replay_stats["eager"] += 1
+        return out.clone()
 
     @staticmethod
     def configure_train_op(train_op):

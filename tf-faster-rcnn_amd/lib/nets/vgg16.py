@@ -72,7 +72,7 @@ class vgg16(Network):
         """slim.dropout(keep_prob=0.5, is_training=True) (vgg16.py:52-58); the mask is a function of (step seed, layer, element)."""
         seed = (int(self._sample_seed) << 8) | int(layer)
         out = self._sess.buf(self._tag + "/dropout%d" % layer, tuple(x.shape))
-        self._sess.mark("op:dropout", 0, lambda: ops.dropout(x, seed, 0.5, out=out), nbytes=8 * x.numel())
+        self._sess.mark("op:dropout", 0, lambda: ops.dropout(x, seed, 0.5, out=out, step_mult=256), nbytes=8 * x.numel())
         self._tape.append(dict(kind="dropout", x=x, y=out, seed=seed, keep=0.5, name="dropout%d" % layer))
         if x.data_ptr() in self._requires_grad:
             self._requires_grad.add(out.data_ptr())
