@@ -491,8 +491,11 @@ int frcnn_add_strided(const float* src_d, int N, int OH, int OW, int C, float* d
                       int accumulate, void* stream);                                        /* skip / subsample gradient */
 int frcnn_spatial_mean_bwd(const float* dy_d, int N, int HW, int C, float* dx_d, void* stream);
 int frcnn_colsum(const float* dy_d, int M, int C, float* db_d, void* stream);                 /* bias gradient */
-/* Gradient of tf.image.crop_and_resize w.r.t. the feature map (scatter-add; dfeat_d must be zeroed or hold
- * the gradient to accumulate into).  No max-pool variant (ResNet crops 7x7 directly). */
+/* Gradient of tf.image.crop_and_resize w.r.t. the feature map: dfeat_d += sum over the output samples of their four bilinear taps
+ * (dfeat_d must be zeroed or hold the gradient to accumulate into).  DETERMINISTIC since round 5: a gather per feature row in ascending
+ * (roi, sample row, sample column, tap) order, no float atomics (TensorFlow's CropAndResizeGradImage scatters with atomics; its sum
+ * order, hence the last bits, vary from run to run).  W * 1024 + R * pool * 4 bytes of LDS must fit 160 KB (FRCNN_E_UNSUPPORTED).
+ * No max-pool variant (ResNet crops 7x7 directly). */
 int frcnn_crop_and_resize_bwd(const float* dout_d, int H, int W, int C, const float* rois_d, int R, float feat_stride,
                               int pool, float* dfeat_d, void* stream);
 /* tf.train.MomentumOptimizer step on a packed master filter [Cout][K] (+ refresh of the BN-folded copy):

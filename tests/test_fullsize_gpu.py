@@ -131,9 +131,12 @@ def test_fullsize_train_step_parity(dev, policy):
     assert rep["ok"], text
 
 
-def test_fullsize_batch_invariance_under_the_shipped_configuration(dev):
-    """configs[1], calibrated weights, shipped cfg.HIP: the harness image ALONE (batch 1: latency mode, tools/test_net.py) and in slots
-    0 and 3 of a 4-image batch whose other slots hold other images (bench.py's step) must give the same BITS -- RPN tensors, proposals,
+@pytest.mark.parametrize("config,batch,slots", [("c2", 4, (0, 3)), ("c2", 8, (0, 3, 7)), ("c3", 4, (0, 2, 3))])
+def test_fullsize_batch_invariance_under_the_shipped_configuration(dev, config, batch, slots):
+    """configs[1] / configs[2], calibrated weights, shipped cfg.HIP: the harness image ALONE (batch 1: latency mode, tools/test_net.py)
+    and in the first, a middle and the last slot of a batch whose other slots hold other images -- at the batch bench.py SHIPS (8 images
+    per launch for configs[1], 4 for configs[2]; the tile configuration of frcnn_gemm_h2, e.g. the ping-pong schedule for K >= 1024
+    launches with at least one 256-row tile per CU, is a function of the launch size) -- must give the same BITS: RPN tensors, proposals,
     head outputs, detections.  The reference is strictly batch-1 (lib/model/test.py:88, lib/nets/network.py:388): a result that
     depends on the neighbours in a launch would make tie-breaks and eps-close NMS decisions depend on them too.  What it takes: the
     pipe a GEMM runs on and every split-K plan follow the PER-IMAGE shape (lib/nets/network.py _plan_rows, csrc/conv_igemm.hip
@@ -143,8 +146,8 @@ def test_fullsize_batch_invariance_under_the_shipped_configuration(dev):
     from frcnn_hip.runtime import Session
     from model.config import cfg
     _shipped_policy()
-    c = fs.CONFIGS["c2"]
-    net, v, image, im_info, fx = fs.build("c2", "calibrated")
+    c = fs.CONFIGS[config]
+    net, v, image, im_info, fx = fs.build(config, "calibrated")
     saved = {k: cfg.HIP[k] for k in cfg.HIP}
     saved_post, saved_nms = cfg.TEST.RPN_POST_NMS_TOP_N, cfg.USE_GPU_NMS
     try:
@@ -169,10 +172,10 @@ def test_fullsize_batch_invariance_under_the_shipped_configuration(dev):
             out["per"] = int(net._rois_per_image)
             return out
         one = run(image)
-        four = run(np.concatenate([image, fs.synth_image(c, 11), fs.synth_image(c, 12), image], axis=0))
+        four = run(np.concatenate([image if b in slots else fs.synth_image(c, 11 + b) for b in range(batch)], axis=0))
         per = four["per"]
         assert one["per"] == per
-        for slot in (0, 3):
+        for slot in slots:
             sl = slice(slot * per, (slot + 1) * per)
             assert np.array_equal(four["head"][slot], one["head"][0]), "head, slot %d" % slot
             for k in ("rpn_cls_prob", "rpn_bbox_pred"):

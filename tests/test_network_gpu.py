@@ -62,6 +62,23 @@ def test_test_image_matches_dense_oracle(small_net):
     assert abs(cls_prob.sum(axis=1) - 1).max() < 1e-5
 
 
+def test_extract_head_gives_the_bits_of_the_full_forward(small_net):
+    """Network.extract_head (network.py:452-457 of the reference: the head alone) runs under the same batch-invariant launch plan as
+    forward_device, so the same image gives the same head features bit for bit -- also when the pipe rules bite (h2 from 2 tiles)."""
+    from model.config import cfg
+    sess, net, image, im_info = small_net
+    old = cfg.HIP.H2_MIN_TILES
+    try:
+        for min_tiles in (old, 2):
+            cfg.HIP.H2_MIN_TILES = min_tiles
+            net.test_image(sess, image, im_info)
+            want = net._layers["head"].cpu().numpy().copy()
+            got = net.extract_head(sess, image)
+            assert np.array_equal(got, want), min_tiles
+    finally:
+        cfg.HIP.H2_MIN_TILES = old
+
+
 def test_proposals_match_oracle_on_identical_rpn_outputs(small_net):
     sess, net, image, im_info = small_net
     _, _, _, rois = net.test_image(sess, image, im_info)
@@ -421,6 +438,16 @@ def test_fused_tail_mean_matches_the_unfused_path(small_net):
         cfg.HIP.FUSE_TAIL_MEAN = True
     assert np.array_equal(fused[3], base[3])                                     # same proposals
     for a, b in ((fused[0], base[0]), (fused[2], base[2])):                      # cls_score, bbox_pred (this fixture's logits are O(1e3))
+        assert rel_err(a, b) <= 2e-5
+    # the tail's conv2 on the direct kernel and no lazy split: no operand planes reach the last conv3 -> the graph falls back to the
+    # unfused pair instead of refusing to build (h2 from 2 tiles so that the fused form WOULD apply at this toy size)
+    keep = (cfg.HIP.WINOGRAD_DIRECT_SCOPES, cfg.HIP.H2_LAZY_SPLIT, cfg.HIP.H2_MIN_TILES)
+    try:
+        cfg.HIP.WINOGRAD_DIRECT_SCOPES, cfg.HIP.H2_LAZY_SPLIT, cfg.HIP.H2_MIN_TILES = ("block4",), False, 2
+        direct = net.test_image(sess, image, im_info)
+    finally:
+        cfg.HIP.WINOGRAD_DIRECT_SCOPES, cfg.HIP.H2_LAZY_SPLIT, cfg.HIP.H2_MIN_TILES = keep
+    for a, b in ((direct[0], base[0]), (direct[2], base[2])):
         assert rel_err(a, b) <= 2e-5
 
 

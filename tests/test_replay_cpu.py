@@ -130,6 +130,25 @@ def test_host_ops_run_now_and_at_every_replay_and_see_the_bound_streams():
     assert log == ["plain", ("send on", "side2")]
 
 
+def test_tensor_operations_of_a_step_are_replayed_whatever_they_return():
+    log = []
+    main = FakeStream("main", 0x1000, log)
+    a, b = torch.arange(6, dtype=torch.float32), torch.zeros(6)
+    rec = replay.Recording(main)
+    frcnn_hip.recorder = rec
+    try:
+        ops.t_copy(b, a)                       # (Tensor.copy_ / zero_ return the tensor: not a status code)
+        ops.t_zero(a)
+        ops.host_op(lambda: torch.add(b, 1.0, out=b))
+    finally:
+        frcnn_hip.recorder = None
+    assert b.tolist() == [1.0, 2.0, 3.0, 4.0, 5.0, 6.0] and float(a.abs().sum()) == 0.0
+    a.copy_(torch.full((6,), 7.0))
+    rec.bind([main])
+    rec.replay(dict(seed=0, gt=0))
+    assert b.tolist() == [8.0] * 6 and float(a.abs().sum()) == 0.0
+
+
 def test_arena_hands_out_the_same_tensors_every_step_and_only_while_active():
     class Sess(object):
         buffers, device = {}, torch.device("cpu")
@@ -165,3 +184,135 @@ def test_every_entry_without_a_stream_argument_is_classified():
     rec = replay.Recording(FakeStream("main", 0x1000, log))
     rec.add_call(FakeFn("frcnn_generate_anchors", [I, P, I, P, I, P], log), "frcnn_generate_anchors", (16, P(1), 3, P(2), 3, P(3)))
     assert rec.cmds == []
+
+
+# ---- the control flow of Network.train_step_async under cfg.HIP.TRAIN_REPLAY, with stand-ins for everything that needs a GPU -------------
+class _Stream(FakeStream):
+    def synchronize(self):
+        self.log.append(("sync", self.name))
+
+    def wait_stream(self, other):
+        self.log.append(("wait_stream", self.name, other.name))
+
+
+class _Prepared(object):
+    def __init__(self):
+        self.version, self.ready_version, self.plan, self.ready, self.readers, self.epoch = 3, 3, {"k": 1}, frozenset(["k"]), {}, 0
+
+    def refreshed(self):
+        self.epoch += 1
+
+
+class _Sess(object):
+    def __init__(self):
+        self.graphs, self.buffers, self.device, self.prepared = {}, {}, torch.device("cpu"), _Prepared()
+
+    def buf(self, name, shape, dtype=torch.float32, zero=False):
+        key = (name, tuple(shape), dtype)
+        if key not in self.buffers:
+            self.buffers[key] = torch.zeros(tuple(shape), dtype=dtype)
+        return self.buffers[key]
+
+
+class _TrainOp(object):
+    lr, params, _sgd_table = 1e-3, {"w": 1}, object()
+
+    def replay_signature(self):
+        return ("sig",)
+
+
+def _stub_net(monkeypatch, log):
+    sys.path.insert(0, os.path.join(ROOT, "tf-faster-rcnn_amd", "lib"))
+    from nets.network import Network
+    main = _Stream("main", 0x1000, log)
+    side = _Stream("side", 0x2000, log)
+    made = []
+
+    def new_stream(device=None):
+        st = _Stream("pool%d" % len(made), 0x9000 + 16 * len(made), log)
+        made.append(st)
+        return st
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda device=None: main)
+    monkeypatch.setattr(torch.cuda, "Stream", new_stream)
+    conv = FakeFn("frcnn_conv", [P, I, P], log)
+    target = FakeFn("frcnn_target", [P, I, LL, P], log)
+
+    class Net(Network):
+        def _stage_train_inputs(self, sess, blobs):
+            self._sess, self._image, self._im_info = sess, torch.zeros(blobs["shape"]), (1.0, 2.0, 1.0)
+            self._gt_boxes = sess.buf("gt", (128, 5))[:blobs["G"]]
+
+        def _train_step_body(self, sess, train_op, out):
+            if frcnn_hip.recorder is not None:
+                frcnn_hip.recorder.slot(side)                   # (the real step meets a helper stream first in an event wait: ops.st_wait_event)
+            for fn, name, args in ((conv, "frcnn_conv", (P(0xA0), 7, P(0x1000))), (target, "frcnn_target", (P(0xB0), int(self._gt_boxes.shape[0]), self._sample_seed, P(0x1000))),
+                                   (conv, "frcnn_conv", (P(0xC0), 9, P(0x2000)))):
+                fn(*[t(a) if not isinstance(a, ctypes._SimpleCData) else a for t, a in zip(fn.argtypes, args)])
+                if frcnn_hip.recorder is not None:
+                    frcnn_hip.recorder.add_call(fn, name, args)
+                    if name == "frcnn_target":
+                        frcnn_hip.recorder.patch_last(1, var="gt")
+                        frcnn_hip.recorder.patch_last(2)
+            self._predictions, self._losses, self._proposal_targets, self._anchor_targets = {"p": 1}, {"l": 1}, {"pt": 1}, {"at": 1}
+            self._sample_seed += 2
+            return out
+    net = Net()
+    net._mode, net._tag, net._num_classes, net._anchor_scales, net._anchor_ratios = "TRAIN", "t", 21, (8,), (1,)
+    return net, main, side, made
+
+
+def test_train_step_goes_eager_then_recorded_then_replayed(monkeypatch):
+    from model.config import cfg
+    log = []
+    net, main, side, made = _stub_net(monkeypatch, log)
+    sess, op = _Sess(), _TrainOp()
+    old = (cfg.HIP.TRAIN_REPLAY, cfg.HIP.TRAIN_PICK_STREAMS)
+    cfg.HIP.TRAIN_REPLAY, cfg.HIP.TRAIN_PICK_STREAMS = True, 0
+    try:
+        for i, G in enumerate((3, 5, 2, 9)):
+            del log[:]
+            net.train_step_async(sess, dict(shape=(1, 4, 6, 4), G=G), op)
+            assert [e for e in log if e[0] == "frcnn_target"] == [("frcnn_target", 0xB0, G, 2 * i, 0x1000)], (i, log)      # this step's box count and seed
+            assert len([e for e in log if e[0] == "frcnn_conv"]) == 2
+        assert net.replay_stats == dict(eager=1, recorded=1, replayed=2) and net._sample_seed == 8 and sess.prepared.epoch == 2
+        net.train_step_async(sess, dict(shape=(1, 4, 8, 4), G=1), op)                 # another image shape: eager again
+        assert net.replay_stats == dict(eager=2, recorded=1, replayed=2)
+        sess.prepared.version += 1                                                    # filters changed behind the solver's back: not steady, no recording
+        net.train_step_async(sess, dict(shape=(1, 4, 8, 4), G=1), op)
+        assert net.replay_stats == dict(eager=3, recorded=1, replayed=2)
+        cfg.HIP.TRAIN_REPLAY = False
+        net.train_step_async(sess, dict(shape=(1, 4, 6, 4), G=3), op)
+        assert net.replay_stats == dict(eager=3, recorded=1, replayed=2)              # (the switch off: not counted, nothing replayed)
+    finally:
+        cfg.HIP.TRAIN_REPLAY, cfg.HIP.TRAIN_PICK_STREAMS = old
+
+
+def test_stream_picker_times_real_steps_and_keeps_the_fastest_binding(monkeypatch):
+    """cfg.HIP.TRAIN_PICK_STREAMS = 2: baseline window + one window per (helper slot, pool stream), every window between two
+    synchronisations of the main stream; the binding with the shortest window wins and later steps run on it."""
+    import time
+    from model.config import cfg
+    log = []
+    net, main, side, made = _stub_net(monkeypatch, log)
+    sess, op = _Sess(), _TrainOp()
+    cost = {0x2000: 0.004, 0x9000: 0.001, 0x9010: 0.006}                              # seconds a step "takes" with the helper slot on that stream
+    real = FakeFn.__call__
+
+    def slow(self, *args):
+        if args[0].value == 0xC0:
+            time.sleep(cost[args[-1].value])
+        return real(self, *args)
+    monkeypatch.setattr(FakeFn, "__call__", slow)
+    old = (cfg.HIP.TRAIN_REPLAY, cfg.HIP.TRAIN_PICK_STREAMS)
+    cfg.HIP.TRAIN_REPLAY, cfg.HIP.TRAIN_PICK_STREAMS = True, 2
+    try:
+        for i in range(2 + 3 * 3 + 2):
+            net.train_step_async(sess, dict(shape=(1, 4, 6, 4), G=3), op)
+        assert [w for w, _ in sess.pick_log] == ["inherited", "slot 1 -> pool[0]", "slot 1 -> pool[1]"]
+        assert [int(s.cuda_stream) for s in sess.picked_streams] == [0x9000] and not sess.picking
+        del log[:]
+        net.train_step_async(sess, dict(shape=(1, 4, 6, 4), G=3), op)
+        assert [e for e in log if e[0] == "frcnn_conv"][-1] == ("frcnn_conv", 0xC0, 9, 0x9000)
+        assert net.replay_stats["replayed"] == 3 * 3 + 2 + 1
+    finally:
+        cfg.HIP.TRAIN_REPLAY, cfg.HIP.TRAIN_PICK_STREAMS = old

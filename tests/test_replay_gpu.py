@@ -77,7 +77,7 @@ def test_replayed_steps_equal_eager_steps_bit_for_bit(dev, family):
     finally:
         cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.H2_MIN_TILES = old
     assert s0 == dict(eager=0, recorded=0, replayed=0)
-    assert s1 == dict(eager=1, recorded=1, replayed=5), s1
+    assert s1 == dict(eager=1, recorded=1, replayed=5), s1       # step 1 eager (builds everything), step 2 recorded, steps 3-7 replayed
     assert all(np.isfinite(v) for step in l0 for v in step)
     assert len({tuple(s) for s in l0}) == 7                       # seven different steps (images, seeds, weights move)
     assert l1 == l0, (l0, l1)                                      # float -> python float is exact: the same bits
@@ -100,9 +100,10 @@ def _load_state(ts, net, state, seed):
     net._sample_seed = seed
 
 
-def _repeat_one_step(net, sess, ts, blob, repeats):
-    """the SAME step (state, image, seeds) `repeats` times: -> set of (loss bits, parameter digest)"""
-    state, seed = _save_state(ts), net._sample_seed
+def _repeat_one_step(net, sess, ts, blob, repeats, start=None):
+    """the SAME step (state, image, seeds) `repeats` times: -> set of (loss bits, parameter digest); start = (state, seed) to begin from
+    (default: where the solver is now)"""
+    state, seed = (_save_state(ts), net._sample_seed) if start is None else start
     seen = set()
     for _ in range(repeats):
         _load_state(ts, net, state, seed)
@@ -158,10 +159,11 @@ def test_fullsize_c5_step_is_deterministic_and_replay_equals_eager(dev):
         for i in range(3):                                      # eager, recorded, replayed
             net.train_step(sess, blobs[i % 2], ts)
         assert net.replay_stats == dict(eager=1, recorded=1, replayed=1)
-        replayed = _repeat_one_step(net, sess, ts, blobs[1], 20)
+        start = (_save_state(ts), net._sample_seed)
+        replayed = _repeat_one_step(net, sess, ts, blobs[1], 20, start)
         assert net.replay_stats["replayed"] == 21
         cfg.HIP.TRAIN_REPLAY = False
-        eager = _repeat_one_step(net, sess, ts, blobs[1], 20)
+        eager = _repeat_one_step(net, sess, ts, blobs[1], 20, start)
     finally:
         cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.TRAIN.DOUBLE_BIAS, cfg.HIP.TRAIN_REPLAY = old
     assert len(replayed) == 1 and len(eager) == 1, (len(replayed), len(eager))

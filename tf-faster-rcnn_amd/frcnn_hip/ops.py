@@ -124,6 +124,13 @@ def host_op(fn):
     return out
 
 
+def _chk(t, dtype=torch.float32):
+    if not (t.is_cuda and t.is_contiguous() and t.dtype == dtype):
+        raise ValueError("expected a contiguous CUDA %s tensor, got %s %s contiguous=%s" %
+                         (dtype, t.device, t.dtype, t.is_contiguous()))
+    return t
+
+
 def workspace(nbytes, device, tag="default"):
     """Grow-only scratch buffer per (device, tag); never reallocated inside a captured region
     as long as the first (warm-up) call already saw the largest request."""

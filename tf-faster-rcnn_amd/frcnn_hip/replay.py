@@ -101,7 +101,9 @@ class Recording(object):
 
     def add_op(self, closure):
         """closure(rec): a stream-level operation of the step (event record / wait, tensor copy, collective); streams by rec.stream(slot)"""
-        self.cmds.append((self.OP, closure))
+        def op(rec, closure=closure):                           # (whatever the operation returns -- a tensor, a work handle -- is not a status code)
+            closure(rec)
+        self.cmds.append((self.OP, op))
 
     # ---- replay ------------------------------------------------------------------------------------------------------------------------
     def stream(self, slot):
@@ -149,6 +151,76 @@ class Recording(object):
             if rc:
                 from . import check
                 check(rc, getattr(fn, "__name__", "recorded call"))
+
+
+class StreamPicker(object):
+    """Which PHYSICAL stream each helper slot of a recorded step runs on, chosen by timing real steps.
+
+    ROCm multiplexes HIP streams onto a few hardware queues (4 by default), and whether a helper stream of the step -- filter gradients,
+    solver, filter preparation -- shares a queue with the data-gradient chain it is meant to run beside is decided by the order in which
+    streams were created in the process: an RCCL process group that merely EXISTS moved the step from 19.4 to 23.4 ms in round 4
+    (profiles/r04_ao_dp_pieces.txt), GPU_MAX_HW_QUEUES=8 gave that back and cost the single-GPU step 24 ms.  A recording names streams by
+    slot, so the assignment can be searched instead of inherited: one pass of coordinate descent -- for every helper slot in turn, every
+    stream of a small pool -- each candidate timed over a window of `window` real training steps between two device synchronisations, a
+    candidate kept when it beats the best so far by more than 1 %.  Any binding is CORRECT (the list's events order the streams whatever
+    they are; two slots on one stream merely serialise), so the search cannot change a bit of the result -- the steps it times are
+    ordinary training steps."""
+
+    def __init__(self, rec, main, pool, window=3, gain=0.01):
+        self.rec, self.pool, self.window, self.gain = rec, list(pool), int(window), float(gain)
+        self.best = rec.default_binding(main)
+        self.best_s = None
+        self.queue = [None]                                  # None = the inherited binding (the baseline), then (slot, pool index)
+        self.queue += [(s, i) for s in range(1, len(self.best)) for i in range(len(self.pool))]
+        self.left, self.t0, self.cur = 0, 0.0, None
+        self.done = len(self.best) < 2
+        self.log = []                                        # (what, seconds per step)
+
+    def _binding(self, cand):
+        b = list(self.best)
+        if cand is not None:
+            b[cand[0]] = self.pool[cand[1]]
+        return b
+
+    def before_step(self, main):
+        import time
+        if self.done or self.left:
+            return
+        while self.queue:
+            self.cur = self.queue.pop(0)
+            b = self._binding(self.cur)
+            b[0] = main
+            if self.cur is None or int(b[self.cur[0]].cuda_stream) != int(self.best[self.cur[0]].cuda_stream):
+                break                                        # (a candidate equal to the slot's current stream was measured already)
+        else:
+            self._finish(main)
+            return
+        main.synchronize()
+        self.rec.bind(b)
+        self.left, self.t0 = self.window, time.perf_counter()
+
+    def after_step(self, main):
+        import time
+        if self.done or not self.left:
+            return
+        self.left -= 1
+        if self.left:
+            return
+        main.synchronize()
+        s = (time.perf_counter() - self.t0) / self.window
+        self.log.append(("inherited" if self.cur is None else "slot %d -> pool[%d]" % self.cur, s))
+        if self.best_s is None or s < self.best_s * (1.0 - self.gain):
+            self.best_s = s
+            if self.cur is not None:
+                self.best[self.cur[0]] = self.pool[self.cur[1]]
+        if not self.queue:
+            self._finish(main)
+
+    def _finish(self, main):
+        b = list(self.best)
+        b[0] = main
+        self.rec.bind(b)
+        self.done = True
 
 
 # Entries of include/frcnn_hip.h WITHOUT a trailing `void* stream` (tests/test_replay_cpu.py checks the two sets against the header):

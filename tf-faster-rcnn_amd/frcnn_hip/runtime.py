@@ -142,13 +142,27 @@ class PreparedFilters(object):
         self.version, self.ready_version = 0, -1
         self.stream = None
         self.events = None                      # one per tier
-        self.waited = [True, True, True]
+        self.epoch = 0                          # counts refreshes (incl. replayed ones: refreshed())
+        self.waited = {}                        # stream handle -> [epoch whose tier-t event this stream has waited for, t = 0, 1, 2]
+        self.readers = {}                       # stream handle -> torch stream: who has read the buffers since the last refresh
 
     def _wait(self, tier):
-        if not self.waited[tier]:               # tiers complete in order on one stream: waiting for one covers the earlier ones
-            ops.st_wait_event(torch.cuda.current_stream(self.device), self.events[tier])
+        """Per STREAM: a TEST-mode network on its own stream and the training stream each wait for the refresh once (one shared flag let
+        the second reader skip its wait).  Tiers complete in order on the refresh stream: waiting for one covers the earlier ones."""
+        cur = torch.cuda.current_stream(self.device)
+        h = int(cur.cuda_stream)
+        w = self.waited.get(h)
+        if w is None:
+            w = self.waited[h] = [0, 0, 0]
+        self.readers[h] = cur
+        if w[tier] < self.epoch:
+            ops.st_wait_event(cur, self.events[tier])
             for t in range(tier + 1):
-                self.waited[t] = True
+                w[t] = self.epoch
+
+    def refreshed(self):
+        """the tier events were re-recorded by somebody else than refresh() (a replayed training step's refresh): every reader waits again"""
+        self.epoch += 1
 
     def get(self, key, fn):
         if self.enabled and self.ready_version == self.version and key in self.ready:
@@ -185,6 +199,10 @@ class PreparedFilters(object):
         if self.stream is None:
             self.stream, self.events = torch.cuda.Stream(device=self.device), [torch.cuda.Event() for _ in range(3)]
         ops.st_wait_stream(self.stream, main)   # the update itself, and the last step's reads of these buffers
+        for h, st in list(self.readers.items()):   # ... and whoever else read them (a TEST-mode network on another stream)
+            if h != int(main.cuda_stream):
+                ops.st_wait_stream(self.stream, st)
+        self.readers = {}
         with ops.pinned_stream(self.stream):
             if pre is not None:
                 pre()
@@ -197,7 +215,8 @@ class PreparedFilters(object):
                 if key[0] != "fwd":
                     fn()
         ops.ev_record(self.events[2], self.stream)
-        self.ready, self.ready_version, self.waited = frozenset(self.plan), self.version, [False, False, False]
+        self.ready, self.ready_version = frozenset(self.plan), self.version
+        self.epoch += 1
 
     def invalidate(self):
         """The filter tensors were replaced or rewritten by somebody else than the solver (restore, initialise): forget the plan (its

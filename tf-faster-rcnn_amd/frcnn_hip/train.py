@@ -144,7 +144,7 @@ class TrainState(object):
         ar = getattr(self, "all_reduce", None)
         return (float(self.momentum), float(self.weight_decay), bool(self.double_bias), bool(self.bias_decay), bool(self.fuse_chain),
                 bool(self.pipe_dgrads), bool(self.prep_stream), bool(getattr(self, "solver_in_sweep", True)), int(getattr(self, "world_size", 1)),
-                bool(getattr(self, "force_dp", False)), None if ar is None else id(ar), len(self.params))
+                bool(getattr(self, "force_dp", False)), None if ar is None else id(ar))
 
     def _sweep(self, seeds, main, fuse_solver=False):
         sess, net = self.sess, self.net

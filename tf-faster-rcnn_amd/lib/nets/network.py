@@ -277,11 +277,12 @@ class Network(object):
                   nbytes=4 * (rows * Cin + w.numel() + out.numel() + (rows * Cout if residual is not None else 0)))
         return self._wrote(out)
 
-    def _mean_fusable(self, rows, cout, cin, scope):
+    def _mean_fusable(self, rows, cout, cin, scope, group_rows=1):
         """cfg.HIP.FUSE_TAIL_MEAN applies where the tail's last convolution runs in frcnn_gemm_h2 (TEST mode, h2-eligible shape and filter)
-        and the RoI rows split evenly over the images of the batch."""
+        and the RoI rows split evenly over the images of the batch (whole groups of `group_rows` rows per image)."""
         G = max(1, getattr(self, "_plan_batch", 0))
-        return (bool(cfg.HIP.FUSE_TAIL_MEAN) and self._mode == "TEST" and rows % G == 0 and self._h2_eligible(rows, cout, cin, 1, scope)
+        return (bool(cfg.HIP.FUSE_TAIL_MEAN) and self._mode == "TEST" and rows % G == 0 and (rows // G) % max(1, int(group_rows)) == 0
+                and self._h2_eligible(rows, cout, cin, 1, scope)
                 and bool(cfg.HIP.H2_LAZY_SPLIT or cfg.HIP.WINOGRAD))         # its input must exist as planes: emitted by the Winograd conv2, or split lazily
 
     # ------------------------------------------------------------------ ImageNet-pretrained weights (train_val.py:177-202)
@@ -548,14 +549,26 @@ class Network(object):
         B = getattr(self, "_plan_batch", 0)
         return M // B * self.PLAN_IMAGES if (B > 0 and M % B == 0) else M
 
-    def _build_network(self, is_training=True):
-        from frcnn_hip import lib
-        self._plan_batch = 0 if is_training else int(self._image.shape[0])
-        lib().frcnn_set_tuning(8, self._plan_batch)      # the same rule inside the library (split-K plan of frcnn_conv2d_nhwc_ws)
-        try:
-            return self._build_network_impl(is_training)
-        finally:
+    class _plan_context(object):
+        """The batch-invariant launch plan around a graph build: TEST-mode rules (matrix pipe, split-K plan, f32 tile configuration)
+        see the PER-IMAGE shape whatever the batch is -- _plan_rows here, launch context key 8 inside the library."""
+
+        def __init__(self, net, is_training):
+            self.net, self.batch = net, 0 if is_training else int(net._image.shape[0])
+
+        def __enter__(self):
+            from frcnn_hip import lib
+            self.net._plan_batch = self.batch
+            lib().frcnn_set_tuning(8, self.batch)        # the same rule inside the library (split-K plan of frcnn_conv2d_nhwc_ws)
+
+        def __exit__(self, *exc):
+            from frcnn_hip import lib
             lib().frcnn_set_tuning(8, 0)
+            return False
+
+    def _build_network(self, is_training=True):
+        with self._plan_context(self, is_training):
+            return self._build_network_impl(is_training)
 
     def _build_network_impl(self, is_training=True):
         self._tape = []
@@ -672,7 +685,9 @@ class Network(object):
         sess.prepared.wait_planes()
         self._image = self._stage_image(sess, image)
         self._h2_of, self._f32_missing = {}, set()
-        feat = self._image_to_head(False)
+        ops.ws_scope = self._tag
+        with self._plan_context(self, False):          # the same launch plan as forward_device: the same bits for the same image
+            feat = self._image_to_head(False)
         return feat.cpu().numpy()
 
     # only useful during testing mode
@@ -783,13 +798,35 @@ class Network(object):
         out = sess.buf(self._tag + "/train/losses", (5,))
         rec = ent["rec"]
         if rec is not None:
-            if not rec.bound_to(main):
-                rec.bind(rec.default_binding(main))
+            # which physical stream every helper slot runs on: inherited from the recording, or (cfg.HIP.TRAIN_PICK_STREAMS = pool size)
+            # searched once per session by timing real steps (replay.StreamPicker) and then shared by every recording with the same slots
+            pk = ent.get("picker")
+            picked = getattr(sess, "picked_streams", None)
+            if pk is None and int(cfg.HIP.TRAIN_PICK_STREAMS) > 0 and picked is None and not getattr(sess, "picking", False):
+                pool = [torch.cuda.Stream(device=sess.device) for _ in range(int(cfg.HIP.TRAIN_PICK_STREAMS))]
+                pk = ent["picker"] = replay.StreamPicker(rec, main, pool)
+                sess.picking = True
+            if pk is not None and not pk.done:
+                pk.before_step(main)
+                if pk.done:                                       # (nothing to try)
+                    sess.picked_streams, sess.picking, sess.pick_log = list(pk.best[1:]), False, list(pk.log)
+            if pk is None or pk.done:
+                helpers = picked if (picked is not None and len(picked) == len(rec.streams) - 1) else list(rec.streams[1:])
+                if rec.bound is None or [int(x.cuda_stream) for x in rec.bound] != [int(x.cuda_stream) for x in [main] + helpers]:
+                    rec.bind([main] + helpers)
+            for h, st in list(sess.prepared.readers.items()):     # a TEST-mode network on another stream read the filter images since the
+                if h != int(main.cuda_stream):                    # last refresh: the list's refresh waits for `main` only, so main waits for it
+                    main.wait_stream(st)
+            sess.prepared.readers = {}
             rec.replay(dict(seed=self._sample_seed, gt=int(self._gt_boxes.shape[0])))
-            sess.prepared.waited = [False, False, False]      # (the replayed refresh re-recorded the tier events: every reader waits again)
+            sess.prepared.refreshed()                         # (the replayed refresh re-recorded the tier events: every reader waits again)
             self._predictions, self._losses, self._proposal_targets, self._anchor_targets = ent["views"]
             self._sample_seed += 2
             self.replay_stats["replayed"] += 1
+            if pk is not None and not pk.done:
+                pk.after_step(main)
+                if pk.done:
+                    sess.picked_streams, sess.picking, sess.pick_log = list(pk.best[1:]), False, list(pk.log)
             return out.clone()
         arena = getattr(self, "_train_arena", None)
         if arena is None or arena.sess is not sess:

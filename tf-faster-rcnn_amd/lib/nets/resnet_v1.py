@@ -88,11 +88,15 @@ class resnetv1(Network):
         pad = (1, 1, 1, 1) if stride == 1 else _same_pad(3, stride)
         N, H, W, _ = r.shape
         M3 = N * ops.conv_out_size(H, 3, stride, pad[0], pad[1]) * ops.conv_out_size(W, 3, stride, pad[2], pad[3])
-        if mean_rows and res_stride == 1 and stride == 1 and self._mean_fusable(M3, depth, base, prefix + "/conv3"):
+        if mean_rows and res_stride == 1 and stride == 1 and self._mean_fusable(M3, depth, base, prefix + "/conv3", mean_rows):
             r = self._conv(r, prefix + "/conv2", 3, stride, pad, act=ACT_RELU, bn_eps=BN_EPS, emit_h2=True, want_f32=False)
             if self._h2_input(r) is not None:      # planes from conv2's output transform, or (direct conv2) a lazy split of its f32 result
                 return self._conv1x1_mean(r, prefix + "/conv3", mean_rows, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut)
-            raise RuntimeError("graph construction error: FUSE_TAIL_MEAN expected operand planes from " + prefix + "/conv2")
+            # conv2 took the direct kernel (WINOGRAD_DIRECT_SCOPES / WINOGRAD_MIN_CIN) and H2_LAZY_SPLIT is off: no planes exist, so the
+            # unfused pair -- conv3 on whatever pipe its float32 input allows, then the spatial mean
+            x = self._conv(r, prefix + "/conv3", 1, 1, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut, res_stride=1)
+            out = self._sess.buf(self._tag + "/fc7", (x.shape[0], x.shape[-1]))
+            return self._sess.mark("op:spatial_mean", 0, lambda: ops.spatial_mean(x, out=out), nbytes=4 * (x.numel() + out.numel()))
         c3_h2 = res_stride == 1 and self._h2_eligible(M3, depth, base, 1, prefix + "/conv3")
         r = self._conv(r, prefix + "/conv2", 3, stride, pad, act=ACT_RELU, bn_eps=BN_EPS, emit_h2=c3_h2, want_f32=not c3_h2)
         return self._conv(r, prefix + "/conv3", 1, 1, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut, res_stride=res_stride,
@@ -171,7 +175,7 @@ class resnetv1(Network):
         x = self._conv(r, prefix + "/conv3", 1, 1, act=ACT_RELU, bn_eps=BN_EPS, residual=shortcut, res_stride=1, emit_h2=n_units >= 2,
                        want_f32=not (n_units >= 2 and self._trunk_planes_only(R * P * P, base, stride if n_units == 2 else 1,
                                                                               "%s/%s/unit_2/bottleneck_v1" % (self._scope, name))))
-        fused = stride == 1 and n_units >= 2 and self._mean_fusable(R * P * P, 4 * base, base, "%s/%s/unit_%d/bottleneck_v1/conv3" % (self._scope, name, n_units))
+        fused = stride == 1 and n_units >= 2 and self._mean_fusable(R * P * P, 4 * base, base, "%s/%s/unit_%d/bottleneck_v1/conv3" % (self._scope, name, n_units), P * P)
         for u in range(2, n_units + 1):
             x = self._bottleneck(x, "%s/%s/unit_%d/bottleneck_v1" % (self._scope, name, u), base, stride if u == n_units else 1,
                                  mean_rows=P * P if (fused and u == n_units) else 0, emit_out=u < n_units,
@@ -185,7 +189,7 @@ class resnetv1(Network):
     def _head_to_tail(self, pool5, is_training, reuse=None):
         name, base, n_units, stride = self._blocks[-1]
         if stride == 1 and self._mean_fusable(pool5.shape[0] * pool5.shape[1] * pool5.shape[2], 4 * base, base,
-                                              "%s/%s/unit_%d/bottleneck_v1/conv3" % (self._scope, name, n_units)):
+                                              "%s/%s/unit_%d/bottleneck_v1/conv3" % (self._scope, name, n_units), pool5.shape[1] * pool5.shape[2]):
             x = pool5
             hw = pool5.shape[1] * pool5.shape[2]
             for u in range(1, n_units + 1):
