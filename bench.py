@@ -298,8 +298,8 @@ def train_bench(args, c, dev, world, rank, dist):
     sess.dp_note = None
     if args.dp_constrained and world == 1:
         import torch.distributed as dist1
-        sess.dp_note = "one replica under the data-parallel rules: <= 1 filter-gradient side stream, bucketed all-reduce (64 MiB) issued from " \
-                       "inside the sweep over a one-rank RCCL group (backend %s), eager sweep" % dist1.get_backend()
+        sess.dp_note = "one replica under the data-parallel rules: bucketed all-reduce (64 MiB) issued from inside the sweep over a one-rank RCCL " \
+                       "group (backend %s), ordered after both filter-gradient streams; the solver updates behind each reduced bucket" % dist1.get_backend()
         dist1.destroy_process_group()
     return elapsed, sess
 
@@ -548,7 +548,7 @@ def main():
                                "launch": "%s (forward, reverse sweep, solver), filter gradients on %d side stream(s)" % (
                                    "one recorded launch list per step, replayed (cfg.HIP.TRAIN_REPLAY: %r)" % (sess.replay_stats,)
                                    if cfg.HIP.TRAIN_REPLAY else "eager: every step enqueued by the Python code",
-                                   min(int(cfg.HIP.WGRAD_STREAM), 1 if (world > 1 or args.dp_constrained) else 99)),
+                                   int(cfg.HIP.WGRAD_STREAM)),
                                "host_enqueue_ms_per_step": round(1000.0 * sess.host_enqueue_s / args.steps, 3),
                                "gflop_per_step_reference_graph": c["gflop_ref"]},
                        roofline=train_roofline(sess.step_flops_by_pipe, elapsed / args.steps, c["gflop_ref"]))

@@ -447,8 +447,8 @@ def test_fused_tail_mean_matches_the_unfused_path(small_net):
         direct = net.test_image(sess, image, im_info)
     finally:
         cfg.HIP.WINOGRAD_DIRECT_SCOPES, cfg.HIP.H2_LAZY_SPLIT, cfg.HIP.H2_MIN_TILES = keep
-    for a, b in ((direct[0], base[0]), (direct[2], base[2])):
-        assert rel_err(a, b) <= 2e-5
+    for a, b in ((direct[0], base[0]), (direct[2], base[2])):   # (block4's 3x3 layers direct instead of Winograd, conv3 on another pipe: f32 rounding
+        assert rel_err(a, b) <= 2e-4                             # of a different operation order, not the fused form's 2e-5)
 
 
 def test_h2_static_filter_criterion_falls_back_to_x3(dev):

@@ -192,3 +192,21 @@ def test_a_new_shape_a_new_learning_rate_or_new_weights_start_a_new_recording(de
         assert not [k for k in sess.graphs if isinstance(k, tuple) and k and k[0] == "train_replay"]
     finally:
         cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO = old
+
+
+def test_the_stream_picker_finishes_and_changes_no_bit(dev):
+    """cfg.HIP.TRAIN_PICK_STREAMS: the helper slots of the recorded step are re-bound to other physical streams while real steps are timed
+    (replay.StreamPicker).  Any binding is correct by construction -- checked by bits against a run that never replays -- and the search
+    ends with a binding every later step uses."""
+    from model.config import cfg
+    old = (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.TRAIN_PICK_STREAMS)
+    cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.TRAIN_PICK_STREAMS = 64, 0.0, 2
+    steps = 2 + 3 * (1 + 4 * 2) + 4
+    try:
+        l0, d0, _, _, _, _ = _run(dev, _nets()["res50"], "pk0", False, steps)
+        l1, d1, s1, net, sess, _ = _run(dev, _nets()["res50"], "pk1", True, steps)
+    finally:
+        cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.TRAIN_PICK_STREAMS = old
+    assert s1 == dict(eager=1, recorded=1, replayed=steps - 2)
+    assert l1 == l0 and d1 == d0
+    assert not sess.picking and len(sess.picked_streams) == 4 and len(sess.pick_log) <= 9 and sess.pick_log[0][0] == "inherited"

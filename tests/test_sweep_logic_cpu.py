@@ -404,3 +404,95 @@ def test_the_solver_inside_the_sweep_updates_every_tensor_exactly_once_with_the_
     # in-sweep order: the END of the table (the layers the sweep visits first) is updated first
     table_order = [p.w.data_ptr() for p in n1.params.values()]
     assert order1[1][:3] == table_order[-3:] or set(order1[1][:3]) <= set(table_order[-4:])
+
+
+class FakeExchange(object):
+    """stand-in for parallel.BucketedAllReduce: the same range bookkeeping, the 'all-reduce' doubles the range in place (two identical
+    replicas: sum = 2 g) and logs what it was given; wait_sent logs who waited"""
+    multi_stream = True
+
+    def __init__(self, bucket):
+        self.bucket, self.sent_from, self.final_from, self.log = bucket, None, None, []
+
+    def ready(self, flat, data_ptr, stream=None, streams=None):
+        n = flat.numel()
+        if self.sent_from is None:
+            self.sent_from = n
+        off = (int(data_ptr) - flat.data_ptr()) // 4
+        assert self.final_from is None or off <= self.final_from
+        self.final_from = off
+        while self.sent_from - self.final_from >= self.bucket:
+            lo = self.sent_from - self.bucket
+            flat[lo:self.sent_from] *= 2.0
+            self.log.append(("send", lo, self.sent_from, len(streams or [])))
+            self.sent_from = lo
+
+    def wait_sent(self, stream):
+        self.log.append(("wait", self.sent_from))
+
+    def finish(self, flat):
+        hi = flat.numel() if self.sent_from is None else self.sent_from
+        if hi > 0:
+            flat[0:hi] *= 2.0
+            self.log.append(("send", 0, hi, 0))
+        self.sent_from = self.final_from = None
+        return flat
+
+
+def run_dp_steps(monkeypatch, in_sweep, steps=3, chunk=3, bucket=40000):
+    from frcnn_hip import train
+    ops = FakeOps()
+    monkeypatch.setattr(train, "ops", ops)
+    monkeypatch.setattr(torch.cuda, "Stream", lambda device=None: FakeStream())
+    monkeypatch.setattr(torch.cuda, "Event", FakeEvent)
+    sess = FakeSession()
+    net, seeds = build(sess, 5)
+    total = sum(p.grad_w.numel() for p in net.params.values())
+    flat, off = torch.zeros(total), 0
+    for p in net.params.values():                            # the flat gradient buffer in forward order (TrainState.build)
+        n = p.grad_w.numel()
+        p.grad_w = flat[off:off + n].view(p.grad_w.shape)
+        off += n
+    ts = train.TrainState.__new__(train.TrainState)
+    ts.sess, ts.net, ts.params, ts.flat = sess, net, net.params, flat
+    ts._wgrad_events, ts.reg_scopes = None, []
+    ts.momentum, ts.weight_decay, ts.double_bias, ts.bias_decay = 0.9, 1e-4, False, False
+    ts.fuse_chain, ts.pipe_dgrads, ts.winograd, ts.h2_train = True, True, (4, 64, True), 1
+    ts.wgrad_stream, ts.wgrad_tn, ts.wgrad_h2, ts.prep_stream = 2, True, True, False
+    ts.solver_in_sweep, ts.SOLVER_CHUNK, ts.lr = in_sweep, chunk, 1e-4
+    ts.world_size, ts.all_reduce = 2, FakeExchange(bucket)
+    order, sends = [], []
+    for _ in range(steps):
+        ops.updated, ts.all_reduce.log = [], []
+        ts._sweep([(t, g.clone()) for t, g in seeds], FakeStream(), in_sweep)
+        ts.apply(ts.lr, world_size=2, all_reduce=ts.all_reduce)
+        order.append(list(ops.updated))
+        sends.append(list(ts.all_reduce.log))
+    return net, ops.log, order, sends, total
+
+
+def test_data_parallel_sweep_updates_behind_the_exchange_and_equals_the_update_after_the_sweep(monkeypatch):
+    """Data parallel (world 2) with the bucketed exchange: the in-sweep solver may only touch parameters whose gradients the exchange has
+    already taken ([sent_from, end) of the flat buffer), waits for those collectives first, folds the mean (1 / world) into the update,
+    and apply() finishes the rest -- the result equals the solver after the sweep bit for bit, every tensor once per step, and the
+    exchange is told about BOTH filter-gradient streams."""
+    n0, log0, order0, sends0, total = run_dp_steps(monkeypatch, False)
+    n1, log1, order1, sends1, _ = run_dp_steps(monkeypatch, True)
+    for sc in n0.params:
+        assert torch.equal(n0.params[sc].w, n1.params[sc].w), sc
+        assert torch.equal(n0.params[sc].acc_w, n1.params[sc].acc_w), sc
+    every = sorted(p.w.data_ptr() for p in n1.params.values())
+    for upd in order1:
+        assert sorted(upd) == every
+    assert log0["sgd_range"] == 3 and log1["sgd_range"] > 3 + 2          # in-sweep launches from step 2 on
+    step = sends1[1]
+    ranges = [e for e in step if e[0] == "send"]
+    assert ranges[0][2] == total and ranges[-1][1] == 0 and all(a[1] == b[2] for a, b in zip(ranges, ranges[1:]))      # the buffer, back to front, no gap
+    assert any(e[3] == 2 for e in ranges)                                   # ordered after both filter-gradient streams
+    waits = [e for e in step if e[0] == "wait"]
+    assert waits, "the in-sweep solver never waited for the exchange"
+    # every in-sweep update came after a wait, and covered only offsets >= what had been sent by then
+    offs = {p.w.data_ptr(): (p.grad_w.data_ptr() - n1.params[next(iter(n1.params))].grad_w.data_ptr()) // 4 for p in n1.params.values()}
+    sent_at_wait = min(w[1] for w in waits)
+    in_sweep_updates = order1[1][:len(order1[1]) - 1]
+    assert all(offs[w] >= sent_at_wait for w in in_sweep_updates[:3])

@@ -123,6 +123,21 @@ class BucketedAllReduce(object):
         self.final_from = None
         self.handles = []
 
+    multi_stream = True                # ready() takes every stream the gradients may have been enqueued on (TrainState._sweep: two side streams)
+
+    def _order_after(self, streams):
+        """One stream that is behind everything enqueued so far on `streams`: the collective is issued with it current (torch.distributed
+        orders a collective after torch's current stream only)."""
+        from . import ops
+        streams = [st for st in (streams or []) if st is not None]
+        if len(streams) <= 1:
+            return streams[0] if streams else None
+        if getattr(self, "_order", None) is None:
+            self._order = torch.cuda.Stream(device=streams[0].device)
+        for st in streams:
+            ops.st_wait_stream(self._order, st)
+        return self._order
+
     def _send(self, flat, lo, hi, stream=None):
         """One asynchronous all-reduce over flat[lo:hi].  A step that is being recorded (frcnn_hip/replay.py) keeps the call as a host
         operation of the step: a replayed step issues the same collectives at the same points of its launch list."""
@@ -147,10 +162,26 @@ class BucketedAllReduce(object):
             self.host_s += time.perf_counter() - t0
         ops.host_op(send)
 
-    def ready(self, flat, data_ptr, stream=None):
-        """stream: the stream the gradient kernels up to this parameter were enqueued on (the reverse sweep's filter-gradient side
-        stream).  Only a call that actually sends a bucket switches torch's current stream -- a handful per step, not one per parameter
-        (the per-parameter `with torch.cuda.stream(...)` of round 3 cost the host ~4 ms of a 20 ms step)."""
+    def wait_sent(self, stream):
+        """`stream` waits for every all-reduce issued so far (the in-sweep solver: an update reads the summed gradients).  RCCL: a
+        stream-level wait, the host does not block; gloo (tests): the host waits."""
+        from . import ops
+        import frcnn_hip as _binding
+        R = _binding.recorder
+        slot = None if R is None else R.slot(stream)
+
+        def wait(rec):
+            st = stream if (rec is None or slot is None) else rec.bound[slot]
+            with torch.cuda.stream(st):
+                for h in self.handles:
+                    h.wait()
+        ops.host_op(wait)
+
+    def ready(self, flat, data_ptr, stream=None, streams=None):
+        """stream: the stream this parameter's gradient kernels were enqueued on; streams: every stream gradients of LATER parameters
+        (already visited by the reverse sweep) may still be running on -- the collective is ordered after all of them.  Only a call
+        that actually sends a bucket touches streams -- a handful per step, not one per parameter (the per-parameter
+        `with torch.cuda.stream(...)` of round 3 cost the host ~4 ms of a 20 ms step)."""
         n = flat.numel()
         if self.sent_from is None:
             self.sent_from = n
@@ -161,9 +192,12 @@ class BucketedAllReduce(object):
             raise RuntimeError("BucketedAllReduce.ready: offsets must not increase (%d after %d): the flat gradient buffer is not in "
                                "reverse backward order, or a parameter has more than one tape record" % (off, self.final_from))
         self.final_from = off
+        order = None
         while self.sent_from - self.final_from >= self.bucket:
+            if order is None:
+                order = self._order_after(streams if streams else [stream])
             lo = self.sent_from - self.bucket
-            self._send(flat, lo, self.sent_from, stream)
+            self._send(flat, lo, self.sent_from, order)
             self.sent_from = lo
 
     def finish(self, flat):

@@ -158,8 +158,10 @@ class TrainState(object):
         # event recorded after the activation gradient, and is joined before backward() returns.  Data parallel: one side stream, so
         # that "everything behind this offset of the flat gradient is final" holds on the stream the collective is issued from.
         nside = int(getattr(self, "wgrad_stream", 0))
-        if self.data_parallel():
-            nside = min(nside, 1)
+        ar = getattr(self, "all_reduce", None)
+        dp = self.data_parallel() and ar is not None and hasattr(ar, "ready")        # the bucketed, overlapped exchange (parallel.BucketedAllReduce)
+        if self.data_parallel() and not (dp and getattr(ar, "multi_stream", False)):
+            nside = min(nside, 1)                                # a plain all-reduce callable orders itself after ONE stream
         sides = self._wgrad_side_streams(nside)
         turn = [0]
         if self._wgrad_events is None:
@@ -176,7 +178,8 @@ class TrainState(object):
         # regulariser value reads the filters BEFORE any update: it opens the solver stream's step.
         self._sgd_done_from = None
         solver = None
-        if (fuse_solver and sides and not self.data_parallel() and getattr(self, "_sgd_table", None) is not None and getattr(self, "lr", None) is not None
+        if (fuse_solver and sides and (not self.data_parallel() or (dp and getattr(ar, "multi_stream", False)))
+                and getattr(self, "_sgd_table", None) is not None and getattr(self, "lr", None) is not None
                 and getattr(self, "solver_in_sweep", True) and not any(getattr(p, "dw", False) for p in self.params.values())):
             solver = self._solver_stream_obj()
             ops.st_wait_stream(solver, main)                     # (the previous step's apply() -- nothing else of this step matters to it)
@@ -186,6 +189,8 @@ class TrainState(object):
             self._sgd_done_from = self._sgd_count
         pending = [0]                                            # filter gradients enqueued since the last solver launch
 
+        gs = 1.0 / float(getattr(self, "world_size", 1)) if self.data_parallel() else 1.0     # the mean over replicas, folded into the update
+
         def solver_step(first):
             """update table[first, done_from) on the solver stream"""
             while len(self._solver_events) < 1 + len(sides):     # (cfg.HIP.WGRAD_STREAM is not bounded)
@@ -194,10 +199,22 @@ class TrainState(object):
                 ev = self._solver_events[i]
                 ops.ev_record(ev, st)
                 ops.st_wait_event(solver, ev)
+            if dp:
+                ar.wait_sent(solver)                             # ... and behind the all-reduces that sum these gradients over the replicas
             with ops.pinned_stream(solver):
-                ops.sgd_momentum_range(self._sgd_table, first, self._sgd_done_from - first, self.lr, self.momentum, 1.0)
+                ops.sgd_momentum_range(self._sgd_table, first, self._sgd_done_from - first, self.lr, self.momentum, gs)
             self._sgd_done_from = first
             pending[0] = 0
+
+        def dp_solver_step():
+            """data parallel: every parameter whose gradient lies inside the range already handed to the all-reduce ([sent_from, end) of
+            the flat buffer; the descriptor table is in the buffer's order) can be updated behind that collective"""
+            if solver is None or ar.sent_from is None:
+                return
+            import bisect
+            first = bisect.bisect_left(self._sgd_offsets, int(ar.sent_from))
+            if first < self._sgd_done_from:
+                solver_step(first)
 
         def on_side(fn):
             if not sides:
@@ -320,9 +337,8 @@ class TrainState(object):
                 if p is not None:
                     def dw_wgrad(sfx, side, gy=gy, x=x, rec=rec, p=p):
                         ops.dwconv3x3_wgrad(gy, x, rec["stride"], rec["pad"], p.scale, p.grad_w)
-                        ar = getattr(self, "all_reduce", None)
-                        if ar is not None and self.data_parallel() and hasattr(ar, "ready"):
-                            ar.ready(self.flat, p.grad_w.data_ptr(), side)
+                        if dp:
+                            ar.ready(self.flat, p.grad_w.data_ptr(), side, sides)
                     on_side(dw_wgrad)
                 if x.data_ptr() in needs:
                     gx, had = accumulate_into(x, x.shape, sc + "/in")
@@ -370,9 +386,8 @@ class TrainState(object):
                         self.count_flops("h2" if getattr(self, "wgrad_h2", False) else "f32", 2 * M * Cout * p.K)
                         if p.bias is not None:
                             ops.colsum(gy.view(M, Cout), p.grad_b)
-                        ar = getattr(self, "all_reduce", None)
-                        if ar is not None and self.data_parallel() and hasattr(ar, "ready"):
-                            ar.ready(self.flat, p.grad_w.data_ptr(), side)
+                        if dp:
+                            ar.ready(self.flat, p.grad_w.data_ptr(), side, sides)
                         return
                     Mp = (M + 31) // 32 * 32
                     gyT = ops.transpose_pad(gy.view(M, Cout), Mp, out=sess.buf("bwd/gyT" + sfx, (Cout, Mp)))
@@ -385,12 +400,11 @@ class TrainState(object):
                     self.count_flops("f32", 2 * M * Cout * p.K)
                     if p.bias is not None:
                         ops.colsum(gy.view(M, Cout), p.grad_b)
-                    ar = getattr(self, "all_reduce", None)
-                    if ar is not None and self.data_parallel() and hasattr(ar, "ready"):
+                    if dp:
                         # this parameter's gradient is enqueued: everything from its offset to the end of the flat buffer is final
-                        # (the tape is walked backwards, the buffer is laid out in forward order, and every wgrad is enqueued on the
-                        # same stream -- the collective orders itself after the stream it is issued from)
-                        ar.ready(self.flat, p.grad_w.data_ptr(), side)
+                        # (the tape is walked backwards, the buffer is laid out in forward order; the collective orders itself after
+                        # every side stream a filter gradient may have been enqueued on)
+                        ar.ready(self.flat, p.grad_w.data_ptr(), side, sides)
                 on_side(wgrad)
             if x.data_ptr() in needs:
                 key = x.data_ptr()
@@ -496,7 +510,10 @@ class TrainState(object):
             if solver is not None and p is not None:
                 pending[0] += 1
                 first = self._sgd_entry.get(sc)
-                if pending[0] >= self.SOLVER_CHUNK and first is not None and first < self._sgd_done_from:
+                if dp:
+                    if pending[0] >= self.SOLVER_CHUNK:
+                        dp_solver_step()                         # (what the exchange has taken so far; pending counts on if nothing new was sent)
+                elif pending[0] >= self.SOLVER_CHUNK and first is not None and first < self._sgd_done_from:
                     solver_step(first)                           # this record's data gradient is enqueued: its filter has no reader left
         for side in sides:
             ops.st_wait_stream(main, side)       # the solver (and the next forward pass, which overwrites x) come after every wgrad
@@ -559,6 +576,9 @@ class TrainState(object):
                                     wd if self.bias_decay else 0.0))
             self._sgd_count = len(entries)
             self._sgd_table = ops.sgd_desc_table(entries, self.sess.device)
+            # gradient offset of every descriptor inside the flat buffer (ascending: the table is in forward order like the buffer)
+            self._sgd_offsets = None if self.flat is None else [(e[3].data_ptr() - self.flat.data_ptr()) // 4 for e in entries]
+            assert self._sgd_offsets is None or self._sgd_offsets == sorted(self._sgd_offsets)
             self._sgd_entry, i = {}, 0                 # scope -> index of its first descriptor (filter, then bias)
             for p in self.params.values():
                 self._sgd_entry[p.scope] = i

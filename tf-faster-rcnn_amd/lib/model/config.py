@@ -115,13 +115,15 @@ __C = AttrDict(
     # launches).  False: every step is enqueued by the Python code (the form rounds 1-4 measured).
     # TRAIN_PICK_STREAMS (with TRAIN_REPLAY): n > 0 -- the physical streams of the step's helper slots (filter gradients, solver, filter
     # preparation) are chosen once per session by timing real steps over a pool of n fresh streams (frcnn_hip/replay.py StreamPicker): which
-    # hardware queue a stream lands on depends on who created streams before (an RCCL group that merely exists: +4 ms per step in round 4).
+    # hardware queue a stream lands on depends on who created streams before (an RCCL group that merely exists: +4 ms per step in round 4;
+    # with the picker the data-parallel-rules step went from 25.2 to 20.0 ms, profiles/r05_j_c5_dp_rules_ab_stream_picker.txt).  Default 6:
+    # 1 + 6 x (helper slots) windows of 3 real steps at start-up (~2 s); 0 = keep the streams the step was recorded on.
     # H2_TILE_CFG: -1 = tile shape by launch size (csrc/gemm_h2.hip), else a frcnn_gemm_h2 configuration id for every launch (A/B runs).
     HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=64, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=("block1", "block2"), WINOGRAD_DIRECT_SCOPES=(),
              WINOGRAD_TRAIN=True,
              WINOGRAD_7X7=True, FUSE_TAIL_MEAN=True, MFMA_X3=True,
              MFMA_H2=True, H2_LAZY_SPLIT=True, H2_MIN_TILES=150, H2_TRUNK_PLANES=True, H2_TILE_CFG=-1,
-             X3_TILE_CFG=-1, H2_TRAIN=True, WGRAD_STREAM=2, WGRAD_TN=True, WGRAD_H2=True, PREP_STREAM=True, TRAIN_REPLAY=True, TRAIN_PICK_STREAMS=0))
+             X3_TILE_CFG=-1, H2_TRAIN=True, WGRAD_STREAM=2, WGRAD_TN=True, WGRAD_H2=True, PREP_STREAM=True, TRAIN_REPLAY=True, TRAIN_PICK_STREAMS=6))
 __C.DATA_DIR = osp.abspath(osp.join(__C.ROOT_DIR, 'data'))
 cfg = __C
 
