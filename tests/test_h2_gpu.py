@@ -237,12 +237,17 @@ def test_depthwise_conv_emits_the_planes_of_its_f32_result(dev, N, H, W, C, stri
 
 
 @pytest.mark.parametrize("shape", [(1, 256 * 300 + 40, 512, 512, True), (1, 58800, 512, 2048, False), (121, 1200, 512, 512, False),
-                                   (1, 9576, 1024, 256, True), (3, 300, 128, 128, False)], ids=["many_tiles", "b4c1", "w7", "b3c3", "tiny"])
-@pytest.mark.parametrize("pp", [21, 12])
+                                   (1, 9576, 1024, 256, True), (3, 300, 128, 128, False), (1, 9576, 1024, 256, "planes"),
+                                   (1, 128 * 70 + 9, 2048, 512, "planes")],
+                         ids=["many_tiles", "b4c1", "w7", "b3c3", "tiny", "b3c3_trunk_planes", "b4c3_trunk_planes"])
+@pytest.mark.parametrize("pp", [21, 12, 30, 31, 32, 33, -1])
 def test_gemm_h2_ping_pong_is_bit_identical_to_the_one_barrier_schedule(dev, shape, pp):
-    """cfg 21 (256 x 128 tiles, two wave groups a segment apart, 3-slot ring) and cfg 12 (64-row tiles) multiply and fold in the same order as cfg 9: the f32
-    result, the emitted planes and the block scales must be the same BITS, on every one of several launches (a schedule with a race
-    differs from launch to launch), with several tiles per resident workgroup and M tails."""
+    """cfg 21 (256 x 128 tiles, two wave groups a segment apart, 3-slot ring), cfg 12 (64-row tiles), round 5's cfgs 30-33 (the light tile
+    boundary: filter scales + bias through LDS, the residual raw in the accumulators until the first fold, counted vmcnt, 16-byte plane
+    stores) and the by-shape choice (-1) multiply and fold in the same order as cfg 9: the f32 result, the emitted planes and the block
+    scales must be the same BITS, on every one of several launches (a schedule with a race differs from launch to launch), with several
+    tiles per resident workgroup and M tails -- incl. the conv3 class (K = 256 / 512, residual + f32 + planes) with the residual given as
+    float32 or as operand planes (cfg.HIP.H2_TRUNK_PLANES, the default since round 5)."""
     from frcnn_hip import ops
     G, M, N, K, with_res = shape
     torch.manual_seed(G + M)
@@ -250,6 +255,8 @@ def test_gemm_h2_ping_pong_is_bit_identical_to_the_one_barrier_schedule(dev, sha
     w = torch.randn(G, N, K, device=dev) / K ** 0.5
     b = torch.randn(N, device=dev) if G == 1 else None
     r = torch.randn(G * M, N, device=dev) if with_res else None
+    if with_res == "planes":
+        r = ops.h2_split(r.clamp(min=0) * torch.exp(torch.rand(G * M, N, device=dev) * 4 - 2))
     xp, wp = ops.h2_split(x), ops.h2_pack_w(w)
     ref, refp = torch.empty(G * M, N, device=dev), ops.H2.empty(G * M, N, dev)
     ops.gemm_h2(xp, wp, G, M, N, K, b, r, 1, out=ref, out_planes=refp, cfg=9)
