@@ -278,7 +278,7 @@ int frcnn_gemm_x3(const float* x_d, const void* planes_d, const float* bias_d, c
  *   frcnn_gemm_h2:    y[g] = act(x[g] W[g]^T + bias + res[g]), g < G; x as planes [2][G*M][K] + x_inv [K/128][G*M]; res / y [G*M][N] f32 (y may be
  *                     NULL); res_planes / res_inv (instead of res, may be NULL): the residual as operand planes [2][G*M][N] + [N/128][G*M],
  *                     read as (h + l) * 2^-e -- the trunk of a bottleneck chain kept as planes only (cfg.HIP.H2_TRUNK_PLANES); y_planes / y_inv (may be NULL): the result as operand planes [2][G*M][N] + [N/128][G*M] for the next GEMM, emitted
- *                     from the register epilogue (bit-identical to frcnn_h2_split of y).  K % 128 == 0, N % 128 == 0, any M.  cfg: -1 = by shape, else a tile configuration id (per call: no process-wide state). */
+ *                     from the register epilogue (bit-identical to frcnn_h2_split of y).  K % 128 == 0, N % 128 == 0, any M.  cfg: -1 = by shape (-2 ... -5: other by-shape rules, A/B runs), else a tile configuration id (per call: no process-wide state; every configuration gives the same bits). */
 size_t frcnn_h2_planes_bytes(long long rows, int K);
 int frcnn_h2_pack_w(const float* w_d, int G, int N, int K, void* planes_d, float* w_inv_d, void* stream);
 int frcnn_h2_split(const float* x_d, long long M, int K, void* planes_d, float* inv_d, void* stream);

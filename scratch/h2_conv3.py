@@ -26,6 +26,8 @@ shapes = {  # name: (G, M, N, K, residual, f32 out, planes out, mean rows)
     "b4c3x8m": (8, 14700, 2048, 512, True, False, False, 49),      # block4 unit 3 conv3 + reduce_mean (one batch entry per image)
     "b3c3x8":  (1, 19152, 1024, 256, True, True, True, 0),         # block3 conv3 (23 per step)
     "b2c3x8":  (1, 75000, 512, 128, True, True, True, 0),          # block2 conv3
+    "b4c3x8p": (1, 117600, 2048, 512, "planes", False, True, 0),   # ... as shipped since round 5 (cfg.HIP.H2_TRUNK_PLANES): residual read as planes, planes only out
+    "b3c3x8p": (1, 19152, 1024, 256, "planes", False, True, 0),
     "b3scx8":  (1, 19152, 1024, 512, False, True, True, 0),        # block3 unit 1 shortcut
     "w7x8":    (121, 2400, 512, 512, False, True, False, 0),       # 7 x 7 Winograd products of the tail's conv2
     "w3x8":    (36, 1280, 256, 256, False, True, False, 0),        # block3 conv2's Winograd products
@@ -47,6 +49,8 @@ for name in only:
     w = torch.randn(1 if shared_w else G, N, K, device=dev) * 0.05
     b = torch.randn(N, device=dev) if (G == 1 or shared_w) else None
     res = torch.randn(G * M, N, device=dev) if has_res else None
+    if has_res == "planes":
+        res = ops.h2_split(res.clamp(min=0))
     xp, wp = ops.h2_split(x), ops.h2_pack_w(w)
     del x
     outs, outp = {}, {}

@@ -240,7 +240,7 @@ def test_depthwise_conv_emits_the_planes_of_its_f32_result(dev, N, H, W, C, stri
                                    (1, 9576, 1024, 256, True), (3, 300, 128, 128, False), (1, 9576, 1024, 256, "planes"),
                                    (1, 128 * 70 + 9, 2048, 512, "planes")],
                          ids=["many_tiles", "b4c1", "w7", "b3c3", "tiny", "b3c3_trunk_planes", "b4c3_trunk_planes"])
-@pytest.mark.parametrize("pp", [21, 12, 30, 31, 32, 33, -1])
+@pytest.mark.parametrize("pp", [21, 12, 30, 31, 32, 33, 34, -1, -4])
 def test_gemm_h2_ping_pong_is_bit_identical_to_the_one_barrier_schedule(dev, shape, pp):
     """cfg 21 (256 x 128 tiles, two wave groups a segment apart, 3-slot ring), cfg 12 (64-row tiles), round 5's cfgs 30-33 (the light tile
     boundary: filter scales + bias through LDS, the residual raw in the accumulators until the first fold, counted vmcnt, 16-byte plane

@@ -1112,19 +1112,23 @@ static int run_h2(GemmH2Params& p, int cfg, hipStream_t st) {
 #ifndef FRCNN_H2_PP_MIN_K
 #define FRCNN_H2_PP_MIN_K 1024          // (scratch/bench_ablation.py rebuilds with other values: 512 measured in the pipeline, profiles/r04_u)
 #endif
-    const bool pp = K >= FRCNN_H2_PP_MIN_K && mt256 * 256 * 100 <= (long long)M * 104 && mt256 * (N / 128) * G >= 256;
+    // cfg -3 / -4 / -5 (A/B runs, round 5): the ping-pong tiles with 16-byte plane stores (cfg 34) and / or the conv3 class (K = 512,
+    // result tensor written: not the fused-mean form, which loses on one workgroup per CU -- profiles/r05_b) on the ping-pong schedule too
+    const int pp_min_k = ((cfg == -4 || cfg == -5) && !p.mean_part) ? 512 : FRCNN_H2_PP_MIN_K;
+    const int pp_cfg = (cfg == -3 || cfg == -4) ? 34 : 21;
+    const bool pp = K >= pp_min_k && mt256 * 256 * 100 <= (long long)M * 104 && mt256 * (N / 128) * G >= 256;
     // fewer than 150 tiles of 128 x 128 (a single image's launches: batch-1 latency mode): 64-row tiles, three workgroups per CU
     // (profiles/r03_g_h2_sweep.txt: 21.8 vs 30.9 us on one image's block3 conv1); in the 4-image pipeline these lose (r03_l_ab.txt)
     const bool tiny = (long long)((M + 127) / 128) * (N / 128) * G < 150;
     // cfg == -2: round 4's choice (A/B runs).  Round 5: the same tiles with the light tile boundary and 16-byte plane stores (31, 33):
     // bit-identical, 5-16 % faster on the short-K launches, indifferent elsewhere (profiles/r05_b_h2_conv3.txt)
-    cfg = pp ? 21 : tiny ? (cfg == -2 ? 12 : 33) : (cfg == -2 ? 9 : 31);
+    cfg = pp ? pp_cfg : tiny ? (cfg == -2 ? 12 : 33) : (cfg == -2 ? 9 : 31);
   }
   if (p.mask) switch (cfg) {            // frcnn_gemm_h2_masked: round 4's three configurations with the mask in the epilogue (the light tile
     case 9: case 30: case 31: case 32:  // boundary of cfgs 30-33 has no masked instantiation: those ids take the schedule they derive from)
       return launch_h2<128, 128, 64, 64, 2, 2, 2 + 128>(p, st);
     case 12: case 33: return launch_h2<64, 128, 32, 64, 2, 2, 128>(p, st);
-    case 21: return launch_h2<256, 128, 64, 64, 3, 2, 34 + 128>(p, st);
+    case 21: case 34: return launch_h2<256, 128, 64, 64, 3, 2, 34 + 128>(p, st);
     default: return FRCNN_E_ARG;
   }
   switch (cfg) {
@@ -1135,6 +1139,7 @@ static int run_h2(GemmH2Params& p, int cfg, hipStream_t st) {
     case 31: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 256 + 512>(p, st);  // ... and 16-byte plane stores
     case 32: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 512>(p, st);        // cfg 9 with 16-byte plane stores only
     case 33: return launch_h2<64, 128, 32, 64, 2, 2, 256 + 512>(p, st);       // cfg 12 with both
+    case 34: return launch_h2<256, 128, 64, 64, 3, 2, 34 + 512>(p, st);       // cfg 21 (ping-pong) with 16-byte plane stores
 #ifdef FRCNN_ABLATION
     // measurement builds only (scratch/ablation_lib.py): the configurations the sweeps under profiles/r03_*, r04_* compare.  All of
     // them multiply and fold in the same order as the three above (bit-identical results; measured, not shipped).
