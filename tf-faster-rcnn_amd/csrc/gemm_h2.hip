@@ -1114,8 +1114,9 @@ static int run_h2(GemmH2Params& p, int cfg, hipStream_t st) {
 #endif
     // cfg -3 / -4 / -5 (A/B runs, round 5): the ping-pong tiles with 16-byte plane stores (cfg 34) and / or the conv3 class (K = 512,
     // result tensor written: not the fused-mean form, which loses on one workgroup per CU -- profiles/r05_b) on the ping-pong schedule too
-    const int pp_min_k = ((cfg == -4 || cfg == -5) && !p.mean_part) ? 512 : FRCNN_H2_PP_MIN_K;
-    const int pp_cfg = (cfg == -3 || cfg == -4) ? 34 : 21;
+    // -6: cfg 34 for the conv3 class only, the long-K launches stay on cfg 21
+    const int pp_min_k = ((cfg == -4 || cfg == -5 || cfg == -6) && !p.mean_part) ? 512 : FRCNN_H2_PP_MIN_K;
+    const int pp_cfg = (cfg == -3 || cfg == -4 || (cfg == -6 && K < FRCNN_H2_PP_MIN_K)) ? 34 : 21;
     const bool pp = K >= pp_min_k && mt256 * 256 * 100 <= (long long)M * 104 && mt256 * (N / 128) * G >= 256;
     // fewer than 150 tiles of 128 x 128 (a single image's launches: batch-1 latency mode): 64-row tiles, three workgroups per CU
     // (profiles/r03_g_h2_sweep.txt: 21.8 vs 30.9 us on one image's block3 conv1); in the 4-image pipeline these lose (r03_l_ab.txt)

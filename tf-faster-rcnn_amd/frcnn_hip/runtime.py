@@ -47,17 +47,28 @@ class VariableStore(object):
             truncated = bool(cfg.TRAIN.TRUNCATED)
         except ImportError:
             pass
+        def randn_scaled(shape, scale):
+            """(rng.randn(*shape) * scale).astype(float32), drawn in 2^20-sample pieces: the same stream and the same float64 product, without
+            the two float64 temporaries of the whole tensor (VGG16's fc6 is 103 M elements: 1.6 GB of first-touch pages per network)."""
+            n = int(np.prod(shape))
+            out = np.empty((n,), dtype=np.float32)
+            for o in range(0, n, 1 << 20):
+                m = min(1 << 20, n - o)
+                out[o:o + m] = rng.randn(m) * scale
+            return out.reshape(shape)
+
         for name, sp in specs.items():
             if sp.init == "he":
                 fan_in = int(np.prod(sp.shape[:-1]))
-                v = rng.randn(*sp.shape) * np.sqrt(2.0 / fan_in)
+                v = randn_scaled(sp.shape, np.sqrt(2.0 / fan_in))
+            elif sp.init == "normal" and not truncated:
+                v = randn_scaled(sp.shape, sp.arg)
             elif sp.init == "normal":
-                v = rng.randn(*sp.shape)
-                if truncated:                 # cfg.TRAIN.TRUNCATED (network.py:235-240): tf.truncated_normal_initializer re-draws |z| > 2
+                v = rng.randn(*sp.shape)      # cfg.TRAIN.TRUNCATED (network.py:235-240): tf.truncated_normal_initializer re-draws |z| > 2
+                bad = np.abs(v) > 2.0
+                while bad.any():
+                    v[bad] = rng.randn(int(bad.sum()))
                     bad = np.abs(v) > 2.0
-                    while bad.any():
-                        v[bad] = rng.randn(int(bad.sum()))
-                        bad = np.abs(v) > 2.0
                 v = v * sp.arg
             elif sp.init == "zeros":
                 v = np.zeros(sp.shape)
