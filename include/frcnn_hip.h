@@ -156,7 +156,8 @@ int frcnn_crop_and_resize_batched(const float* feat_d, int N, int H, int W, int 
 int frcnn_crop_and_resize_bias_act(const float* feat_d, int N, int H, int W, int C, const float* rois_d, int R,
                                    float feat_stride, int pool, const float* bias_d, int act, float* out_d,
                                    void* stream);
-/* tuning knob for A/B runs: key 4 = channel-slab count of the crop kernels (-1 automatic). */
+/* tuning knobs for A/B runs (thread-local): key 4 = channel-slab count of the crop kernels (-1 automatic); key 5 = 1: the crop as one workgroup
+ * per (roi, output row, slab) (rounds 2-4) instead of one per (roi, slab) -- the same bits. */
 int frcnn_detect_set_tuning(int key, int value);
 
 /* ---- test-time post-processing: replaces lib/model/test.py:95-102 (im_detect) and :162-180

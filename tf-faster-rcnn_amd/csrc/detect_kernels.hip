@@ -987,7 +987,65 @@ __global__ __launch_bounds__(256) void k_crop_and_resize(const float4* __restric
   }
 }
 
+// Round 5: one workgroup per (roi, channel slab) -- all pool x pool output pixels of the RoI -- instead of one per (roi, output row, slab).
+// The row form launches R * pool * 8 workgroups of 112-448 float4 results each (C = 512: 144 of 256 threads idle) and every one of them
+// re-derives the RoI's geometry; the launch was bound by workgroup dispatch (134 400 workgroups in 249 us), not by bytes.  Same
+// crop_sample per element: the same bits.  ITEMS results per thread are in flight together (their 4 taps each are independent loads).
+template <bool MAX2, int ITEMS>
+__global__ __launch_bounds__(256) void k_crop_and_resize_roi(const float4* __restrict__ feat_all, int NIMG, int H, int W, int C4,
+                                                             int nslab, const float* __restrict__ rois, float stride, int pool,
+                                                             const float4* __restrict__ bias, int act, float4* __restrict__ out) {
+  const int slab = blockIdx.x % nslab, r = blockIdx.x / nslab;
+  const int SC4 = C4 / nslab, c40 = slab * SC4;
+  const float height = ((float)H - 1.0f) * stride, width = ((float)W - 1.0f) * stride;   // network.py:146-147
+  const float* roi = rois + 5 * (size_t)r;
+  const int img = (int)roi[0];
+  float4* obase = out + (size_t)r * pool * pool * C4;
+  const int total = pool * pool * SC4;
+  if (img < 0 || img >= NIMG) {
+    for (int t = threadIdx.x; t < total; t += 256) obase[(size_t)(t / SC4) * C4 + c40 + t % SC4] = make_float4(0, 0, 0, 0);
+    return;
+  }
+  const float4* feat = feat_all + (size_t)img * H * W * C4;
+  const float x1 = roi[1] / width, y1 = roi[2] / height, x2 = roi[3] / width, y2 = roi[4] / height;
+  const int P = MAX2 ? 2 * pool : pool;
+  const float hs = (y2 - y1) * (float)(H - 1) / (float)(P - 1);
+  const float ws = (x2 - x1) * (float)(W - 1) / (float)(P - 1);
+  for (int t0 = threadIdx.x; t0 < total; t0 += 256 * ITEMS) {
+    float4 v[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const int t = t0 + k * 256;
+      if (t >= total) { v[k] = make_float4(0, 0, 0, 0); continue; }
+      const int pix = t / SC4, c4 = c40 + t % SC4;
+      const int py = pix / pool, px = pix - py * pool;
+      if (MAX2) {
+        v[k] = crop_sample(feat, H, W, C4, c4, y1, x1, hs, ws, 2 * py, 2 * px);
+        v[k] = max4(v[k], crop_sample(feat, H, W, C4, c4, y1, x1, hs, ws, 2 * py, 2 * px + 1));
+        v[k] = max4(v[k], crop_sample(feat, H, W, C4, c4, y1, x1, hs, ws, 2 * py + 1, 2 * px));
+        v[k] = max4(v[k], crop_sample(feat, H, W, C4, c4, y1, x1, hs, ws, 2 * py + 1, 2 * px + 1));
+      } else {
+        v[k] = crop_sample(feat, H, W, C4, c4, y1, x1, hs, ws, py, px);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+      const int t = t0 + k * 256;
+      if (t >= total) continue;
+      const int pix = t / SC4, c4 = c40 + t % SC4;
+      float4 o = v[k];
+      if (bias) {
+        const float4 bv = bias[c4];
+        o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+      }
+      if (act == FRCNN_ACT_RELU) o = act_relu(o);
+      obase[(size_t)pix * C4 + c4] = o;
+    }
+  }
+}
+
 static thread_local int g_crop_slabs = -1;      // tuning (frcnn_set_tuning key 4): -1 automatic, else the channel-slab count
+static thread_local int g_crop_form = 0;        // tuning key 5 (A/B runs): 0 = one workgroup per (roi, slab) [round 5]; 1 = per (roi, output row, slab)
 
 static int launch_crop(const float* feat_d, int NIMG, int H, int W, int C, const float* rois_d, int R, float feat_stride, int pool,
                        int fuse_max2x2, const float* bias_d, int act, float* out_d, void* stream) {
@@ -997,9 +1055,23 @@ static int launch_crop(const float* feat_d, int NIMG, int H, int W, int C, const
   hipStream_t st = (hipStream_t)stream;
   const int C4 = C / 4;
   int nslab = (C4 % 8 == 0 && C4 / 8 >= 16) ? 8 : 1;    // >= 256-byte runs per slab
+  // the per-RoI form wants >= 512-byte runs (profiles/r05_o_crop_forms.txt: C = 512 on 4 slabs 74 us, on 8 slabs 83, on 16 104; C = 2048 on 8
+  // slabs 349 us, on 4 slabs 400): 4 slabs put slab s on XCDs s and s + 4
+  if (g_crop_form == 0 && nslab == 8 && C4 / 8 < 32) nslab = 4;
   if (g_crop_slabs > 0 && C4 % g_crop_slabs == 0) nslab = g_crop_slabs;
   const long long blocks = (long long)R * pool * nslab;
   if (blocks >= (1ll << 31)) return FRCNN_E_UNSUPPORTED;
+  if (g_crop_form == 0) {
+    const unsigned grid = (unsigned)((long long)R * nslab);
+    if (fuse_max2x2)
+      hipLaunchKernelGGL((k_crop_and_resize_roi<true, 2>), dim3(grid), dim3(256), 0, st, (const float4*)feat_d, NIMG, H, W, C4, nslab, rois_d,
+                         feat_stride, pool, (const float4*)bias_d, act, (float4*)out_d);
+    else
+      hipLaunchKernelGGL((k_crop_and_resize_roi<false, 4>), dim3(grid), dim3(256), 0, st, (const float4*)feat_d, NIMG, H, W, C4, nslab, rois_d,
+                         feat_stride, pool, (const float4*)bias_d, act, (float4*)out_d);
+    LAUNCH_CHECK();
+    return FRCNN_OK;
+  }
   if (fuse_max2x2)
     hipLaunchKernelGGL(k_crop_and_resize<true>, dim3((unsigned)blocks), dim3(256), 0, st, (const float4*)feat_d, NIMG, H, W, C4, nslab,
                        rois_d, feat_stride, pool, (const float4*)bias_d, act, (float4*)out_d);
@@ -1012,6 +1084,7 @@ static int launch_crop(const float* feat_d, int NIMG, int H, int W, int C, const
 
 extern "C" int frcnn_detect_set_tuning(int key, int value) {
   if (key == 4) { g_crop_slabs = value; return FRCNN_OK; }
+  if (key == 5) { g_crop_form = value; return FRCNN_OK; }
   return FRCNN_E_ARG;
 }
 
