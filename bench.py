@@ -99,9 +99,9 @@ class Telemetry(object):
     """Shader clock / socket power sampled from the amdgpu sysfs nodes while a region runs (a thread reading a few small files every
     100 ms: no subprocess, nothing on the device).  The node shows every card of the machine, also those other tenants run on: the card
     of THIS process is found by its PCI address (`pci` = "domain:bus:device" of the torch device); only when that fails, the card drawing
-    the most power is taken.  `other_cards_max_w` = the busiest OTHER card during the region: a neighbour under load shares the host's
-    PCIe / memory fabric, which a chain of ~300 dependent 10 us launches (the batch-1 latency) feels (profiles/r05_z vs r05_n: 4.96 ms
-    beside a 1.2 kW neighbour, 4.04 ms on a quiet node).  None when the nodes are not there."""
+    the most power is taken.  `other_cards_max_w` = the busiest OTHER card during the region (context for a reader: the node is shared;
+    profiles/r05_t shows the batch-1 latency at 4.00 ms beside neighbours at 1.1-1.4 kW, so their load alone does not explain the 4.95 ms
+    some boxes give).  None when the nodes are not there."""
 
     def __init__(self, pci=None):
         import glob
@@ -372,6 +372,7 @@ def run_timed(step, steps, warmup, dist=None, sync=None, between=None):
         step(k)
         if between:
             between()
+    run_timed.enqueue_s = time.perf_counter() - t0          # the host's share: every step enqueued, the device not yet waited for
     sync()
     if dist is not None:
         dist.barrier()
@@ -647,6 +648,7 @@ def main():
                 break
             prev = t
     elapsed = timed_region()
+    host_enqueue_s = getattr(run_timed, "enqueue_s", 0.0)       # (of the timed region that counts: a graph launch per step and chain)
     exchange_ok = None
     if world > 1:
         # self-check of the collective, untimed: one more step on every chain, then every rank verifies every slot (a wrong or stale
@@ -715,6 +717,7 @@ def main():
         out["config"] = {"workload": c["label"] + "; image in HBM -> <=100 detections in HBM", "images_per_gpu_per_step": B,
                          "chains_in_flight_per_gpu": S, "parallelism": "dp%d (one batch per GPU, all-gather of detection records)" % world,
                          "launch": "eager" if args.no_graph else "hipGraph replay", "rois": n_rois, "detections": n_det,
+                         "host_enqueue_ms_per_step": round(1000.0 * host_enqueue_s / args.steps, 3),
                          "nms_rule": "cpu_nms (ovr >= thresh)",
                          "winograd": {"m": int(cfg.HIP.WINOGRAD_M), "f2_scopes": list(cfg.HIP.WINOGRAD_F2_SCOPES),
                                       "direct_scopes": list(cfg.HIP.WINOGRAD_DIRECT_SCOPES), "crops_7x7": bool(cfg.HIP.WINOGRAD_7X7)}
@@ -848,7 +851,7 @@ def main():
                                          "from image in HBM to detections in HBM; warmed until two consecutive windows agree within 1 %",
                                          "steps": lat["steps"], "sclk_mhz": lat.get("sclk_mhz"), "socket_w": lat.get("socket_w"),
                                          "warm_windows": lat.get("warm_windows"), "other_cards_max_w": lat.get("other_cards_max_w"),
-                                         "note": "a chain of ~300 dependent launches of ~10 us: sensitive to the dispatch latency the host fabric gives; "
+                                         "note": "a chain of ~300 dependent graph nodes of ~10 us; two regimes box by box (4.0 / 4.95 ms, DESIGN section 0); "
                                                  "other_cards_max_w = the busiest neighbouring card of the node during the run"}
             elif lat:
                 out["latency_batch1"] = lat
