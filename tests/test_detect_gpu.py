@@ -226,6 +226,17 @@ def test_crop_and_resize_vs_oracle(dev, H, W, C, R, pool, mp):
     assert got.shape == want.shape
     assert np.array_equal(got, want)                                   # same f32 op order, no contraction
     assert (want == 0).any() and (want != 0).any()
+    # both work splits of the kernel (round 5: one workgroup per (roi, slab); rounds 2-4: per (roi, output row, slab)) and other slab
+    # counts: the same crop_sample per element -> the same bits
+    import frcnn_hip
+    L = frcnn_hip.lib()
+    try:
+        for form, slabs in ((1, -1), (0, 1), (0, 2), (1, 2)):
+            L.frcnn_detect_set_tuning(5, form); L.frcnn_detect_set_tuning(4, slabs)
+            alt = ops.crop_and_resize(T(feat, dev), T(rois, dev), 16.0, pool, max_pool=mp).cpu().numpy()
+            assert np.array_equal(alt, want), (form, slabs)
+    finally:
+        L.frcnn_detect_set_tuning(5, 0); L.frcnn_detect_set_tuning(4, -1)
 
 
 @pytest.mark.parametrize("tag,R,C,W,H", [("voc_300x21", 300, 21, 1000.0, 600.0), ("coco_1000x81", 1000, 81, 1333.0, 800.0)])
