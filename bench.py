@@ -760,12 +760,19 @@ def main():
                         break
                     except Exception:
                         traffic = None
-            # what rocprofv3 counters say binds the conv3-class launch (block4 conv3 alone, profiles/r05_a_pmc_b4c3x8_cfg9.txt): the waves
-            # wait on s_waitcnt 0.57 of their cycles, the matrix pipe is busy 0.24, write requests stall 0.02 of the cycles -- latency inside
-            # the tile's serial chain, neither pipe nor HBM
-            counters = {"source": "profiles/r05_a_pmc_b4c3x8_cfg9.txt (block4 conv3 alone, 8 images)", "SQ_WAIT_INST_ANY/SQ_WAVE_CYCLES": 0.573,
-                        "SQ_WAIT_ANY/SQ_WAVE_CYCLES": 0.244, "mfma_busy": 0.243, "TCC_EA0_WRREQ_STALL/TCC_EA0_WRREQ": 0.023,
-                        "SQ_LDS_BANK_CONFLICT": 0, "reading": "latency-bound: waves parked on s_waitcnt, neither the matrix pipe nor HBM saturated"}
+            # what rocprofv3 counters say binds the conv3-class launch as it is shipped (block4 conv3 alone: residual as planes, planes out,
+            # cfg 31; separate --pmc passes, scratch/gpu_r05_v.sh -> the committed JSON): the waves wait on s_waitcnt half of their cycles,
+            # the matrix pipe is busy 0.28, write requests stall 0.06 -- latency inside the tile's serial chain, neither pipe nor HBM
+            counters = None
+            cpath = os.path.join(ROOT, "profiles", "r05_counters_conv3.json")
+            if os.path.exists(cpath):
+                try:
+                    cj = json.load(open(cpath))
+                    counters = {k: cj[k] for k in ("source", "SQ_WAIT_INST_ANY/SQ_WAVE_CYCLES", "SQ_WAIT_ANY/SQ_WAVE_CYCLES", "mfma_busy",
+                                                   "TCC_EA0_WRREQ_STALL/TCC_EA0_WRREQ", "SQ_LDS_BANK_CONFLICT", "hbm_bytes_per_launch") if k in cj}
+                    counters["reading"] = "latency-bound: waves parked on s_waitcnt, neither the matrix pipe nor HBM saturated"
+                except Exception:
+                    counters = None
             whole_launched = flops_per_image * value / world / 1e12
             peaks = {"h2": H2_PEAK_TFLOPS, "x3": X3_PEAK_TFLOPS, "f32": F32_MFMA_PEAK_TFLOPS}
             t_at_peak = sum(pp[1] / (peaks[k] * 1e12) for k, pp in pipes.items())       # seconds the issued MFMA mix needs at its pipes' peaks
