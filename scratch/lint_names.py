@@ -36,4 +36,28 @@ for f in files:
         if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load) and n.id not in bound:
             print("%s:%d: undefined name %r" % (os.path.relpath(f, ROOT), n.lineno, n.id))
             bad += 1
+    # `self` / `cls` loaded inside a method that does not receive it (a @staticmethod edited as if it were a method: round 5 lost 8 GPU-minutes
+    # to exactly that); nested functions and lambdas see the enclosing method's arguments
+    def scan(fn, seen):
+        a = fn.args
+        seen = seen | {x.arg for x in a.posonlyargs + a.args + a.kwonlyargs + ([a.vararg] if a.vararg else []) + ([a.kwarg] if a.kwarg else [])}
+        out = []
+        for ch in ast.iter_child_nodes(fn):
+            stack = [ch]
+            while stack:
+                n = stack.pop()
+                if isinstance(n, (ast.FunctionDef, ast.AsyncFunctionDef, ast.Lambda)):
+                    out += scan(n, seen)
+                    continue
+                if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load) and n.id in ("self", "cls") and n.id not in seen:
+                    out.append((n.lineno, n.id))
+                stack.extend(ast.iter_child_nodes(n))
+        return out
+    for c in ast.walk(tree):
+        if isinstance(c, ast.ClassDef):
+            for m in c.body:
+                if isinstance(m, (ast.FunctionDef, ast.AsyncFunctionDef)):
+                    for ln, name in scan(m, set()):
+                        print("%s:%d: %r used in %s.%s, which does not receive it" % (os.path.relpath(f, ROOT), ln, name, c.name, m.name))
+                        bad += 1
 sys.exit(1 if bad else 0)

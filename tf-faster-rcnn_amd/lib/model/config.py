@@ -97,6 +97,9 @@ __C = AttrDict(
     # every config of the full-size harness inside the float32 control's own loss (policy `shipped`; `shipped_f32trunk` is the old form): ON.
     # H2_TRAIN: TRAIN mode too -- the pointwise convolutions of the forward pass and their data gradients (>= H2_MIN_TILES tiles, i.e. the
     # RoI tail) run in frcnn_gemm_h2; filters are re-split after every solver step, float32 activations are kept for the tape.
+    # H2_TRAIN_MIN_TILES: the TRAIN-mode threshold (tiles of 128 x 128 a launch must have).  One image per step: 150 puts block3's conv3
+    # (152 tiles) and block2's conv3 (300) on frcnn_gemm_h2, where the split-K f32 kernel is the shorter launch at that size -- 320 keeps only
+    # the RoI tail (392 ... 1 568 tiles): 17.17 -> 16.93 ms per step (160: 17.07; 1000: 18.0; 38: 18.2; profiles/r05_w_*), set to 320.
     # WGRAD_STREAM: the reverse sweep enqueues the filter gradients (operand transposes, split-K GEMM, bias column sum) round-robin on this
     # many side HIP streams beside the data-gradient chain (0: all on one stream); joined before the solver.  Same kernels, same bits --
     # only the overlap changes.  Data-parallel runs use at most one (the bucketed all-reduce orders itself after a single stream).
@@ -122,7 +125,7 @@ __C = AttrDict(
     HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=64, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=("block1", "block2"), WINOGRAD_DIRECT_SCOPES=(),
              WINOGRAD_TRAIN=True,
              WINOGRAD_7X7=True, FUSE_TAIL_MEAN=True, MFMA_X3=True,
-             MFMA_H2=True, H2_LAZY_SPLIT=True, H2_MIN_TILES=150, H2_TRUNK_PLANES=True, H2_TILE_CFG=-1,
+             MFMA_H2=True, H2_LAZY_SPLIT=True, H2_MIN_TILES=150, H2_TRAIN_MIN_TILES=320, H2_TRUNK_PLANES=True, H2_TILE_CFG=-1,
              X3_TILE_CFG=-1, H2_TRAIN=True, WGRAD_STREAM=2, WGRAD_TN=True, WGRAD_H2=True, PREP_STREAM=True, TRAIN_REPLAY=True, TRAIN_PICK_STREAMS=6))
 __C.DATA_DIR = osp.abspath(osp.join(__C.ROOT_DIR, 'data'))
 cfg = __C

@@ -168,8 +168,21 @@ class Network(object):
         if scope is not None and self._mode == "TEST" and self._sess.h2_channel_spread(scope) < self.H2_MIN_CHANNEL_RATIO:
             return False              # a filter whose entries for one input channel are < 2^-18 of the rest: exact x3 split instead
         return (bool(cfg.HIP.MFMA_H2) and (self._mode == "TEST" or bool(cfg.HIP.H2_TRAIN)) and K % 128 == 0 and N % 128 == 0
-                and ((self._plan_rows(M) + 127) // 128) * (N // 128) * G >= int(cfg.HIP.H2_MIN_TILES)
+                and ((self._plan_rows(M) + 127) // 128) * (N // 128) * G >= self._h2_min_tiles()
                 and 4 * rows * K < (1 << 32) and 4 * N * K < (1 << 32) and M * N < (1 << 29))
+
+    @staticmethod
+    def h2_min_tiles(mode):
+        """Tiles a launch must have to take frcnn_gemm_h2.  cfg.HIP.H2_MIN_TILES is the knob of both modes (tests set it to 1 / 2 to force
+        the kernel onto toy networks); TRAIN mode -- one image per step -- applies the larger of it and H2_TRAIN_MIN_TILES when the knob
+        stands at its default."""
+        mt = int(cfg.HIP.H2_MIN_TILES)
+        if mode == "TRAIN" and mt == 150:
+            mt = max(mt, int(cfg.HIP.H2_TRAIN_MIN_TILES))
+        return mt
+
+    def _h2_min_tiles(self):
+        return self.h2_min_tiles(self._mode)
 
     def _h2_input(self, x):
         """Operand planes of activation x: those its producer emitted, else (cfg.HIP.H2_LAZY_SPLIT) a frcnn_h2_split pass, else None."""
@@ -861,7 +874,7 @@ class Network(object):
         """cfg.HIP -> the solver handle's switches for the reverse sweep (frcnn_hip/train.py)."""
         train_op.winograd = ((int(cfg.HIP.WINOGRAD_M), int(cfg.HIP.WINOGRAD_MIN_CIN), bool(cfg.HIP.WINOGRAD_7X7))
                              if (cfg.HIP.WINOGRAD and cfg.HIP.WINOGRAD_TRAIN) else None)
-        train_op.h2_train = int(cfg.HIP.H2_MIN_TILES) if (cfg.HIP.MFMA_H2 and cfg.HIP.H2_TRAIN) else None
+        train_op.h2_train = Network.h2_min_tiles("TRAIN") if (cfg.HIP.MFMA_H2 and cfg.HIP.H2_TRAIN) else None
         train_op.wgrad_stream = int(cfg.HIP.WGRAD_STREAM)
         train_op.wgrad_tn = bool(cfg.HIP.WGRAD_TN)
         train_op.prep_stream = bool(cfg.HIP.PREP_STREAM)
