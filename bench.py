@@ -103,10 +103,10 @@ class Telemetry(object):
     profiles/r05_t shows the batch-1 latency at 4.00 ms beside neighbours at 1.1-1.4 kW, so their load alone does not explain the 4.95 ms
     some boxes give).  None when the nodes are not there."""
 
-    def __init__(self, pci=None):
+    def __init__(self, pci=None, root="/sys/class/drm"):
         import glob
         self.cards, self.own = [], None
-        for sclk in sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk")):
+        for sclk in sorted(glob.glob(os.path.join(root, "card[0-9]*", "device", "pp_dpm_sclk"))):
             d = os.path.dirname(sclk)
             hw = sorted(glob.glob(os.path.join(d, "hwmon", "hwmon*", "power1_average")) + glob.glob(os.path.join(d, "hwmon", "hwmon*", "power1_input")))
             fq = sorted(glob.glob(os.path.join(d, "hwmon", "hwmon*", "freq1_input")))
