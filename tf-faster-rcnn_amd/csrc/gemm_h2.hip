@@ -1122,7 +1122,7 @@ static int run_h2(GemmH2Params& p, int cfg, hipStream_t st) {
     // (profiles/r03_g_h2_sweep.txt: 21.8 vs 30.9 us on one image's block3 conv1); in the 4-image pipeline these lose (r03_l_ab.txt)
     const bool tiny = (long long)((M + 127) / 128) * (N / 128) * G < 150;
     // cfg == -2: round 4's choice (A/B runs).  Round 5: the same tiles with the light tile boundary and 16-byte plane stores (31, 33):
-    // bit-identical, 5-16 % faster on the short-K launches, indifferent elsewhere (profiles/r05_b_h2_conv3.txt)
+    // bit-identical, 5-16 % faster on the short-K launches, indifferent elsewhere (profiles/r05_b_h2_conv3_light_boundary.txt)
     cfg = pp ? pp_cfg : tiny ? (cfg == -2 ? 12 : 33) : (cfg == -2 ? 9 : 31);
   }
   if (p.mask) switch (cfg) {            // frcnn_gemm_h2_masked: round 4's three configurations with the mask in the epilogue (the light tile
