@@ -495,10 +495,14 @@ int frcnn_colsum(const float* dy_d, int M, int C, float* db_d, void* stream);   
 /* Gradient of tf.image.crop_and_resize w.r.t. the feature map: dfeat_d += sum over the output samples of their four bilinear taps
  * (dfeat_d must be zeroed or hold the gradient to accumulate into).  DETERMINISTIC since round 5: a gather per feature row in ascending
  * (roi, sample row, sample column, tap) order, no float atomics (TensorFlow's CropAndResizeGradImage scatters with atomics; its sum
- * order, hence the last bits, vary from run to run).  W * 1024 + R * pool * 4 bytes of LDS must fit 160 KB (FRCNN_E_UNSUPPORTED).
+ * order, hence the last bits, vary from run to run).  Any R; W up to ~600 feature columns (FRCNN_E_UNSUPPORTED beyond): the launch plan
+ * picks 256 / 128 / 64 channels per workgroup so that the row buffer fits the LDS and walks the hit list in windows -- the same bits under
+ * every plan.  _plan: the same with an explicit LDS budget in bytes (0 = the CU's 160 KB; tests force the narrow / windowed plans).
  * No max-pool variant (ResNet crops 7x7 directly). */
 int frcnn_crop_and_resize_bwd(const float* dout_d, int H, int W, int C, const float* rois_d, int R, float feat_stride,
                               int pool, float* dfeat_d, void* stream);
+int frcnn_crop_and_resize_bwd_plan(const float* dout_d, int H, int W, int C, const float* rois_d, int R, float feat_stride,
+                                   int pool, float* dfeat_d, size_t max_lds_bytes, void* stream);
 /* tf.train.MomentumOptimizer step on a packed master filter [Cout][K] (+ refresh of the BN-folded copy):
  * g = grad_scale*grad*scale[n] + weight_decay*w ; acc = momentum*acc + g ; w -= lr*acc ; w_folded = w*scale[n].
  * scale_d / w_folded_d may be NULL (biases, fc). */

@@ -30,6 +30,29 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in frcnn_hip.lib().frcnn_build_info()
 
 
+def test_library_exports_the_reference_mangled_nms_name():
+    """lib/nms/gpu_nms.hpp:1-2 declares `_nms` with C++ linkage and lib/nms/gpu_nms.pyx:13-14 binds it that way: a prebuilt gpu_nms
+    extension of the reference imports `_Z4_nmsPiS_PKfiifi` (the very name tests/test_detect_gpu.py binds in the oracle build of the
+    reference's nms_kernel.cu).  The library exports it beside the extern "C" name, so that extension relinks unchanged."""
+    import subprocess
+    import frcnn_hip
+    L = ctypes.CDLL(frcnn_hip.LIB_PATH)
+    assert hasattr(L, "_Z4_nmsPiS_PKfiifi") and hasattr(L, "_nms")
+    out = subprocess.run(["c++filt", "_Z4_nmsPiS_PKfiifi"], capture_output=True, text=True).stdout.strip()
+    if out:                                                # (binutils present) the name demangles to the reference's declaration
+        assert out.replace(" ", "") == "_nms(int*,int*,floatconst*,int,int,float,int)"
+    # no device: both names return num_out = 0 through their only error channel
+    keep, n = np.zeros(4, dtype=np.int32), ctypes.c_int(7)
+    boxes = np.zeros((4, 5), dtype=np.float32)
+    fn = L._Z4_nmsPiS_PKfiifi
+    fn.restype = None
+    import torch
+    if not torch.cuda.is_available():
+        fn(keep.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n), boxes.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(4), ctypes.c_int(5),
+           ctypes.c_float(0.5), ctypes.c_int(0))
+        assert n.value == 0
+
+
 def test_host_generate_anchors_matches_oracle():
     from frcnn_hip import ops
     for scales in ((8, 16, 32), (4, 8, 16, 32), (2, 4, 8, 16, 32)):

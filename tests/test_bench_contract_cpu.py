@@ -64,8 +64,8 @@ def test_telemetry_reports_this_process_s_card_not_the_busiest_one(tmp_path):
 
 
 def test_train_mode_tile_threshold_rule():
-    """cfg.HIP.H2_MIN_TILES is the knob of both modes; TRAIN applies H2_TRAIN_MIN_TILES only while the knob stands at its default (tests force
-    frcnn_gemm_h2 onto toy networks with H2_MIN_TILES = 1 / 2)."""
+    """TEST mode reads cfg.HIP.H2_MIN_TILES, TRAIN mode cfg.HIP.H2_TRAIN_MIN_TILES; None there = "the same knob as TEST" (how tests force
+    frcnn_gemm_h2 onto toy TRAIN networks).  No value is compared against a default: an explicit 150 means 150."""
     from model.config import cfg
     from nets.network import Network
     keep = (cfg.HIP.H2_MIN_TILES, cfg.HIP.H2_TRAIN_MIN_TILES)
@@ -73,7 +73,9 @@ def test_train_mode_tile_threshold_rule():
         assert keep == (150, 320)
         assert Network.h2_min_tiles("TEST") == 150 and Network.h2_min_tiles("TRAIN") == 320
         cfg.HIP.H2_MIN_TILES = 2
-        assert Network.h2_min_tiles("TEST") == 2 and Network.h2_min_tiles("TRAIN") == 2
+        assert Network.h2_min_tiles("TEST") == 2 and Network.h2_min_tiles("TRAIN") == 320
+        cfg.HIP.H2_TRAIN_MIN_TILES = None
+        assert Network.h2_min_tiles("TRAIN") == 2
 
         class Op(object):
             pass
@@ -82,6 +84,8 @@ def test_train_mode_tile_threshold_rule():
         assert op.h2_train == 2
         cfg.HIP.H2_MIN_TILES, cfg.HIP.H2_TRAIN_MIN_TILES = 150, 100
         Network.configure_train_op(op)
-        assert op.h2_train == 150 and Network.h2_min_tiles("TRAIN") == 150
+        assert op.h2_train == 100 and Network.h2_min_tiles("TRAIN") == 100 and Network.h2_min_tiles("TEST") == 150
+        cfg.HIP.H2_TRAIN_MIN_TILES = 150                    # an explicit 150 is 150, not "unset"
+        assert Network.h2_min_tiles("TRAIN") == 150
     finally:
         cfg.HIP.H2_MIN_TILES, cfg.HIP.H2_TRAIN_MIN_TILES = keep

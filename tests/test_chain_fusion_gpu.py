@@ -56,7 +56,7 @@ def test_conv2d_masked_equals_conv2d_then_relu_bwd(dev, case):
         assert torch.equal(buf, want)
 
 
-@pytest.mark.parametrize("cfg", [-1, 9, 12, 21])
+@pytest.mark.parametrize("cfg", [-1, 9, 12, 21, 30, 31, 32, 33, 34])       # round 6: the light-boundary configurations have masked twins
 @pytest.mark.parametrize("shape", [(2394, 1024, 256), (12544, 2048, 512), (300, 128, 128)])
 def test_gemm_h2_masked_equals_gemm_h2_then_relu_bwd(dev, shape, cfg):
     from frcnn_hip import ops
@@ -162,14 +162,14 @@ def test_fused_chain_rule_passes_change_nothing(dev, min_tiles):
     out of the Winograd output transform (another valid scale than the splitter's: results differ in the last bits), so everything is
     held to the noise bar.  The fused sweep launches no residual copy, a fraction of the relu_bwd / h2_split passes, the same GEMMs."""
     from model.config import cfg
-    old = (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.H2_MIN_TILES)
-    cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO = 64, 0.0
+    old = (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.H2_MIN_TILES, cfg.HIP.H2_TRAIN_MIN_TILES)
+    cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.H2_TRAIN_MIN_TILES = 64, 0.0, None      # None: TRAIN mode reads H2_MIN_TILES (set by _one_step)
     try:
         l0, g0, c0 = _one_step(dev, False, "cf0_%d" % min_tiles, min_tiles)
         l1, g1, c1 = _one_step(dev, True, "cf1_%d" % min_tiles, min_tiles)
         l2, g2, c2 = _one_step(dev, True, "cf2_%d" % min_tiles, min_tiles, pipe=False)
     finally:
-        cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.H2_MIN_TILES = old
+        cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.H2_MIN_TILES, cfg.HIP.H2_TRAIN_MIN_TILES = old
     assert l0[0] == l1[0]
     assert np.allclose(np.array(l0[1:]), np.array(l1[1:]), rtol=1e-4, atol=0), (l0, l1)
     assert len(g0) == len(g1) > 40

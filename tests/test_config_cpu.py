@@ -73,6 +73,21 @@ def test_type_mismatch_and_unknown_keys_are_rejected(tmp_path, restore_cfg):
         C.cfg_from_list(["TEST.NMS", "abc"])                              # str does not match float
     C.cfg_from_list(["TRAIN.SCALES", "[600, 800]"])                        # list literal -> the default's tuple type
     assert C.cfg.TRAIN.SCALES == (600, 800)
+    # the one nullable int knob: None = "TRAIN mode reads H2_MIN_TILES"; both loaders take None and an int back, nothing else
+    C.cfg_from_list(["HIP.H2_TRAIN_MIN_TILES", "None"])
+    assert C.cfg.HIP.H2_TRAIN_MIN_TILES is None
+    C.cfg_from_list(["HIP.H2_TRAIN_MIN_TILES", "200"])
+    assert C.cfg.HIP.H2_TRAIN_MIN_TILES == 200
+    f.write_text("HIP:\n  H2_TRAIN_MIN_TILES: null\n")
+    C.cfg_from_file(str(f))
+    assert C.cfg.HIP.H2_TRAIN_MIN_TILES is None
+    f.write_text("HIP:\n  H2_TRAIN_MIN_TILES: 320\n")
+    C.cfg_from_file(str(f))
+    assert C.cfg.HIP.H2_TRAIN_MIN_TILES == 320
+    with pytest.raises(AssertionError):
+        C.cfg_from_list(["HIP.H2_TRAIN_MIN_TILES", "abc"])
+    with pytest.raises(AssertionError):
+        C.cfg_from_list(["HIP.H2_MIN_TILES", "None"])                     # every other int knob stays an int
 
 
 def test_device_path_switches_exist_with_documented_defaults():

@@ -111,6 +111,25 @@ def test_nms_sorted_and_host_compat__nms(dev):
     assert keep_h[:n_h.value].tolist() == ora.gpu_nms(ds, 0.3)             # the CUDA kernel's rule (nms_kernel.cu:71), float threshold
 
 
+def test_nms_under_the_reference_mangled_name(dev):
+    """The reference's `_nms` has C++ linkage (lib/nms/gpu_nms.hpp:1-2, bound by lib/nms/gpu_nms.pyx:13-31): libfrcnn_hip.so exports
+    `_Z4_nmsPiS_PKfiifi` too, bound here exactly the way _ref_gpu_nms binds the reference's own build -- same keep list as the
+    extern "C" name and as the CUDA kernel's rule."""
+    import ctypes
+    import frcnn_hip
+    d = synth.random_dets(3000, seed=11, cluster=12)
+    ds = np.ascontiguousarray(d[ora.order_desc(d[:, 4])])
+    fn = ctypes.CDLL(frcnn_hip.LIB_PATH)._Z4_nmsPiS_PKfiifi
+    fn.restype = None
+    keep = np.zeros(3000, dtype=np.int32)
+    n = ctypes.c_int(0)
+    fn(keep.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n), ds.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(3000), ctypes.c_int(5),
+       ctypes.c_float(0.3), ctypes.c_int(0))
+    assert keep[:n.value].tolist() == ora.gpu_nms(ds, 0.3)
+    ref = _ref_gpu_nms("libref_gpu_nms.so")
+    assert keep[:n.value].tolist() == ref(ds, 0.3)
+
+
 def _ref_gpu_nms(name):
     """The reference's CUDA kernel + host loop, hipified and compiled from /root/reference/lib/nms/nms_kernel.cu by
     oracle/build_ref.py::build_gpu_nms into oracle/_ref/nms/ (the binaries travel with the snapshot)."""

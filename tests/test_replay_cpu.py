@@ -199,13 +199,22 @@ class _Prepared(object):
     def __init__(self):
         self.version, self.ready_version, self.plan, self.ready, self.readers, self.epoch = 3, 3, {"k": 1}, frozenset(["k"]), {}, 0
 
+        self.gen, self.forgot = 0, []
+
     def refreshed(self):
         self.epoch += 1
+
+    def forget_waits(self, stream):
+        self.forgot.append(stream.name)
 
 
 class _Sess(object):
     def __init__(self):
         self.graphs, self.buffers, self.device, self.prepared = {}, {}, torch.device("cpu"), _Prepared()
+        self.derived_gen = 0
+
+    def derived_generation(self):
+        return (self.derived_gen, self.prepared.gen)
 
     def buf(self, name, shape, dtype=torch.float32, zero=False):
         key = (name, tuple(shape), dtype)
@@ -285,6 +294,82 @@ def test_train_step_goes_eager_then_recorded_then_replayed(monkeypatch):
         assert net.replay_stats == dict(eager=3, recorded=1, replayed=2)              # (the switch off: not counted, nothing replayed)
     finally:
         cfg.HIP.TRAIN_REPLAY, cfg.HIP.TRAIN_PICK_STREAMS = old
+
+
+def test_recording_is_dropped_when_the_derived_filter_set_grows(monkeypatch):
+    """a recorded step re-derives exactly the filter images that existed when it was recorded.  When the set grows
+    afterwards (a TEST-mode network's first run on the shared session adds operand planes; another shape adds a plan key), the recording
+    no longer covers it: the next step of that shape runs EAGERLY (weights_changed + refresh see the whole set), the one after it is
+    recorded again, then replays resume.  Also: a recording starts with the stream's tier waits forgotten (every tier's first use is
+    recorded), and two solver handles never share a recording."""
+    from model.config import cfg
+    log = []
+    net, main, side, made = _stub_net(monkeypatch, log)
+    sess, op = _Sess(), _TrainOp()
+    old = (cfg.HIP.TRAIN_REPLAY, cfg.HIP.TRAIN_PICK_STREAMS)
+    cfg.HIP.TRAIN_REPLAY, cfg.HIP.TRAIN_PICK_STREAMS = True, 0
+    blobs = dict(shape=(1, 4, 6, 4), G=3)
+    try:
+        for _ in range(3):
+            net.train_step_async(sess, blobs, op)
+        assert net.replay_stats == dict(eager=1, recorded=1, replayed=1) and sess.prepared.forgot == ["main"]
+        sess.derived_gen += 1                                   # e.g. Session.h2_planes added an entry for a TEST-mode network
+        net.train_step_async(sess, blobs, op)
+        assert net.replay_stats == dict(eager=1, recorded=2, replayed=1)      # steady state still holds -> recorded afresh right away
+        net.train_step_async(sess, blobs, op)
+        assert net.replay_stats == dict(eager=1, recorded=2, replayed=2)
+        sess.prepared.gen += 1                                  # a plan key added by another shape's eager step
+        sess.prepared.version += 1                              # ... whose solver step has not refreshed yet: not steady
+        net.train_step_async(sess, blobs, op)
+        assert net.replay_stats == dict(eager=2, recorded=2, replayed=2)
+        sess.prepared.ready_version = sess.prepared.version
+        net.train_step_async(sess, blobs, op)
+        net.train_step_async(sess, blobs, op)
+        assert net.replay_stats == dict(eager=2, recorded=3, replayed=3)
+        # a step that derives an image WHILE it is recorded is not the steady state: kept eager
+        body = type(net)._train_step_body
+
+        def growing(self, sess_, train_op, out):
+            sess_.derived_gen += 1
+            return body(self, sess_, train_op, out)
+        monkeypatch.setattr(type(net), "_train_step_body", growing)
+        sess.derived_gen += 1                                   # the recording is stale -> the step runs (and would be recorded) eagerly, growing the set
+        net.train_step_async(sess, blobs, op)
+        assert net.replay_stats == dict(eager=3, recorded=3, replayed=3)
+        monkeypatch.setattr(type(net), "_train_step_body", body)
+        op2 = _TrainOp()                                        # a second solver handle with the same signature: its own entry
+        net.train_step_async(sess, blobs, op2)
+        assert net.replay_stats["replayed"] == 3 and len([k for k in sess.graphs if k[0] == "train_replay"]) == 2
+    finally:
+        cfg.HIP.TRAIN_REPLAY, cfg.HIP.TRAIN_PICK_STREAMS = old
+
+
+def test_evicting_the_entry_that_runs_the_stream_search_ends_the_search(monkeypatch):
+    """the StreamPicker belongs to ONE shape's entry; when that entry is evicted (REPLAY_CAP) or its recording dropped while
+    the search is running, sess.picking is cleared so that another recording can start a search."""
+    from model.config import cfg
+    log = []
+    net, main, side, made = _stub_net(monkeypatch, log)
+    sess, op = _Sess(), _TrainOp()
+    old = (cfg.HIP.TRAIN_REPLAY, cfg.HIP.TRAIN_PICK_STREAMS, type(net).REPLAY_CAP)
+    cfg.HIP.TRAIN_REPLAY, cfg.HIP.TRAIN_PICK_STREAMS, type(net).REPLAY_CAP = True, 2, 2
+    try:
+        a, b, c = (dict(shape=(1, 4, w, 4), G=3) for w in (6, 8, 10))
+        for _ in range(3):
+            net.train_step_async(sess, a, op)                   # eager, recorded, first replay: the search starts on shape a
+        assert sess.picking and getattr(sess, "picked_streams", None) is None
+        net.train_step_async(sess, b, op)
+        net.train_step_async(sess, b, op)
+        assert sess.picking                                     # (shape a's entry is still there)
+        net.train_step_async(sess, c, op)                       # third shape: the least recently used entry -- a's -- goes
+        assert not sess.picking and len([k for k in sess.graphs if k[0] == "train_replay"]) == 2
+        net.train_step_async(sess, b, op)                       # b's recording may start its own search now
+        assert sess.picking
+        sess.derived_gen += 1                                   # ... and dropping b's recording ends that one too
+        net.train_step_async(sess, b, op)
+        assert not sess.picking
+    finally:
+        cfg.HIP.TRAIN_REPLAY, cfg.HIP.TRAIN_PICK_STREAMS, type(net).REPLAY_CAP = old
 
 
 def test_stream_picker_times_real_steps_and_keeps_the_fastest_binding(monkeypatch):

@@ -68,14 +68,14 @@ def _nets():
 @pytest.mark.parametrize("family", ["res50", "vgg16", "mobile"])
 def test_replayed_steps_equal_eager_steps_bit_for_bit(dev, family):
     from model.config import cfg
-    old = (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.H2_MIN_TILES)
-    cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.H2_MIN_TILES = 64, 0.0, 2      # (frcnn_gemm_h2 launches at this toy size too)
+    old = (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.H2_MIN_TILES, cfg.HIP.H2_TRAIN_MIN_TILES)
+    cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.H2_MIN_TILES, cfg.HIP.H2_TRAIN_MIN_TILES = 64, 0.0, 2, None   # (frcnn_gemm_h2 launches at this toy size too)
     try:
         make = _nets()[family]
         l0, d0, s0, _, _, _ = _run(dev, make, "rp0_" + family, False, 7)
         l1, d1, s1, net, _, _ = _run(dev, make, "rp1_" + family, True, 7)
     finally:
-        cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.H2_MIN_TILES = old
+        cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.H2_MIN_TILES, cfg.HIP.H2_TRAIN_MIN_TILES = old
     assert s0 == dict(eager=0, recorded=0, replayed=0)
     assert s1 == dict(eager=1, recorded=1, replayed=5), s1       # step 1 eager (builds everything), step 2 recorded, steps 3-7 replayed
     assert all(np.isfinite(v) for step in l0 for v in step)
@@ -192,6 +192,56 @@ def test_a_new_shape_a_new_learning_rate_or_new_weights_start_a_new_recording(de
         assert not [k for k in sess.graphs if isinstance(k, tuple) and k and k[0] == "train_replay"]
     finally:
         cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO = old
+
+
+def test_filter_images_added_after_a_recording_are_kept_current(dev):
+    """ADVICE r5 (medium).  A recorded step re-derives the filter images that existed when it was recorded.  A TEST-mode network run on
+    the SAME session afterwards derives more (Winograd U of the 3x3 filters, bf16 / fp16 operand planes of layers the training step never
+    split): before round 6 the replays kept refreshing the old set only, and the TEST-mode network went on multiplying by images of
+    filters the solver had since moved.  Now the recording carries the session's derived-set generation; when it differs the step runs
+    eagerly, is recorded again, and EVERY cached image is the image of the filter as it stands -- checked against a fresh derivation."""
+    from frcnn_hip import ops
+    from model.config import cfg
+    from nets.resnet_v1 import resnetv1
+    old = (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.H2_MIN_TILES, cfg.HIP.H2_TRAIN_MIN_TILES, cfg.TEST.RPN_POST_NMS_TOP_N)
+    cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.H2_MIN_TILES, cfg.HIP.H2_TRAIN_MIN_TILES, cfg.TEST.RPN_POST_NMS_TOP_N = 64, 0.0, 2, None, 48
+    try:
+        _, _, stats, net, sess, ts = _run(dev, _nets()["res50"], "gen", True, 4)
+        assert stats == dict(eager=1, recorded=1, replayed=2)
+        cfg.HIP.TRAIN_REPLAY = True
+
+        def images():
+            wino = [k for k in sess.packed if isinstance(k, tuple) and k and k[0] == "wino"]
+            return len(sess.h2), len(sess.x3), len(wino)
+        before, gen0 = images(), sess.derived_generation()
+        tnet = resnetv1(num_layers=50)
+        tnet.create_architecture("TEST", 21, tag="gen_test", anchor_scales=(4, 8, 16), anchor_ratios=(0.5, 1, 2))
+        b = _blobs(224, 288)
+        tnet.test_image(sess, b[0]["data"], b[0]["im_info"])
+        after = images()
+        assert sum(after) > sum(before) and sess.derived_generation() != gen0, (before, after)
+        for i in range(3):
+            net.train_step(sess, b[i % len(b)], ts)
+        assert net.replay_stats == dict(eager=1, recorded=2, replayed=4), net.replay_stats      # step 5 recorded afresh, steps 6-7 replayed
+        tnet.test_image(sess, b[1]["data"], b[1]["im_info"])           # (orders itself behind the replayed refresh: wait_planes)
+        torch.cuda.synchronize()
+        n = 0
+        for packed, w in sess.h2.values():
+            fresh = ops.h2_pack_w(w)
+            assert torch.equal(fresh[0], packed[0]) and torch.equal(fresh[1], packed[1])
+            n += 1
+        for planes, w in sess.x3.values():
+            assert torch.equal(ops.gemm_x3_pack(w), planes)
+            n += 1
+        for key, val in sess.packed.items():
+            if isinstance(key, tuple) and key and key[0] == "wino":
+                info = sess.conv_info.get(key[1])
+                if info is not None and info["w"].dim() == 4 and info["w"].shape[1] == 3:
+                    assert torch.equal(ops.winograd_filter_transform_device(info["w"], key[3], False), val[0]), key
+                    n += 1
+        assert n == sum(images()) and n > sum(before)
+    finally:
+        cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.H2_MIN_TILES, cfg.HIP.H2_TRAIN_MIN_TILES, cfg.TEST.RPN_POST_NMS_TOP_N = old
 
 
 def test_the_stream_picker_finishes_and_changes_no_bit(dev):

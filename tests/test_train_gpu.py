@@ -152,9 +152,10 @@ def test_full_train_step_matches_torch_autograd(dev, wino, h2):
     from nets.resnet_v1 import resnetv1
     SC, RT = (4, 8, 16), (0.5, 1, 2)
     old = (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.WINOGRAD_TRAIN)
-    old_h2 = (cfg.HIP.H2_TRAIN, cfg.HIP.H2_MIN_TILES)
+    old_h2 = (cfg.HIP.H2_TRAIN, cfg.HIP.H2_MIN_TILES, cfg.HIP.H2_TRAIN_MIN_TILES)
     cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.WINOGRAD_TRAIN = 64, 0.0, wino
     cfg.HIP.H2_TRAIN, cfg.HIP.H2_MIN_TILES = bool(h2), (1 if h2 else cfg.HIP.H2_MIN_TILES)
+    cfg.HIP.H2_TRAIN_MIN_TILES = None if h2 else cfg.HIP.H2_TRAIN_MIN_TILES       # None: TRAIN mode reads the same knob as TEST mode
     try:
         sess = Session(device=dev, seed=5)
         net = resnetv1(num_layers=50)
@@ -223,7 +224,7 @@ def test_full_train_step_matches_torch_autograd(dev, wino, h2):
             assert torch.equal(fresh[0], wq[0]) and torch.equal(fresh[1], wq[1])
     finally:
         cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.WINOGRAD_TRAIN = old
-        cfg.HIP.H2_TRAIN, cfg.HIP.H2_MIN_TILES = old_h2
+        cfg.HIP.H2_TRAIN, cfg.HIP.H2_MIN_TILES, cfg.HIP.H2_TRAIN_MIN_TILES = old_h2
 
 
 def test_sgd_steps_on_a_fixed_batch_reduce_the_loss(dev):

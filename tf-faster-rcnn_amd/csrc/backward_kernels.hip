@@ -236,21 +236,61 @@ extern "C" int frcnn_colsum(const float* dy_d, int M, int C, float* db_d, void* 
 //      function of the inputs only); (2) thread = channel walks the list and adds the samples' taps into its own column of an LDS row
 //      buffer [W][256] in (roi, py, px, tap) order; (3) the row buffer is added to dfeat.  No atomics, a fixed order per element, and
 //      the 2 x 7 x 256 RoI rows that touch a feature row are read once, coalesced over the channels.
-__global__ __launch_bounds__(256) void k_crop_bwd_rows(const float* __restrict__ dout, int H, int W, int C, const float* __restrict__ rois,
-                                                       int R, float stride, int pool, float* __restrict__ dfeat) {
+//      Sizes (round 6): NT = 256 / 128 / 64 channels per workgroup so that the row buffer [W][NT] fits the CU's LDS at any W up
+//      to ~600 feature columns, and the hit list is a window of `lcap` entries that is walked and refilled in ascending order when R * pool
+//      exceeds it -- the same (roi, py, px, tap) order per element in every shape of the launch, hence the same bits.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_crop_bwd_rows(const float* __restrict__ dout, int H, int W, int C, const float* __restrict__ rois,
+                                                      int R, float stride, int pool, int lcap, float* __restrict__ dfeat) {
   extern __shared__ float crop_lds[];
-  float* acc = crop_lds;                                   // [W][256]
-  int* list = (int*)(crop_lds + (size_t)W * 256);          // [R * pool] hits, ascending
-  __shared__ int wcnt[4];
+  float* acc = crop_lds;                                   // [W][NT]
+  int* list = (int*)(crop_lds + (size_t)W * NT);           // [lcap] hits, ascending
+  __shared__ int wcnt[NT / 64];
   __shared__ int total_s;
-  const int h = blockIdx.x, tid = threadIdx.x, c = blockIdx.y * 256 + tid;
+  const int h = blockIdx.x, tid = threadIdx.x, c = blockIdx.y * NT + tid;
   const int lane = tid & 63, wave = tid >> 6;
   const float height = ((float)H - 1.0f) * stride, width = ((float)W - 1.0f) * stride;
-  for (int w = 0; w < W; ++w) acc[w * 256 + tid] = 0.f;
+  for (int w = 0; w < W; ++w) acc[w * NT + tid] = 0.f;
   if (tid == 0) total_s = 0;
   __syncthreads();
   const int n = R * pool;
-  for (int base = 0; base < n; base += 256) {
+  const bool live = c < C;
+  auto walk = [&](int hits) {                              // thread = channel: the listed sample rows into this thread's column of acc
+    for (int k = 0; k < hits; ++k) {
+      const int i = list[k];
+      const int r = i / pool, py = i - r * pool;
+      const float* roi = rois + 5 * (size_t)r;
+      const float x1 = roi[1] / width, y1 = roi[2] / height, x2 = roi[3] / width, y2 = roi[4] / height;
+      const float hs = (y2 - y1) * (float)(H - 1) / (float)(pool - 1);
+      const float ws = (x2 - x1) * (float)(W - 1) / (float)(pool - 1);
+      const float in_y = y1 * (float)(H - 1) + (float)py * hs;
+      const int top = (int)floorf(in_y), bot = (int)ceilf(in_y);
+      const float ly = in_y - (float)top;
+      const float* drow = dout + ((size_t)r * pool + py) * pool * C;
+      for (int px = 0; px < pool; ++px) {
+        const float in_x = x1 * (float)(W - 1) + (float)px * ws;
+        if (in_x < 0 || in_x > (float)(W - 1)) continue;
+        const int left = (int)floorf(in_x), right = (int)ceilf(in_x);
+        const float lx = in_x - (float)left;
+        const float g = live ? drow[(size_t)px * C + c] : 0.f;
+        if (top == h) {
+          acc[left * NT + tid] += g * (1.f - ly) * (1.f - lx);
+          acc[right * NT + tid] += g * (1.f - ly) * lx;
+        }
+        if (bot == h) {
+          acc[left * NT + tid] += g * ly * (1.f - lx);
+          acc[right * NT + tid] += g * ly * lx;
+        }
+      }
+    }
+  };
+  for (int base = 0; base < n; base += NT) {
+    if (total_s + NT > lcap) {                             // (uniform) the window is full: walk it, then refill from here
+      walk(total_s);
+      __syncthreads();
+      if (tid == 0) total_s = 0;
+      __syncthreads();
+    }
     const int i = base + tid;
     bool hit = false;
     if (i < n) {
@@ -264,59 +304,55 @@ __global__ __launch_bounds__(256) void k_crop_bwd_rows(const float* __restrict__
     const unsigned long long m = __ballot(hit);
     if (lane == 0) wcnt[wave] = __popcll(m);
     __syncthreads();
-    int off = total_s;
-    for (int q = 0; q < wave; ++q) off += wcnt[q];
+    int off = total_s, all = 0;
+    for (int q = 0; q < NT / 64; ++q) {
+      if (q < wave) off += wcnt[q];
+      all += wcnt[q];
+    }
     if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = i;
     __syncthreads();
-    if (tid == 0) total_s += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (tid == 0) total_s += all;
     __syncthreads();
   }
-  const int hits = total_s;
-  const bool live = c < C;
-  for (int k = 0; k < hits; ++k) {
-    const int i = list[k];
-    const int r = i / pool, py = i - r * pool;
-    const float* roi = rois + 5 * (size_t)r;
-    const float x1 = roi[1] / width, y1 = roi[2] / height, x2 = roi[3] / width, y2 = roi[4] / height;
-    const float hs = (y2 - y1) * (float)(H - 1) / (float)(pool - 1);
-    const float ws = (x2 - x1) * (float)(W - 1) / (float)(pool - 1);
-    const float in_y = y1 * (float)(H - 1) + (float)py * hs;
-    const int top = (int)floorf(in_y), bot = (int)ceilf(in_y);
-    const float ly = in_y - (float)top;
-    const float* drow = dout + ((size_t)r * pool + py) * pool * C;
-    for (int px = 0; px < pool; ++px) {
-      const float in_x = x1 * (float)(W - 1) + (float)px * ws;
-      if (in_x < 0 || in_x > (float)(W - 1)) continue;
-      const int left = (int)floorf(in_x), right = (int)ceilf(in_x);
-      const float lx = in_x - (float)left;
-      const float g = live ? drow[(size_t)px * C + c] : 0.f;
-      if (top == h) {
-        acc[left * 256 + tid] += g * (1.f - ly) * (1.f - lx);
-        acc[right * 256 + tid] += g * (1.f - ly) * lx;
-      }
-      if (bot == h) {
-        acc[left * 256 + tid] += g * ly * (1.f - lx);
-        acc[right * 256 + tid] += g * ly * lx;
-      }
-    }
-  }
+  walk(total_s);
   if (live) {
     float* drow = dfeat + (size_t)h * W * C + c;
-    for (int w = 0; w < W; ++w) drow[(size_t)w * C] += acc[w * 256 + tid];
+    for (int w = 0; w < W; ++w) drow[(size_t)w * C] += acc[w * NT + tid];
   }
+}
+template <int NT>
+static int launch_crop_bwd(const float* dout_d, int H, int W, int C, const float* rois_d, int R, float feat_stride, int pool, int lcap,
+                           float* dfeat_d, hipStream_t st) {
+  static KernelOnce once;
+  HIP_TRY(kernel_once(once, (const void*)k_crop_bwd_rows<NT>, NT, 160 * 1024 - 64));
+  hipLaunchKernelGGL(k_crop_bwd_rows<NT>, dim3(H, cdiv(C, NT)), dim3(NT), (size_t)W * NT * 4 + (size_t)lcap * 4, st, dout_d, H, W, C, rois_d, R,
+                     feat_stride, pool, lcap, dfeat_d);
+  LAUNCH_CHECK();
+  return FRCNN_OK;
+}
+// max_lds_bytes > 0: the LDS budget of the launch plan (tests force the narrow / windowed forms on small inputs); 0 = the CU's 160 KB
+extern "C" int frcnn_crop_and_resize_bwd_plan(const float* dout_d, int H, int W, int C, const float* rois_d, int R, float feat_stride,
+                                              int pool, float* dfeat_d, size_t max_lds_bytes, void* stream) {
+  if (!dout_d || !rois_d || !dfeat_d || H < 2 || W < 2 || C <= 0 || R < 0 || pool < 2) return FRCNN_E_ARG;
+  if (R == 0) return FRCNN_OK;
+  const size_t budget = (max_lds_bytes > 0 && max_lds_bytes < 160 * 1024 - 64) ? max_lds_bytes : 160 * 1024 - 64;
+  const long long n = (long long)R * pool;
+  for (int nt = 256; nt >= 64; nt >>= 1) {
+    // widest channel slab whose row buffer leaves room for a hit window of at least 4 x NT entries (or the whole list)
+    const size_t accb = (size_t)W * nt * 4;
+    const long long want = (n + nt - 1) / nt * nt;
+    if (accb + (size_t)min(want, (long long)4 * nt) * 4 > budget) continue;
+    const int lcap = (int)min(want, (long long)((budget - accb) / 4 / nt * nt));
+    hipStream_t st = (hipStream_t)stream;
+    if (nt == 256) return launch_crop_bwd<256>(dout_d, H, W, C, rois_d, R, feat_stride, pool, lcap, dfeat_d, st);
+    if (nt == 128) return launch_crop_bwd<128>(dout_d, H, W, C, rois_d, R, feat_stride, pool, lcap, dfeat_d, st);
+    return launch_crop_bwd<64>(dout_d, H, W, C, rois_d, R, feat_stride, pool, lcap, dfeat_d, st);
+  }
+  return FRCNN_E_UNSUPPORTED;             // W > ~600 feature columns (an image side of ~10 000 pixels at stride 16)
 }
 extern "C" int frcnn_crop_and_resize_bwd(const float* dout_d, int H, int W, int C, const float* rois_d, int R, float feat_stride,
                                          int pool, float* dfeat_d, void* stream) {
-  if (!dout_d || !rois_d || !dfeat_d || H < 2 || W < 2 || C <= 0 || R < 0 || pool < 2) return FRCNN_E_ARG;
-  if (R == 0) return FRCNN_OK;
-  const size_t lds = (size_t)W * 256 * 4 + (size_t)R * pool * 4;
-  if (lds > 160 * 1024 - 64) return FRCNN_E_UNSUPPORTED;  // W <= ~140 feature columns at 256 RoIs x 14 rows (a 2 240-pixel image side)
-  static KernelOnce once;
-  HIP_TRY(kernel_once(once, (const void*)k_crop_bwd_rows, 256, 160 * 1024 - 64));
-  hipLaunchKernelGGL(k_crop_bwd_rows, dim3(H, cdiv(C, 256)), dim3(256), lds, (hipStream_t)stream, dout_d, H, W, C, rois_d, R, feat_stride,
-                     pool, dfeat_d);
-  LAUNCH_CHECK();
-  return FRCNN_OK;
+  return frcnn_crop_and_resize_bwd_plan(dout_d, H, W, C, rois_d, R, feat_stride, pool, dfeat_d, 0, stream);
 }
 
 // ---- momentum SGD (lib/model/train_val.py:128-145: tf.train.MomentumOptimizer(lr, 0.9)) on the packed

@@ -771,6 +771,16 @@ void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, i
   (void)hipFree(d_boxes); (void)hipFree(d_keep); (void)hipFree(d_ws);
 }
 
+// The reference declares `_nms` WITHOUT extern "C" (nms/gpu_nms.hpp:1-2; nms/gpu_nms.pyx:13-14 binds it as `cdef extern`), so an
+// already-built gpu_nms extension of the reference imports the Itanium-mangled name `_Z4_nmsPiS_PKfiifi`.  The same entry under that
+// name: the prebuilt extension relinks against libfrcnn_hip.so unchanged (binary compatible, not only source compatible).
+extern "C" void frcnn_nms_cxx_name(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
+                                   float nms_overlap_thresh, int device_id) __asm__("_Z4_nmsPiS_PKfiifi");
+extern "C" void frcnn_nms_cxx_name(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
+                                   float nms_overlap_thresh, int device_id) {
+  _nms(keep_out, num_out, boxes_host, boxes_num, boxes_dim, nms_overlap_thresh, device_id);
+}
+
 // ------------------------------------------------------------------------------------------------
 // proposal layers
 // ------------------------------------------------------------------------------------------------

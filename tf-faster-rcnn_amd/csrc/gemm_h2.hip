@@ -503,6 +503,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
 #pragma unroll
             for (int e = 0; e < 4; ++e) tot[i][j][4 * q + e] = __uint_as_float(k[q][e]) > 0.f ? tot[i][j][4 * q + e] : 0.f;
         }
+      pend += TM * TN * 4;              // (vector-memory instructions issued after the last slab load: the light boundary's counted wait)
     }
     // ---- frcnn_gemm_h2_mean: reduce_mean over row groups instead of a result tensor (the tail's last convolution feeds only the spatial
     //      mean, lib/nets/resnet_v1.py:115-125).  A 32-row accumulator block (lanes = rows) meets at most two groups (mean_rows >= 32):
@@ -1125,11 +1126,15 @@ static int run_h2(GemmH2Params& p, int cfg, hipStream_t st) {
     // bit-identical, 5-16 % faster on the short-K launches, indifferent elsewhere (profiles/r05_b_h2_conv3_light_boundary.txt)
     cfg = pp ? pp_cfg : tiny ? (cfg == -2 ? 12 : 33) : (cfg == -2 ? 9 : 31);
   }
-  if (p.mask) switch (cfg) {            // frcnn_gemm_h2_masked: round 4's three configurations with the mask in the epilogue (the light tile
-    case 9: case 30: case 31: case 32:  // boundary of cfgs 30-33 has no masked instantiation: those ids take the schedule they derive from)
-      return launch_h2<128, 128, 64, 64, 2, 2, 2 + 128>(p, st);
-    case 12: case 33: return launch_h2<64, 128, 32, 64, 2, 2, 128>(p, st);
-    case 21: case 34: return launch_h2<256, 128, 64, 64, 3, 2, 34 + 128>(p, st);
+  if (p.mask) switch (cfg) {            // frcnn_gemm_h2_masked (TUNE & 128: the ReLU-gradient select in the epilogue): every shipped
+    case 9: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 128>(p, st);           // configuration has its masked twin since round 6 -- the
+    case 12: return launch_h2<64, 128, 32, 64, 2, 2, 128>(p, st);               // data-gradient chain of the training step takes the light
+    case 21: return launch_h2<256, 128, 64, 64, 3, 2, 34 + 128>(p, st);         // tile boundary and the 16-byte plane stores by shape, like
+    case 30: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 256 + 128>(p, st);    // the forward pass (the mask's loads are counted in `pend`)
+    case 31: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 256 + 512 + 128>(p, st);
+    case 32: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 512 + 128>(p, st);
+    case 33: return launch_h2<64, 128, 32, 64, 2, 2, 256 + 512 + 128>(p, st);
+    case 34: return launch_h2<256, 128, 64, 64, 3, 2, 34 + 512 + 128>(p, st);
     default: return FRCNN_E_ARG;
   }
   switch (cfg) {

@@ -142,6 +142,7 @@ SIGNATURES = {
     "frcnn_spatial_mean_bwd": (c_int, [_P, c_int, c_int, c_int, _P, _P]),
     "frcnn_colsum": (c_int, [_P, c_int, c_int, _P, _P]),
     "frcnn_crop_and_resize_bwd": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_float, c_int, _P, _P]),
+    "frcnn_crop_and_resize_bwd_plan": (c_int, [_P, c_int, c_int, c_int, _P, c_int, c_float, c_int, _P, c_size_t, _P]),
     "frcnn_sgd_momentum": (c_int, [_P, _P, _P, _P, _P, c_longlong, c_int, c_float, c_float, c_float, c_float, _P]),
     "frcnn_sgd_desc_bytes": (c_size_t, []),
     "frcnn_sgd_momentum_multi": (c_int, [_P, c_int, c_float, c_float, c_float, _P]),

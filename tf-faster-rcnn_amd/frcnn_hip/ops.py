@@ -1050,11 +1050,15 @@ def colsum(dy2d, out):
     return out
 
 
-def crop_and_resize_bwd(dout, rois, feat_stride, dfeat):
+def crop_and_resize_bwd(dout, rois, feat_stride, dfeat, max_lds=0):
+    """dfeat += gradient of crop_and_resize w.r.t. the feature map.  max_lds (bytes; tests): the LDS budget of the launch plan."""
     _chk(dout), _chk(rois), _chk(dfeat)
     R, P, _, C = dout.shape
     H, W = dfeat.shape[-3], dfeat.shape[-2]
-    call("frcnn_crop_and_resize_bwd", _ptr(dout), H, W, C, _ptr(rois), R, float(feat_stride), P, _ptr(dfeat), _stream())
+    if max_lds:
+        call("frcnn_crop_and_resize_bwd_plan", _ptr(dout), H, W, C, _ptr(rois), R, float(feat_stride), P, _ptr(dfeat), int(max_lds), _stream())
+    else:
+        call("frcnn_crop_and_resize_bwd", _ptr(dout), H, W, C, _ptr(rois), R, float(feat_stride), P, _ptr(dfeat), _stream())
     return dfeat
 
 

@@ -33,6 +33,8 @@ class VariableStore(object):
         self.conv_info = {}                             # scope -> {w (folded, device), b, scale (np or None), bn}
         self.graphs = {}
         self.seed = seed
+        self.device_filters_moved = False               # a solver updated the device filters in place: the host variables are older (TrainState)
+        self.derived_gen = 0                            # bumped whenever a derived filter image is ADDED or the set is dropped (derived_generation)
 
     # ---- variables ---------------------------------------------------------------------------
     def init_variables(self, specs, seed=None):
@@ -97,6 +99,8 @@ class VariableStore(object):
         self.h2.clear()
         self.h2_spread.clear()
         self.graphs.clear()
+        self.derived_gen += 1
+        self.device_filters_moved = False               # (the device images are rebuilt from the host variables from here on)
         prepared = getattr(self, "prepared", None)
         if prepared is not None:
             prepared.invalidate()
@@ -154,6 +158,7 @@ class PreparedFilters(object):
         self.stream = None
         self.events = None                      # one per tier
         self.epoch = 0                          # counts refreshes (incl. replayed ones: refreshed())
+        self.gen = 0                            # bumped when a key is added to the plan / the plan is dropped (Session.derived_generation)
         self.waited = {}                        # stream handle -> [epoch whose tier-t event this stream has waited for, t = 0, 1, 2]
         self.readers = {}                       # stream handle -> torch stream: who has read the buffers since the last refresh
 
@@ -181,8 +186,17 @@ class PreparedFilters(object):
             return self.plan[key][1]
         out = fn()
         if self.enabled:
+            if key not in self.plan:
+                self.gen += 1
             self.plan[key] = (fn, out)
         return out
+
+    def forget_waits(self, stream):
+        """A recording of a training step starts on `stream`: whatever this stream has already waited for this epoch (a TEST-mode forward or
+        wait_planes() between two steps), the RECORDED step must carry the wait of every tier at its first use -- a replay re-records the
+        tier events and its forward pass has to order itself behind them (a recording made after an earlier tier-0 wait had
+        no wait on events[0])."""
+        self.waited.pop(int(stream.cuda_stream), None)
 
     def wait_planes(self):
         """Before a launch reads a cached filter image of the session (Session.h2_planes / x3_planes / winograd_params, and a TEST-mode
@@ -233,6 +247,7 @@ class PreparedFilters(object):
         """The filter tensors were replaced or rewritten by somebody else than the solver (restore, initialise): forget the plan (its
         closures hold the tensors); the next step prepares inline again."""
         self.version += 1
+        self.gen += 1
         self.plan, self.ready = {}, frozenset()
 
 
@@ -293,15 +308,31 @@ class Session(VariableStore):
         self.prepared.wait_planes()
         if key in self.packed:
             return self.packed[key]
-        w = self.variables[scope + "/weights"]
-        scale, bias = None, None
-        if bn_eps is not None:
-            scale, bias = self.fold_bn(scope, bn_eps)
-        elif (scope + "/biases") in self.variables:
-            bias = self.variables[scope + "/biases"]
-        res = (self.to_device(ops.winograd_filter_transform(w, scale, m)), None if bias is None else self.to_device(bias))
+        info = self.conv_info.get(scope)
+        if self.device_filters_moved and info is not None and info["w"].dim() == 4 and tuple(info["w"].shape[1:3]) == (3, 3) and info["bn"] == (bn_eps is not None):
+            # a solver on this session has updated the filters IN PLACE on the device since the host variables were loaded (TrainState.
+            # refresh_derived): U comes from the live folded filter -- what wino_refresh() will re-derive it from after every later step
+            # -- and the bias is the live tensor; the host copy is the pre-training filter
+            res = (ops.winograd_filter_transform_device(info["w"], m, False), info["b"])
+        else:
+            w = self.variables[scope + "/weights"]
+            scale, bias = None, None
+            if bn_eps is not None:
+                scale, bias = self.fold_bn(scope, bn_eps)
+            elif (scope + "/biases") in self.variables:
+                bias = self.variables[scope + "/biases"]
+            res = (self.to_device(ops.winograd_filter_transform(w, scale, m)), None if bias is None else self.to_device(bias))
         self.packed[key] = res
+        self.derived_gen += 1
         return res
+
+    def derived_generation(self):
+        """Identifies the SET of filter images derived from the variables: the session's cached operand planes / Winograd filters
+        (h2, x3, ("wino", ...)) and the prepared-filter plan.  A recorded training step (lib/nets/network.py _train_step_replayed) re-derives
+        exactly the set that existed when it was recorded; an entry added later -- a TEST-mode network first run on the shared session, another
+        image shape's plan key -- would never be refreshed by its replays while ready / ready_version keep reporting it current.  The
+        recording stores this value and is dropped when it no longer matches."""
+        return (self.derived_gen, self.prepared.gen)
 
     def buf(self, name, shape, dtype=torch.float32, zero=False):
         key = (name, tuple(shape), dtype)
@@ -321,6 +352,7 @@ class Session(VariableStore):
         if ent is None:
             ent = (ops.gemm_x3_pack(w), w)
             self.x3[key] = ent
+            self.derived_gen += 1
         return ent[0]
 
     def wino_refresh(self):
@@ -372,6 +404,7 @@ class Session(VariableStore):
         if ent is None:
             ent = (ops.h2_pack_w(w), w)
             self.h2[key] = ent
+            self.derived_gen += 1
         return ent[0]
 
     def h2_refresh(self):

@@ -599,6 +599,7 @@ class TrainState(object):
         no-op when no ('wino', ...) entry is cached), then the pre-split planes of everything (x3 / h2) -- and the prepared gradient
         filters.  Weight-only launches: with cfg.HIP.PREP_STREAM they run on the side stream, beside the next forward pass
         (Session.h2_planes & co. wait for them at their first use: PreparedFilters.wait_planes)."""
+        self.sess.device_filters_moved = True        # (Session.winograd_params: later first uses derive from the live device filters)
         for p in self.params.values():
             if getattr(p, "dw", False):
                 ops.dwconv3x3_refold(p.w, p.scale, p.wf)

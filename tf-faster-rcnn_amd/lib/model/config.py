@@ -97,7 +97,8 @@ __C = AttrDict(
     # every config of the full-size harness inside the float32 control's own loss (policy `shipped`; `shipped_f32trunk` is the old form): ON.
     # H2_TRAIN: TRAIN mode too -- the pointwise convolutions of the forward pass and their data gradients (>= H2_MIN_TILES tiles, i.e. the
     # RoI tail) run in frcnn_gemm_h2; filters are re-split after every solver step, float32 activations are kept for the tape.
-    # H2_TRAIN_MIN_TILES: the TRAIN-mode threshold (tiles of 128 x 128 a launch must have).  One image per step: 150 puts block3's conv3
+    # H2_TRAIN_MIN_TILES: the TRAIN-mode threshold (tiles of 128 x 128 a launch must have); None = TRAIN mode reads H2_MIN_TILES like TEST
+    # mode (every value means what it says -- nothing is compared against a default).  One image per step: 150 puts block3's conv3
     # (152 tiles) and block2's conv3 (300) on frcnn_gemm_h2, where the split-K f32 kernel is the shorter launch at that size -- 320 keeps only
     # the RoI tail (392 ... 1 568 tiles): 17.17 -> 16.93 ms per step (160: 17.07; 1000: 18.0; 38: 18.2; profiles/r05_w_*), set to 320.
     # WGRAD_STREAM: the reverse sweep enqueues the filter gradients (operand transposes, split-K GEMM, bias column sum) round-robin on this
@@ -146,6 +147,9 @@ def get_output_tb_dir(imdb, weights_filename):
     return outdir
 
 
+_NULLABLE_KEYS = ("H2_TRAIN_MIN_TILES",)      # int or None (None = "the same as H2_MIN_TILES"): the two loaders accept either
+
+
 def _merge_a_into_b(a, b):
     """Recursive merge with the reference's type checks (config.py:325-356)."""
     if not isinstance(a, dict):
@@ -161,6 +165,8 @@ def _merge_a_into_b(a, b):
                 v = tuple(v)
             elif isinstance(old, list) and isinstance(v, tuple):
                 v = list(v)
+            elif k in _NULLABLE_KEYS and (v is None or old is None) and isinstance(old if v is None else v, int):
+                pass                                        # an int knob whose None means "follow another key"
             else:
                 raise ValueError('Type mismatch ({} vs. {}) for config key: {}'.format(type(old), type(v), k))
         if isinstance(v, dict):
@@ -200,5 +206,6 @@ def cfg_from_list(cfg_list):
             value = tuple(value)
         if isinstance(old, list) and isinstance(value, tuple):
             value = list(value)
-        assert type(value) == type(old), 'type {} does not match original type {}'.format(type(value), type(old))
+        nullable = leaf in _NULLABLE_KEYS and (value is None or old is None) and isinstance(old if value is None else value, int)
+        assert nullable or type(value) == type(old), 'type {} does not match original type {}'.format(type(value), type(old))
         d[leaf] = value

@@ -173,13 +173,12 @@ class Network(object):
 
     @staticmethod
     def h2_min_tiles(mode):
-        """Tiles a launch must have to take frcnn_gemm_h2.  cfg.HIP.H2_MIN_TILES is the knob of both modes (tests set it to 1 / 2 to force
-        the kernel onto toy networks); TRAIN mode -- one image per step -- applies the larger of it and H2_TRAIN_MIN_TILES when the knob
-        stands at its default."""
-        mt = int(cfg.HIP.H2_MIN_TILES)
-        if mode == "TRAIN" and mt == 150:
-            mt = max(mt, int(cfg.HIP.H2_TRAIN_MIN_TILES))
-        return mt
+        """Tiles a launch must have to take frcnn_gemm_h2.  TEST: cfg.HIP.H2_MIN_TILES.  TRAIN (one image per step): cfg.HIP.H2_TRAIN_MIN_TILES,
+        or -- when that is None -- the same knob as TEST mode (tests force the kernel onto toy TRAIN networks with H2_MIN_TILES = 1 and
+        H2_TRAIN_MIN_TILES = None).  Each value means what it says: no comparison against a default."""
+        if mode == "TRAIN" and cfg.HIP.H2_TRAIN_MIN_TILES is not None:
+            return int(cfg.HIP.H2_TRAIN_MIN_TILES)
+        return int(cfg.HIP.H2_MIN_TILES)
 
     def _h2_min_tiles(self):
         return self.h2_min_tiles(self._mode)
@@ -794,7 +793,7 @@ class Network(object):
         hip = tuple((k, tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in sorted(cfg.HIP.items()))
         t = cfg.TRAIN
         key = ("train_replay", self._tag, tuple(self._image.shape), self._im_info, int(self._gt_boxes.data_ptr()), float(train_op.lr),
-               train_op.replay_signature(), hip, self._num_classes, self._anchor_scales, self._anchor_ratios, bool(cfg.RESNET.MAX_POOL),
+               id(train_op), train_op.replay_signature(), hip, self._num_classes, self._anchor_scales, self._anchor_ratios, bool(cfg.RESNET.MAX_POOL),
                bool(cfg.USE_GPU_NMS), bool(cfg.USE_E2E_TF), cfg.POOLING_SIZE,
                (t.RPN_PRE_NMS_TOP_N, t.RPN_POST_NMS_TOP_N, t.RPN_NMS_THRESH, t.BATCH_SIZE, t.FG_FRACTION, t.FG_THRESH, t.BG_THRESH_HI, t.BG_THRESH_LO,
                 t.RPN_BATCHSIZE, t.RPN_FG_FRACTION, t.RPN_POSITIVE_OVERLAP, t.RPN_NEGATIVE_OVERLAP, bool(t.RPN_CLOBBER_POSITIVES),
@@ -804,12 +803,18 @@ class Network(object):
         if ent is None:
             live = [k for k in sess.graphs if isinstance(k, tuple) and k and k[0] == "train_replay"]
             if len(live) >= self.REPLAY_CAP:
-                del sess.graphs[min(live, key=lambda k: sess.graphs[k]["used"])]
+                self._drop_recording(sess, min(live, key=lambda k: sess.graphs[k]["used"]))
             ent = sess.graphs[key] = dict(seen=0, rec=None, used=0)
         self._replay_clock = getattr(self, "_replay_clock", 0) + 1
         ent["used"] = self._replay_clock
         out = sess.buf(self._tag + "/train/losses", (5,))
         rec = ent["rec"]
+        if rec is not None and ent.get("gen") != sess.derived_generation():
+            # the set of derived filter images changed after the recording (a TEST-mode network's first run on this session, another
+            # shape's plan key): its refresh launches no longer cover the set -> this step runs eagerly (weights_changed + refresh see
+            # everything) and the shape is recorded again at its next steady step
+            self._forget_recording(sess, ent)
+            rec = None
         if rec is not None:
             # which physical stream every helper slot runs on: inherited from the recording, or (cfg.HIP.TRAIN_PICK_STREAMS = pool size)
             # searched once per session by timing real steps (replay.StreamPicker) and then shared by every recording with the same slots
@@ -849,10 +854,11 @@ class Network(object):
         steady = (ent["seen"] >= 1 and bool(train_op.params) and getattr(train_op, "_sgd_table", None) is not None
                   and frcnn_hip.recorder is None
                   and (not cfg.HIP.PREP_STREAM or (prep.ready_version == prep.version and len(prep.plan) > 0 and len(prep.ready) == len(prep.plan))))
-        plan_before = len(prep.plan)
+        gen_before = sess.derived_generation()
         ops.arena = arena
         try:
             if steady:
+                prep.forget_waits(main)                       # the recorded step carries every tier's wait at its first use
                 rec = replay.Recording(main)
                 rec.vars = dict(seed=self._sample_seed, gt=int(self._gt_boxes.shape[0]))
                 frcnn_hip.recorder = rec
@@ -861,13 +867,31 @@ class Network(object):
             ops.arena = None
             frcnn_hip.recorder = None
         ent["seen"] += 1
-        if steady and len(prep.plan) == plan_before:          # (a filter prepared inline during the step = not the steady state yet)
+        if steady and sess.derived_generation() == gen_before:     # (a filter image derived inline during the step = not the steady state yet)
             ent["rec"] = rec
+            ent["gen"] = gen_before
             ent["views"] = (dict(self._predictions), dict(self._losses), dict(self._proposal_targets), dict(self._anchor_targets))
             self.replay_stats["recorded"] += 1
         else:
             self.replay_stats["eager"] += 1
         return out.clone()
+
+    @staticmethod
+    def _forget_recording(sess, ent):
+        """Drops an entry's recording (kept: its `seen` count, so the next steady step records again).  A stream search that was running on
+        this recording ends with it -- sess.picking must not stay set, or no other recording could ever start one."""
+        pk = ent.pop("picker", None)
+        if pk is not None and not pk.done:
+            sess.picking = False
+        ent["rec"] = None
+        ent.pop("views", None)
+        ent.pop("gen", None)
+
+    @classmethod
+    def _drop_recording(cls, sess, key):
+        """LRU eviction of a recorded step (REPLAY_CAP)."""
+        cls._forget_recording(sess, sess.graphs[key])
+        del sess.graphs[key]
 
     @staticmethod
     def configure_train_op(train_op):
