@@ -764,13 +764,17 @@ def main():
             # cfg 31; separate --pmc passes, scratch/gpu_r05_v.sh -> the committed JSON): the waves wait on s_waitcnt half of their cycles,
             # the matrix pipe is busy 0.28, write requests stall 0.06 -- latency inside the tile's serial chain, neither pipe nor HBM
             counters = None
-            cpath = os.path.join(ROOT, "profiles", "r05_counters_conv3.json")
+            cpath = next((q for q in (os.path.join(ROOT, "profiles", n_) for n_ in ("r06_counters_conv3.json", "r05_counters_conv3.json")) if os.path.exists(q)),
+                         os.path.join(ROOT, "profiles", "r05_counters_conv3.json"))
             if os.path.exists(cpath):
                 try:
                     cj = json.load(open(cpath))
                     counters = {k: cj[k] for k in ("source", "SQ_WAIT_INST_ANY/SQ_WAVE_CYCLES", "SQ_WAIT_ANY/SQ_WAVE_CYCLES", "mfma_busy",
                                                    "TCC_EA0_WRREQ_STALL/TCC_EA0_WRREQ", "SQ_LDS_BANK_CONFLICT", "hbm_bytes_per_launch") if k in cj}
-                    counters["reading"] = "latency-bound: waves parked on s_waitcnt, neither the matrix pipe nor HBM saturated"
+                    counters["reading"] = cj.get("reading", "latency-bound: waves parked on s_waitcnt, neither the matrix pipe nor HBM saturated")
+                    if cj.get("hbm_bytes_per_launch") and cj.get("algorithmic_bytes_per_launch"):
+                        counters["traffic_ratio"] = round(cj["hbm_bytes_per_launch"] / cj["algorithmic_bytes_per_launch"], 3)
+                        counters["algorithmic_bytes_per_launch"] = cj["algorithmic_bytes_per_launch"]
                 except Exception:
                     counters = None
             whole_launched = flops_per_image * value / world / 1e12
@@ -822,6 +826,10 @@ def main():
                 # launched FLOPs over the TIMED region's clock (all chains, non-conv stages included), same per-pipe peaks
                 "frac_timed_region": round(whole_launched / ceiling, 4),
                 "mfma_busy": busy, "traffic": traffic, "traffic_source": tsrc,
+                # pipeline average (all GEMM launches) and the DOMINANT launch alone (block4 conv3 as shipped; `counters`): counter bytes /
+                # algorithmic bytes -- well above 1 = re-fetched operands, the first thing to fix
+                "traffic_ratio_all_gemm_launches": None if not traffic else round(traffic / max(conv[3] // max(conv[2], 1), 1), 3),
+                "traffic_ratio_dominant_launch": None if not counters else counters.get("traffic_ratio"),
                 "sclk_mhz": None if telemetry is None else telemetry["sclk_mhz"], "socket_w": None if telemetry is None else telemetry["socket_w"],
                 # the dense peaks above are quoted at the 2.4 GHz boost clock; every configuration of this pipeline runs at the socket
                 # power limit (1 400 W) with the firmware picking the clock (profiles/r04_e_h2_power.txt), so the same fraction against
@@ -863,6 +871,17 @@ def main():
             elif lat:
                 out["latency_batch1"] = lat
             out["other_configs"] = oc
+        # LAST on the line on purpose: a log tail that cuts the line from the front still carries the numbers a reader compares first
+        # (round 5's driver tail lost `x3_variant`)
+        out["summary"] = {"images_per_sec": out["value"], "ms_per_step": out["ms_per_step"],
+                          "x3_variant_images_per_sec": None if x3_variant is None else x3_variant["value"],
+                          "f32_mfma_variant_images_per_sec": None if f32_variant is None else f32_variant["value"],
+                          "roofline_frac": (out.get("roofline") or {}).get("frac"),
+                          "traffic_ratio_dominant_launch": (out.get("roofline") or {}).get("traffic_ratio_dominant_launch"),
+                          "latency_ms_batch1": out.get("latency_ms_batch1"),
+                          "socket_w": None if telemetry is None else telemetry.get("socket_w"),
+                          "j_per_image": None if (telemetry is None or not telemetry.get("socket_w")) else round(telemetry["socket_w"] / value, 3)}
+        out["j_per_image"] = out["summary"]["j_per_image"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -6,6 +6,7 @@ import ctypes
 import os
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -216,6 +217,11 @@ class _Sess(object):
     def derived_generation(self):
         return (self.derived_gen, self.prepared.gen)
 
+    def shape_scope(self, key, group=None, cap=None):
+        import contextlib
+        self.scope_log = getattr(self, "scope_log", []) + [(key, group, cap)]
+        return contextlib.nullcontext()
+
     def buf(self, name, shape, dtype=torch.float32, zero=False):
         key = (name, tuple(shape), dtype)
         if key not in self.buffers:
@@ -247,6 +253,9 @@ def _stub_net(monkeypatch, log):
     target = FakeFn("frcnn_target", [P, I, LL, P], log)
 
     class Net(Network):
+        def _train_scope(self, sess, blobs):
+            return Network._train_scope(self, sess, dict(blobs, data=np.zeros(tuple(blobs["shape"][:3]) + (3,), dtype=np.float32)))
+
         def _stage_train_inputs(self, sess, blobs):
             self._sess, self._image, self._im_info = sess, torch.zeros(blobs["shape"]), (1.0, 2.0, 1.0)
             self._gt_boxes = sess.buf("gt", (128, 5))[:blobs["G"]]
@@ -284,6 +293,9 @@ def test_train_step_goes_eager_then_recorded_then_replayed(monkeypatch):
             assert [e for e in log if e[0] == "frcnn_target"] == [("frcnn_target", 0xB0, G, 2 * i, 0x1000)], (i, log)      # this step's box count and seed
             assert len([e for e in log if e[0] == "frcnn_conv"]) == 2
         assert net.replay_stats == dict(eager=1, recorded=1, replayed=2) and net._sample_seed == 8 and sess.prepared.epoch == 2
+        # every step ran inside its image shape's buffer scope (Session.shape_scope), LRU group = the network tag
+        assert sess.scope_log == [(("train_shape", "t", (1, 4, 6, 4)), ("train", "t"), int(cfg.HIP.TRAIN_CACHE_SHAPES))] * 4
+        assert all(e.get("scope") == ("train_shape", "t", (1, 4, 6, 4)) for k, e in sess.graphs.items() if k[0] == "train_replay")
         net.train_step_async(sess, dict(shape=(1, 4, 8, 4), G=1), op)                 # another image shape: eager again
         assert net.replay_stats == dict(eager=2, recorded=1, replayed=2)
         sess.prepared.version += 1                                                    # filters changed behind the solver's back: not steady, no recording

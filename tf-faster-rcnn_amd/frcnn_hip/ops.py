@@ -16,6 +16,26 @@ _ws_cache = {}
 _ws_retired = []
 ws_scope = "default"     # set by callers that run several independent chains concurrently (one scope per stream)
 
+# The per-SHAPE buffer set of the build that is running (Session.shape_scope; None outside one).  Everything whose size follows the image --
+# named activation buffers, operand planes, arena results, scratch -- is registered there while it is set, so that evicting a shape's
+# captured graph / recorded step frees (returns to torch's size-class pools) exactly what that shape needed.  Weight-shaped buffers stay
+# session-wide: their producers run under `unscoped()`.
+scope_store = None
+
+
+class unscoped(object):
+    """`with unscoped():` -- buffers allocated inside belong to the session, not to the image shape being built (filter images, solver state)."""
+
+    def __enter__(self):
+        global scope_store
+        self.prev, scope_store = scope_store, None
+        return self
+
+    def __exit__(self, *exc):
+        global scope_store
+        scope_store = self.prev
+        return False
+
 
 stream_pin = None        # a ctypes stream handle: every launch of this module goes there instead of torch's current stream (see pinned_stream)
 
@@ -134,13 +154,16 @@ def _chk(t, dtype=torch.float32):
 def workspace(nbytes, device, tag="default"):
     """Grow-only scratch buffer per (device, tag); never reallocated inside a captured region
     as long as the first (warm-up) call already saw the largest request."""
-    key = (str(device), tag, ws_scope)
-    buf = _ws_cache.get(key)
+    # inside a shape scope the scratch belongs to the shape (freed with it); a buffer a captured graph may still address is retired INTO the
+    # same store, i.e. lives exactly as long as that graph
+    store = _ws_cache if scope_store is None else scope_store
+    key = ("ws", str(device), tag, ws_scope)
+    buf = store.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:
-            _ws_retired.append(buf)         # a captured hipGraph may still hold this address: never hand it back to the allocator
+            (_ws_retired if scope_store is None else store.setdefault(("ws_retired",), [])).append(buf)
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
+        store[key] = buf
     return buf
 
 

@@ -36,9 +36,10 @@ class Arena(object):
     def take(self, shape, dtype, device):
         key = ("arena", self.tag, self.n, tuple(int(s) for s in shape), dtype)
         self.n += 1
-        t = self.sess.buffers.get(key)
+        store = self.sess._store() if hasattr(self.sess, "_store") else self.sess.buffers      # (per image shape inside Session.shape_scope)
+        t = store.get(key)
         if t is None:
-            t = self.sess.buffers[key] = torch.empty(key[3], dtype=dtype, device=self.sess.device if device is None else device)
+            t = store[key] = torch.empty(key[3], dtype=dtype, device=self.sess.device if device is None else device)
         return t
 
 

@@ -184,7 +184,8 @@ class PreparedFilters(object):
         if self.enabled and self.ready_version == self.version and key in self.ready:
             self._wait(1 if key[0] == "fwd" else 2)     # the forward pass does not wait for the gradient filters queued behind its own
             return self.plan[key][1]
-        out = fn()
+        with ops.unscoped():                # filter images are per session, not per image shape (Session.shape_scope)
+            out = fn()
         if self.enabled:
             if key not in self.plan:
                 self.gen += 1
@@ -219,7 +220,6 @@ class PreparedFilters(object):
             if pre is not None:
                 pre()
             return
-        from . import ops
         main = torch.cuda.current_stream(self.device)
         if self.stream is None:
             self.stream, self.events = torch.cuda.Stream(device=self.device), [torch.cuda.Event() for _ in range(3)]
@@ -228,7 +228,7 @@ class PreparedFilters(object):
             if h != int(main.cuda_stream):
                 ops.st_wait_stream(self.stream, st)
         self.readers = {}
-        with ops.pinned_stream(self.stream):
+        with ops.pinned_stream(self.stream), ops.unscoped():
             if pre is not None:
                 pre()
             ops.ev_record(self.events[0], self.stream)
@@ -258,7 +258,9 @@ class Session(VariableStore):
         VariableStore.__init__(self, seed)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.stream = torch.cuda.Stream(device=self.device)
-        self.buffers = {}
+        self.buffers = {}                               # session-wide buffers (weight-shaped, solver state, anything allocated outside a scope)
+        self.scopes = collections.OrderedDict()         # shape-scope key -> {buffer key: tensor}, least recently entered first (shape_scope)
+        self.scope_group = {}                           # shape-scope key -> LRU group
         self.profile = None                             # list of (tag, flops, ev0, ev1) when profiling
         self.flops_last_forward = 0
         self.flops_by_pipe = None                       # dict while somebody wants the split (Session.mark)
@@ -334,12 +336,74 @@ class Session(VariableStore):
         recording stores this value and is dropped when it no longer matches."""
         return (self.derived_gen, self.prepared.gen)
 
+    # ---- buffers: per session, or per image shape -------------------------------------------------------------------------------------
+    # The reference's graph takes [1, None, None, 3] and test_net walks an imdb whose images all differ in size (lib/nets/network.py:386-390,
+    # lib/model/test.py:138-185).  Here every distinct shape has its own static buffers (a captured hipGraph / a recorded step addresses
+    # them), so they are grouped per shape and the groups are kept least-recently-used: entering a scope beyond the group's cap drops the
+    # oldest shapes -- captured graph, activation buffers, operand planes, arena results, scratch -- back to torch's allocator, whose
+    # size-class pools hand the blocks to the next shape.  Memory is bounded by cap shapes per group, not by the imdb.
+    class _Scope(object):
+        def __init__(self, sess, key, group, cap):
+            self.sess, self.key, self.group, self.cap = sess, key, group, cap
+
+        def __enter__(self):
+            s = self.sess
+            if self.key not in s.scopes:
+                if self.cap is not None:
+                    live = [k for k in s.scopes if s.scope_group.get(k) == self.group]
+                    drop = live[:max(0, len(live) + 1 - max(1, int(self.cap)))]
+                    if drop:
+                        torch.cuda.synchronize(s.device)          # a replay of an evicted graph may still be running
+                        for k in drop:
+                            s.drop_scope(k)
+                s.scopes[self.key] = {}
+                s.scope_group[self.key] = self.group
+            s.scopes.move_to_end(self.key)
+            self.prev, ops.scope_store = ops.scope_store, s.scopes[self.key]
+            return self
+
+        def __exit__(self, *exc):
+            ops.scope_store = self.prev
+            return False
+
+    def shape_scope(self, key, group=None, cap=None):
+        """`with sess.shape_scope(key, group, cap):` -- buffers requested inside belong to `key` (an image shape's graph key / recorded-step
+        key).  At most `cap` scopes of a group stay alive; the least recently entered ones go first, with their sess.graphs entry."""
+        return Session._Scope(self, key, group, cap)
+
+    def drop_scope(self, key):
+        """Forget one shape: its captured graph / recording (sess.graphs[key]) and every buffer registered under it.  The caller makes sure
+        nothing that addresses them is still running (shape_scope synchronises before an eviction)."""
+        for k, ent in list(self.graphs.items()):          # the shape's own graph, and every recorded step that addresses its buffers
+            if k == key or (isinstance(ent, dict) and ent.get("scope") == key):
+                pk = ent.get("picker") if isinstance(ent, dict) else None
+                if pk is not None and not pk.done:
+                    self.picking = False                  # (a stream search that was running on the dropped recording ends with it)
+                del self.graphs[k]
+        self.scope_group.pop(key, None)
+        return self.scopes.pop(key, None) is not None
+
+    def _store(self):
+        return self.buffers if ops.scope_store is None else ops.scope_store
+
+    def scope_bytes(self, key=None):
+        """bytes held by one shape scope (key) or by all of them: what an eviction returns"""
+        def size(v):
+            if torch.is_tensor(v):
+                return v.numel() * v.element_size()
+            if isinstance(v, (tuple, list)):
+                return sum(size(x) for x in v)
+            return sum(size(getattr(v, a)) for a in ("planes", "inv") if hasattr(v, a))
+        stores = [self.scopes[key]] if key is not None else list(self.scopes.values())
+        return sum(size(v) for st in stores for v in st.values())
+
     def buf(self, name, shape, dtype=torch.float32, zero=False):
         key = (name, tuple(shape), dtype)
-        t = self.buffers.get(key)
+        store = self._store()
+        t = store.get(key)
         if t is None:
             t = (torch.zeros if zero else torch.empty)(tuple(shape), dtype=dtype, device=self.device)
-            self.buffers[key] = t
+            store[key] = t
         return t
 
     # ---- profiling hook: HIP events around selected launches, on the stream they run on ----------
@@ -415,9 +479,10 @@ class Session(VariableStore):
     def h2_buf(self, name, rows, K):
         """Static operand-plane buffer (ops.H2) for an activation tensor of [rows, K]."""
         key = ("h2", name, int(rows), int(K))
-        t = self.buffers.get(key)
+        store = self._store()
+        t = store.get(key)
         if t is None:
-            t = self.buffers[key] = ops.H2.empty(rows, K, self.device)
+            t = store[key] = ops.H2.empty(rows, K, self.device)
         return t
 
     def buf_pair(self, name, N, K):
@@ -449,6 +514,8 @@ class Session(VariableStore):
 
     def close(self):
         self.graphs.clear()
+        self.scopes.clear()
+        self.scope_group.clear()
         self.buffers.clear()
         self.packed.clear()
         self.x3.clear()

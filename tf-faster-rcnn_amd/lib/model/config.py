@@ -123,11 +123,16 @@ __C = AttrDict(
     # with the picker the data-parallel-rules step went from 25.2 to 20.0 ms, profiles/r05_j_c5_dp_rules_ab_stream_picker.txt).  Default 6:
     # 1 + 6 x (helper slots) windows of 3 real steps at start-up (~2 s); 0 = keep the streams the step was recorded on.
     # H2_TILE_CFG: -1 = tile shape by launch size (csrc/gemm_h2.hip), else a frcnn_gemm_h2 configuration id for every launch (A/B runs).
+    # GRAPH_CACHE_SHAPES / TRAIN_CACHE_SHAPES: image shapes per network tag whose captured hipGraph (TEST) / recorded steps (TRAIN) and static
+    # buffers are kept; the least recently used shape is dropped first and its buffers go back to the allocator (Session.shape_scope).  The
+    # reference's graph takes any [1, H, W, 3] (lib/nets/network.py:386-390) and an imdb has hundreds of sizes: memory is bounded by these
+    # caps, not by the imdb.  ResNet-101 at 600 x 1000 holds ~2 GB per shape.
     HIP=dict(WINOGRAD=True, WINOGRAD_MIN_CIN=64, WINOGRAD_M=4, WINOGRAD_F2_SCOPES=("block1", "block2"), WINOGRAD_DIRECT_SCOPES=(),
              WINOGRAD_TRAIN=True,
              WINOGRAD_7X7=True, FUSE_TAIL_MEAN=True, MFMA_X3=True,
              MFMA_H2=True, H2_LAZY_SPLIT=True, H2_MIN_TILES=150, H2_TRAIN_MIN_TILES=320, H2_TRUNK_PLANES=True, H2_TILE_CFG=-1,
-             X3_TILE_CFG=-1, H2_TRAIN=True, WGRAD_STREAM=2, WGRAD_TN=True, WGRAD_H2=True, PREP_STREAM=True, TRAIN_REPLAY=True, TRAIN_PICK_STREAMS=6))
+             X3_TILE_CFG=-1, H2_TRAIN=True, WGRAD_STREAM=2, WGRAD_TN=True, WGRAD_H2=True, PREP_STREAM=True, TRAIN_REPLAY=True, TRAIN_PICK_STREAMS=6,
+             GRAPH_CACHE_SHAPES=4, TRAIN_CACHE_SHAPES=16))
 __C.DATA_DIR = osp.abspath(osp.join(__C.ROOT_DIR, 'data'))
 cfg = __C
 

@@ -17,7 +17,7 @@ def im_detect(sess, net, blob, im_scale, im_shape):
     Returns (scores [R,C], pred_boxes [R,4C]) like lib/model/test.py:86-107 -- decode + clip of the
     per-class boxes included -- computed from the device tensors."""
     im_info = np.array([blob.shape[1], blob.shape[2], im_scale], dtype=np.float32)
-    img = net._stage_image(sess, blob)
+    img = net._stage_image(sess, blob, im_info)
     p = net.forward_device(sess, img, im_info)
     n = p["rois"].shape[0] if net._num_rois is None else int(net._num_rois.item())
     rois, bbox_pred = p["rois"][:n].contiguous(), (p["bbox_pred"][:n].contiguous() if cfg.TEST.BBOX_REG else None)
@@ -31,7 +31,8 @@ def _get_image_blob(sess, net, im):
     if isinstance(im, np.ndarray):
         im = torch.from_numpy(np.ascontiguousarray(im)).to(sess.device, non_blocking=True)     # 3 B/pixel over PCIe
     im_scale, OH, OW = ops.prep_image_shape(im.shape[0], im.shape[1], cfg.TEST.SCALES[0], cfg.TEST.MAX_SIZE)
-    out = sess.buf(net._tag + "/image", (1, OH, OW, 4))
+    with net.shape_scope(sess, (1, OH, OW, 4), (OH, OW)):        # the staged image belongs to its shape's scope (freed with the shape's graph)
+        out = sess.buf(net._tag + "/image", (1, OH, OW, 4))
     ops.prep_image(im, cfg.PIXEL_MEANS, im_scale, (OH, OW), out=out, out_c=4)
     return out, im_scale
 
@@ -61,7 +62,7 @@ def detect(sess, net, blob, im_scale, im_shape, max_per_image=100, thresh=0.):
     """Whole per-image body of test_net (test.py:156-180) on the GPU -> all_boxes-style list over
     classes of [n,5] arrays (x1,y1,x2,y2,score)."""
     im_info = np.array([blob.shape[1], blob.shape[2], im_scale], dtype=np.float32)
-    img = net._stage_image(sess, blob)
+    img = net._stage_image(sess, blob, im_info)
     dets, cnt = net.detect_device(sess, img, im_info, im_shape, max_per_image=max_per_image, thresh=thresh)
     n = min(int(cnt.item()), dets.shape[0])
     rec = dets[:n].cpu().numpy()

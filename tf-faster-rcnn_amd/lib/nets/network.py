@@ -646,67 +646,85 @@ class Network(object):
         return {k: k for k in names}
 
     # ------------------------------------------------------------------ execution
-    def _stage_image(self, sess, image):
+    def _stage_image(self, sess, image, im_info=None):
         """[1,H,W,3] (BGR - PIXEL_MEANS, like blobs['data']) -> static device buffer [1,H,W,4]; the
-        zero 4th channel lets the 7x7/3x3 stem run as a channel-folded MFMA GEMM."""
+        zero 4th channel lets the 7x7/3x3 stem run as a channel-folded MFMA GEMM.  im_info given: the buffer belongs to that image
+        shape's scope (freed with the shape's graph); otherwise to the session."""
         if isinstance(image, np.ndarray):
             image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32))
         B, H, W, C = image.shape
-        buf = sess.buf(self._tag + "/image", (B, H, W, 4), zero=True)
+        if im_info is None:
+            buf = sess.buf(self._tag + "/image", (B, H, W, 4), zero=True)
+        else:
+            with self.shape_scope(sess, (B, H, W, 4), im_info):
+                buf = sess.buf(self._tag + "/image", (B, H, W, 4), zero=True)
         buf[..., :C].copy_(image, non_blocking=True)
         return buf
 
+    def graph_key(self, image_shape, im_info):
+        """Everything a captured TEST-mode chain depends on: network, image shape, im_info and every switch that changes a launch."""
+        c = cfg[self._mode]
+        return (self._tag, self._scope, self._num_classes, self._anchor_scales, self._anchor_ratios, bool(cfg.RESNET.MAX_POOL),
+                bool(cfg.USE_GPU_NMS), tuple(int(v) for v in image_shape), (float(im_info[0]), float(im_info[1])), self._mode, cfg.TEST.MODE, self._fuse_tail_entry,
+                c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH, cfg.TEST.RPN_TOP_N, cfg.POOLING_SIZE,
+                bool(cfg.HIP.WINOGRAD), int(cfg.HIP.WINOGRAD_MIN_CIN), int(cfg.HIP.WINOGRAD_M), tuple(cfg.HIP.WINOGRAD_F2_SCOPES),
+                tuple(cfg.HIP.WINOGRAD_DIRECT_SCOPES), bool(cfg.HIP.WINOGRAD_7X7), bool(cfg.HIP.FUSE_TAIL_MEAN), bool(cfg.HIP.MFMA_X3), bool(cfg.USE_E2E_TF),
+                bool(cfg.HIP.MFMA_H2), bool(cfg.HIP.H2_LAZY_SPLIT), int(cfg.HIP.H2_MIN_TILES), bool(cfg.HIP.H2_TRUNK_PLANES), int(cfg.HIP.H2_TILE_CFG), int(cfg.HIP.X3_TILE_CFG), bool(cfg.HIP.H2_TRAIN))
+
+    def shape_scope(self, sess, image_shape, im_info):
+        """The buffer scope of one image shape of this network (frcnn_hip/runtime.py Session.shape_scope): at most cfg.HIP.GRAPH_CACHE_SHAPES
+        shapes per network tag keep their captured graph and buffers; the least recently used shape goes first.  The reference's graph takes
+        [1, None, None, 3] and test_net walks an imdb of hundreds of sizes (lib/nets/network.py:386-390, lib/model/test.py:138-185)."""
+        return sess.shape_scope(self.graph_key(image_shape, im_info), group=("graphs", self._tag), cap=int(cfg.HIP.GRAPH_CACHE_SHAPES))
+
     def forward_device(self, sess, image_d, im_info, use_graph=True):
         """Runs the network on a staged device image; fills self._predictions with DEVICE tensors.
-        The whole chain is captured into one hipGraph per (tag, image shape) and replayed."""
+        The whole chain is captured into one hipGraph per (tag, image shape) and replayed; graph and buffers live in the shape's scope."""
         self._sess = sess
         self._image = image_d
         self._im_info = (float(im_info[0]), float(im_info[1]), float(im_info[2]))
         sess.prepared.wait_planes()                    # a solver sharing the session re-derives filter planes on a side stream (a replay reads them)
         ops.ws_scope = self._tag                       # scratch buffers are per network tag (= per stream)
-        c = cfg[self._mode]
-        key = (self._tag, self._scope, self._num_classes, self._anchor_scales, self._anchor_ratios, bool(cfg.RESNET.MAX_POOL),
-               bool(cfg.USE_GPU_NMS), tuple(image_d.shape), self._im_info[:2], self._mode, cfg.TEST.MODE, self._fuse_tail_entry,
-               c.RPN_PRE_NMS_TOP_N, c.RPN_POST_NMS_TOP_N, c.RPN_NMS_THRESH, cfg.TEST.RPN_TOP_N, cfg.POOLING_SIZE,
-               bool(cfg.HIP.WINOGRAD), int(cfg.HIP.WINOGRAD_MIN_CIN), int(cfg.HIP.WINOGRAD_M), tuple(cfg.HIP.WINOGRAD_F2_SCOPES),
-               tuple(cfg.HIP.WINOGRAD_DIRECT_SCOPES), bool(cfg.HIP.WINOGRAD_7X7), bool(cfg.HIP.FUSE_TAIL_MEAN), bool(cfg.HIP.MFMA_X3), bool(cfg.USE_E2E_TF),
-               bool(cfg.HIP.MFMA_H2), bool(cfg.HIP.H2_LAZY_SPLIT), int(cfg.HIP.H2_MIN_TILES), bool(cfg.HIP.H2_TRUNK_PLANES), int(cfg.HIP.H2_TILE_CFG), int(cfg.HIP.X3_TILE_CFG), bool(cfg.HIP.H2_TRAIN))
+        key = self.graph_key(image_d.shape, self._im_info)
         cur = torch.cuda.current_stream(sess.device)
-        if not use_graph or sess.profile is not None:
-            sess.flops_last_forward = 0
-            self._build_network(self._mode == "TRAIN")
-            return self._predictions
-        if key not in sess.graphs:
-            with torch.cuda.stream(sess.stream):
-                sess.stream.wait_stream(cur)
+        with self.shape_scope(sess, image_d.shape, self._im_info):
+            if not use_graph or sess.profile is not None:
                 sess.flops_last_forward = 0
-                self._build_network(False)                   # warm-up: allocates buffers, packs weights
-                sess.stream.synchronize()
-                flops = sess.flops_last_forward
-                g = ops.Graph().capture(lambda: self._build_network(False))
-                sess.stream.synchronize()
-            sess.graphs[key] = (g, dict(self._predictions), self._num_rois, flops, self._rois_per_image)
-        g, preds, num, flops, per = sess.graphs[key]
-        self._predictions, self._num_rois, sess.flops_last_forward, self._rois_per_image = dict(preds), num, flops, per
-        g.launch()
+                self._build_network(self._mode == "TRAIN")
+                return self._predictions
+            if key not in sess.graphs:
+                with torch.cuda.stream(sess.stream):
+                    sess.stream.wait_stream(cur)
+                    sess.flops_last_forward = 0
+                    self._build_network(False)                   # warm-up: allocates buffers, packs weights
+                    sess.stream.synchronize()
+                    flops = sess.flops_last_forward
+                    g = ops.Graph().capture(lambda: self._build_network(False))
+                    sess.stream.synchronize()
+                sess.graphs[key] = (g, dict(self._predictions), self._num_rois, flops, self._rois_per_image)
+            g, preds, num, flops, per = sess.graphs[key]
+            self._predictions, self._num_rois, sess.flops_last_forward, self._rois_per_image = dict(preds), num, flops, per
+            g.launch()
         return self._predictions
 
     # only useful during testing mode
     def extract_head(self, sess, image):
         self._sess = sess
         sess.prepared.wait_planes()
-        self._image = self._stage_image(sess, image)
-        self._h2_of, self._f32_missing = {}, set()
-        ops.ws_scope = self._tag
-        with self._plan_context(self, False):          # the same launch plan as forward_device: the same bits for the same image
-            feat = self._image_to_head(False)
-        return feat.cpu().numpy()
+        shape = (int(image.shape[0]), int(image.shape[1]), int(image.shape[2]), 4)
+        with sess.shape_scope(("extract_head", self._tag, shape), group=("head", self._tag), cap=int(cfg.HIP.GRAPH_CACHE_SHAPES)):
+            self._image = self._stage_image(sess, image)
+            self._h2_of, self._f32_missing = {}, set()
+            ops.ws_scope = self._tag
+            with self._plan_context(self, False):          # the same launch plan as forward_device: the same bits for the same image
+                feat = self._image_to_head(False)
+            return feat.cpu().numpy()
 
     # only useful during testing mode
     def test_image(self, sess, image, im_info):
         """network.py:470-479: returns cls_score, cls_prob, bbox_pred, rois as numpy arrays (rows of
         the `num_rois` proposals that survived NMS)."""
-        img = self._stage_image(sess, image)
+        img = self._stage_image(sess, image, im_info)
         p = self.forward_device(sess, img, im_info)
         assert img.shape[0] == 1, "test_image keeps the reference's single-image contract (network.py:388); use detect_device for batches"
         n = p["rois"].shape[0] if self._num_rois is None else int(self._num_rois.item())
@@ -759,19 +777,30 @@ class Network(object):
         tensor copy and collective of the step, streams as slots) and every later step of that shape replays the list -- the same
         launches, arguments, streams and order, hence the same bits, without the ~14 ms of Python a step costs the host."""
         assert self._mode == "TRAIN"
-        self._stage_train_inputs(sess, blobs)
-        if not cfg.HIP.TRAIN_REPLAY:
-            return self._train_step_body(sess, train_op, sess.buf(self._tag + "/train/losses", (5,))).clone()
-        return self._train_step_replayed(sess, train_op)
+        with self._train_scope(sess, blobs):
+            self._stage_train_inputs(sess, blobs)
+            if not cfg.HIP.TRAIN_REPLAY:
+                return self._train_step_body(sess, train_op, sess.buf(self._tag + "/train/losses", (5,))).clone()
+            return self._train_step_replayed(sess, train_op)
+
+    def _train_scope(self, sess, blobs):
+        """A roidb's images differ in size from step to step (lib/roi_data_layer/layer.py:80-93); the step's activations, gradients, arena
+        results and scratch are static per image SHAPE (a recorded step addresses them), so they live in the shape's buffer scope and at
+        most cfg.HIP.TRAIN_CACHE_SHAPES shapes are kept -- the least recently used shape's buffers and recordings are dropped together."""
+        d = blobs["data"]
+        shape = (int(d.shape[0]), int(d.shape[1]), int(d.shape[2]), 4)
+        self._train_scope_key = ("train_shape", self._tag, shape)
+        return sess.shape_scope(self._train_scope_key, group=("train", self._tag), cap=int(cfg.HIP.TRAIN_CACHE_SHAPES))
 
     def _train_step_body(self, sess, train_op, out):
         """forward + losses + reverse sweep + solver, enqueued eagerly; the five losses into the static tensor `out`"""
         losses = self._train_forward_staged(sess)
         if not train_op.params:
-            train_op.build()
-            if getattr(train_op, "pending_slots", None) is not None:          # resumed run: momentum before the first update
-                train_op.import_slots(train_op.pending_slots)
-                train_op.pending_slots = None
+            with ops.unscoped():                                                  # solver state is per session, not per image shape
+                train_op.build()
+                if getattr(train_op, "pending_slots", None) is not None:          # resumed run: momentum before the first update
+                    train_op.import_slots(train_op.pending_slots)
+                    train_op.pending_slots = None
         self.configure_train_op(train_op)
         train_op.backward(self._loss_seeds, fuse_solver=True)
         reg = train_op.regularization_value()
@@ -804,7 +833,7 @@ class Network(object):
             live = [k for k in sess.graphs if isinstance(k, tuple) and k and k[0] == "train_replay"]
             if len(live) >= self.REPLAY_CAP:
                 self._drop_recording(sess, min(live, key=lambda k: sess.graphs[k]["used"]))
-            ent = sess.graphs[key] = dict(seen=0, rec=None, used=0)
+            ent = sess.graphs[key] = dict(seen=0, rec=None, used=0, scope=getattr(self, "_train_scope_key", None))
         self._replay_clock = getattr(self, "_replay_clock", 0) + 1
         ent["used"] = self._replay_clock
         out = sess.buf(self._tag + "/train/losses", (5,))
@@ -918,11 +947,12 @@ class Network(object):
         # rows of the output: test.py:176-180 keeps every detection that TIES the max_per_image-th score, so the list can exceed
         # max_per_image; the default buffer holds 28 extra rows (a 128-row record), `count` reports the true number
         max_out = None if out is None else out.shape[-2]
-        if B > 1:
-            max_out = (max_per_image + 28) if out is None else max_out
-            out = sess.buf(self._tag + "/dets", (B, max_out, 6)) if out is None else out
-            count = sess.buf(self._tag + "/det_count", (B,), torch.int32) if count is None else count
-        return sess.mark("op:detect_post", 0, lambda: ops.detect_post(
-            p["cls_prob"], p["bbox_pred"] if cfg.TEST.BBOX_REG else None, p["rois"], self._num_rois, float(im_info[2]), int(im_shape[0]), int(im_shape[1]),
-            float(cfg.TEST.NMS), float(thresh), int(max_per_image), max_out=max_out, out=out, count=count, batch=B,
-            rule=self._nms_rule()), nbytes=B * R * 20 * C)
+        with self.shape_scope(sess, image_d.shape, im_info):         # (the post-processing scratch follows the proposal count of the shape's graph)
+            if B > 1:
+                max_out = (max_per_image + 28) if out is None else max_out
+                out = sess.buf(self._tag + "/dets", (B, max_out, 6)) if out is None else out
+                count = sess.buf(self._tag + "/det_count", (B,), torch.int32) if count is None else count
+            return sess.mark("op:detect_post", 0, lambda: ops.detect_post(
+                p["cls_prob"], p["bbox_pred"] if cfg.TEST.BBOX_REG else None, p["rois"], self._num_rois, float(im_info[2]), int(im_shape[0]), int(im_shape[1]),
+                float(cfg.TEST.NMS), float(thresh), int(max_per_image), max_out=max_out, out=out, count=count, batch=B,
+                rule=self._nms_rule()), nbytes=B * R * 20 * C)
