@@ -492,6 +492,8 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the other BASELINE configs / the batch-1 latency run that the "
                     "default invocation appends as `other_configs` / `latency_ms_batch1`")
     ap.add_argument("--layer-report", default=None, help="write a per-layer table of the event pass to this file")
+    ap.add_argument("--skip-calls", default="", help="MEASUREMENT ONLY (the energy ledger, scratch/energy_ledger.py): comma-separated C-ABI entry names "
+                    "(prefix match) whose launches are dropped -- the results are WRONG by construction and the line says so (`ablated`)")
     args = ap.parse_args()
     c = CONFIGS[args.config]
 
@@ -522,6 +524,20 @@ def main():
     frcnn_hip.lib()
     from frcnn_hip.runtime import Session
     from model.config import cfg
+    skipped = [n for n in args.skip_calls.split(",") if n]
+    if skipped:
+        real_call = frcnn_hip.call
+
+        ablate_on = [False]              # switched on after one complete un-ablated pass: every buffer then holds realistic values (the
+                                         # matrix pipe's power follows its operands), and the graphs are captured again without the launches
+
+        def ablated_call(name, *a):
+            if ablate_on[0] and any(name.startswith(n) for n in skipped):
+                return None
+            return real_call(name, *a)
+        frcnn_hip.call = ablated_call
+        from frcnn_hip import ops as _ops
+        _ops.call = ablated_call
 
     cfg.HIP.MFMA_H2 = args.mfma == "h2"
     cfg.HIP.MFMA_X3 = args.mfma in ("h2", "x3")
@@ -633,6 +649,10 @@ def main():
                 sess.profile = []
         return run_timed(step, args.steps, max(args.warmup, S), dist, torch.cuda.synchronize, reset_profile)
 
+    if skipped:
+        timed_region()
+        ablate_on[0] = True
+        sess.graphs.clear()
     warm_windows = None
     if args.warm_until_stable:
         # a sub-second run on an idle GPU is timed before the clock has ramped (driver 4.84 ms vs 4.07 ms builder-run in round 4): repeat the
@@ -734,6 +754,8 @@ def main():
                                         "v_mfma_f32_32x32x2_f32", "f32": "v_mfma_f32_32x32x2_f32 everywhere"}[args.mfma],
                          "gflop_per_image_launched": round(flops_per_image / 1e9, 2), "gflop_per_image_reference_graph": c["gflop_ref"]}
         out["telemetry"] = telemetry
+        if skipped:
+            out["ablated"] = {"skipped_calls": skipped, "note": "MEASUREMENT ONLY: these launches were dropped, the detections are wrong by construction"}
         if warm_windows is not None:
             out["warm_windows_before_the_timed_one"] = warm_windows
         if exchange_ok is not None:

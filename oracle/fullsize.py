@@ -339,12 +339,12 @@ def run_harness(config, weights, policy, dev, fuse_tail=True):
         wr, ws = ora.proposal_layer(p["rpn_cls_prob"], p["rpn_bbox_pred"], im_info, "TEST", [16], anchors, A, pre_nms_topN=c["pre"],
                                     post_nms_topN=c["post"], nms_thresh=0.7)
         same_shape = wr.shape == rois.shape
-        rep["prop_own_scores_exact"] = bool(same_shape and np.array_equal(net._sess.buffers[(net._tag + "/roi_scores", (c["post"], 1), torch.float32)][:n_rois].cpu().numpy(), ws))
+        rep["prop_own_scores_exact"] = bool(same_shape and np.array_equal(net._sess.find_buf(net._tag + "/roi_scores", (c["post"], 1), torch.float32)[:n_rois].cpu().numpy(), ws))
         rep["prop_own_box_abs_px"] = float(np.abs(rois - wr).max()) if same_shape else float("inf")
         check("proposals vs oracle on identical inputs", rep["prop_own_scores_exact"] and rep["prop_own_box_abs_px"] <= TOL * max(c["H"], c["W"]))
         # ---- ... and a valid outcome of the reference algorithm on the REFERENCE's RPN tensors (decision margins)
         cb, cs = proposal_candidates(fx["rpn_cls_prob"], fx["rpn_bbox_pred"], im_info, c["scales"], c["ratios"])
-        sc_dev = net._sess.buffers[(net._tag + "/roi_scores", (c["post"], 1), torch.float32)][:n_rois].cpu().numpy().ravel()
+        sc_dev = net._sess.find_buf(net._tag + "/roi_scores", (c["post"], 1), torch.float32)[:n_rois].cpu().numpy().ravel()
         m = mg.match_to_candidates(rois[:, 1:5], sc_dev, cb, cs, TOL * max(c["H"], c["W"]) * 4, EPS_SCORE)
         pr = mg.check_greedy_nms(cb, cs, m, 0.7, EPS_SCORE, EPS_IOU, topn=c["pre"], max_keep=c["post"])
         ref_m = mg.match_to_candidates(fx["rois"][:, 1:5], fx["roi_scores"].ravel(), cb, cs, 1e-6, 0.0)

@@ -8,12 +8,39 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "tf-faster-rcnn_amd")
 
 
+PREBUILT = os.path.join(ROOT, "scratch", "libfrcnn_hip_ablation.so")      # built here by prebuild() (git-ignored, travels with the gpurun snapshot)
+
+
+def prebuild(extra=()):
+    """The ablation library compiled in-tree, one hipcc per translation unit in parallel (on the CPU box: the GPU box then loads it
+    instead of spending minutes of GPU time in the compiler)."""
+    sys.path[:0] = [PKG]
+    from concurrent.futures import ThreadPoolExecutor
+    from frcnn_hip import build as B
+    obj_dir = os.path.join(B.CSRC, "build", "ablation")
+    os.makedirs(obj_dir, exist_ok=True)
+    objs = [os.path.join(obj_dir, s.replace(".hip", ".o")) for s in B.SOURCES]
+    cmds = [[B._hipcc()] + B.FLAGS + ["-DFRCNN_ABLATION"] + list(extra) + ["-c", os.path.join(B.CSRC, s), "-o", o] for s, o in zip(B.SOURCES, objs)]
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(subprocess.check_call, cmds))
+    subprocess.check_call([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", PREBUILT] + objs)
+    return PREBUILT
+
+
 def use(extra=()):
     sys.path[:0] = [PKG]
     from frcnn_hip import build as B
+    if not extra and os.path.exists(PREBUILT) and os.path.getmtime(PREBUILT) >= max(os.path.getmtime(os.path.join(B.CSRC, s)) for s in B.SOURCES):
+        import frcnn_hip
+        frcnn_hip.LIB_PATH = PREBUILT
+        return PREBUILT
     so = "/tmp/libfrcnn_hip_ablation.so"
     srcs = [os.path.join(B.CSRC, s) for s in B.SOURCES]
     subprocess.check_call([B._hipcc()] + B.FLAGS + ["-DFRCNN_ABLATION"] + list(extra) + ["-shared", "-o", so] + srcs)
     import frcnn_hip
     frcnn_hip.LIB_PATH = so
     return so
+
+
+if __name__ == "__main__":
+    print(prebuild())

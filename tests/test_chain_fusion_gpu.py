@@ -56,7 +56,7 @@ def test_conv2d_masked_equals_conv2d_then_relu_bwd(dev, case):
         assert torch.equal(buf, want)
 
 
-@pytest.mark.parametrize("cfg", [-1, 9, 12, 21, 30, 31, 32, 33, 34])       # round 6: the light-boundary configurations have masked twins
+@pytest.mark.parametrize("cfg", [-1, 9, 12, 21, 30, 31, 32, 33, 34, 40, 41])       # round 6: the light-boundary / deferred-epilogue configurations have masked twins
 @pytest.mark.parametrize("shape", [(2394, 1024, 256), (12544, 2048, 512), (300, 128, 128)])
 def test_gemm_h2_masked_equals_gemm_h2_then_relu_bwd(dev, shape, cfg):
     from frcnn_hip import ops

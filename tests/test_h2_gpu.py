@@ -240,14 +240,16 @@ def test_depthwise_conv_emits_the_planes_of_its_f32_result(dev, N, H, W, C, stri
                                    (1, 9576, 1024, 256, True), (3, 300, 128, 128, False), (1, 9576, 1024, 256, "planes"),
                                    (1, 128 * 70 + 9, 2048, 512, "planes")],
                          ids=["many_tiles", "b4c1", "w7", "b3c3", "tiny", "b3c3_trunk_planes", "b4c3_trunk_planes"])
-@pytest.mark.parametrize("pp", [21, 12, 30, 31, 32, 33, 34, -1, -4])
+@pytest.mark.parametrize("pp", [21, 12, 30, 31, 32, 33, 34, 40, 41, -1, -4, -8])
 def test_gemm_h2_ping_pong_is_bit_identical_to_the_one_barrier_schedule(dev, shape, pp):
     """cfg 21 (256 x 128 tiles, two wave groups a segment apart, 3-slot ring), cfg 12 (64-row tiles), round 5's cfgs 30-33 (the light tile
     boundary: filter scales + bias through LDS, the residual raw in the accumulators until the first fold, counted vmcnt, 16-byte plane
     stores) and the by-shape choice (-1) multiply and fold in the same order as cfg 9: the f32 result, the emitted planes and the block
     scales must be the same BITS, on every one of several launches (a schedule with a race differs from launch to launch), with several
     tiles per resident workgroup and M tails -- incl. the conv3 class (K = 256 / 512, residual + f32 + planes) with the residual given as
-    float32 or as operand planes (cfg.HIP.H2_TRUNK_PLANES, the default since round 5)."""
+    float32 or as operand planes (cfg.HIP.H2_TRUNK_PLANES, the default since round 5).  Round 6: cfgs 40 / 41 = the deferred epilogue
+    (tile t's results leave under tile t + 1's first three slabs, the residual arrives raw in the accumulator's own registers), -8 = DE
+    wherever it exists."""
     from frcnn_hip import ops
     G, M, N, K, with_res = shape
     torch.manual_seed(G + M)
@@ -268,6 +270,48 @@ def test_gemm_h2_ping_pong_is_bit_identical_to_the_one_barrier_schedule(dev, sha
         torch.cuda.synchronize()
         assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), "f32 result, launch %d" % rep
         assert torch.equal(gotp.planes.view(torch.int16), refp.planes.view(torch.int16)) and torch.equal(gotp.inv, refp.inv), "planes, launch %d" % rep
+
+
+@pytest.mark.parametrize("form", ["planes_res_planes_out", "planes_res_f32_out", "f32_res_planes_out", "no_res_planes_out", "no_res_no_bias_f32"])
+@pytest.mark.parametrize("shape", [(1, 128 * 70 + 9, 2048, 512), (1, 19152, 1024, 256), (1, 128 * 90 + 1, 512, 128), (4, 128 * 9 + 77, 256, 128),
+                                   (1, 100, 128, 128), (2, 128, 128, 384)],
+                         ids=["b4c3", "b3c3", "b2c3_four_slabs_per_tile", "batched_tails", "one_partial_tile", "one_tile_per_entry"])
+def test_gemm_h2_deferred_epilogue_every_form_is_bit_identical(dev, shape, form):
+    """The deferred epilogue (cfgs 40 / 41, csrc/gemm_h2.hip "TUNE & 1024") in the forms the network launches -- the SHIPPED one first:
+    residual read as operand planes, planes only out (the identity units of a trunk kept as planes) -- against cfg 9 on the same
+    operands: same f32 bits, same plane bits, same block scales, six launches each.  Covers K = 128 (a tile is exactly the four slabs
+    the drain needs), one tile per workgroup (nothing to defer: the standalone epilogue alone), M tails inside batch entries (rows past
+    M are dropped by the descriptor's range, loads return 0), and every residual kind through the one branch-free load stream."""
+    from frcnn_hip import ops
+    G, M, N, K = shape
+    torch.manual_seed(M + K)
+    x = torch.randn(G * M, K, device=dev).clamp(min=0) * torch.exp(torch.rand(G * M, K, device=dev) * 6 - 3)
+    w = torch.randn(G, N, K, device=dev) / K ** 0.5
+    b = torch.randn(N, device=dev) if (G == 1 and "no_bias" not in form) else None
+    r = None
+    if form.startswith("planes_res"):
+        r = ops.h2_split(torch.randn(G * M, N, device=dev).clamp(min=0) * torch.exp(torch.rand(G * M, N, device=dev) * 4 - 2))
+    elif form.startswith("f32_res"):
+        r = torch.randn(G * M, N, device=dev)
+    f32_out, planes_out = form.endswith("f32_out") or form.endswith("f32"), form.endswith("planes_out")
+    xp, wp = ops.h2_split(x), ops.h2_pack_w(w)
+
+    def run(c):
+        y = torch.full((G * M, N), float("nan"), device=dev) if f32_out else None
+        yp = ops.H2.empty(G * M, N, dev) if planes_out else None
+        if yp is not None:
+            yp.planes.zero_(); yp.inv.zero_()
+        ops.gemm_h2(xp, wp, G, M, N, K, b, r, 1, out=y, out_planes=yp, want_f32=f32_out, cfg=c)
+        torch.cuda.synchronize()
+        return y, yp
+    ref, refp = run(9)
+    for c in (40, 41, -1):
+        for rep in range(6 if c > 0 else 2):
+            y, yp = run(c)
+            if f32_out:
+                assert torch.equal(y.view(torch.int32), ref.view(torch.int32)), (c, rep)
+            if planes_out:
+                assert torch.equal(yp.planes.view(torch.int16), refp.planes.view(torch.int16)) and torch.equal(yp.inv, refp.inv), (c, rep)
 
 
 @pytest.mark.parametrize("R,K,N,with_res", [(300, 512, 2048, True), (37, 128, 256, False), (48, 256, 128, True)])
@@ -297,5 +341,5 @@ def test_gemm_h2_mean_is_slot_invariant_and_matches_conv_then_mean(dev, R, K, N,
     assert one.shape == (R, N) and err <= 2e-6
     three = run([0, 1, 0], 9)
     assert np.array_equal(three[:R], one) and np.array_equal(three[2 * R:], one) and not np.array_equal(three[R:2 * R], one)
-    for cfg in (12, 21, -1):
+    for cfg in (12, 21, -1, 40, 41):              # (40 / 41: the fused-mean form keeps the standalone epilogue -- the ids map to 31 / 33)
         assert np.array_equal(run([0], cfg), one), cfg

@@ -101,8 +101,8 @@ def test_tools_test_net_on_a_devkit_with_fifty_two_image_sizes(dev, tmp_path, ca
     index, _, _, _ = gge.build_devkit(str(voc), gt, dets, n)
     os.makedirs(str(voc / "JPEGImages"))
     rng = np.random.RandomState(0)
-    sizes = [(96 + 4 * (i % 13), 128 + 12 * (i // 13) + 2 * (i % 13)) for i in range(n)]
-    assert len(set(sizes)) == n
+    sizes = [(100, 125 + 3 * i) for i in range(n)]                      # short side -> 160: network inputs 160 x (200 + 4.8 i), all different
+    assert len({int(np.floor(w * 1.6 + 0.5)) for _, w in sizes}) == n
     for name, (h, w) in zip(index, sizes):
         Image.fromarray((rng.rand(h, w, 3) * 255).astype(np.uint8)).save(str(voc / "JPEGImages" / (name + ".jpg")))
     net = resnetv1(num_layers=50)
@@ -127,7 +127,7 @@ def test_tools_test_net_on_a_devkit_with_fifty_two_image_sizes(dev, tmp_path, ca
     try:
         # images keep (almost) their own size (short side -> 160): 52 distinct network input shapes
         rc = mod.main(["--imdb", "voc_2007_test", "--net", "res50", "--model", ckpt, "--comp", "--set", "DATA_DIR", str(data_dir),
-                       "ROOT_DIR", str(tmp_path), "TEST.SCALES", "[160]", "TEST.MAX_SIZE", "400", "HIP.GRAPH_CACHE_SHAPES", "2",
+                       "ROOT_DIR", str(tmp_path), "TEST.SCALES", "[160]", "TEST.MAX_SIZE", "1000", "HIP.GRAPH_CACHE_SHAPES", "2",
                        "TEST.RPN_POST_NMS_TOP_N", "64"])
     finally:
         Session._Scope.__enter__ = real_enter
@@ -141,3 +141,35 @@ def test_tools_test_net_on_a_devkit_with_fifty_two_image_sizes(dev, tmp_path, ca
     boxes = pickle.load(open(str(tmp_path / "output" / "res50" / "voc_2007_test" / "default" / "detections.pkl"), "rb"))
     assert len(boxes) == 21 and len(boxes[1]) == n
     assert all(sum(len(boxes[j][i]) for j in range(1, 21)) > 0 for i in range(n))
+
+
+def test_a_graph_follows_the_image_wherever_the_caller_staged_it(dev):
+    """A captured graph reads the image at the address it was captured with.  Two entry points stage at different addresses -- test_image /
+    im_detect into the shape's scope, _stage_image(sess, image) without im_info (bench.py, a caller's own buffer) into the session -- and
+    share one graph per shape: whichever comes second must still be computed on ITS image (the graph's input is refreshed by a
+    device-to-device copy when the addresses differ), not on whatever the other entry point left behind."""
+    from model.config import cfg
+    old = cfg.TEST.RPN_POST_NMS_TOP_N
+    cfg.TEST.RPN_POST_NMS_TOP_N = 48
+    try:
+        sess, net = _net(dev, "addr")
+        H, W = 128, 176
+        a, b = _image(H, W, 1), _image(H, W, 2)
+        info = np.array([H, W, 1.0], dtype=np.float32)
+        ra = [x.copy() for x in net.test_image(sess, a, info)]                      # captured with the scope's staging buffer, image a
+        own = net._stage_image(sess, b)                                              # the session-wide staging buffer, image b
+        p = net.forward_device(sess, own, info)
+        torch.cuda.synchronize()
+        n = int(net._num_rois.item())
+        got_b = [p[k][:n].cpu().numpy() for k in ("cls_score", "cls_prob", "bbox_pred", "rois")]
+        s2, n2 = _net(dev, "addr_fresh")
+        want_b = n2.test_image(s2, b, info)
+        assert all(np.array_equal(x, y) for x, y in zip(got_b, want_b))
+        assert not np.array_equal(got_b[0], ra[0][:got_b[0].shape[0]]) or got_b[0].shape != ra[0].shape      # (b is not a)
+        mine = torch.from_numpy(np.concatenate([a, np.zeros((1, H, W, 1), np.float32)], axis=3)).to(dev)    # a caller's own [1,H,W,4] tensor
+        p = net.forward_device(sess, mine, info)
+        torch.cuda.synchronize()
+        n = int(net._num_rois.item())
+        assert all(np.array_equal(p[k][:n].cpu().numpy(), y) for k, y in zip(("cls_score", "cls_prob", "bbox_pred", "rois"), ra))
+    finally:
+        cfg.TEST.RPN_POST_NMS_TOP_N = old

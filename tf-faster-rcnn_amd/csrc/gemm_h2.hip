@@ -128,12 +128,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
   constexpr bool PP = (TUNE & 32) != 0;           // the ping-pong schedule (below): 8 waves in two groups, one barrier apart
   constexpr bool LTB = (TUNE & 256) != 0;         // the light tile boundary (round 5, below): no dependent memory round trip, no store drain
   constexpr bool W21 = (TUNE & 512) != 0;         // plane stores widened to 16 B per lane by v_permlane32_swap pairs (half the instructions)
+  constexpr bool DE = (TUNE & 1024) != 0;         // the deferred epilogue (round 6, below): tile t drains under the first 128-k block of tile t + 1
   constexpr int S_OFF = 2 * XP + 2 * WP, STAGE = S_OFF + (PP ? 0 : 1024);
   constexpr int RED_OFF = NS * STAGE;             // row-maximum exchange of the plane-emitting epilogue: [BN / WN][BM] floats
   constexpr int S2_OFF = RED_OFF + (BN / WN) * BM * 4;      // TUNE & 2: two 1 KB block-scale regions, alternating per 128-k block
                                                             // PP: [wave][parity] 256 B: each wave's own 64 row scales
   constexpr int CB_OFF = S2_OFF + (PP ? NW * 512 : (TUNE & 2) ? 2048 : 0);   // LTB: [tile parity][filter scales BN | bias BN] floats
   static_assert(!LTB || (!PP && NS == 2 && NW >= 3 && BN % 64 == 0), "light boundary: the two-slot one-barrier-per-slab schedule");
+  static_assert(!DE || (LTB && W21 && BN == H2_KB), "deferred epilogue: built on the light boundary's LDS constants and counted waits");
   static_assert(!PP || (NW == 8 && NS == 3 && (TUNE & 2) && ((BM == 256 && WM == 64) || (BM == 128 && WM == 32)) && BN == 128 && WN == 64),
                 "ping-pong geometry: 8 waves as 4 (M) x 2 (N), waves 0-3 = the upper half of the rows");
   static_assert((2 * BM / 16) % NW == 0 && (2 * BN / 16) % NW == 0, "tile/wave mismatch");
@@ -249,14 +251,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
     const unsigned cb = lds0 + CB_OFF + i_cpar * (2 * BN * 4);
     if (wave == 1) {
 #pragma unroll
-      for (int j = 0; j < BN / 64; ++j)
-        h2_glds4((unsigned)(lane * 4 + j * 256), uniform_ptr((const char*)(p.w_inv + (size_t)(p.wshare ? 0 : i_g) * p.N + i_bn0)),
+      for (int j = 0; j < BN / 64; ++j)          // (j in the scalar base: one per-lane offset for all the loads)
+        h2_glds4((unsigned)(lane * 4), uniform_ptr((const char*)(p.w_inv + (size_t)(p.wshare ? 0 : i_g) * p.N + i_bn0 + j * 64)),
                  __builtin_amdgcn_readfirstlane(cb + j * 256));
     }
     if (wave == 2 && p.bias) {
 #pragma unroll
       for (int j = 0; j < BN / 64; ++j)
-        h2_glds4((unsigned)(lane * 4 + j * 256), uniform_ptr((const char*)(p.bias + i_bn0)), __builtin_amdgcn_readfirstlane(cb + BN * 4 + j * 256));
+        h2_glds4((unsigned)(lane * 4), uniform_ptr((const char*)(p.bias + i_bn0 + j * 64)), __builtin_amdgcn_readfirstlane(cb + BN * 4 + j * 256));
     }
     i_cpar ^= 1;
   };
@@ -264,6 +266,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
   // retires in issue order, loads and stores alike (gfx9), so with n = the instructions issued AFTER the slab loads the wave needs, the
   // epilogue's stores and the next tile's residual loads stay in flight across the wait.
   auto wait_pending = [&](int n) {
+    if constexpr (DE) {           // the drained tile's stores and the new tile's residual come a few per slab: steps of 8, as a depth-3 tree
+      if (n >= 32) {
+        if (n >= 48) { if (n >= 56) h2_wait_vmcnt<56>(); else h2_wait_vmcnt<48>(); }
+        else { if (n >= 40) h2_wait_vmcnt<40>(); else h2_wait_vmcnt<32>(); }
+      } else {
+        if (n >= 16) { if (n >= 24) h2_wait_vmcnt<24>(); else h2_wait_vmcnt<16>(); }
+        else { if (n >= 8) h2_wait_vmcnt<8>(); else h2_wait_vmcnt<0>(); }
+      }
+      return;
+    }
     if (n >= 63) h2_wait_vmcnt<63>();
     else if (n >= 48) h2_wait_vmcnt<48>();
     else if (n >= 32) h2_wait_vmcnt<32>();
@@ -280,6 +292,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
   // over its NM MFMAs, the first after MFMA 1) instead of in a burst after the barrier: a load's issue stall (~60-150 cycles) then falls
   // under the matrix-pipe time of the MFMAs already issued, not in front of the slab's first fragment reads.
   constexpr int NM = 2 * 3 * TM * TN, ND = G + SL;
+  // FRCNN_ABLATION builds (the energy ledger, scratch/energy_ledger.py; wrong results by construction): TUNE & 2048 = no MFMAs (the
+  // fragments are still read), TUNE & 4096 = no fragment reads (the MFMAs run on whatever the registers hold), TUNE & 8192 = no slab
+  // loads after the prologue (the ring is never refilled)
+#ifdef FRCNN_ABLATION
+  constexpr bool NO_MFMA = (TUNE & 2048) != 0, NO_FRAG = (TUNE & 4096) != 0, NO_LOAD = (TUNE & 8192) != 0;
+#else
+  constexpr bool NO_MFMA = false, NO_FRAG = false, NO_LOAD = false;
+#endif
+  h8 kxh[NO_FRAG ? TM : 1], kxl[NO_FRAG ? TM : 1], kwh[NO_FRAG ? TN : 1], kwl[NO_FRAG ? TN : 1];     // (ablation: the kept fragments)
+  (void)kxh; (void)kxl; (void)kwh; (void)kwl;
   auto slab_mfma = [&](int cur, auto first_c, auto&& between, auto&& after) {
     constexpr bool FIRST = decltype(first_c)::value;
     const char* sb = smem + cur * STAGE;
@@ -287,6 +309,26 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
     for (int t = 0; t < 2; ++t) {                    // two groups of 16 k per 32-wide slab
       if (t == 1) between();
       h8 xh[TM], xl[TM], wh[TN], wl[TN];
+      if constexpr (NO_FRAG) {          // (ablation) the first 16-k group of every 128-k block is read and serves the whole block: real operand
+        if (FIRST && t == 0) {          // values (the matrix pipe's power follows its data), 1 / 8 of the LDS fragment reads
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const char* q = sb + w_row + j * 32 * 64 + ((khalf ^ sw) * 16);
+            kwh[j] = __builtin_bit_cast(h8, *(const uint4*)(q));
+            kwl[j] = __builtin_bit_cast(h8, *(const uint4*)(q + WP));
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const char* q = sb + x_row + i * 32 * 64 + ((khalf ^ sw) * 16);
+            kxh[i] = __builtin_bit_cast(h8, *(const uint4*)(q));
+            kxl[i] = __builtin_bit_cast(h8, *(const uint4*)(q + XP));
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { wh[j] = kwh[j]; wl[j] = kwl[j]; asm volatile("" : "+v"(wh[j]), "+v"(wl[j])); }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { xh[i] = kxh[i]; xl[i] = kxl[i]; asm volatile("" : "+v"(xh[i]), "+v"(xl[i])); }
+      } else {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const char* q = sb + w_row + j * 32 * 64 + (((2 * t + khalf) ^ sw) * 16);
@@ -298,6 +340,22 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
         const char* q = sb + x_row + i * 32 * 64 + (((2 * t + khalf) ^ sw) * 16);
         xh[i] = __builtin_bit_cast(h8, *(const uint4*)(q));
         xl[i] = __builtin_bit_cast(h8, *(const uint4*)(q + XP));
+      }
+      }
+      if constexpr (NO_MFMA) {          // (ablation) the fragments are consumed by an empty asm, the accumulators stay as they are
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(wh[j]), "v"(wl[j]));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" :: "v"(xh[i]), "v"(xl[i]));
+        if (FIRST && t == 0) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) tmp[i][j][r] = 0.f;
+        }
+        continue;
       }
       // term-major order: consecutive MFMAs write different accumulators
 #pragma unroll
@@ -346,6 +404,25 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)max(0ll, min(bytes, 0x7fffffffll)), 0x00020000);
   };
 
+  struct TileRef { int bm0, bn0, g, cpar; };             // a tile by value: the epilogue parts work on the tile they are handed, not on the c_* cursor
+  // ONE descriptor per tensor and batch entry: base = the entry's first row, range = its M * N elements, so the rows of a tile past M fall
+  // out of range (stores dropped, loads return 0) whichever sub-tile they belong to; the position inside the entry travels in the per-lane
+  // offset = a lane constant (lo4 / lo2 / lo2w below) + a wave-uniform sub-tile offset.  (Rounds 3-5 built a descriptor per 32 x 32
+  // sub-tile: four 64-bit address computations and 16 SGPRs per sub-tile and tensor, which the deferred epilogue's pieces cannot afford
+  // inside the slab loop.)  M * N < 2^29 elements (checked by the callers): every offset fits 31 bits.
+  auto ent_rsrc = [&](const void* base, int g, int esize) {
+    const char* b = (const char*)base + (size_t)g * p.M * p.N * esize;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)b, 0, p.M * p.N * esize, 0x00020000);
+  };
+  const int lo4 = (frow * p.N + 4 * khalf) * 4;          // float32 tensors: 16-byte accesses of the accumulator layout
+  // planes: 8-byte accesses (lo2) / 16-byte accesses after the v_permlane32_swap pairing (lo2w, W21) -- derived from lo4 where they are
+  // used (the empty asm keeps the compiler from hoisting two more lane constants into registers that live through the whole K loop)
+  auto lo2_of = [&]() { int v = lo4; asm volatile("" : "+v"(v)); return v >> 1; };
+  auto lo2w_of = [&]() { int v = lo4; asm volatile("" : "+v"(v)); return (v >> 1) + 8 * (int)(threadIdx.x >> 5 & 1); };
+  auto sub_off = [&](const auto& T, int i, int j) {      // elements from the entry's first row to sub-tile (i, j) of tile T: wave-uniform
+    return __builtin_amdgcn_readfirstlane((T.bm0 + wm0 + i * 32) * p.N + T.bn0 + wn0 + j * 32);
+  };
+
 #ifdef FRCNN_H2_TRACE
   int tr_slab = 0;
   auto stamp = [&](int point) {       // [workgroup < 16][wave][slab < 64][point < 8]
@@ -362,10 +439,42 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
   auto stamp = [](int) {};
   auto bstamp = [](int) {};
 #endif
+  float rri[TM];                                                // DE: the residual planes' block scales of the tile's rows (raw residual: first fold)
+  (void)rri;
+  // The tile's residual (tile under the c_* cursor), sub-tile row i, RAW into tot[i][*]: always four 16-byte loads per sub-tile through ONE instruction stream --
+  // float32 residual: quad q <- columns 8 q + 4 khalf .. + 3; residual as operand planes: the inverse of the W21 store pairing -- load 2 p
+  // <- H words of columns 16 p + 8 khalf .. + 7, load 2 p + 1 <- the L words of the same columns (un-paired by v_permlane32_swap in the first
+  // fold); no residual: the same loads through a zero-length descriptor return 0.  The three cases differ in descriptors and offsets
+  // (wave-uniform selects), not in control flow: a branch per case made the register allocator keep a second copy of the accumulators.
+  auto load_res_raw = [&](int i) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const TileRef C{c_bm0, c_bn0, c_g, c_cpar};
+    const bool planes = !p.res && p.resp;
+    const auto none = __builtin_amdgcn_make_buffer_rsrc((void*)nullptr, 0, 0, 0x00020000);
+    const auto r_even = p.res ? ent_rsrc(p.res, c_g, 4) : planes ? ent_rsrc(p.resp, c_g, 2) : none;
+    const auto r_odd = p.res ? r_even : planes ? ent_rsrc(p.resp + (size_t)p.Mtot * p.N, c_g, 2) : none;
+    const int step_q = planes ? 0 : 32, step_p = planes ? 32 : 0;
+    int base = lo4;
+    asm volatile("" : "+v"(base));
+    if (planes) base = (base >> 1) + 8 * (int)(threadIdx.x >> 5 & 1);          // lo2w: (frow * N + 8 khalf) * 2
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int vo = base + sub_off(C, i, j) * (planes ? 2 : 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const u32x4 ld = __builtin_amdgcn_raw_buffer_load_b128((q & 1) ? r_odd : r_even, vo, q * step_q + (q >> 1) * step_p, 0);
+        tot[i][j][4 * q + 0] = __uint_as_float(ld[0]); tot[i][j][4 * q + 1] = __uint_as_float(ld[1]);
+        tot[i][j][4 * q + 2] = __uint_as_float(ld[2]); tot[i][j][4 * q + 3] = __uint_as_float(ld[3]);
+      }
+      pend += 4;
+    }
+    if (p.resp) rri[i] = p.resp_inv[(size_t)(c_bn0 / H2_KB) * p.Mtot + (size_t)c_g * p.M + min(c_bm0 + wm0 + i * 32 + frow, p.M - 1)];
+  };
   // The accumulators of a tile START at (bias + res) * 2^e_w: the filter row's scale w_inv = 2^-e_w is an exact power of two, so the
   // final  tot * w_inv  = products + bias + res  is one f32 sum evaluated in the scaled domain -- and the residual is fetched when the
   // tile starts (its latency hides under the first 128-k block; it is first touched by that block's fold) instead of after the last MFMA.
   auto init_tot = [&]() {
+    if constexpr (DE) return;          // deferred epilogue: the residual arrives with the drain pieces (load_res_raw), sub-tile row by row
     // Every load of the tile start is issued before the first one is used: the filter scales and the bias of the tile's columns
     // (TN x 4 float4 each) and the residual straight into `tot`.  (Round 3 interleaved load, wait and arithmetic per 4 columns inside
     // runtime `if (p.res)` branches: ~30 dependent memory round trips per tile, as long as the whole K loop of a K = 256 tile.)
@@ -464,17 +573,17 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
       }
   };
 
-  auto epilogue = [&]() {
-    const size_t row_base = (size_t)c_g * p.M;
-    bstamp(0);
-    // ---- v = act(tot * w_inv), kept in tot (bias and residual went in with init_tot) ----------------------------------------------
+  // ---- the epilogue in parts: the standalone form runs them back to back after a tile's last fold; the deferred form (DE) runs them as
+  //      pieces under the next tile's first slabs.  A part reads the tile it works on from a TileRef, not from the c_* cursor.
+  // v = act(tot * w_inv), kept in tot (bias and residual went in with the start value)
+  auto ep_scale_act = [&](const TileRef& T) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int n0 = c_bn0 + wn0 + j * 32 + 4 * khalf;
+      const int n0 = T.bn0 + wn0 + j * 32 + 4 * khalf;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 wi = LTB ? *(const float4*)(smem + CB_OFF + c_cpar * (2 * BN * 4) + (wn0 + j * 32 + 4 * khalf + 8 * q) * 4)
-                             : *(const float4*)(p.w_inv + (size_t)(p.wshare ? 0 : c_g) * p.N + n0 + 8 * q);
+        const float4 wi = LTB ? *(const float4*)(smem + CB_OFF + T.cpar * (2 * BN * 4) + (wn0 + j * 32 + 4 * khalf + 8 * q) * 4)
+                             : *(const float4*)(p.w_inv + (size_t)(p.wshare ? 0 : T.g) * p.N + n0 + 8 * q);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           tot[i][j][4 * q + 0] = act_clamp(tot[i][j][4 * q + 0] * wi.x, act_lo, act_hi);
@@ -484,20 +593,21 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
         }
       }
     }
-    bstamp(1);
-    // ---- frcnn_gemm_h2_masked: the ReLU gradient of the tensor this result is the gradient of (an exact select; NaN / inf of the result
-    //      pass where the mask is positive, like frcnn_relu_bwd) -------------------------------------------------------------------------
-    if ((TUNE & 128) && p.mask) {       // TUNE & 128: the training instantiations (the inference kernels do not carry this code)
+  };
+  // frcnn_gemm_h2_masked: the ReLU gradient of the tensor this result is the gradient of (an exact select; NaN / inf of the result pass
+  // where the mask is positive, like frcnn_relu_bwd).  TUNE & 128: the training instantiations (the inference kernels do not carry this code)
+  auto ep_mask = [&](const TileRef& T) {
+    if ((TUNE & 128) && p.mask) {
+      const auto rk = ent_rsrc(p.mask, T.g, 4);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const int m0 = c_bm0 + wm0 + i * 32, nc = c_bn0 + wn0 + j * 32;
-          const auto rk = rsrc_f(p.mask + (long long)(row_base + m0) * p.N + nc, (long long)(p.M - m0) * p.N - nc, 4);
+          const int vo = lo4 + sub_off(T, i, j) * 4;
           typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
           u32x4 k[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) k[q] = __builtin_amdgcn_raw_buffer_load_b128(rk, (frow * p.N + 4 * khalf) * 4 + 32 * q, 0, 0);
+          for (int q = 0; q < 4; ++q) k[q] = __builtin_amdgcn_raw_buffer_load_b128(rk, vo + 32 * q, 0, 0);
 #pragma unroll
           for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -505,155 +615,174 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
         }
       pend += TM * TN * 4;              // (vector-memory instructions issued after the last slab load: the light boundary's counted wait)
     }
-    // ---- frcnn_gemm_h2_mean: reduce_mean over row groups instead of a result tensor (the tail's last convolution feeds only the spatial
-    //      mean, lib/nets/resnet_v1.py:115-125).  A 32-row accumulator block (lanes = rows) meets at most two groups (mean_rows >= 32):
-    //      the rows of the group its first row belongs to, and of the next one, are added over the 32 lanes by a fixed xor butterfly
-    //      and written as two partial rows; k_h2_mean_finish adds a group's 2-3 blocks in ascending order.  Which rows meet in which
-    //      block depends only on the row index inside the batch entry, so with one batch entry per image the same RoI gives the same
-    //      bits in every batch slot and at every batch size.
-    if (p.mean_part) {
-      const int nblk = (p.M + 31) >> 5;
+  };
+  // frcnn_gemm_h2_mean: reduce_mean over row groups instead of a result tensor (the tail's last convolution feeds only the spatial
+  // mean, lib/nets/resnet_v1.py:115-125).  A 32-row accumulator block (lanes = rows) meets at most two groups (mean_rows >= 32):
+  // the rows of the group its first row belongs to, and of the next one, are added over the 32 lanes by a fixed xor butterfly
+  // and written as two partial rows; k_h2_mean_finish adds a group's 2-3 blocks in ascending order.  Which rows meet in which
+  // block depends only on the row index inside the batch entry, so with one batch entry per image the same RoI gives the same
+  // bits in every batch slot and at every batch size.
+  auto ep_mean = [&](const TileRef& T) {
+    const int nblk = (p.M + 31) >> 5;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int mb = c_bm0 + wm0 + i * 32;
-        if (mb >= p.M) continue;                                            // wave-uniform: the block lies past the entry's rows
-        const int m = mb + frow, g0 = mb / p.mean_rows, gid = m / p.mean_rows;
-        const bool in_a = m < p.M && gid == g0, in_b = m < p.M && gid == g0 + 1;
-        float* dst = p.mean_part + ((size_t)c_g * nblk + (mb >> 5)) * 2 * p.N;
+    for (int i = 0; i < TM; ++i) {
+      const int mb = T.bm0 + wm0 + i * 32;
+      if (mb >= p.M) continue;                                            // wave-uniform: the block lies past the entry's rows
+      const int m = mb + frow, g0 = mb / p.mean_rows, gid = m / p.mean_rows;
+      const bool in_a = m < p.M && gid == g0, in_b = m < p.M && gid == g0 + 1;
+      float* dst = p.mean_part + ((size_t)T.g * nblk + (mb >> 5)) * 2 * p.N;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int n0 = c_bn0 + wn0 + j * 32 + 4 * khalf;
+      for (int j = 0; j < TN; ++j) {
+        const int n0 = T.bn0 + wn0 + j * 32 + 4 * khalf;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float a[4], b[4];
+        for (int q = 0; q < 4; ++q) {
+          float a[4], b[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = tot[i][j][4 * q + e];
+            a[e] = in_a ? v : 0.f;
+            b[e] = in_b ? v : 0.f;
+          }
+#pragma unroll
+          for (int o = 1; o < 32; o <<= 1)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float v = tot[i][j][4 * q + e];
-              a[e] = in_a ? v : 0.f;
-              b[e] = in_b ? v : 0.f;
+              a[e] += __shfl_xor(a[e], o, 64);
+              b[e] += __shfl_xor(b[e], o, 64);
             }
-#pragma unroll
-            for (int o = 1; o < 32; o <<= 1)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                a[e] += __shfl_xor(a[e], o, 64);
-                b[e] += __shfl_xor(b[e], o, 64);
-              }
-            if (frow == 0) {
-              *(float4*)(dst + n0 + 8 * q) = make_float4(a[0], a[1], a[2], a[3]);
-              *(float4*)(dst + p.N + n0 + 8 * q) = make_float4(b[0], b[1], b[2], b[3]);
-            }
-            pend += 2;
+          if (frow == 0) {
+            *(float4*)(dst + n0 + 8 * q) = make_float4(a[0], a[1], a[2], a[3]);
+            *(float4*)(dst + p.N + n0 + 8 * q) = make_float4(b[0], b[1], b[2], b[3]);
           }
+          pend += 2;
         }
       }
+    }
+  };
+  // the float32 result of sub-tile row i (16-byte stores in the accumulator layout).
+  // (Measured and not kept, profiles/r04_y_*: the same stores ROW-MAJOR through a wave-private LDS block -- 8 rows x one full 128-byte
+  // line per instruction instead of 32 rows x 32 bytes -- double the tile boundary (30.8 -> 57.8 thousand cycles for residual + float32 +
+  // planes): the extra LDS round trips and the registers they hold cost more than the request count saves.)
+  auto ep_store_f32 = [&](const TileRef& T, int i) {
+    if (!p.y) return;
+    const auto ry = ent_rsrc(p.y, T.g, 4);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int lo = lo4 + sub_off(T, i, j) * 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 o;
+        // (__float_as_uint, not __builtin_bit_cast: bit_cast of an ext-vector ELEMENT lvalue reads element 0 -- clang 19 / ROCm 7.2)
+        o[0] = __float_as_uint(tot[i][j][4 * q + 0]); o[1] = __float_as_uint(tot[i][j][4 * q + 1]);
+        o[2] = __float_as_uint(tot[i][j][4 * q + 2]); o[3] = __float_as_uint(tot[i][j][4 * q + 3]);
+        __builtin_amdgcn_raw_buffer_store_b128(o, ry, lo + 32 * q, 0, 0);
+      }
+      pend += 4;
+      if constexpr (DE) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // the next layer's operand planes: block scale over this workgroup's 128 columns, per row.  Row maxima: per lane over the registers,
+  // then between the column waves through LDS (`red`); the caller puts a workgroup barrier between the two halves.
+  auto ep_rowmax_write = [&](float (&mx)[TM]) {
+    float* red = (float*)(smem + RED_OFF);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      float m = 0.f;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(tot[i][j][r]));
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      mx[i] = m;
+      if (BN / WN > 1 && khalf == 0) red[wni * BM + wm0 + i * 32 + frow] = m;
+    }
+  };
+  auto ep_rowmax_merge = [&](float (&mx)[TM]) {
+    const float* red = (const float*)(smem + RED_OFF);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int o = 0; o < BN / WN; ++o) mx[i] = fmaxf(mx[i], red[o * BM + wm0 + i * 32 + frow]);
+  };
+  auto ep_store_planes = [&](const TileRef& T, int i, float mxi) {
+    const size_t row_base = (size_t)T.g * p.M;
+    const size_t yplane = (size_t)p.Mtot * p.N;                                 // elements
+    float scale, inv;
+    h2_block_scale(mxi, scale, inv);
+    const int m0 = T.bm0 + wm0 + i * 32;
+    if (wni == 0 && khalf == 0 && m0 + frow < p.M)
+      p.y_inv[(size_t)(T.bn0 / H2_KB) * p.Mtot + row_base + m0 + frow] = inv;
+    const auto rh = ent_rsrc(p.yp, T.g, 2), rl = ent_rsrc(p.yp + yplane, T.g, 2);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int so = sub_off(T, i, j) * 2;
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      if constexpr (W21) {
+        // The accumulator layout gives a lane 4 consecutive columns (8 bytes of a plane) per register quad q and puts the next 4 in lane + 32.
+        // v_permlane32_swap(vdst = quad 2p, src = quad 2p + 1) exchanges the upper half of vdst with the lower half of src: afterwards a
+        // lower lane holds columns 16p .. 16p+7 of its row as [own 2p | upper's 2p], an upper lane columns 16p+8 .. 16p+15 as
+        // [lower's 2p+1 | own 2p+1] -- ONE 16-byte store per pair and plane instead of two 8-byte stores: the same bytes at the same
+        // addresses from half the store instructions (the epilogue is bound by store ISSUE, not by bytes).
+        const int lo = lo2w_of() + so;
+#pragma unroll
+        for (int pq = 0; pq < 2; ++pq) {
+          h4 ha, la, hb, lb;
+          h2_split4(make_float4(tot[i][j][8 * pq + 0], tot[i][j][8 * pq + 1], tot[i][j][8 * pq + 2], tot[i][j][8 * pq + 3]), scale, ha, la);
+          h2_split4(make_float4(tot[i][j][8 * pq + 4], tot[i][j][8 * pq + 5], tot[i][j][8 * pq + 6], tot[i][j][8 * pq + 7]), scale, hb, lb);
+          const u32x2 uha = __builtin_bit_cast(u32x2, ha), uhb = __builtin_bit_cast(u32x2, hb);
+          const u32x2 ula = __builtin_bit_cast(u32x2, la), ulb = __builtin_bit_cast(u32x2, lb);
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          const auto h0 = __builtin_amdgcn_permlane32_swap(uha[0], uhb[0], false, false), h1 = __builtin_amdgcn_permlane32_swap(uha[1], uhb[1], false, false);
+          const auto l0 = __builtin_amdgcn_permlane32_swap(ula[0], ulb[0], false, false), l1 = __builtin_amdgcn_permlane32_swap(ula[1], ulb[1], false, false);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{h0[0], h1[0], h0[1], h1[1]}, rh, lo + 32 * pq, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{l0[0], l1[0], l0[1], l1[1]}, rl, lo + 32 * pq, 0, 0);
+        }
+        pend += 4;
+        if constexpr (DE) __builtin_amdgcn_sched_barrier(0);        // (one sub-tile's split temporaries at a time: the pieces run beside 128 live accumulators)
+      } else {
+        const int lo = lo2_of() + so;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          h4 hh, ll;
+          h2_split4(make_float4(tot[i][j][4 * q + 0], tot[i][j][4 * q + 1], tot[i][j][4 * q + 2], tot[i][j][4 * q + 3]), scale, hh, ll);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), rh, lo + 16 * q, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), rl, lo + 16 * q, 0, 0);
+        }
+        pend += 8;
+      }
+    }
+  };
+
+  // the standalone epilogue of the tile under the c_* cursor: every part back to back, after the tile's last fold
+  auto epilogue = [&]() {
+    const TileRef T{c_bm0, c_bn0, c_g, c_cpar};
+    bstamp(0);
+    ep_scale_act(T);
+    bstamp(1);
+    ep_mask(T);
+    if (p.mean_part) {
+      ep_mean(T);
       c_cpar ^= 1;
       return;
     }
-    // (Measured and not kept, profiles/r04_y_*: the same stores ROW-MAJOR through a wave-private LDS block -- 8 rows x one full 128-byte
-    // line per instruction instead of 32 rows x 32 bytes -- double the tile boundary (30.8 -> 57.8 thousand cycles for residual + float32 +
-    // planes): the extra LDS round trips and the registers they hold cost more than the request count saves.)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int m0 = c_bm0 + wm0 + i * 32;                                  // first row of the sub-tile inside the batch entry
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int nc = c_bn0 + wn0 + j * 32;
-        const long long sbase = (long long)(row_base + m0) * p.N + nc;     // element offset of the sub-tile
-        const long long left_e = (long long)(p.M - m0) * p.N - nc;         // elements from there to the end of the batch entry's rows
-        const int lo = (frow * p.N + 4 * khalf) * 4;
-        if (p.y) {
-          const auto ry = rsrc_f(p.y + sbase, left_e, 4);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            u32x4 o;
-            // (__float_as_uint, not __builtin_bit_cast: bit_cast of an ext-vector ELEMENT lvalue reads element 0 -- clang 19 / ROCm 7.2)
-            o[0] = __float_as_uint(tot[i][j][4 * q + 0]); o[1] = __float_as_uint(tot[i][j][4 * q + 1]);
-            o[2] = __float_as_uint(tot[i][j][4 * q + 2]); o[3] = __float_as_uint(tot[i][j][4 * q + 3]);
-            __builtin_amdgcn_raw_buffer_store_b128(o, ry, lo + 32 * q, 0, 0);
-          }
-          pend += 4;
-        }
-      }
-    }
+    for (int i = 0; i < TM; ++i) ep_store_f32(T, i);
     bstamp(2);
-    // ---- the next layer's operand planes: block scale over this workgroup's 128 columns, per row ------------------------------------
     if (p.yp) {
-      float* red = (float*)(smem + RED_OFF);
       float mx[TM];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        float m = 0.f;
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(tot[i][j][r]));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        mx[i] = m;
-        if (BN / WN > 1 && khalf == 0) red[wni * BM + wm0 + i * 32 + frow] = m;
-      }
+      ep_rowmax_write(mx);
       if (BN / WN > 1) {
         // raw barrier + lgkmcnt(0): the exchange goes through LDS only.  __syncthreads() would add vmcnt(0), i.e. wait until the float32
         // stores just issued (and the slabs in flight) have COMPLETED -- 7-9 thousand cycles per drain under a write burst
         // (profiles/r04_w_h2_tile_boundary.txt)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int o = 0; o < BN / WN; ++o) mx[i] = fmaxf(mx[i], red[o * BM + wm0 + i * 32 + frow]);
+        ep_rowmax_merge(mx);
       }
       bstamp(3);
-      const size_t yplane = (size_t)p.Mtot * p.N;                                 // elements
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        float scale, inv;
-        h2_block_scale(mx[i], scale, inv);
-        const int m0 = c_bm0 + wm0 + i * 32;
-        if (wni == 0 && khalf == 0 && m0 + frow < p.M)
-          p.y_inv[(size_t)(c_bn0 / H2_KB) * p.Mtot + row_base + m0 + frow] = inv;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int nc = c_bn0 + wn0 + j * 32;
-          const long long sbase = (long long)(row_base + m0) * p.N + nc;
-          const long long left_e = (long long)(p.M - m0) * p.N - nc;
-          const auto rh = rsrc_f(p.yp + sbase, left_e, 2), rl = rsrc_f(p.yp + yplane + sbase, left_e, 2);
-          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-          if constexpr (W21) {
-            // The accumulator layout gives a lane 4 consecutive columns (8 bytes of a plane) per register quad q and puts the next 4 in lane + 32.
-            // v_permlane32_swap(vdst = quad 2p, src = quad 2p + 1) exchanges the upper half of vdst with the lower half of src: afterwards a
-            // lower lane holds columns 16p .. 16p+7 of its row as [own 2p | upper's 2p], an upper lane columns 16p+8 .. 16p+15 as
-            // [lower's 2p+1 | own 2p+1] -- ONE 16-byte store per pair and plane instead of two 8-byte stores: the same bytes at the same
-            // addresses from half the store instructions (the epilogue is bound by store ISSUE, not by bytes).
-            const int lo = (frow * p.N + 8 * khalf) * 2;
-#pragma unroll
-            for (int pq = 0; pq < 2; ++pq) {
-              h4 ha, la, hb, lb;
-              h2_split4(make_float4(tot[i][j][8 * pq + 0], tot[i][j][8 * pq + 1], tot[i][j][8 * pq + 2], tot[i][j][8 * pq + 3]), scale, ha, la);
-              h2_split4(make_float4(tot[i][j][8 * pq + 4], tot[i][j][8 * pq + 5], tot[i][j][8 * pq + 6], tot[i][j][8 * pq + 7]), scale, hb, lb);
-              const u32x2 uha = __builtin_bit_cast(u32x2, ha), uhb = __builtin_bit_cast(u32x2, hb);
-              const u32x2 ula = __builtin_bit_cast(u32x2, la), ulb = __builtin_bit_cast(u32x2, lb);
-              typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-              const auto h0 = __builtin_amdgcn_permlane32_swap(uha[0], uhb[0], false, false), h1 = __builtin_amdgcn_permlane32_swap(uha[1], uhb[1], false, false);
-              const auto l0 = __builtin_amdgcn_permlane32_swap(ula[0], ulb[0], false, false), l1 = __builtin_amdgcn_permlane32_swap(ula[1], ulb[1], false, false);
-              __builtin_amdgcn_raw_buffer_store_b128(u32x4{h0[0], h1[0], h0[1], h1[1]}, rh, lo + 32 * pq, 0, 0);
-              __builtin_amdgcn_raw_buffer_store_b128(u32x4{l0[0], l1[0], l0[1], l1[1]}, rl, lo + 32 * pq, 0, 0);
-            }
-            pend += 4;
-          } else {
-            const int lo = (frow * p.N + 4 * khalf) * 2;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              h4 hh, ll;
-              h2_split4(make_float4(tot[i][j][4 * q + 0], tot[i][j][4 * q + 1], tot[i][j][4 * q + 2], tot[i][j][4 * q + 3]), scale, hh, ll);
-              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hh), rh, lo + 16 * q, 0, 0);
-              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ll), rl, lo + 16 * q, 0, 0);
-            }
-            pend += 8;
-          }
-        }
-      }
+      for (int i = 0; i < TM; ++i) ep_store_planes(T, i, mx[i]);
       bstamp(4);
       if (BN / WN > 1) {                                                         // red[] is reused by the next tile
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -664,10 +793,54 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
     c_cpar ^= 1;
   };
 
+  // ---- the deferred epilogue (TUNE & 1024, round 6) -----------------------------------------------------------------------------------
+  // The counters of the conv3-class launches (profiles/r05_counters_conv3.json: waves on s_waitcnt 0.50 of their cycles, matrix pipe busy
+  // 0.28) say one workgroup's serial chain binds: K loop -> scale / row maxima / barrier / split / stores -> residual round trip -> K
+  // loop.  A second accumulator set would let tile t + 1 multiply while tile t drains -- and the registers for it exist without a third
+  // set: the running sum `tot` is first WRITTEN by a tile's first fold, at the end of its fourth slab; until then only the block
+  // accumulator `tmp` is live.  So tile t's results stay in `tot` and leave in PIECES under tile t + 1's first three slabs
+  //     slab 0:  v = act(tot * w_inv); row maxima over the registers -> LDS          (the slab barrier of slab 1 orders the exchange)
+  //     slab 1:  maxima of the other column wave; sub-tile rows [0, HALF): f32 / plane stores, then tile t + 1's residual for those
+  //              rows is loaded RAW into the registers the stores have just read
+  //     slab 2:  the same for sub-tile rows [HALF, TM)
+  // and the first fold (end of slab 3) turns the raw residual into the start value as the light boundary does.  Every element goes
+  // through the same operations in the same order as in the standalone epilogue: bit-identical to cfg 9.  The stores are a few per slab
+  // (counted in `pend`, waited for in steps of 4), no wait ever names them; the only tile without cover is a workgroup's last one.
+  constexpr int HALF = (TM + 1) / 2;
+  bool have_prev = false;
+  TileRef P{0, 0, 0, 0};                                        // the tile whose results are still in `tot`
+  float dmx[TM];                                                // its merged row maxima (slab 1 -> slab 2)
+  (void)dmx;
+  auto de_piece = [&](auto pos_c) {
+    constexpr int POS = decltype(pos_c)::value;
+    if constexpr (POS == 0) {
+      if (have_prev) {
+        ep_scale_act(P);
+        ep_mask(P);
+        if (p.yp) ep_rowmax_write(dmx);
+      }
+    } else if constexpr (POS == 1 || POS == 2) {
+      constexpr int I0 = POS == 1 ? 0 : HALF, I1 = POS == 1 ? HALF : TM;
+      if (have_prev) {
+        if (POS == 1 && p.yp && BN / WN > 1) ep_rowmax_merge(dmx);
+#pragma unroll
+        for (int i = I0; i < I1; ++i) {
+          ep_store_f32(P, i);
+          if (p.yp) ep_store_planes(P, i, dmx[i]);
+        }
+      }
+#pragma unroll
+      for (int i = I0; i < I1; ++i) load_res_raw(i);
+    }
+  };
+
   // one slab of the stream: wait for it, let the ring slot it frees be refilled (loads spread over nothing here: they are issued
   // right after the barrier, G + SL instructions, and land under the 24 * TM * TN / 4 MFMAs of this slab and the next NS - 2)
-  auto slab = [&](auto first_c, bool fold, bool first_block) {
+  auto slab = [&](auto pos_c, bool fold, bool first_block) {
+    constexpr int POS = decltype(pos_c)::value;          // position inside the 128-k block: 0 .. 3 (0: the block's first MFMAs take C = 0)
+    const std::integral_constant<bool, POS == 0> first_c{};
     stamp(0);
+    if constexpr (DE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (a drain piece's row maxima are in LDS before the barrier)
     if constexpr (LTB) {
       wait_pending(pend);                              // the slab's loads are older than the `pend` instructions that may stay in flight
     } else if (left >= 1) {                            // steady state: NS - 2 younger slabs may stay in flight
@@ -679,8 +852,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
     __builtin_amdgcn_s_barrier();
     stamp(2);
     const bool more = left > 0;
-    constexpr int HALF = (TUNE & 4) ? 0 : (TUNE & 1) ? (G + SL) / 2 : G + SL;
-    static_assert(!LTB || HALF == G + SL, "light boundary: the slab's loads are issued in one burst");
+    constexpr int HALF = NO_LOAD ? 0 : (TUNE & 4) ? 0 : (TUNE & 1) ? (G + SL) / 2 : G + SL;
+    static_assert(!LTB || NO_LOAD || HALF == G + SL, "light boundary: the slab's loads are issued in one burst");
     if (more) {
 #pragma unroll
       for (int t = 0; t < HALF; ++t) issue_one(nxt, t);
@@ -690,6 +863,13 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
       }
     }
     stamp(3);
+    if constexpr (DE) {
+      // (scheduling fences: the piece's temporaries die before the slab's fragments are read -- without them the scheduler interleaves the
+      // two and the kernel spills)
+      __builtin_amdgcn_sched_barrier(0);
+      if (first_block) de_piece(pos_c);                // the previous tile drains / this tile's residual arrives, under this slab's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+    }
     float ainv[TM];
     if (fold) {
       const int soff = (TUNE & 2) ? S2_OFF + c_par * 1024 : cur * STAGE + S_OFF;
@@ -700,7 +880,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
     if (!(TUNE & 4)) {
       slab_mfma(cur, first_c, [&]() {
         stamp(4);
-        if (more) {
+        if (more && !NO_LOAD) {
 #pragma unroll
           for (int t = HALF; t < G + SL; ++t) issue_one(nxt, t);
         }
@@ -724,6 +904,32 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
         // The tile's first fold: `tot` holds the raw residual (or zeros); the start value (bias + res) * 2^e_w is formed here, from the
         // filter scales and the bias in LDS -- the same add, multiply and fma as init_tot's, bit for bit.
         const float* cbp = (const float*)(smem + CB_OFF + c_cpar * (2 * BN * 4));
+        if (DE && !p.res && p.resp) {
+          // the residual arrived as RAW plane words in the accumulator's own registers (load_res_raw): words 8 p .. 8 p + 3 = the H
+          // words of columns 16 p + 8 khalf .. + 7, words 8 p + 4 .. + 7 the L words.  v_permlane32_swap of (first pair, second pair)
+          // hands every lane its own two quads 2 p, 2 p + 1 (the inverse of the W21 store pairing); (h + l) is exact in f32, times the
+          // block's power-of-two scale -- init_tot's expression, bit for bit.
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int pq = 0; pq < 2; ++pq) {
+                unsigned w[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[e] = __float_as_uint(tot[i][j][8 * pq + e]);
+                const auto h0 = __builtin_amdgcn_permlane32_swap(w[0], w[2], false, false), h1 = __builtin_amdgcn_permlane32_swap(w[1], w[3], false, false);
+                const auto l0 = __builtin_amdgcn_permlane32_swap(w[4], w[6], false, false), l1 = __builtin_amdgcn_permlane32_swap(w[5], w[7], false, false);
+                const h4 ha = __builtin_bit_cast(h4, u32x2{h0[0], h1[0]}), hb = __builtin_bit_cast(h4, u32x2{h0[1], h1[1]});
+                const h4 la = __builtin_bit_cast(h4, u32x2{l0[0], l1[0]}), lb = __builtin_bit_cast(h4, u32x2{l0[1], l1[1]});
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  tot[i][j][8 * pq + e] = ((float)ha[e] + (float)la[e]) * rri[i];
+                  tot[i][j][8 * pq + 4 + e] = ((float)hb[e] + (float)lb[e]) * rri[i];
+                }
+              }
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -926,10 +1132,20 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
     ++tr_tile;                                         // (stamps 0-5 of tile t's epilogue and stamp 6 of tile t + 1's start share an index)
 #endif
     for (int kb = 0; kb < nkb; ++kb) {
-      slab(std::true_type{}, false, kb == 0);
-      slab(std::false_type{}, false, kb == 0);
-      slab(std::false_type{}, false, kb == 0);
-      slab(std::false_type{}, true, kb == 0);
+      slab(std::integral_constant<int, 0>{}, false, kb == 0);
+      slab(std::integral_constant<int, 1>{}, false, kb == 0);
+      slab(std::integral_constant<int, 2>{}, false, kb == 0);
+      slab(std::integral_constant<int, 3>{}, true, kb == 0);
+    }
+    if constexpr (DE) {
+      if (tl + 1 < my_tiles) {                           // the results stay in `tot` and drain under the next tile's first slabs
+        P = TileRef{c_bm0, c_bn0, c_g, c_cpar};
+        have_prev = true;
+        c_cpar ^= 1;
+        c_tile += W8;
+        set_ctile(c_tile);
+        continue;
+      }
     }
     epilogue();
     c_tile += W8;
@@ -1124,8 +1340,16 @@ static int run_h2(GemmH2Params& p, int cfg, hipStream_t st) {
     const bool tiny = (long long)((M + 127) / 128) * (N / 128) * G < 150;
     // cfg == -2: round 4's choice (A/B runs).  Round 5: the same tiles with the light tile boundary and 16-byte plane stores (31, 33):
     // bit-identical, 5-16 % faster on the short-K launches, indifferent elsewhere (profiles/r05_b_h2_conv3_light_boundary.txt)
-    cfg = pp ? pp_cfg : tiny ? (cfg == -2 ? 12 : 33) : (cfg == -2 ? 9 : 31);
+    // Round 6: the deferred epilogue (cfgs 40 / 41: tile t drains under tile t + 1's first slabs) wherever a result tensor is written --
+    // not the fused-mean form (its epilogue is a reduction, kept standalone).  cfg == -7: round 5's choice (A/B runs).
+    // Measured (profiles/r06_d_h2_de.txt, isolated 8-image launches): it pays where the boundary is longest -- residual read as planes,
+    // planes only out, the identity units of a trunk kept as planes: block3 conv3 65.6 -> 60.0 us, block4 conv3 1 190 -> 1 172 us -- and
+    // costs 1-5 % where the standalone epilogue was short (float32 out without residual: its stores then sit in the next tile's slabs
+    // instead of beside the co-resident workgroup's K loop); 64-row tiles (cfg 41) lose everywhere.  cfg == -8: DE wherever it exists.
+    const bool de = cfg != -2 && cfg != -7 && !p.mean_part && !p.mask && ((p.resp && p.yp && !p.y) || cfg == -8);
+    cfg = pp ? pp_cfg : tiny ? (cfg == -2 ? 12 : (de && cfg == -8) ? 41 : 33) : (cfg == -2 ? 9 : de ? 40 : 31);
   }
+  if (p.mean_part && (cfg == 40 || cfg == 41)) cfg = cfg == 40 ? 31 : 33;     // (the fused-mean form keeps the standalone epilogue: same tiles)
   if (p.mask) switch (cfg) {            // frcnn_gemm_h2_masked (TUNE & 128: the ReLU-gradient select in the epilogue): every shipped
     case 9: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 128>(p, st);           // configuration has its masked twin since round 6 -- the
     case 12: return launch_h2<64, 128, 32, 64, 2, 2, 128>(p, st);               // data-gradient chain of the training step takes the light
@@ -1135,6 +1359,8 @@ static int run_h2(GemmH2Params& p, int cfg, hipStream_t st) {
     case 32: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 512 + 128>(p, st);
     case 33: return launch_h2<64, 128, 32, 64, 2, 2, 256 + 512 + 128>(p, st);
     case 34: return launch_h2<256, 128, 64, 64, 3, 2, 34 + 512 + 128>(p, st);
+    case 40: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 256 + 512 + 1024 + 128>(p, st);
+    case 41: return launch_h2<64, 128, 32, 64, 2, 2, 256 + 512 + 1024 + 128>(p, st);
     default: return FRCNN_E_ARG;
   }
   switch (cfg) {
@@ -1146,6 +1372,8 @@ static int run_h2(GemmH2Params& p, int cfg, hipStream_t st) {
     case 32: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 512>(p, st);        // cfg 9 with 16-byte plane stores only
     case 33: return launch_h2<64, 128, 32, 64, 2, 2, 256 + 512>(p, st);       // cfg 12 with both
     case 34: return launch_h2<256, 128, 64, 64, 3, 2, 34 + 512>(p, st);       // cfg 21 (ping-pong) with 16-byte plane stores
+    case 40: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 256 + 512 + 1024>(p, st);   // cfg 31 with the deferred epilogue (round 6)
+    case 41: return launch_h2<64, 128, 32, 64, 2, 2, 256 + 512 + 1024>(p, st);        // cfg 33 with the deferred epilogue
 #ifdef FRCNN_ABLATION
     // measurement builds only (scratch/ablation_lib.py): the configurations the sweeps under profiles/r03_*, r04_* compare.  All of
     // them multiply and fold in the same order as the three above (bit-identical results; measured, not shipped).
@@ -1162,6 +1390,13 @@ static int run_h2(GemmH2Params& p, int cfg, hipStream_t st) {
     case 22: return launch_h2<256, 128, 64, 64, 3, 2, 34 + 64>(p, st);   // ping-pong with cache-resident X (wrong results by construction)
     case 23: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 64>(p, st);    // cfg 9 with cache-resident X
     case 20: return launch_h2<128, 128, 64, 64, 2, 2, 18>(p, st); // cfg 9's byte count as full-line loads (wrong results by construction)
+    // the energy ledger (scratch/energy_ledger.py): cfg 31 with one ingredient of the slab loop taken out (wrong results by construction)
+    case 50: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 256 + 512 + 2048>(p, st);          // no MFMAs
+    case 51: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 256 + 512 + 4096>(p, st);          // no fragment reads (LDS -> registers)
+    case 52: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 256 + 512 + 8192>(p, st);          // no slab loads (L2 -> LDS) after the prologue
+    case 53: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 256 + 512 + 2048 + 4096>(p, st);   // loads + epilogue only
+    case 54: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 256 + 512 + 4096 + 8192>(p, st);   // MFMAs + epilogue only
+    case 55: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 256 + 512 + 2048 + 4096 + 8192>(p, st);   // the epilogue (and the loop skeleton) only
 #endif
     default: return FRCNN_E_ARG;
   }

@@ -5,6 +5,7 @@
 torch is used for device memory and streams only.
 """
 import collections
+import os
 import time
 
 import numpy as np
@@ -261,6 +262,10 @@ class Session(VariableStore):
         self.buffers = {}                               # session-wide buffers (weight-shaped, solver state, anything allocated outside a scope)
         self.scopes = collections.OrderedDict()         # shape-scope key -> {buffer key: tensor}, least recently entered first (shape_scope)
         self.scope_group = {}                           # shape-scope key -> LRU group
+        # debugging aids (tests; FRCNN_SCOPE_POISON=1 / FRCNN_SCOPE_CAP=n in the environment): new buffers start as NaN patterns instead of
+        # whatever the allocator hands out, so a launch that reads memory nobody wrote shows up at once; a cap for every LRU group
+        self.poison_new_buffers = os.environ.get("FRCNN_SCOPE_POISON", "") not in ("", "0")
+        self.scope_cap_override = int(os.environ.get("FRCNN_SCOPE_CAP", "0")) or None
         self.profile = None                             # list of (tag, flops, ev0, ev1) when profiling
         self.flops_last_forward = 0
         self.flops_by_pipe = None                       # dict while somebody wants the split (Session.mark)
@@ -350,8 +355,9 @@ class Session(VariableStore):
             s = self.sess
             if self.key not in s.scopes:
                 if self.cap is not None:
+                    cap = getattr(s, "scope_cap_override", None) or self.cap
                     live = [k for k in s.scopes if s.scope_group.get(k) == self.group]
-                    drop = live[:max(0, len(live) + 1 - max(1, int(self.cap)))]
+                    drop = live[:max(0, len(live) + 1 - max(1, int(cap)))]
                     if drop:
                         torch.cuda.synchronize(s.device)          # a replay of an evicted graph may still be running
                         for k in drop:
@@ -386,6 +392,16 @@ class Session(VariableStore):
     def _store(self):
         return self.buffers if ops.scope_store is None else ops.scope_store
 
+    def find_buf(self, name, shape, dtype=torch.float32):
+        """A named buffer wherever it lives: the active scope, the most recently entered shape scopes, the session (tests / harnesses that
+        inspect an intermediate tensor after a run; the product path asks through buf() inside the right scope)."""
+        key = (name, tuple(shape), dtype)
+        stores = ([ops.scope_store] if ops.scope_store is not None else []) + list(reversed(self.scopes.values())) + [self.buffers]
+        for st in stores:
+            if key in st:
+                return st[key]
+        raise KeyError(key)
+
     def scope_bytes(self, key=None):
         """bytes held by one shape scope (key) or by all of them: what an eviction returns"""
         def size(v):
@@ -403,6 +419,8 @@ class Session(VariableStore):
         t = store.get(key)
         if t is None:
             t = (torch.zeros if zero else torch.empty)(tuple(shape), dtype=dtype, device=self.device)
+            if getattr(self, "poison_new_buffers", False) and not zero:
+                t.view(torch.uint8).fill_(0xFF)         # float32 / fp16 NaN, int32 -1
             store[key] = t
         return t
 

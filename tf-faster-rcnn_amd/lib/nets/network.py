@@ -701,9 +701,14 @@ class Network(object):
                     flops = sess.flops_last_forward
                     g = ops.Graph().capture(lambda: self._build_network(False))
                     sess.stream.synchronize()
-                sess.graphs[key] = (g, dict(self._predictions), self._num_rois, flops, self._rois_per_image)
-            g, preds, num, flops, per = sess.graphs[key]
+                sess.graphs[key] = (g, dict(self._predictions), self._num_rois, flops, self._rois_per_image, image_d)
+            g, preds, num, flops, per, captured = sess.graphs[key]
             self._predictions, self._num_rois, sess.flops_last_forward, self._rois_per_image = dict(preds), num, flops, per
+            if captured.data_ptr() != image_d.data_ptr():
+                # the graph reads the image at the address it was captured with; a caller that staged this image somewhere else (its own
+                # buffer, the session-wide staging buffer vs. the shape scope's) gets it copied there first -- 4 B per pixel and channel,
+                # device to device, on the stream the graph is launched on
+                captured.copy_(image_d, non_blocking=True)
             g.launch()
         return self._predictions
 
