@@ -40,9 +40,10 @@ extern "C" {
 /* Bumps when an exported signature changes.  2: batched detection stages, NMS rule.  3: `opts` argument of the target-layer entries,
  * per-call cfg / terms of frcnn_gemm_x3 (frcnn_gemm_x3_set_* removed), frcnn_gemm_h2 + operand planes.  4: frcnn_gemm_h2_mean replaces
  * frcnn_conv1x1_mean (whose reduction order depended on the batch slot).  5: the *_masked entries of the training step's data-gradient
- * chain (a library without them must not be loaded by a caller that expects them).  A caller compiled against
+ * chain (a library without them must not be loaded by a caller that expects them).  6: frcnn_crop_and_resize_bwd_plan, the
+ * reference-mangled `_Z4_nmsPiS_PKfiifi` export beside `_nms`, frcnn_gemm_h2 configuration ids 40 / 41.  A caller compiled against
  * this header compares frcnn_abi_version() with FRCNN_ABI_VERSION before its first call (the ctypes binding does, on load). */
-#define FRCNN_ABI_VERSION 5
+#define FRCNN_ABI_VERSION 6
 int frcnn_abi_version(void);
 const char* frcnn_build_info(void);          /* "gfx950 ..." */
 
@@ -229,7 +230,8 @@ int frcnn_conv2d_nhwc_ws(const float* x_d, int N, int H, int W, int Cin, const f
  * launches the calling thread makes afterwards, so the thread-safety contract above holds); no product path sets keys 0-7.  key 0 = force a
  * conv tile configuration id (-1 = automatic); key 1 = ablation bits; key 5 = phase stagger of co-resident workgroups; key 6 = 0 keeps
  * the short-K GEMMs off k_gemm_stream; key 7 = the workgroup count a split-K launch aims at (0 = the default 640; 160 ... 640 move the
- * ResNet-152 training step by +-1 %).  frcnn_gemm_x3 / frcnn_gemm_h2 take their configuration per call instead.
+ * ResNet-152 training step by +-1 %); key 9 = the workgroup count below which the F(4x4,3x3) Winograd transforms run in their
+ * row-per-thread form (0 = the default 256; both forms give the same bits).  frcnn_gemm_x3 / frcnn_gemm_h2 take their configuration per call instead.
  * key 8 is NOT a measurement knob but launch context, set by the TEST-mode graph builder around its launches (lib/nets/network.py
  * _build_network): the number of independent images that share the following launches.  Split-K changes a sum's order, so
  * frcnn_conv2d_nhwc_ws plans it for the launch as it would look in a 4-image batch (per-image rows x 4) whatever the batch is -- the

@@ -34,6 +34,7 @@ shapes = {  # name: (G, M, N, K, residual, f32 out, planes out, mean rows)
     "wrpnx8":  (36, 1280, 512, 1024, False, True, False, 0),
     "b4c1x8":  (1, 117600, 512, 2048, False, False, True, 0),      # block4 conv1: planes only (feeds the Winograd input transform? no: f32) -- long K control
     "b3c1x8":  (1, 19152, 256, 1024, False, True, False, 0),
+    "cal_k128": (1, 117600, 128, 128, "planes", False, True, 0),    # counter calibration: ONE column tile (the filter planes are 64 KB: no re-fetch), X = residual = out = 60.2 MB
     "b4c3x1":  (1, 14700, 2048, 512, True, True, True, 0),         # single image (latency mode)
     "b3c3x1":  (1, 2394, 1024, 256, True, True, True, 0),
 }

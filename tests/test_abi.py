@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), "missing export: " + s
     assert sorted(frcnn_hip.SIGNATURES) == syms            # binding table == header
     declared = int(re.search(r"#define\s+FRCNN_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "frcnn_hip.h")).read()).group(1))
-    assert frcnn_hip.lib().frcnn_abi_version() == declared == frcnn_hip.ABI_VERSION == 5
+    assert frcnn_hip.lib().frcnn_abi_version() == declared == frcnn_hip.ABI_VERSION == 6
     assert b"gfx950" in frcnn_hip.lib().frcnn_build_info()
 
 

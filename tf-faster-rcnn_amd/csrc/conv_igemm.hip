@@ -675,7 +675,9 @@ static thread_local int g_force_cfg = -1, g_dbg = 0, g_stagger = 0, g_stream = 1
 // batch -- the same image then gives the same bits at batch 1, 4 or 8 (lib/model/test.py:88 is strictly batch-1).  0 = plan by the launch.
 static thread_local int g_plan_images = 0;
 static constexpr int PLAN_IMAGES = 4;
+extern thread_local int g_wino_rows_below;              // csrc/winograd.hip: workgroup count below which the F(4,3) transforms run row-per-thread
 extern "C" int frcnn_set_tuning(int key, int value) {
+  if (key == 9) { g_wino_rows_below = value > 0 ? value : 256; return FRCNN_OK; }
   if (key == 0) { g_force_cfg = value; return FRCNN_OK; }
   if (key == 1) { g_dbg = value; return FRCNN_OK; }
   if (key == 5) { g_stagger = value; return FRCNN_OK; }        // 0 off; n > 0: second-slot workgroups start n/8 of a tile late

@@ -129,6 +129,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
   constexpr bool LTB = (TUNE & 256) != 0;         // the light tile boundary (round 5, below): no dependent memory round trip, no store drain
   constexpr bool W21 = (TUNE & 512) != 0;         // plane stores widened to 16 B per lane by v_permlane32_swap pairs (half the instructions)
   constexpr bool DE = (TUNE & 1024) != 0;         // the deferred epilogue (round 6, below): tile t drains under the first 128-k block of tile t + 1
+  constexpr int NTA = (TUNE & 16384) ? 2 : 0;     // `nt` on the streams a tile touches once (residual loads, result stores): cache-policy experiment (cfg 42)
   constexpr int S_OFF = 2 * XP + 2 * WP, STAGE = S_OFF + (PP ? 0 : 1024);
   constexpr int RED_OFF = NS * STAGE;             // row-maximum exchange of the plane-emitting epilogue: [BN / WN][BM] floats
   constexpr int S2_OFF = RED_OFF + (BN / WN) * BM * 4;      // TUNE & 2: two 1 KB block-scale regions, alternating per 128-k block
@@ -173,9 +174,29 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
     if (TUNE & 16) b_off[t] = (unsigned)((size_t)(u * 8 + (lane >> 3)) * p.K * 2 + (lane & 7) * 16);
 #endif
   }
+  // tile id -> (batch entry, row tile, column tile).  TUNE & 32768 (experiment, cfg 43): inside a batch entry the ids walk PANELS of 8 row
+  // tiles x 8 column tiles, the column groups of odd panels in reverse -- the 64 tiles an XCD has resident then touch 2 + 2 MB of operands
+  // per round (K = 512) instead of 1 + 4 MB in the row-major order (the filter planes re-fetched every round, profiles/r06_counters_conv3.json)
+  constexpr bool PANEL = (TUNE & 32768) != 0;
+  auto tile_coords = [&](int tl, int& g, int& mt, int& nt) {
+    g = tl / per;
+    const int rem = tl - g * per;
+    if (PANEL && (p.ntiles & 7) == 0) {
+      const int per_panel = 8 * p.ntiles, panel = rem / per_panel, r2 = rem - panel * per_panel;
+      const int pm = min(8, p.mtiles - panel * 8), per_grp = pm * 8;
+      int grp = r2 / per_grp;
+      const int r3 = r2 - grp * per_grp;
+      if (panel & 1) grp = (p.ntiles >> 3) - 1 - grp;
+      mt = panel * 8 + (r3 >> 3);
+      nt = grp * 8 + (r3 & 7);
+      return;
+    }
+    mt = rem / p.ntiles;
+    nt = rem - mt * p.ntiles;
+  };
   auto set_tile = [&](int tl) {
-    const int g = tl / per, rem = tl - g * per;
-    const int mt = rem / p.ntiles, nt = rem - mt * p.ntiles;
+    int g, mt, nt;
+    tile_coords(tl, g, mt, nt);
     const int bm0 = mt * BM, bn0 = nt * BN;
     const size_t row0 = (size_t)g * p.M + bm0;
     i_g = g; i_bn0 = bn0;
@@ -392,8 +413,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
   int c_tile = tile0, c_step = 0, cur = 0, nxt = 0;          // nxt: ring slot of the next slab to issue
   int c_bm0 = 0, c_bn0 = 0, c_g = 0;
   auto set_ctile = [&](int tl) {
-    const int g = tl / per, rem = tl - g * per;
-    const int mt = rem / p.ntiles, nt = rem - mt * p.ntiles;
+    int g, mt, nt;
+    tile_coords(tl, g, mt, nt);
     c_bm0 = mt * BM; c_bn0 = nt * BN; c_g = g;
   };
   const float act_lo = p.act == FRCNN_ACT_NONE ? -__builtin_inff() : 0.f;
@@ -462,7 +483,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
       const int vo = base + sub_off(C, i, j) * (planes ? 2 : 4);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const u32x4 ld = __builtin_amdgcn_raw_buffer_load_b128((q & 1) ? r_odd : r_even, vo, q * step_q + (q >> 1) * step_p, 0);
+        const u32x4 ld = __builtin_amdgcn_raw_buffer_load_b128((q & 1) ? r_odd : r_even, vo, q * step_q + (q >> 1) * step_p, NTA);
         tot[i][j][4 * q + 0] = __uint_as_float(ld[0]); tot[i][j][4 * q + 1] = __uint_as_float(ld[1]);
         tot[i][j][4 * q + 2] = __uint_as_float(ld[2]); tot[i][j][4 * q + 3] = __uint_as_float(ld[3]);
       }
@@ -676,7 +697,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
         // (__float_as_uint, not __builtin_bit_cast: bit_cast of an ext-vector ELEMENT lvalue reads element 0 -- clang 19 / ROCm 7.2)
         o[0] = __float_as_uint(tot[i][j][4 * q + 0]); o[1] = __float_as_uint(tot[i][j][4 * q + 1]);
         o[2] = __float_as_uint(tot[i][j][4 * q + 2]); o[3] = __float_as_uint(tot[i][j][4 * q + 3]);
-        __builtin_amdgcn_raw_buffer_store_b128(o, ry, lo + 32 * q, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o, ry, lo + 32 * q, 0, NTA);
       }
       pend += 4;
       if constexpr (DE) __builtin_amdgcn_sched_barrier(0);
@@ -735,8 +756,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) __attribute__((amdgpu_w
           typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
           const auto h0 = __builtin_amdgcn_permlane32_swap(uha[0], uhb[0], false, false), h1 = __builtin_amdgcn_permlane32_swap(uha[1], uhb[1], false, false);
           const auto l0 = __builtin_amdgcn_permlane32_swap(ula[0], ulb[0], false, false), l1 = __builtin_amdgcn_permlane32_swap(ula[1], ulb[1], false, false);
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{h0[0], h1[0], h0[1], h1[1]}, rh, lo + 32 * pq, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{l0[0], l1[0], l0[1], l1[1]}, rl, lo + 32 * pq, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{h0[0], h1[0], h0[1], h1[1]}, rh, lo + 32 * pq, 0, NTA);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{l0[0], l1[0], l0[1], l1[1]}, rl, lo + 32 * pq, 0, NTA);
         }
         pend += 4;
         if constexpr (DE) __builtin_amdgcn_sched_barrier(0);        // (one sub-tile's split temporaries at a time: the pieces run beside 128 live accumulators)
@@ -1390,6 +1411,12 @@ static int run_h2(GemmH2Params& p, int cfg, hipStream_t st) {
     case 22: return launch_h2<256, 128, 64, 64, 3, 2, 34 + 64>(p, st);   // ping-pong with cache-resident X (wrong results by construction)
     case 23: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 64>(p, st);    // cfg 9 with cache-resident X
     case 20: return launch_h2<128, 128, 64, 64, 2, 2, 18>(p, st); // cfg 9's byte count as full-line loads (wrong results by construction)
+    // cache-policy experiments on the conv3 class (profiles/r06_h_*; all bit-identical, none shipped): `nt` on the once-touched streams
+    // (residual loads, result stores) 1 152 -> 1 472 us on block4 conv3 with MORE L2 misses; the 8 x 8 panel order 1 152 -> 1 138 us (-1.2 %,
+    // L2 misses -2 %: the residual / result streams dominate them) and +2 % on block3 conv3
+    case 42: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 256 + 512 + 1024 + 16384>(p, st);
+    case 43: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 256 + 512 + 1024 + 32768>(p, st);
+    case 44: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 256 + 512 + 1024 + 16384 + 32768>(p, st);
     // the energy ledger (scratch/energy_ledger.py): cfg 31 with one ingredient of the slab loop taken out (wrong results by construction)
     case 50: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 256 + 512 + 2048>(p, st);          // no MFMAs
     case 51: return launch_h2<128, 128, 64, 64, 2, 2, 2 + 256 + 512 + 4096>(p, st);          // no fragment reads (LDS -> registers)

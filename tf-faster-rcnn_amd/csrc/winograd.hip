@@ -332,8 +332,10 @@ __global__ void __launch_bounds__(256) k_wino4_output_rows(const float4* __restr
   }
 }
 
-// launches below this many workgroups of the tile-per-thread form run the row-per-thread form (256 CUs)
-#define WINO_ROWS_BELOW 256
+// launches below this many workgroups of the tile-per-thread form run the row-per-thread form (256 CUs).  Both forms evaluate the same
+// expressions (same bits); frcnn_set_tuning(9, n) moves the threshold for the calling thread (A/B runs, scratch/wino_bench.py).
+thread_local int g_wino_rows_below = 256;
+#define WINO_ROWS_BELOW g_wino_rows_below
 
 template <bool H2>
 static int wino_input_launch(const float* x_d, int N, int H, int W, int C, int m, const WinoSink<H2>& sink, hipStream_t st) {

@@ -12,7 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libfrcnn_hip.so")
 _lib = None
 
-ABI_VERSION = 5                          # include/frcnn_hip.h FRCNN_ABI_VERSION: the signatures below are this version's
+ABI_VERSION = 6                          # include/frcnn_hip.h FRCNN_ABI_VERSION: the signatures below are this version's
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 NMS_RULE_CPU, NMS_RULE_GPU = 0, 1        # FRCNN_NMS_RULE_*: `(double)ovr >= thresh` (cpu_nms.pyx:65) / `ovr > (float)thresh` (nms_kernel.cu:71)
 
