@@ -771,7 +771,7 @@ def main():
             # HBM bytes per GEMM launch and matrix-pipe busy fraction from the committed rocprofv3 PMC passes of THIS command
             # (scratch/pmc_traffic.py; regenerated per round, the file names the commit it was taken at)
             traffic, tsrc, busy = None, None, None
-            for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):          # the newest committed pass
+            for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json"):          # the newest committed pass
                 tpath = os.path.join(ROOT, "profiles", name)
                 if os.path.exists(tpath) and args.config == "c2" and not args.reference_order and args.mfma == "h2":
                     try:

@@ -173,3 +173,46 @@ def test_a_graph_follows_the_image_wherever_the_caller_staged_it(dev):
         assert all(np.array_equal(p[k][:n].cpu().numpy(), y) for k, y in zip(("cls_score", "cls_prob", "bbox_pred", "rois"), ra))
     finally:
         cfg.TEST.RPN_POST_NMS_TOP_N = old
+
+
+def test_training_over_changing_image_shapes_stays_bounded_and_reproducible(dev):
+    """A roidb's images differ in size from step to step (lib/roi_data_layer/layer.py:80-93, lib/model/train_val.py:236-260).  With two
+    shapes cached (cfg.HIP.TRAIN_CACHE_SHAPES = 2) a run over five shapes evicts and rebuilds scopes and recordings all the time; it must
+    (a) hold no more than two shapes' buffers and recordings, (b) give, step for step, the loss bits of the same run with every shape
+    cached -- eviction, re-allocation from recycled memory and re-recording change nothing."""
+    from frcnn_hip.runtime import Session
+    from frcnn_hip.train import TrainState
+    from model.config import cfg
+    from nets.resnet_v1 import resnetv1
+    shapes = [(128, 160), (144, 176), (128, 192), (160, 160), (112, 208)]
+    order = [0, 1, 0, 2, 3, 0, 1, 4, 4, 4, 2, 0, 0, 3, 1, 1]
+    gt = np.array([[16, 16, 79, 79, 3], [60, 30, 150, 110, 7]], dtype=np.float32)
+
+    def run(tag, cap):
+        old = (cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.TRAIN_CACHE_SHAPES)
+        cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.TRAIN_CACHE_SHAPES = 64, 0.0, cap
+        try:
+            sess = Session(device=dev, seed=9)
+            net = resnetv1(num_layers=50)
+            net.create_architecture("TRAIN", 21, tag=tag, anchor_scales=SCALES, anchor_ratios=RATIOS)
+            sess.init_variables(net.variable_specs())
+            ts = TrainState(sess, net, momentum=0.9, weight_decay=1e-4)
+            ts.lr = 1e-3
+            losses, most = [], 0
+            for k, i in enumerate(order):
+                H, W = shapes[i]
+                blobs = dict(data=_image(H, W, 100 + i) * np.float32(1 / 256.0), im_info=np.array([H, W, 1.0], dtype=np.float32), gt_boxes=gt)
+                losses.append(tuple(np.float32(v).tobytes() for v in net.train_step(sess, blobs, ts)))
+                live = [s for s in sess.scopes if isinstance(s, tuple) and s and s[0] == "train_shape"]
+                recs = [key for key in sess.graphs if isinstance(key, tuple) and key and key[0] == "train_replay"]
+                most = max(most, len(live))
+                assert all(sess.graphs[key].get("scope") in sess.scopes for key in recs)       # no recording outlives its buffers
+            torch.cuda.synchronize()
+            return losses, most, dict(net.replay_stats)
+        finally:
+            cfg.TRAIN.BATCH_SIZE, cfg.TRAIN.BG_THRESH_LO, cfg.HIP.TRAIN_CACHE_SHAPES = old
+    all_cached, most_a, stats_a = run("shapes_all", 16)
+    two_cached, most_b, stats_b = run("shapes_two", 2)
+    assert most_a == 5 and most_b == 2
+    assert two_cached == all_cached                                   # the same bits, step for step
+    assert stats_a["replayed"] > stats_b["replayed"] >= 1 and stats_b["eager"] > stats_a["eager"]      # (the small cache really evicted)
