@@ -415,6 +415,8 @@ static int wino_output_launch(const float* m_d, int N, int H, int W, int C, int 
                               hipStream_t st, const float* mask_d = nullptr) {
   const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
   const long long tot = (long long)N * TH * TW * (C / 4);
+  // (measured, profiles/r06_g_wino_bench.txt: twice the threshold would take block3's output transform at 8 images from 16.5 to 14.2 us
+  // but the row form loses 2 x on wide layers -- RPN, C = 512: 48 -> 89 us -- so the threshold stays one chip's worth of workgroups)
   const bool rows = (tot + 255) / 256 < WINO_ROWS_BELOW;
   if (m == 4 && mask_d && rows)
     hipLaunchKernelGGL((k_wino4_output_rows<H2, true>), dim3((unsigned)((tot * 4 + 255) / 256)), dim3(256), 0, st, (const float4*)m_d, N, H, W,
